@@ -1,0 +1,150 @@
+/*
+ * specscan.h — C ABI of the MI355X spectral-scan engine (libspecscan.so).
+ *
+ * This is the drop-in boundary for ONE path of shajen/rtl-sdr-scanner-cpp: the chain of GNU Radio
+ * blocks that `SdrDevice::setupChains` wires right after the Blocker
+ * (reference sources/radio/sdr_device.cpp:161-168):
+ *
+ *   Decimator<gr_complex>   sources/radio/blocks/decimator.h:11-22    keep first N of each N*D item
+ *   fft_v<gr_complex,true>  sources/radio/sdr_device.cpp:164          Hamming window, forward FFT, shift
+ *   PSD                     sources/radio/blocks/psd.cpp:11-22        10*log10(|X|^2 / fs)
+ *   NoiseLearner            sources/radio/blocks/noise_learner.cpp:11-67   learn max, then subtract
+ *   Transmission (front)    sources/radio/blocks/transmission.cpp:57-61,88-96
+ *       Averager::push      sources/radio/averager.cpp:14-25,52-61    mean of the last 21 frames
+ *       average()           sources/utils/utils.cpp:31-53             centred 21-bin mean
+ *       threshold           sources/radio/blocks/transmission.cpp:90-94   startLevel, range, ignored
+ *
+ * Every block above is a gr::sync_block whose only entry point is
+ *   int work(int noutput_items, gr_vector_const_void_star& in, gr_vector_void_star& out)
+ * (sources/radio/blocks/psd.h:11). ss_process() is that call for the fused chain: `nframes` input items
+ * of N*D complex samples in, per-bin planes and per-frame candidate lists out. The control entry
+ * points mirror the calls the Scanner thread makes into the blocks.
+ *
+ * No exceptions cross this ABI. Every function returns 0 (SS_OK) or a negative ss_status;
+ * ss_last_error() gives the message for the last failure on that context.
+ *
+ * The CPU oracle (oracle/specscan_oracle.h) exports the same set with the prefix orc_.
+ */
+#ifndef SPECSCAN_H
+#define SPECSCAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_ABI_VERSION 1
+
+typedef enum ss_status {
+  SS_OK = 0,
+  SS_ERR_INVALID = -1,       /* bad argument / bad config field */
+  SS_ERR_NO_DEVICE = -2,     /* no HIP device, or device_id out of range */
+  SS_ERR_HIP = -3,           /* a HIP runtime call failed (message has the HIP error string) */
+  SS_ERR_BATCH = -4,         /* nframes > max_batch */
+  SS_ERR_CAND_OVERFLOW = -5, /* more candidates than cand_cap; cand_off is still exact */
+  SS_ERR_NOMEM = -6
+} ss_status;
+
+/* Sample format of the IQ stream handed to ss_process. The reference always asks SoapySDR for CF32
+ * (sources/radio/blocks/sdr_source.cpp:52,75); CS8/CU8 are what RTL-SDR/HackRF produce natively, and
+ * the engine converts them in the FFT kernel's load stage: cf32 = (int8 - offset) * int_scale. */
+typedef enum ss_format {
+  SS_FMT_CF32 = 0, /* interleaved float re,im  (gr_complex)            8 B/sample */
+  SS_FMT_CS8 = 1,  /* interleaved int8  re,im  (HackRF)                2 B/sample */
+  SS_FMT_CU8 = 2   /* interleaved uint8 re,im, offset 127.5 (RTL-SDR)  2 B/sample */
+} ss_format;
+
+/* Which per-bin plane ss_read_window returns. */
+typedef enum ss_plane {
+  SS_PLANE_PSD = 0, /* PSD::work output, dB                                      */
+  SS_PLANE_REL = 1, /* NoiseLearner::work output (rawPower in Transmission)      */
+  SS_PLANE_AVG = 2  /* average(Averager.average()) (avgPower in Transmission)    */
+} ss_plane;
+
+#define SS_NO_DATA (-100.0f) /* setNoData sentinel, sources/utils/radio_utils.cpp:72-76 */
+
+typedef struct ss_config {
+  int32_t abi_version; /* SS_ABI_VERSION */
+  int32_t fft_size;    /* N, power of two, 64 .. 2^20. Reference rule: getFft(fs, 250), radio_utils.cpp:98-104 */
+  int32_t sample_rate; /* fs in Hz (Frequency = int32_t, help_structures.h:13)                 */
+  int32_t decim;       /* D >= 1: an input item is N*D samples and only the first N are used
+                          (sdr_device.cpp:152, decimator.h:15-22)                              */
+  int32_t in_format;   /* ss_format */
+  float int_scale;     /* CS8/CU8 -> float scale; 0 selects 1/128 (CS8) or 1/127.5 (CU8)       */
+  const float* window; /* N taps, or NULL for gr::fft::window::hamming(N) (sdr_device.cpp:164)  */
+  int32_t grouping_x;  /* bins averaged in frequency, odd; GROUPING_X = 21 (config.h:28)        */
+  int32_t grouping_y;  /* frames averaged in time;       GROUPING_Y = 21 (config.h:29)          */
+  float start_level;   /* Device::m_startLevel, dB over the learned ceiling (config.h:30)       */
+  int32_t range_lo;    /* scanned range in Hz; centre = (lo+hi)/2 (sdr_device.cpp:66,146)       */
+  int32_t range_hi;
+  int32_t n_ignored;       /* Config::ignoredRanges(): n pairs lo,hi in Hz                      */
+  const int32_t* ignored;  /* 2*n_ignored values, copied at create                              */
+  int32_t learn_frames;    /* frames absorbed by the noise ceiling per centre frequency when no
+                              timestamps are given (2 s * 50 fps = 100 in the reference's regime) */
+  int32_t learn_ms;        /* NOISE_LEARNING_TIME (config.h:24) used when timestamps are given  */
+  int32_t max_batch;       /* largest nframes a single ss_process call may carry                */
+  int32_t device_id;       /* HIP device ordinal                                                */
+  uint32_t flags;          /* reserved, 0                                                       */
+} ss_config;
+
+typedef struct ss_ctx ss_ctx;
+
+/* Fill `cfg` with the reference's compile-time constants (config.h:24-33) for sample rate `fs`:
+ * N = getFft(fs, 250), D = max(1, int(fs/N/50)), grouping 21x21, start level 8 dB, learn 2000 ms /
+ * 100 frames, Hamming window, CF32 input, range = centre +- fs/2. */
+void ss_default_config(ss_config* cfg, int32_t sample_rate, int32_t center_hz);
+
+int ss_device_count(void);
+
+/* Replaces the construction of Decimator/fft_v/PSD/NoiseLearner/Transmission in
+ * SdrDevice::setupChains (sdr_device.cpp:148-168). */
+int ss_create(const ss_config* cfg, ss_ctx** out);
+void ss_destroy(ss_ctx* ctx);
+const char* ss_last_error(const ss_ctx* ctx); /* ctx may be NULL: message of the last failed ss_create */
+
+/* One work() call of the fused chain on HOST buffers (copied in and out before returning; buffers
+ * stay owned by the caller, as GNU Radio's scheduler owns them in the reference).
+ *   iq        nframes items of N*D samples in cfg.in_format
+ *   t_ms      per-frame wall-clock in ms (what getTime() returned in the reference, utils.cpp:14), or
+ *             NULL for frame-count noise learning
+ *   psd_db, rel_db, avg_db   nframes*N floats each, any may be NULL
+ *   cand_off  nframes+1 offsets into cand_idx (CSR); may be NULL when cand_cap == 0
+ *   cand_idx  bins i with start_level <= avg[i] && inRange(i) && !ignored(i), ascending per frame
+ *             (transmission.cpp:90-94, before the sort at :95)
+ *   cand_avg  avg[i] for each candidate (the sort key of transmission.cpp:95), may be NULL
+ * Returns SS_OK or a negative status. */
+int ss_process(ss_ctx* ctx, const void* iq, int32_t nframes, const int64_t* t_ms,
+               float* psd_db, float* rel_db, float* avg_db,
+               int32_t* cand_off, int32_t* cand_idx, float* cand_avg, int32_t cand_cap);
+
+/* Same call on DEVICE buffers (hipMalloc'd on cfg.device_id), enqueued on the context's stream and
+ * NOT synchronised: call ss_sync before reading results. n_learn = how many leading frames of this
+ * batch belong to the noise-learning phase is decided on the host from learn_frames. */
+int ss_process_device(ss_ctx* ctx, const void* d_iq, int32_t nframes,
+                      float* d_psd_db, float* d_rel_db, float* d_avg_db,
+                      int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int32_t cand_cap);
+int ss_sync(ss_ctx* ctx);
+void* ss_stream(ss_ctx* ctx); /* the hipStream_t ss_process_device enqueues on */
+
+/* SdrDevice::setFrequencyRange's effect on the chain (sdr_device.cpp:66,77,146): new scanned range,
+ * centre = (lo+hi)/2. Noise ceilings are kept per centre frequency (noise_learner.h:33). */
+int ss_set_frequency_range(ss_ctx* ctx, int32_t lo_hz, int32_t hi_hz);
+/* Transmission::resetBuffers -> Averager::reset (transmission.cpp:42-55, averager.cpp:27-34). */
+int ss_reset(ss_ctx* ctx);
+/* NoiseLearner::resetBuffers (noise_learner.cpp:69-72): forget every learned ceiling. */
+int ss_reset_noise(ss_ctx* ctx);
+
+/* Fetch bins [lo,hi) of one plane for frame `frame` of the LAST processed batch; frame may be
+ * negative down to -(grouping_y-1) for SS_PLANE_REL, addressing the averager ring rows that
+ * Transmission::getBestIndex walks (transmission.cpp:132-154). */
+int ss_read_window(ss_ctx* ctx, int32_t plane, int32_t frame, int32_t lo, int32_t hi, float* out);
+
+/* Learned ceiling for the current centre frequency: N floats, -FLT_MAX where nothing was learned.
+ * Returns 1 if learning is complete, 0 if still learning, <0 on error. */
+int ss_read_noise(ss_ctx* ctx, float* thr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECSCAN_H */

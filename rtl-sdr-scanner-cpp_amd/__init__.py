@@ -1,0 +1,6 @@
+"""MI355X spectral-scan engine: host-side Python plumbing around libspecscan.so (C ABI in
+include/specscan.h). The compute path is hand-written HIP for gfx950 under csrc/; Python is used only
+for tests, the benchmark and the one-process-per-GPU launcher."""
+from . import abi, synth  # noqa: F401
+
+__all__ = ["abi", "synth"]

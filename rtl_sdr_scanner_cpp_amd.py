@@ -1,0 +1,12 @@
+"""Import alias for the package directory ``rtl-sdr-scanner-cpp_amd/`` (its name is not a valid Python
+identifier). ``import rtl_sdr_scanner_cpp_amd`` loads that directory as a regular package."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rtl-sdr-scanner-cpp_amd")
+_spec = importlib.util.spec_from_file_location(
+    __name__, os.path.join(_dir, "__init__.py"), submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)
