@@ -1,0 +1,41 @@
+"""Build libspecscan.so (HIP, gfx950) in-tree with hipcc. hipcc cross-compiles without a GPU."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libspecscan.so")
+SOURCES = ["specscan.hip"]
+HEADERS = ["fft_kernels.h", "detect_kernels.h", os.path.join("..", "..", "include", "specscan.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP engine cannot be built (there is no CPU fallback)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if force or needs_build():
+        cmd = [_hipcc(), *FLAGS, "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))

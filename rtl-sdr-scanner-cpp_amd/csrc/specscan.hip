@@ -1,0 +1,568 @@
+// specscan.hip — host side of libspecscan.so: the C ABI of include/specscan.h over the gfx950 kernels
+// in fft_kernels.h / detect_kernels.h. HIP runtime only; no torch, no CPU compute fallback: every entry
+// point that needs the GPU fails with SS_ERR_NO_DEVICE / SS_ERR_HIP when there is none.
+//
+// One ss_ctx = one scan chain of the reference (the blocks SdrDevice::setupChains wires after the
+// Blocker, sources/radio/sdr_device.cpp:161-168) pinned to one HIP device and one stream.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/specscan.h"
+#include "detect_kernels.h"
+#include "fft_kernels.h"
+
+namespace {
+
+thread_local char g_create_err[512] = "";
+
+struct NoiseState {  // NoiseLearner::Noise, sources/radio/blocks/noise_learner.h:11-20, one per centre frequency
+  int32_t center = 0;
+  float* d_thr = nullptr;
+  int samples = 0;
+  bool ready = false;
+  int64_t start_ms = 0;
+  bool have_start = false;
+};
+
+}  // namespace
+
+struct ss_ctx {
+  ss_config cfg{};
+  int n = 0, logn = 0;
+  int32_t range_lo = 0, range_hi = 0;
+  std::vector<int32_t> ignored;
+  hipStream_t stream = nullptr;
+  // constants
+  float* d_win = nullptr;
+  float2* d_tw = nullptr;
+  uint8_t* d_pass = nullptr;
+  bool pass_dirty = true;
+  // state
+  std::vector<NoiseState> noise;
+  int frames_pushed = 0;  // Averager::m_frames, saturates at grouping_y
+  int rot_frames = 0;     // rows of the previous batch still to be folded into the history rows (lazy ring rotation)
+  // planes (frame-major rows of n floats)
+  float* d_rel = nullptr;   // (G-1) history rows + max_batch rows
+  float* d_hist_tmp = nullptr;
+  float* d_psd = nullptr;   // internal PSD plane (used when the caller passes none)
+  float* d_avgy = nullptr;
+  float* d_avg = nullptr;
+  float2* d_work = nullptr;  // four-step intermediate (N > 8192)
+  uint32_t* d_mask = nullptr;
+  int* d_counts = nullptr;
+  int* d_off = nullptr;
+  // host-entry staging
+  void* d_in = nullptr;
+  int* d_cand_idx = nullptr;
+  float* d_cand_avg = nullptr;
+  int cand_cap_alloc = 0;
+  const float* last_psd = nullptr;  // where the last batch's PSD plane lives (device)
+  int last_n = 0;
+  std::mutex mtx;
+  char err[512] = "";
+};
+
+namespace {
+
+int fail(ss_ctx* c, int status, const char* fmt, ...) {
+  char* dst = c ? c->err : g_create_err;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(dst, 512, fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+#define SS_HIP(ctx, call)                                                                              \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) return fail(ctx, SS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+size_t in_bytes_per_sample(int fmt) { return fmt == SS_FMT_CF32 ? 8 : 2; }
+
+// getFft — sources/utils/radio_utils.cpp:98-104
+int get_fft(int32_t sample_rate, int32_t max_step) {
+  uint32_t v = 1;
+  while ((double)max_step < (double)sample_rate / v) v <<= 1;
+  return (int)v;
+}
+
+// isIndexInRange (sources/radio/sdr_device.cpp:153-158) && !isIndexIgnored (transmission.cpp:156-164),
+// evaluated once per retune on the host and kept as one byte per bin on the device.
+void build_pass_mask(const ss_ctx* c, std::vector<uint8_t>& out) {
+  const int n = c->n;
+  const int32_t fs = c->cfg.sample_rate;
+  const double step = (double)fs / n;
+  const int32_t center = (c->range_lo + c->range_hi) / 2;
+  out.resize((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const int32_t f = center + (int32_t)(step * (i + 0.5)) - fs / 2;
+    bool ok = c->range_lo <= f && f <= c->range_hi;
+    for (size_t k = 0; ok && k + 1 < c->ignored.size(); k += 2) {
+      if (c->ignored[k] <= f && f <= c->ignored[k + 1]) ok = false;
+    }
+    out[(size_t)i] = ok ? 1 : 0;
+  }
+}
+
+NoiseState* noise_for(ss_ctx* c, int32_t center) {
+  for (auto& z : c->noise) {
+    if (z.center == center) return &z;
+  }
+  return nullptr;
+}
+
+// ---- FFT + PSD dispatch ---------------------------------------------------------------------------
+template <int LOGN, int FMT>
+void launch_lds(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
+  constexpr int LOGTOT = LOGN < 11 ? 11 : LOGN;
+  constexpr int FPB = (1 << LOGTOT) >> LOGN;
+  const int blocks = (nframes + FPB - 1) / FPB;
+  const size_t lds = sizeof(float2) << LOGTOT;
+  hipLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->stream, d_iq, item_stride,
+                     nframes, c->d_win, c->d_tw, (float)c->cfg.sample_rate, c->cfg.int_scale, d_psd);
+}
+
+template <int LOGN1, int LOGN2, int FMT>
+void launch_four_step(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
+  constexpr int N1 = 1 << LOGN1, N2 = 1 << LOGN2;
+  const size_t lds = sizeof(float2) << 13;
+  const int col_tiles = N2 >> (13 - LOGN1);
+  const int row_tiles = N1 >> (13 - LOGN2);
+  hipLaunchKernelGGL((ss::k_fft_cols<LOGN1, LOGN2, FMT>), dim3(nframes * col_tiles), dim3(ss::kFftThreads), lds, c->stream, d_iq,
+                     item_stride, c->d_win, c->d_tw, c->cfg.int_scale, c->d_work);
+  hipLaunchKernelGGL((ss::k_fft_rows_psd<LOGN1, LOGN2>), dim3(nframes * row_tiles), dim3(ss::kFftThreads), lds, c->stream, c->d_work,
+                     c->d_tw, (float)c->cfg.sample_rate, d_psd);
+}
+
+template <int FMT>
+int launch_fft_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
+  switch (c->logn) {
+    case 6: launch_lds<6, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 7: launch_lds<7, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 8: launch_lds<8, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 9: launch_lds<9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 10: launch_lds<10, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 11: launch_lds<11, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 12: launch_lds<12, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 13: launch_lds<13, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 14: launch_four_step<7, 7, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 15: launch_four_step<7, 8, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 16: launch_four_step<8, 8, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 17: launch_four_step<8, 9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 18: launch_four_step<9, 9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 19: launch_four_step<9, 10, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 20: launch_four_step<10, 10, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    default: return fail(c, SS_ERR_INVALID, "fft_size 2^%d unsupported", c->logn);
+  }
+  return SS_OK;
+}
+
+int launch_fft(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
+  switch (c->cfg.in_format) {
+    case SS_FMT_CF32: return launch_fft_fmt<ss::FMT_CF32>(c, d_iq, item_stride, nframes, d_psd);
+    case SS_FMT_CS8: return launch_fft_fmt<ss::FMT_CS8>(c, d_iq, item_stride, nframes, d_psd);
+    default: return launch_fft_fmt<ss::FMT_CU8>(c, d_iq, item_stride, nframes, d_psd);
+  }
+}
+
+int grid_for(size_t work_items, int block) {
+  size_t g = (work_items + block - 1) / block;
+  const size_t cap = 256 * 16;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// The chain for one batch, everything on c->stream, nothing synchronised.
+// n_learn = leading frames that belong to the noise-learning phase (decided by the caller).
+int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int n_learn, NoiseState* z, float* d_psd_out,
+              float* d_rel_out, float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
+  const int n = c->n;
+  const int G = c->cfg.grouping_y;
+  if (c->pass_dirty) {
+    std::vector<uint8_t> pass;
+    build_pass_mask(c, pass);
+    SS_HIP(c, hipMemcpyAsync(c->d_pass, pass.data(), pass.size(), hipMemcpyHostToDevice, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));  // `pass` is pageable and dies at scope end
+    c->pass_dirty = false;
+  }
+  // Fold the previous batch into the ring: history = newest G-1 rows of [history ++ previous batch].
+  // Done lazily, at the start of the next batch, so that ss_read_window can still address the ring rows
+  // as they were before the batch it describes (Transmission::getBestIndex, transmission.cpp:132-154).
+  if (c->rot_frames > 0 && G > 1) {
+    const size_t cnt4 = (size_t)(G - 1) * n / 4;
+    const float* src = c->d_rel + (size_t)c->rot_frames * n;
+    if (c->rot_frames >= G - 1) {
+      hipLaunchKernelGGL(ss::k_copy_rows, dim3(grid_for(cnt4, 256)), dim3(256), 0, c->stream, src, c->d_rel, cnt4);
+    } else {  // source and destination overlap: bounce through a scratch copy
+      hipLaunchKernelGGL(ss::k_copy_rows, dim3(grid_for(cnt4, 256)), dim3(256), 0, c->stream, src, c->d_hist_tmp, cnt4);
+      hipLaunchKernelGGL(ss::k_copy_rows, dim3(grid_for(cnt4, 256)), dim3(256), 0, c->stream, (const float*)c->d_hist_tmp, c->d_rel, cnt4);
+    }
+  }
+  c->rot_frames = 0;
+  float* d_psd = d_psd_out ? d_psd_out : c->d_psd;
+  int st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
+  if (st != SS_OK) return st;
+
+  float* rel_batch = c->d_rel + (size_t)(G - 1) * n;
+  if (n_learn > 0) {
+    hipLaunchKernelGGL(ss::k_noise_learn, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_psd, n, n_learn, z->d_thr);
+  }
+  hipLaunchKernelGGL(ss::k_noise_apply, dim3(grid_for((size_t)nframes * n / 4, 256)), dim3(256), 0, c->stream, d_psd, z->d_thr, n, nframes,
+                     n_learn, rel_batch, d_rel_out);
+  hipLaunchKernelGGL(ss::k_time_mean, dim3(grid_for((size_t)nframes * n / 4, 256)), dim3(256), 0, c->stream, c->d_rel, n, nframes, G,
+                     c->frames_pushed, c->d_avgy);
+  const int a = c->cfg.grouping_x / 2;
+  const int blocks_per_row = (n + 255) / 256;
+  hipLaunchKernelGGL(ss::k_freq_mean_detect, dim3(nframes * blocks_per_row), dim3(256), sizeof(float) * (256 + 2 * a), c->stream, c->d_avgy,
+                     n, nframes, c->cfg.grouping_x, c->cfg.start_level, c->d_pass, c->d_avg, d_avg_out, c->d_mask);
+  const int wpr = n / 32;
+  hipLaunchKernelGGL(ss::k_cand_count, dim3(nframes), dim3(256), 0, c->stream, c->d_mask, wpr, c->d_counts);
+  hipLaunchKernelGGL(ss::k_cand_scan, dim3(1), dim3(256), 0, c->stream, c->d_counts, nframes, c->d_off, d_cand_off);
+  if (d_cand_idx && cand_cap > 0) {
+    hipLaunchKernelGGL(ss::k_cand_write, dim3(nframes), dim3(256), 0, c->stream, c->d_mask, wpr, n, c->d_off, c->d_avg, cand_cap, d_cand_idx,
+                       d_cand_avg);
+  }
+  SS_HIP(c, hipGetLastError());
+  c->frames_pushed = c->frames_pushed + nframes < G ? c->frames_pushed + nframes : G;
+  c->last_psd = d_psd;
+  c->last_n = nframes;
+  c->rot_frames = nframes;
+  return SS_OK;
+}
+
+// Noise::add's bookkeeping for a batch (noise_learner.cpp:11-28): how many leading frames still learn.
+int plan_learning(ss_ctx* c, NoiseState* z, int nframes, const int64_t* t_ms) {
+  int n_learn = 0;
+  for (int f = 0; f < nframes && !z->ready; ++f) {
+    if (!z->have_start) {  // Noise::Noise() reads getTime() when m_noise[frequency] is first touched (:9, :42)
+      z->start_ms = t_ms ? t_ms[f] : 0;
+      z->have_start = true;
+    }
+    ++n_learn;
+    ++z->samples;
+    const bool done = t_ms ? (z->start_ms + c->cfg.learn_ms <= t_ms[f]) : (z->samples >= c->cfg.learn_frames);
+    if (done) z->ready = true;
+  }
+  return n_learn;
+}
+
+int get_noise(ss_ctx* c, NoiseState** out) {
+  const int32_t center = (c->range_lo + c->range_hi) / 2;
+  NoiseState* z = noise_for(c, center);
+  if (!z) {
+    NoiseState nz;
+    nz.center = center;
+    SS_HIP(c, hipMalloc(&nz.d_thr, sizeof(float) * (size_t)c->n));
+    hipLaunchKernelGGL(ss::k_fill, dim3(grid_for((size_t)c->n, 256)), dim3(256), 0, c->stream, nz.d_thr, (size_t)c->n, -FLT_MAX);
+    c->noise.push_back(nz);
+    z = &c->noise.back();
+  }
+  *out = z;
+  return SS_OK;
+}
+
+void free_ctx(ss_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->cfg.device_id);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& z : c->noise) (void)hipFree(z.d_thr);
+  (void)hipFree(c->d_win);
+  (void)hipFree(c->d_tw);
+  (void)hipFree(c->d_pass);
+  (void)hipFree(c->d_rel);
+  (void)hipFree(c->d_hist_tmp);
+  (void)hipFree(c->d_psd);
+  (void)hipFree(c->d_avgy);
+  (void)hipFree(c->d_avg);
+  (void)hipFree(c->d_work);
+  (void)hipFree(c->d_mask);
+  (void)hipFree(c->d_counts);
+  (void)hipFree(c->d_off);
+  (void)hipFree(c->d_in);
+  (void)hipFree(c->d_cand_idx);
+  (void)hipFree(c->d_cand_avg);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ss_default_config(ss_config* cfg, int32_t sample_rate, int32_t center_hz) {
+  if (!cfg) return;
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->abi_version = SS_ABI_VERSION;
+  cfg->fft_size = get_fft(sample_rate, 250);  // SIGNAL_DETECTION_MAX_STEP, config.h:33; sdr_device.cpp:149
+  cfg->sample_rate = sample_rate;
+  const double step = (double)sample_rate / cfg->fft_size;  // sdr_device.cpp:150
+  const int d = (int)(step / 50);                           // SIGNAL_DETECTION_FPS, config.h:32; sdr_device.cpp:152
+  cfg->decim = d > 1 ? d : 1;
+  cfg->in_format = SS_FMT_CF32;
+  cfg->grouping_x = 21;     // config.h:28
+  cfg->grouping_y = 21;     // config.h:29
+  cfg->start_level = 8.0f;  // config.h:30
+  cfg->range_lo = center_hz - sample_rate / 2;
+  cfg->range_hi = center_hz + sample_rate / 2;
+  cfg->learn_frames = 100;  // NOISE_LEARNING_TIME (config.h:24) at 50 frames/s
+  cfg->learn_ms = 2000;
+  cfg->max_batch = 1024;
+  cfg->device_id = 0;
+}
+
+int ss_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ss_create(const ss_config* cfg, ss_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, SS_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != SS_ABI_VERSION) return fail(nullptr, SS_ERR_INVALID, "abi_version %d != %d", cfg->abi_version, SS_ABI_VERSION);
+  if (!is_pow2(cfg->fft_size) || cfg->fft_size < 64 || cfg->fft_size > (1 << 20))
+    return fail(nullptr, SS_ERR_INVALID, "fft_size %d must be a power of two in [64, 2^20]", cfg->fft_size);
+  if (cfg->sample_rate <= 0 || cfg->decim < 1 || cfg->max_batch < 1 || cfg->n_ignored < 0 || cfg->learn_frames < 1 ||
+      cfg->grouping_y < 1 || cfg->grouping_x < 1 || (cfg->grouping_x & 1) == 0 || cfg->grouping_x > 1025 ||
+      cfg->in_format < SS_FMT_CF32 || cfg->in_format > SS_FMT_CU8 || (cfg->n_ignored > 0 && !cfg->ignored))
+    return fail(nullptr, SS_ERR_INVALID, "invalid ss_config field");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, SS_ERR_NO_DEVICE, "no HIP device available");
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, SS_ERR_NO_DEVICE, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+
+  ss_ctx* c = new (std::nothrow) ss_ctx();
+  if (!c) return fail(nullptr, SS_ERR_NOMEM, "out of host memory");
+  c->cfg = *cfg;
+  c->cfg.window = nullptr;
+  c->cfg.ignored = nullptr;
+  c->n = cfg->fft_size;
+  while ((1 << c->logn) < c->n) ++c->logn;
+  c->range_lo = cfg->range_lo;
+  c->range_hi = cfg->range_hi;
+  c->ignored.assign(cfg->ignored, cfg->ignored + 2 * (size_t)cfg->n_ignored);
+  if (c->cfg.int_scale == 0.0f) c->cfg.int_scale = cfg->in_format == SS_FMT_CU8 ? 1.0f / 127.5f : 1.0f / 128.0f;
+
+  const int n = c->n;
+  const int G = cfg->grouping_y;
+  const size_t plane = sizeof(float) * (size_t)n * (size_t)cfg->max_batch;
+#define CREATE_HIP(call)                                                                      \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      fail(nullptr, SS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));               \
+      free_ctx(c);                                                                            \
+      return SS_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+  CREATE_HIP(hipSetDevice(cfg->device_id));
+  CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CREATE_HIP(hipMalloc(&c->d_win, sizeof(float) * (size_t)n));
+  CREATE_HIP(hipMalloc(&c->d_tw, sizeof(float2) * (size_t)n));
+  CREATE_HIP(hipMalloc(&c->d_pass, (size_t)n));
+  CREATE_HIP(hipMalloc(&c->d_rel, sizeof(float) * (size_t)n * (size_t)(G - 1 + cfg->max_batch)));
+  CREATE_HIP(hipMalloc(&c->d_hist_tmp, sizeof(float) * (size_t)n * (size_t)(G > 1 ? G - 1 : 1)));
+  CREATE_HIP(hipMalloc(&c->d_psd, plane));
+  CREATE_HIP(hipMalloc(&c->d_avgy, plane));
+  CREATE_HIP(hipMalloc(&c->d_avg, plane));
+  CREATE_HIP(hipMalloc(&c->d_mask, sizeof(uint32_t) * (size_t)(n / 32) * (size_t)cfg->max_batch));
+  CREATE_HIP(hipMalloc(&c->d_counts, sizeof(int) * (size_t)cfg->max_batch));
+  CREATE_HIP(hipMalloc(&c->d_off, sizeof(int) * ((size_t)cfg->max_batch + 1)));
+  if (c->logn > 13) CREATE_HIP(hipMalloc(&c->d_work, sizeof(float2) * (size_t)n * (size_t)cfg->max_batch));
+
+  // window: caller's taps or gr::fft::window::hamming(N) (sdr_device.cpp:164; GNU Radio's definition:
+  // 0.54 - 0.46*cos(2*pi*n/(N-1)) in double, stored as float). Twiddles W_N^k from double.
+  {
+    std::vector<float> win((size_t)n);
+    if (cfg->window) {
+      memcpy(win.data(), cfg->window, sizeof(float) * (size_t)n);
+    } else {
+      const float M = (float)(n - 1);
+      for (int i = 0; i < n; ++i) win[(size_t)i] = (float)(0.54 - 0.46 * cos((2.0 * M_PI * i) / M));
+    }
+    std::vector<float2> tw((size_t)n);
+    for (int k = 0; k < n; ++k) {
+      const double ang = -2.0 * M_PI * (double)k / (double)n;
+      tw[(size_t)k] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    CREATE_HIP(hipMemcpy(c->d_win, win.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+  }
+  // Averager ctor: ring rows zero-filled (averager.cpp:7-12)
+  CREATE_HIP(hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)n * (size_t)(G - 1 + cfg->max_batch), c->stream));
+  // 64 KiB of dynamic LDS needs no opt-in on gfx950 (160 KiB/CU), but say so explicitly for clarity
+  CREATE_HIP(hipStreamSynchronize(c->stream));
+#undef CREATE_HIP
+  *out = c;
+  return SS_OK;
+}
+
+void ss_destroy(ss_ctx* ctx) { free_ctx(ctx); }
+
+const char* ss_last_error(const ss_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
+
+void* ss_stream(ss_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int ss_sync(ss_ctx* ctx) {
+  if (!ctx) return SS_ERR_INVALID;
+  SS_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+  SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SS_OK;
+}
+
+int ss_process_device(ss_ctx* c, const void* d_iq, int32_t nframes, float* d_psd_db, float* d_rel_db, float* d_avg_db, int32_t* d_cand_off,
+                      int32_t* d_cand_idx, float* d_cand_avg, int32_t cand_cap) {
+  if (!c) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  if (nframes < 0 || (nframes > 0 && !d_iq) || cand_cap < 0) return fail(c, SS_ERR_INVALID, "bad d_iq/nframes/cand_cap");
+  if (nframes > c->cfg.max_batch) return fail(c, SS_ERR_BATCH, "nframes %d > max_batch %d", nframes, c->cfg.max_batch);
+  if (nframes == 0) {
+    if (d_cand_off) SS_HIP(c, hipMemsetAsync(d_cand_off, 0, sizeof(int32_t), c->stream));
+    c->last_n = 0;
+    return SS_OK;
+  }
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  NoiseState* z = nullptr;
+  int st = get_noise(c, &z);
+  if (st != SS_OK) return st;
+  const int n_learn = plan_learning(c, z, nframes, nullptr);
+  return run_batch(c, d_iq, (long long)c->n * c->cfg.decim, nframes, n_learn, z, d_psd_db, d_rel_db, d_avg_db, d_cand_off, d_cand_idx,
+                   d_cand_avg, cand_cap);
+}
+
+int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, float* psd_db, float* rel_db, float* avg_db,
+               int32_t* cand_off, int32_t* cand_idx, float* cand_avg, int32_t cand_cap) {
+  if (!c) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  if (nframes < 0 || (nframes > 0 && !iq) || cand_cap < 0) return fail(c, SS_ERR_INVALID, "bad iq/nframes/cand_cap");
+  if (nframes > c->cfg.max_batch) return fail(c, SS_ERR_BATCH, "nframes %d > max_batch %d", nframes, c->cfg.max_batch);
+  if (cand_off) cand_off[0] = 0;
+  if (nframes == 0) {
+    c->last_n = 0;
+    return SS_OK;
+  }
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  const int n = c->n;
+  const size_t bps = in_bytes_per_sample(c->cfg.in_format);
+  const size_t row_bytes = (size_t)n * bps;
+  if (!c->d_in) SS_HIP(c, hipMalloc(&c->d_in, row_bytes * (size_t)c->cfg.max_batch));
+  // Decimator: only the first N samples of each N*D item ever reach the GPU (decimator.h:15-22)
+  SS_HIP(c, hipMemcpy2DAsync(c->d_in, row_bytes, iq, row_bytes * (size_t)c->cfg.decim, row_bytes, (size_t)nframes, hipMemcpyHostToDevice,
+                             c->stream));
+  if (cand_cap > c->cand_cap_alloc) {
+    (void)hipFree(c->d_cand_idx);
+    (void)hipFree(c->d_cand_avg);
+    c->d_cand_idx = nullptr;
+    c->d_cand_avg = nullptr;
+    c->cand_cap_alloc = 0;
+    SS_HIP(c, hipMalloc(&c->d_cand_idx, sizeof(int) * (size_t)cand_cap));
+    SS_HIP(c, hipMalloc(&c->d_cand_avg, sizeof(float) * (size_t)cand_cap));
+    c->cand_cap_alloc = cand_cap;
+  }
+  NoiseState* z = nullptr;
+  int st = get_noise(c, &z);
+  if (st != SS_OK) return st;
+  const int n_learn = plan_learning(c, z, nframes, t_ms);
+  const bool want_cands = cand_idx && cand_cap > 0;
+  st = run_batch(c, c->d_in, (long long)n, nframes, n_learn, z, nullptr, nullptr, nullptr, nullptr, want_cands ? c->d_cand_idx : nullptr,
+                 want_cands && cand_avg ? c->d_cand_avg : nullptr, cand_cap);
+  if (st != SS_OK) return st;
+  const size_t plane = sizeof(float) * (size_t)n * (size_t)nframes;
+  if (psd_db) SS_HIP(c, hipMemcpyAsync(psd_db, c->d_psd, plane, hipMemcpyDeviceToHost, c->stream));
+  if (rel_db) SS_HIP(c, hipMemcpyAsync(rel_db, c->d_rel + (size_t)(c->cfg.grouping_y - 1) * n, plane, hipMemcpyDeviceToHost, c->stream));
+  if (avg_db) SS_HIP(c, hipMemcpyAsync(avg_db, c->d_avg, plane, hipMemcpyDeviceToHost, c->stream));
+  std::vector<int> off((size_t)nframes + 1);
+  SS_HIP(c, hipMemcpyAsync(off.data(), c->d_off, sizeof(int) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, c->stream));
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  if (cand_off) memcpy(cand_off, off.data(), sizeof(int) * ((size_t)nframes + 1));
+  const int total = off[(size_t)nframes];
+  if (want_cands) {
+    const int ncopy = total < cand_cap ? total : cand_cap;
+    if (ncopy > 0) {
+      SS_HIP(c, hipMemcpy(cand_idx, c->d_cand_idx, sizeof(int) * (size_t)ncopy, hipMemcpyDeviceToHost));
+      if (cand_avg) SS_HIP(c, hipMemcpy(cand_avg, c->d_cand_avg, sizeof(float) * (size_t)ncopy, hipMemcpyDeviceToHost));
+    }
+  }
+  if (cand_cap > 0 && total > cand_cap) return fail(c, SS_ERR_CAND_OVERFLOW, "%d candidates > cand_cap %d", total, cand_cap);
+  return SS_OK;
+}
+
+int ss_set_frequency_range(ss_ctx* c, int32_t lo_hz, int32_t hi_hz) {
+  if (!c) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  c->range_lo = lo_hz;
+  c->range_hi = hi_hz;
+  c->pass_dirty = true;
+  return SS_OK;
+}
+
+int ss_reset(ss_ctx* c) {  // Transmission::resetBuffers -> Averager::reset: rows and sums to zero, m_frames = 0
+  if (!c) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  const int G = c->cfg.grouping_y;
+  if (G > 1) SS_HIP(c, hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)c->n * (size_t)(G - 1), c->stream));
+  c->frames_pushed = 0;
+  c->rot_frames = 0;
+  c->last_n = 0;
+  return SS_OK;
+}
+
+int ss_reset_noise(ss_ctx* c) {
+  if (!c) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  for (auto& z : c->noise) (void)hipFree(z.d_thr);
+  c->noise.clear();
+  return SS_OK;
+}
+
+int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t hi, float* out) {
+  if (!c || !out) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  const int n = c->n;
+  const int G = c->cfg.grouping_y;
+  if (lo < 0 || hi > n || lo > hi || frame >= c->last_n) return fail(c, SS_ERR_INVALID, "window out of range");
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  const float* src = nullptr;
+  if (frame >= 0) {
+    if (plane == SS_PLANE_PSD) src = c->last_psd + (size_t)frame * n;
+    if (plane == SS_PLANE_AVG) src = c->d_avg + (size_t)frame * n;
+  }
+  // rel keeps [ring before the batch (G-1 rows)] ++ [batch rows] until the next batch starts
+  if (plane == SS_PLANE_REL && frame >= -(G - 1)) src = c->d_rel + (size_t)(G - 1 + frame) * n;
+  if (!src) return fail(c, SS_ERR_INVALID, "bad plane/frame");
+  SS_HIP(c, hipMemcpyAsync(out, src + lo, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToHost, c->stream));
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  return SS_OK;
+}
+
+int ss_read_noise(ss_ctx* c, float* thr) {
+  if (!c || !thr) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  NoiseState* z = noise_for(c, (c->range_lo + c->range_hi) / 2);
+  if (!z) {
+    for (int i = 0; i < c->n; ++i) thr[i] = -FLT_MAX;
+    return 0;
+  }
+  SS_HIP(c, hipMemcpyAsync(thr, z->d_thr, sizeof(float) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  return z->ready ? 1 : 0;
+}
+
+}  // extern "C"

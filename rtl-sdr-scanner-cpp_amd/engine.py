@@ -1,0 +1,71 @@
+"""Host-side mirror of the reference's block interface for the scan path, over libspecscan.so.
+
+``SpectrumEngine`` is one chain (what SdrDevice::setupChains builds per device, reference
+sources/radio/sdr_device.cpp:148-168). Host-buffer calls go through ``process`` (numpy, like
+``work()`` on scheduler-owned buffers); device-resident calls go through ``process_device`` with torch
+tensors used purely as HBM allocations. There is no CPU fallback: if the HIP library is missing or no
+GPU is present, construction raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .build import LIB
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen csrc/libspecscan.so (built by build.build_lib / __graft_entry__.build). Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RuntimeError(f"{LIB} is missing: run `python __graft_entry__.py build` (hipcc, gfx950). "
+                               "The spectral-scan engine has no CPU fallback.")
+        lib = C.CDLL(LIB)
+        abi.bind(lib, "ss_")
+        lib.ss_device_count.restype = C.c_int
+        lib.ss_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        lib.ss_process_device.restype = C.c_int
+        lib.ss_sync.argtypes = [C.c_void_p]
+        lib.ss_sync.restype = C.c_int
+        lib.ss_stream.argtypes = [C.c_void_p]
+        lib.ss_stream.restype = C.c_void_p
+        _lib = lib
+    return _lib
+
+
+EXPORTS = ("ss_default_config", "ss_device_count", "ss_create", "ss_destroy", "ss_last_error", "ss_process",
+           "ss_process_device", "ss_sync", "ss_stream", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
+           "ss_read_window", "ss_read_noise")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class SpectrumEngine(abi.Chain):
+    def __init__(self, sample_rate: int, center_hz: int, **overrides):
+        lib = load_library()
+        if lib.ss_device_count() <= 0:
+            raise RuntimeError("no HIP device: the spectral-scan engine runs on an MI355X only (no CPU fallback)")
+        super().__init__(lib, "ss_", sample_rate, center_hz, **overrides)
+
+    @property
+    def stream_handle(self) -> int:
+        return int(self._lib.ss_stream(self._h) or 0)
+
+    def process_device(self, iq, nframes: int, psd=None, rel=None, avg=None, cand_off=None, cand_idx=None, cand_avg=None):
+        """All arguments are torch tensors resident on this chain's device (or None). Asynchronous on the
+        chain's stream; call ``sync()`` before reading. iq must hold nframes items of N*D samples."""
+        cap = 0 if cand_idx is None else int(cand_idx.numel())
+        st = self._lib.ss_process_device(self._h, _ptr(iq), int(nframes), _ptr(psd), _ptr(rel), _ptr(avg), _ptr(cand_off),
+                                         _ptr(cand_idx), _ptr(cand_avg), cap)
+        self._check(st)
+
+    def sync(self):
+        self._check(self._lib.ss_sync(self._h))

@@ -1,0 +1,72 @@
+"""CPU-side checks of the boundary: the HIP library builds for gfx950, loads, exports every symbol
+include/specscan.h declares, and refuses to compute without a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+import rtl_sdr_scanner_cpp_amd as pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    pkg.build.build_lib()
+    return pkg.load_library()
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:ss|orc)_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared("include/specscan.h")
+    assert set(names) == set(pkg.engine.EXPORTS)
+    for name in names:
+        assert hasattr(lib, name), name
+
+
+def test_oracle_exports_the_same_set(oracle_mod):
+    L = oracle_mod.lib()
+    for name in pkg.engine.EXPORTS:
+        if name in ("ss_device_count", "ss_process_device", "ss_sync", "ss_stream"):
+            continue  # device-only entry points
+        assert hasattr(L, "orc_" + name[3:]), name
+
+
+def test_default_config_follows_reference_constants(lib, oracle_mod):
+    import ctypes as C
+    for L, p in ((lib, "ss_"), (oracle_mod.lib(), "orc_")):
+        pkg.abi.bind(L, p)
+        for fs, n, d in ((2_048_000, 8192, 5), (20_000_000, 131072, 3), (250_000, 1024, 4), (61_440_000, 262144, 4)):
+            cfg = pkg.abi.SsConfig()
+            getattr(L, p + "default_config")(C.byref(cfg), fs, 100_000_000)
+            assert (cfg.fft_size, cfg.decim) == (n, d), (p, fs, cfg.fft_size, cfg.decim)
+            assert (cfg.grouping_x, cfg.grouping_y, cfg.start_level, cfg.learn_ms) == (21, 21, 8.0, 2000)
+            assert (cfg.range_lo, cfg.range_hi) == (100_000_000 - fs // 2, 100_000_000 + fs // 2)
+
+
+def test_no_gpu_means_loud_failure(lib):
+    if lib.ss_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError):
+        pkg.SpectrumEngine(2_048_000, 145_000_000)
+    import ctypes as C
+    cfg = pkg.abi.SsConfig()
+    lib.ss_default_config(C.byref(cfg), 2_048_000, 145_000_000)
+    h = C.c_void_p()
+    assert lib.ss_create(C.byref(cfg), C.byref(h)) == pkg.abi.SS_ERR_NO_DEVICE
+    assert b"HIP device" in lib.ss_last_error(None)
+
+
+def test_product_never_imports_the_oracle():
+    """The package must not reference oracle/ (voids parity claims otherwise)."""
+    pkgdir = os.path.join(ROOT, "rtl-sdr-scanner-cpp_amd")
+    for dirpath, _, files in os.walk(pkgdir):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, fn

@@ -1,0 +1,229 @@
+"""Parity of the HIP engine against the CPU oracle and the reference-made golden planes, through the
+C ABI (ss_process / ss_process_device). Needs an MI355X: run with -m gpu."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import rtl_sdr_scanner_cpp_amd as pkg
+from parity import check_all, check_plane
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_chain_*.npz")))
+
+
+def _chunks(total, chunk):
+    pos = 0
+    while pos < total:
+        yield pos, min(total, pos + chunk)
+        pos += chunk
+
+
+def _run(chain, iq, chunk, t_ms=None, hooks=None):
+    outs = []
+    for a, b in _chunks(iq.shape[0], chunk):
+        if hooks and a in hooks:
+            hooks[a](chain)
+        outs.append(chain.process(iq[a:b], t_ms=None if t_ms is None else t_ms[a:b]))
+    res = {k: np.concatenate([o[k] for o in outs]) for k in ("psd", "rel", "avg", "cand_idx", "cand_avg")}
+    counts = np.concatenate([np.diff(o["cand_off"]) for o in outs])
+    res["cand_off"] = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return res
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+@pytest.mark.parametrize("chunk", [5, 64])
+def test_engine_matches_reference_made_golden(path, chunk):
+    """Planes and candidates produced by the reference's own compiled PSD/NoiseLearner/Transmission code
+    (tests/golden/make_golden.py), timestamps included."""
+    g = np.load(path)
+    n, fs, center = int(g["n"]), int(g["fs"]), int(g["center"])
+    retune_at = int(g["retune_at"])
+    lo, hi = center - fs // 2, center + fs // 2
+    eng = pkg.SpectrumEngine(fs, center, fft_size=n, decim=1, max_batch=64, ignored=g["ignored"])
+    hooks = None
+    if retune_at >= 0:
+        assert retune_at % chunk == 0
+        hooks = {retune_at: lambda c: (c.set_frequency_range(lo + fs, hi + fs), c.reset())}
+    got = _run(eng, g["iq"], chunk, t_ms=g["t_ms"], hooks=hooks)
+    ref = {k: g[k] for k in ("psd", "rel", "avg", "cand_off", "cand_idx")}
+    errs, ncand, ndc = check_all(got, ref)
+    assert ncand > 100 and ndc <= max(2, ncand // 200), (ncand, ndc, errs)
+
+
+CASES = [
+    # n, fs, decim, fmt, nframes, chunk, learn, seed
+    (64, 16_000, 1, "cf32", 120, 17, 20, 1),
+    (1024, 256_000, 1, "cf32", 150, 64, 30, 2),
+    (2048, 512_000, 3, "cf32", 90, 32, 25, 3),
+    (4096, 1_024_000, 1, "cs8", 80, 80, 22, 4),
+    (8192, 2_048_000, 1, "cf32", 96, 48, 24, 5),
+    (8192, 2_048_000, 5, "cu8", 70, 70, 21, 6),
+    (16384, 4_096_000, 1, "cf32", 60, 30, 22, 7),
+    (65536, 20_000_000, 1, "cs8", 50, 25, 22, 8),
+]
+
+
+@pytest.mark.parametrize("n,fs,decim,fmt,nframes,chunk,learn,seed", CASES)
+def test_engine_matches_oracle(oracle_mod, n, fs, decim, fmt, nframes, chunk, learn, seed):
+    center = 145_000_000
+    band = pkg.synth.SyntheticBand(n, decim=decim, seed=seed, on_frame=learn + 25, off_frame=nframes - 8)
+    if fmt == "cf32":
+        iq, in_format = band.frames_cf32(nframes), pkg.abi.SS_FMT_CF32
+    elif fmt == "cs8":
+        iq, in_format = band.frames_cs8(nframes), pkg.abi.SS_FMT_CS8
+    else:
+        iq, in_format = band.frames_cu8(nframes), pkg.abi.SS_FMT_CU8
+    kw = dict(fft_size=n, decim=decim, in_format=in_format, learn_frames=learn, max_batch=max(chunk, 8))
+    eng = pkg.SpectrumEngine(fs, center, **kw)
+    orc = oracle_mod.oracle_chain(fs, center, **kw)
+    got, ref = _run(eng, iq, chunk), _run(orc, iq, chunk)
+    errs, ncand, ndc = check_all(got, ref)
+    assert ncand > 50, "the test vector must produce detections"
+    assert ndc <= max(2, ncand // 200), (ncand, ndc)
+    thr_g, ready_g = eng.read_noise()
+    thr_o, ready_o = orc.read_noise()
+    assert ready_g and ready_o
+    check_plane("noise ceiling", thr_g[None], thr_o[None])
+
+
+def test_one_million_point_frames(oracle_mod):
+    """BASELINE config 5 frame size (2^20), detect chain on a few frames."""
+    n, fs, center = 1 << 20, 61_440_000, 400_000_000
+    band = pkg.synth.SyntheticBand(n, seed=9, on_frame=2, off_frame=100, comb_width=48)
+    iq = band.frames_cf32(5)
+    kw = dict(fft_size=n, decim=1, learn_frames=2, max_batch=8, grouping_y=3)
+    got = pkg.SpectrumEngine(fs, center, **kw).process(iq)
+    ref = oracle_mod.oracle_chain(fs, center, **kw).process(iq)
+    errs, ncand, ndc = check_all(got, ref)
+    assert ncand > 50 and ndc <= 2
+
+
+def test_ignored_ranges_and_partial_range(oracle_mod):
+    n, fs, center = 1024, 256_000, 433_000_000
+    band = pkg.synth.SyntheticBand(n, seed=11, on_frame=40, off_frame=100)
+    iq = band.frames_cf32(110)
+    ign = [center + 40_000, center + 52_000, center - 80_000, center - 60_000]
+    kw = dict(fft_size=n, decim=1, learn_frames=15, max_batch=128, ignored=ign, range_lo=center - 100_000, range_hi=center + 90_000)
+    got = pkg.SpectrumEngine(fs, center, **kw).process(iq)
+    ref = oracle_mod.oracle_chain(fs, center, **kw).process(iq)
+    check_all(got, ref)
+    full = oracle_mod.oracle_chain(fs, center, **{**kw, "ignored": [], "range_lo": center - fs // 2, "range_hi": center + fs // 2}).process(iq)
+    assert len(full["cand_idx"]) > len(ref["cand_idx"]) > 0  # the restrictions removed something, not everything
+
+
+def test_retune_keeps_noise_per_centre_and_resets_averager(oracle_mod):
+    """SdrDevice::setFrequencyRange sequence (sdr_device.cpp:54-80): new centre learns its own ceiling,
+    going back finds the old one (NoiseLearner never forgets, noise_learner.h:33), the averager restarts."""
+    n, fs, c0, c1 = 512, 128_000, 100_000_000, 100_128_000
+    band = pkg.synth.SyntheticBand(n, seed=12, on_frame=30, off_frame=10_000)
+    kw = dict(fft_size=n, decim=1, learn_frames=12, max_batch=64)
+    eng, orc = pkg.SpectrumEngine(fs, c0, **kw), oracle_mod.oracle_chain(fs, c0, **kw)
+    for step, centre in enumerate((c0, c1, c0, c1)):
+        iq = band.frames_cf32(60)
+        for ch in (eng, orc):
+            if step:
+                ch.set_frequency_range(centre - fs // 2, centre + fs // 2)
+                ch.reset()
+        got, ref = eng.process(iq), orc.process(iq)
+        check_all(got, ref)
+        if step >= 2:  # ceiling already known: no learning frames, only the 20-frame averager warm-up
+            assert (ref["rel"][0] != -100).all() and (ref["avg"][19] == -100).all() and (ref["avg"][20] != -100).all()
+    eng.reset_noise(), orc.reset_noise()
+    iq = band.frames_cf32(40)
+    check_all(eng.process(iq), orc.process(iq))
+
+
+def test_timestamp_learning(oracle_mod):
+    n, fs, center = 256, 64_000, 145_000_000
+    band = pkg.synth.SyntheticBand(n, seed=13, on_frame=70, off_frame=120, comb_width=12)
+    iq = band.frames_cf32(130)
+    t = (77 + 37 * np.arange(130)).astype(np.int64)  # 2000 ms elapse on frame 55
+    kw = dict(fft_size=n, decim=1, max_batch=64)
+    got = _run(pkg.SpectrumEngine(fs, center, **kw), iq, 50, t_ms=t)
+    ref = _run(oracle_mod.oracle_chain(fs, center, **kw), iq, 50, t_ms=t)
+    check_all(got, ref)
+    assert (ref["rel"][54] == -100).all() and (ref["rel"][55] != -100).all()
+
+
+def test_edge_cases(oracle_mod):
+    n, fs, center = 256, 64_000, 145_000_000
+    kw = dict(fft_size=n, decim=1, learn_frames=5, max_batch=32)
+    eng = pkg.SpectrumEngine(fs, center, **kw)
+    r = eng.process(np.zeros((0, n), np.complex64))  # empty batch
+    assert r["cand_off"].tolist() == [0] and r["psd"].shape == (0, n)
+    with pytest.raises(pkg.abi.SpecscanError) as e:  # batch larger than max_batch
+        eng.process(np.zeros((33, n), np.complex64))
+    assert e.value.status == pkg.abi.SS_ERR_BATCH
+    z = eng.process(np.zeros((3, n), np.complex64))  # all-zero IQ: log10f(0) = -inf like the reference
+    assert np.isneginf(z["psd"]).all()
+    # candidate overflow: offsets stay exact, list is truncated, status says so
+    band = pkg.synth.SyntheticBand(n, seed=14, on_frame=5, off_frame=60, comb_width=12)
+    iq = band.frames_cf32(32)
+    e2, o2 = pkg.SpectrumEngine(fs, center, **kw), oracle_mod.oracle_chain(fs, center, **kw)
+    got, ref = e2.process(iq, cand_cap=7), o2.process(iq, cand_cap=7)
+    assert got["status"] == ref["status"] == pkg.abi.SS_ERR_CAND_OVERFLOW
+    np.testing.assert_array_equal(got["cand_off"], ref["cand_off"])
+    np.testing.assert_array_equal(got["cand_idx"], ref["cand_idx"])
+    for bad in (dict(fft_size=100), dict(fft_size=32), dict(grouping_x=20), dict(decim=0), dict(in_format=7)):
+        with pytest.raises(pkg.abi.SpecscanError):
+            pkg.SpectrumEngine(fs, center, **{**kw, **bad})
+
+
+def test_read_window_addresses_batch_and_ring_rows(oracle_mod):
+    n, fs, center = 512, 128_000, 145_000_000
+    band = pkg.synth.SyntheticBand(n, seed=15, on_frame=20, off_frame=70)
+    kw = dict(fft_size=n, decim=1, learn_frames=8, max_batch=64)
+    eng, orc = pkg.SpectrumEngine(fs, center, **kw), oracle_mod.oracle_chain(fs, center, **kw)
+    for _ in range(2):
+        iq = band.frames_cf32(40)
+        got, ref = eng.process(iq), orc.process(iq)
+    for plane, key in ((pkg.abi.SS_PLANE_PSD, "psd"), (pkg.abi.SS_PLANE_REL, "rel"), (pkg.abi.SS_PLANE_AVG, "avg")):
+        np.testing.assert_array_equal(eng.read_window(plane, 17, 100, 164), got[key][17, 100:164])
+    for back in (1, 7, 20):  # ring rows from before the batch (Transmission::getBestIndex)
+        a = eng.read_window(pkg.abi.SS_PLANE_REL, -back, 0, n)
+        b = orc.read_window(pkg.abi.SS_PLANE_REL, -back, 0, n)
+        check_plane("ring row", a[None], b[None])
+
+
+def test_device_resident_entry_point_matches_host_entry_point():
+    import torch
+    n, fs, center = 8192, 2_048_000, 145_000_000
+    band = pkg.synth.SyntheticBand(n, seed=16, on_frame=30, off_frame=90)
+    iq = band.frames_cf32(100)
+    kw = dict(fft_size=n, decim=1, learn_frames=10, max_batch=128)
+    host = pkg.SpectrumEngine(fs, center, **kw).process(iq)
+    eng = pkg.SpectrumEngine(fs, center, **kw)
+    dev = torch.device("cuda:0")
+    d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
+    planes = [torch.empty((100, n), dtype=torch.float32, device=dev) for _ in range(3)]
+    off = torch.zeros(101, dtype=torch.int32, device=dev)
+    cap = 100 * n
+    idx = torch.empty(cap, dtype=torch.int32, device=dev)
+    cav = torch.empty(cap, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    eng.process_device(d_iq, 100, *planes, off, idx, cav)
+    eng.sync()
+    for t, k in zip(planes, ("psd", "rel", "avg")):
+        np.testing.assert_array_equal(t.cpu().numpy(), host[k])
+    np.testing.assert_array_equal(off.cpu().numpy(), host["cand_off"])
+    total = int(off[-1])
+    np.testing.assert_array_equal(idx[:total].cpu().numpy(), host["cand_idx"])
+    np.testing.assert_array_equal(cav[:total].cpu().numpy(), host["cand_avg"])
+
+
+def test_two_contexts_are_independent(oracle_mod):
+    n, fs = 1024, 256_000
+    a = pkg.SpectrumEngine(fs, 140_000_000, fft_size=n, decim=1, learn_frames=10, max_batch=64)
+    b = pkg.SpectrumEngine(fs, 142_000_000, fft_size=n, decim=1, learn_frames=10, max_batch=64)
+    ba = pkg.synth.SyntheticBand(n, seed=17, on_frame=30, off_frame=60)
+    bb = pkg.synth.SyntheticBand(n, seed=18, on_frame=25, off_frame=55)
+    xa, xb = ba.frames_cf32(64), bb.frames_cf32(64)
+    ra1, rb1 = a.process(xa[:32]), b.process(xb[:32])
+    ra2, rb2 = a.process(xa[32:]), b.process(xb[32:])
+    oa = oracle_mod.oracle_chain(fs, 140_000_000, fft_size=n, decim=1, learn_frames=10, max_batch=64).process(xa)
+    ob = oracle_mod.oracle_chain(fs, 142_000_000, fft_size=n, decim=1, learn_frames=10, max_batch=64).process(xb)
+    check_plane("a", np.concatenate([ra1["avg"], ra2["avg"]]), oa["avg"])
+    check_plane("b", np.concatenate([rb1["avg"], rb2["avg"]]), ob["avg"])
