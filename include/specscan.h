@@ -127,6 +127,14 @@ int ss_process_device(ss_ctx* ctx, const void* d_iq, int32_t nframes,
 int ss_sync(ss_ctx* ctx);
 void* ss_stream(ss_ctx* ctx); /* the hipStream_t ss_process_device enqueues on */
 
+/* Measurement aid (bench.py): when enabled, every launch of the dominant kernel (fused load + window +
+ * FFT + dB) carries its own start/stop events on the context's stream; ss_kernel_timing_read
+ * synchronises the stream, returns the summed device time in ms and the number of timed launches,
+ * and clears the tally. Replaces the reference's PerformanceLogger::kick (sources/performance_logger.cpp:9-22,
+ * called from PSD::work, psd.cpp:15-17). */
+int ss_kernel_timing(ss_ctx* ctx, int enable);
+int ss_kernel_timing_read(ss_ctx* ctx, double* total_ms, int32_t* launches);
+
 /* SdrDevice::setFrequencyRange's effect on the chain (sdr_device.cpp:66,77,146): new scanned range,
  * centre = (lo+hi)/2. Noise ceilings are kept per centre frequency (noise_learner.h:33). */
 int ss_set_frequency_range(ss_ctx* ctx, int32_t lo_hz, int32_t hi_hz);

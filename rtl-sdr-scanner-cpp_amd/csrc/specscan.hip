@@ -4,6 +4,7 @@
 //
 // One ss_ctx = one scan chain of the reference (the blocks SdrDevice::setupChains wires after the
 // Blocker, sources/radio/sdr_device.cpp:161-168) pinned to one HIP device and one stream.
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -67,6 +68,11 @@ struct ss_ctx {
   int cand_cap_alloc = 0;
   const float* last_psd = nullptr;  // where the last batch's PSD plane lives (device)
   int last_n = 0;
+  // optional per-launch timing of the dominant (FFT+PSD) kernel: start/stop events attached to the
+  // dispatch itself (hipExtLaunchKernelGGL), read back by ss_kernel_timing_read
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_events;  // pairs
+  size_t prof_used = 0;
   std::mutex mtx;
   char err[512] = "";
 };
@@ -124,6 +130,22 @@ NoiseState* noise_for(ss_ctx* c, int32_t center) {
   return nullptr;
 }
 
+// next start/stop event pair for a timed launch, or false when timing is off / the pool is exhausted
+bool prof_pair(ss_ctx* c, hipEvent_t* a, hipEvent_t* b) {
+  if (!c->prof_on) return false;
+  if (c->prof_used + 2 > c->prof_events.size()) {
+    if (c->prof_events.size() >= 2 * 8192) return false;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return false;
+    c->prof_events.push_back(e0);
+    c->prof_events.push_back(e1);
+  }
+  *a = c->prof_events[c->prof_used];
+  *b = c->prof_events[c->prof_used + 1];
+  c->prof_used += 2;
+  return true;
+}
+
 // ---- FFT + PSD dispatch ---------------------------------------------------------------------------
 template <int LOGN, int FMT>
 void launch_lds(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
@@ -131,8 +153,14 @@ void launch_lds(ss_ctx* c, const void* d_iq, long long item_stride, int nframes,
   constexpr int FPB = (1 << LOGTOT) >> LOGN;
   const int blocks = (nframes + FPB - 1) / FPB;
   const size_t lds = sizeof(float2) << LOGTOT;
-  hipLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->stream, d_iq, item_stride,
-                     nframes, c->d_win, c->d_tw, (float)c->cfg.sample_rate, c->cfg.int_scale, d_psd);
+  hipEvent_t e0, e1;
+  if (prof_pair(c, &e0, &e1)) {
+    hipExtLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->stream, e0, e1, 0, d_iq,
+                          item_stride, nframes, c->d_win, c->d_tw, (float)c->cfg.sample_rate, c->cfg.int_scale, d_psd);
+  } else {
+    hipLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->stream, d_iq, item_stride,
+                       nframes, c->d_win, c->d_tw, (float)c->cfg.sample_rate, c->cfg.int_scale, d_psd);
+  }
 }
 
 template <int LOGN1, int LOGN2, int FMT>
@@ -280,6 +308,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipSetDevice(c->cfg.device_id);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& z : c->noise) (void)hipFree(z.d_thr);
+  for (auto e : c->prof_events) (void)hipEventDestroy(e);
   (void)hipFree(c->d_win);
   (void)hipFree(c->d_tw);
   (void)hipFree(c->d_pass);
@@ -420,6 +449,31 @@ int ss_sync(ss_ctx* ctx) {
   if (!ctx) return SS_ERR_INVALID;
   SS_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
   SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SS_OK;
+}
+
+int ss_kernel_timing(ss_ctx* c, int enable) {
+  if (!c) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  c->prof_on = enable != 0;
+  c->prof_used = 0;
+  return SS_OK;
+}
+
+int ss_kernel_timing_read(ss_ctx* c, double* total_ms, int32_t* launches) {
+  if (!c || !total_ms || !launches) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  double sum = 0.0;
+  for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
+    float ms = 0.f;
+    SS_HIP(c, hipEventElapsedTime(&ms, c->prof_events[i], c->prof_events[i + 1]));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = (int32_t)(c->prof_used / 2);
+  c->prof_used = 0;
   return SS_OK;
 }
 

@@ -1,0 +1,82 @@
+"""One process per GPU. Bands (independent scan chains, one per SDR device in the reference:
+sources/main.cpp:50-59) shard across ranks with no data-path collective; the only exchange is a
+broadcast of the POD scan configuration from rank 0 at start-up (RCCL over xGMI when the backend is
+"nccl", gloo in the CPU tests), mirroring the config reload in sources/main.cpp:37-49."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+CONFIG_FIELDS = ("fft_size", "sample_rate", "decim", "in_format", "grouping_x", "grouping_y", "start_level_mdB",
+                 "learn_frames", "learn_ms", "max_batch", "band0_center", "band_spacing", "n_bands", "seed")
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend: str):
+    """init_process_group from the torchrun environment; returns (rank, local_rank, world). No-op at world 1."""
+    rank, local_rank, world = env_world()
+    if world > 1:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if not td.is_initialized():
+            td.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def broadcast_config(cfg: dict | None, device="cpu") -> dict:
+    """Rank 0 passes the dict, everyone gets it back. int64 POD vector, < 1 KiB."""
+    import torch
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return dict(cfg)
+    buf = torch.zeros(len(CONFIG_FIELDS), dtype=torch.int64, device=device)
+    if td.get_rank() == 0:
+        buf = torch.tensor([int(cfg[k]) for k in CONFIG_FIELDS], dtype=torch.int64, device=device)
+    td.broadcast(buf, src=0)
+    vals = buf.cpu().tolist()
+    return dict(zip(CONFIG_FIELDS, vals))
+
+
+def bands_for_rank(n_bands: int, rank: int, world: int) -> list[int]:
+    """band b -> rank b mod world."""
+    return [b for b in range(n_bands) if b % world == rank]
+
+
+def frame_ranges(nframes: int, rank: int, world: int, halo: int):
+    """Contiguous frame range of one band for this rank plus the `halo` frames before it that must be
+    re-read so the 21-frame averager window is complete (no exchange between ranks)."""
+    per = (nframes + world - 1) // world
+    lo, hi = min(nframes, rank * per), min(nframes, (rank + 1) * per)
+    return max(0, lo - halo), lo, hi
+
+
+def max_over_ranks(seconds: float, device="cpu") -> float:
+    import torch
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    import torch.distributed as td
+    if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+        td.barrier()
+
+
+def band_center(cfg: dict, band: int) -> int:
+    return int(cfg["band0_center"]) + band * int(cfg["band_spacing"])
+
+
+def synthetic_batch(cfg: dict, band: int, nframes: int) -> np.ndarray:
+    from . import synth
+    b = synth.SyntheticBand(int(cfg["fft_size"]), decim=int(cfg["decim"]), seed=int(cfg["seed"]) + band,
+                            on_frame=int(cfg["learn_frames"]) + 30, off_frame=nframes - 50)
+    return b.frames_cf32(nframes)

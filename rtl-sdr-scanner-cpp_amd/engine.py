@@ -35,13 +35,17 @@ def load_library() -> C.CDLL:
         lib.ss_sync.restype = C.c_int
         lib.ss_stream.argtypes = [C.c_void_p]
         lib.ss_stream.restype = C.c_void_p
+        lib.ss_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        lib.ss_kernel_timing.restype = C.c_int
+        lib.ss_kernel_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        lib.ss_kernel_timing_read.restype = C.c_int
         _lib = lib
     return _lib
 
 
 EXPORTS = ("ss_default_config", "ss_device_count", "ss_create", "ss_destroy", "ss_last_error", "ss_process",
            "ss_process_device", "ss_sync", "ss_stream", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
-           "ss_read_window", "ss_read_noise")
+           "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read")
 
 
 def _ptr(t):
@@ -69,3 +73,12 @@ class SpectrumEngine(abi.Chain):
 
     def sync(self):
         self._check(self._lib.ss_sync(self._h))
+
+    def kernel_timing(self, enable: bool):
+        self._check(self._lib.ss_kernel_timing(self._h, 1 if enable else 0))
+
+    def kernel_timing_read(self):
+        """(total device ms, launches) of the timed FFT+PSD launches since the last read."""
+        ms, cnt = C.c_double(), C.c_int32()
+        self._check(self._lib.ss_kernel_timing_read(self._h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

@@ -1,0 +1,68 @@
+"""The N>1 path on CPU: two processes, gloo backend. Exercises exactly what bench.py does around the
+GPU work — config broadcast from rank 0 (the job's only collective), band sharding, barrier and the
+max-over-ranks timing reduction — with the oracle standing in for the GPU so that each rank really
+scans a different band."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, os.environ["SS_ROOT"])
+    import numpy as np
+    import rtl_sdr_scanner_cpp_amd as pkg
+    from rtl_sdr_scanner_cpp_amd import dist
+    from oracle import oracle as O
+    rank, local_rank, world = dist.init("gloo")
+    cfg0 = None
+    if rank == 0:
+        cfg0 = dict(fft_size=256, sample_rate=64000, decim=1, in_format=0, grouping_x=21, grouping_y=21, start_level_mdB=8000,
+                    learn_frames=20, learn_ms=2000, max_batch=128, band0_center=140_000_000, band_spacing=2_000_000, n_bands=4, seed=5)
+    cfg = dist.broadcast_config(cfg0)
+    bands = dist.bands_for_rank(int(cfg["n_bands"]), rank, world)
+    out = {"rank": rank, "cfg": cfg, "bands": bands, "cands": {}}
+    dist.barrier()
+    t0 = time.perf_counter()
+    for b in bands:
+        iq = dist.synthetic_batch(cfg, b, 128)
+        ch = O.oracle_chain(int(cfg["sample_rate"]), dist.band_center(cfg, b), fft_size=int(cfg["fft_size"]), decim=1,
+                            learn_frames=int(cfg["learn_frames"]), max_batch=128, start_level=cfg["start_level_mdB"] / 1000.0)
+        out["cands"][str(b)] = int(ch.process(iq, want=())["cand_off"][-1])
+    mine = time.perf_counter() - t0 + (0.25 if rank == 1 else 0.0)
+    out["mine"], out["max"] = mine, dist.max_over_ranks(mine)
+    out["frames"] = dist.frame_ranges(1000, rank, world, 20)
+    print("RESULT " + json.dumps(out), flush=True)
+""")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_band_sharding_over_gloo(oracle_mod, tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SS_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    for p in procs:
+        so, se = p.communicate(timeout=180)
+        assert p.returncode == 0, se[-2000:]
+        res.append(json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][0][7:]))
+    res.sort(key=lambda r: r["rank"])
+    assert res[0]["cfg"] == res[1]["cfg"] and res[1]["cfg"]["fft_size"] == 256 and res[1]["cfg"]["seed"] == 5  # broadcast reached rank 1
+    assert res[0]["bands"] == [0, 2] and res[1]["bands"] == [1, 3]  # band b -> rank b mod world, disjoint and complete
+    assert all(v > 0 for r in res for v in r["cands"].values())  # every band was really scanned
+    assert abs(res[0]["max"] - res[1]["max"]) < 1e-9 and res[0]["max"] >= max(res[0]["mine"], res[1]["mine"]) - 1e-9
+    assert res[0]["frames"] == [0, 0, 500] and res[1]["frames"] == [480, 500, 1000]  # 20-frame halo re-read, no exchange

@@ -34,7 +34,7 @@ def _run(chain, iq, chunk, t_ms=None, hooks=None):
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
-@pytest.mark.parametrize("chunk", [5, 64])
+@pytest.mark.parametrize("chunk", [5, 50])
 def test_engine_matches_reference_made_golden(path, chunk):
     """Planes and candidates produced by the reference's own compiled PSD/NoiseLearner/Transmission code
     (tests/golden/make_golden.py), timestamps included."""
@@ -81,7 +81,7 @@ def test_engine_matches_oracle(oracle_mod, n, fs, decim, fmt, nframes, chunk, le
     orc = oracle_mod.oracle_chain(fs, center, **kw)
     got, ref = _run(eng, iq, chunk), _run(orc, iq, chunk)
     errs, ncand, ndc = check_all(got, ref)
-    assert ncand > 50, "the test vector must produce detections"
+    assert ncand > (50 if n >= 256 else 5), "the test vector must produce detections"
     assert ndc <= max(2, ncand // 200), (ncand, ndc)
     thr_g, ready_g = eng.read_noise()
     thr_o, ready_o = orc.read_noise()
