@@ -62,6 +62,10 @@ typedef enum ss_plane {
   SS_PLANE_AVG = 2  /* average(Averager.average()) (avgPower in Transmission)    */
 } ss_plane;
 
+/* ss_config.flags: keep the full avg plane of every batch on the device so that ss_read_window can serve
+ * SS_PLANE_AVG (the host-side signal tracker needs it); costs 4 B/sample of extra HBM writes. */
+#define SS_FLAG_KEEP_PLANES 1u
+
 #define SS_NO_DATA (-100.0f) /* setNoData sentinel, sources/utils/radio_utils.cpp:72-76 */
 
 typedef struct ss_config {
@@ -85,7 +89,7 @@ typedef struct ss_config {
   int32_t learn_ms;        /* NOISE_LEARNING_TIME (config.h:24) used when timestamps are given  */
   int32_t max_batch;       /* largest nframes a single ss_process call may carry                */
   int32_t device_id;       /* HIP device ordinal                                                */
-  uint32_t flags;          /* reserved, 0                                                       */
+  uint32_t flags;          /* SS_FLAG_* bits                                                    */
 } ss_config;
 
 typedef struct ss_ctx ss_ctx;
@@ -134,6 +138,10 @@ void* ss_stream(ss_ctx* ctx); /* the hipStream_t ss_process_device enqueues on *
  * called from PSD::work, psd.cpp:15-17). */
 int ss_kernel_timing(ss_ctx* ctx, int enable);
 int ss_kernel_timing_read(ss_ctx* ctx, double* total_ms, int32_t* launches);
+
+/* Device self-test of arithmetic shortcuts used by the kernels (which = 0: the 3-instruction division by
+ * 21 equals the IEEE division for every float). Returns the number of mismatches (0 = pass) or < 0. */
+long long ss_selftest(int device_id, int which);
 
 /* SdrDevice::setFrequencyRange's effect on the chain (sdr_device.cpp:66,77,146): new scanned range,
  * centre = (lo+hi)/2. Noise ceilings are kept per centre frequency (noise_learner.h:33). */

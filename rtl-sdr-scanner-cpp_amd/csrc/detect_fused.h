@@ -1,0 +1,341 @@
+// detect_fused.h — fused back end for the reference's own grouping (GROUPING_X = GROUPING_Y = 21,
+// sources/config.h:28-29). Other groupings use the unfused kernels of detect_kernels.h.
+//
+// k_detect_fused reads the PSD plane ONCE and produces candidate mask bits + per-frame counts; nothing
+// else is written unless the caller asked for the rel / avg planes:
+//   rel(f,i) = psd(f,i) - thr(i)   (-100 for learning frames; ring rows before the batch come from hist_in)
+//                                                            sources/radio/blocks/noise_learner.cpp:49,55
+//   avgY     = mean over the newest G frames (or -100 during the averager warm-up)   sources/radio/averager.cpp:52-61
+//   avgXY    = centred GX-bin mean of avgY, window clipped at the band edges         sources/utils/utils.cpp:31-53
+//   hit      = start_level <= avgXY && pass(i)                                       sources/radio/blocks/transmission.cpp:91
+//
+// Tiling: one workgroup = TF frames x 256 bins.
+//   phase 1: thread = column. The G-1+TF rel values of the column sit in registers; each time mean is a
+//            fixed-order G-term sum, oldest frame first (independent of how frames are split into
+//            batches, bit for bit: tests/test_gpu_fullsize.py).
+//   the avgY tile goes through LDS once and changes owner
+//   phase 2: thread = (frame, 16-bin segment). 36 avgY values in registers; the first window of the
+//            segment is a fixed-order GX-term sum, the next 15 slide it the way the reference does
+//            (sum -= leaving bin; sum += entering bin, utils.cpp:39-48) — restarted every 16 bins, so the
+//            drift of the reference's whole-row running sum never builds up.
+// Interior tiles of a steady-state batch (no ring rows, no learning frames, no band edge) take a
+// straight-line path; the few edge tiles take a general path that also maintains the averager ring
+// (the newest G-1 rel rows go to hist_out).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "detect_kernels.h"
+
+namespace ss {
+
+// s / D for a compile-time integer D, correctly rounded like the reference's `sum / count`
+// (float / int -> IEEE division): q0 = s * RN(1/D), one Newton correction with exact residuals (FMA).
+// Verified against the hardware division for every finite float by ss_selftest (tests/test_gpu_selftest.py).
+template <int D>
+__device__ __forceinline__ float div_const(float s) {
+  constexpr float r = 1.0f / (float)D;
+  const float q0 = s * r;
+  const float e = fmaf(-(float)D, q0, s);
+  return fmaf(e, r, q0);
+}
+
+template <int G, int GX, int TF>
+struct DetectTile {
+  static constexpr int A = GX / 2;
+  static constexpr int TB = 256;
+  static constexpr int P = TB + 2 * A;     // tile pitch in floats (276 for GX = 21: rows stay 16-byte aligned)
+  static constexpr int ROWS = G - 1 + TF;  // rel rows a column needs
+  static constexpr int SEGW = 16;          // bins per phase-2 thread
+  static constexpr int NSEG = TB / SEGW;   // 16
+  static constexpr int YW = SEGW + 2 * A;  // 36 avgY values per phase-2 thread
+  static_assert((2 * A) % 4 == 0 && P % 4 == 0 && YW % 4 == 0, "tile rows must stay 16-byte aligned");
+  static_assert(TF == 16 || TF == 32, "phase 2 pairs lanes l and l+TF inside one wave");
+};
+
+struct DetectArgs {
+  const float* psd;
+  const float* thr;
+  const float* hist_in;
+  float* hist_out;
+  int n, nframes, n_learn, pushed_before;
+  float start_level;
+  const uint8_t* pass;
+  uint32_t* maskbits;
+  int* counts;
+  float* rel_out;
+  float* avg_out;
+  float* avg_sparse;
+};
+
+// time means of one column, written into the LDS tile
+template <int G, int TF, int P>
+__device__ __forceinline__ void time_means_to_tile(const float (&x)[G - 1 + TF], float* __restrict__ tile_col) {
+#pragma unroll
+  for (int j = 0; j < TF; ++j) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) sum += x[j + g];  // oldest first
+    tile_col[j * P] = div_const<G>(sum);           // m_sum[i] / m_groupSize
+  }
+}
+
+template <int G, int GX, int TF>
+__global__ __launch_bounds__(256) void k_detect_fused(DetectArgs a) {
+  using T = DetectTile<G, GX, TF>;
+  constexpr int A = T::A, TB = T::TB, P = T::P, ROWS = T::ROWS, SEGW = T::SEGW, NSEG = T::NSEG, YW = T::YW;
+  __shared__ __attribute__((aligned(16))) float tile[TF * P];
+  __shared__ int cnt[TF];
+
+  const int tid = threadIdx.x;
+  const int n = a.n, nframes = a.nframes;
+  const int tiles_per_row = (n + TB - 1) / TB;
+  const int f0 = (blockIdx.x / tiles_per_row) * TF;
+  const int b0 = (blockIdx.x % tiles_per_row) * TB;
+  if (tid < TF) cnt[tid] = 0;
+  // block-uniform classification
+  const bool interior = (b0 - A >= 0) && (b0 + TB + A <= n);
+  const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes - (G - 1));
+
+  // ---------------- phase 1: time means, thread = column ----------------
+  if (steady && interior) {
+    // straight line: ROWS independent, unconditional loads per column; 276 columns over 256 threads
+    {
+      const int col = b0 - A + tid;
+      const float t = a.thr[col];
+      const float* p = a.psd + (size_t)(f0 - (G - 1)) * n + col;
+      float x[ROWS];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) x[r] = p[(size_t)r * n] - t;
+      time_means_to_tile<G, TF, P>(x, &tile[tid]);
+      if (a.rel_out && tid >= A) {
+#pragma unroll
+        for (int j = 0; j < TF; ++j) a.rel_out[(size_t)(f0 + j) * n + col] = x[G - 1 + j];
+      }
+    }
+    if (tid < 2 * A) {
+      const int c = TB + tid;
+      const int col = b0 - A + c;
+      const float t = a.thr[col];
+      const float* p = a.psd + (size_t)(f0 - (G - 1)) * n + col;
+      float x[ROWS];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) x[r] = p[(size_t)r * n] - t;
+      time_means_to_tile<G, TF, P>(x, &tile[c]);
+      if (a.rel_out && c < A + TB) {
+#pragma unroll
+        for (int j = 0; j < TF; ++j) a.rel_out[(size_t)(f0 + j) * n + col] = x[G - 1 + j];
+      }
+    }
+  } else {
+    // general path: ring rows from before the batch, learning frames, averager warm-up, ragged batch end,
+    // band edges, and the ring update. Rows are walked one at a time (few tiles take this path).
+    for (int c = tid; c < P; c += 256) {
+      const int col = b0 - A + c;
+      if (col < 0 || col >= n) {
+        for (int j = 0; j < TF; ++j) tile[j * P + c] = 0.0f;  // outside the band: contributes exactly nothing to the clipped window sums
+        continue;
+      }
+      const bool main_col = c >= A && c < A + TB;
+      const float t = a.thr[col];
+      const int first_hist = nframes - (G - 1);  // newest G-1 frames of this batch become the ring
+      // all loads first, unconditional, on clamped (always legal) addresses: independent and in flight
+      // together; a branch around each load would serialise them on s_waitcnt
+      float x[ROWS];
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const int fr = f0 - (G - 1) + r;  // frame inside the batch; negative = ring rows from before it
+        x[r] = a.psd[(size_t)min(max(fr, 0), nframes - 1) * n + col];
+      }
+      float h[G - 1];
+      if (f0 < G - 1) {  // block-uniform: only the first tiles of a batch see ring rows
+#pragma unroll
+        for (int r = 0; r < G - 1; ++r) h[r] = a.hist_in[(size_t)min(f0 + r, G - 2) * n + col];
+      } else {
+#pragma unroll
+        for (int r = 0; r < G - 1; ++r) h[r] = 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        const int fr = f0 - (G - 1) + r;
+        float v = fr < a.n_learn ? kNoData : x[r] - t;  // noise_learner.cpp:49 / :55
+        if (r < G - 1) v = fr < 0 ? h[r] : v;
+        x[r] = fr < nframes ? v : 0.0f;
+      }
+      if (main_col) {
+#pragma unroll
+        for (int j = 0; j < TF; ++j) {
+          const int fr = f0 + j;
+          if (fr < nframes) {
+            if (a.rel_out) a.rel_out[(size_t)fr * n + col] = x[G - 1 + j];
+            if (fr >= first_hist) a.hist_out[(size_t)(fr - first_hist) * n + col] = x[G - 1 + j];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TF; ++j) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) sum += x[j + g];
+        const bool warm = a.pushed_before + f0 + j + 1 >= G;  // Averager::updateAverage: m_groupSize <= m_frames
+        tile[j * P + c] = warm ? div_const<G>(sum) : kNoData;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase 2: frequency means + threshold, thread = (frame, 16-bin segment) ----------------
+#pragma unroll
+  for (int q0 = 0; q0 < TF * NSEG; q0 += 256) {
+    const int q = q0 + tid;
+    const int fj = q % TF;
+    const int seg = q / TF;
+    const int f = f0 + fj;
+    const int i0 = b0 + seg * SEGW;  // first bin of the segment
+    const bool live = f < nframes && i0 < n;
+    uint32_t bits = 0;
+    if (live) {
+      float outv[SEGW];
+      const float* row = &tile[fj * P + seg * SEGW];  // row[k] = avgY(f, i0 - A + k)
+      float y[YW];
+#pragma unroll
+      for (int k4 = 0; k4 < YW / 4; ++k4) {
+        const float4 v4 = *reinterpret_cast<const float4*>(row + 4 * k4);
+        y[4 * k4] = v4.x;
+        y[4 * k4 + 1] = v4.y;
+        y[4 * k4 + 2] = v4.z;
+        y[4 * k4 + 3] = v4.w;
+      }
+      // Bins outside the band hold 0.0f in the tile, so the same straight-line sums give the reference's
+      // edge-clipped window (adding or subtracting 0.0f is exact); only the divisor changes there.
+      float sum = 0.0f;
+#pragma unroll
+      for (int k = 0; k < GX; ++k) sum += y[k];  // lowest bin first
+      float sums[SEGW];
+      sums[0] = sum;
+#pragma unroll
+      for (int o = 1; o < SEGW; ++o) {
+        sum -= y[o - 1];       // utils.cpp:41  sum -= input[first]
+        sum += y[o + GX - 1];  // utils.cpp:45  sum += input[last]
+        sums[o] = sum;
+      }
+      if (interior) {
+#pragma unroll
+        for (int o = 0; o < SEGW; ++o) outv[o] = div_const<GX>(sums[o]);
+      } else {
+#pragma unroll
+        for (int o = 0; o < SEGW; ++o) {
+          const int i = i0 + o;
+          const int count = min(n - 1, i + A) - max(0, i - A) + 1;
+          outv[o] = sums[o] / (float)count;  // sum / count (float / int), utils.cpp:50
+        }
+      }
+      const uint4 pm = *reinterpret_cast<const uint4*>(a.pass + i0);  // 16 pass bytes (n is a multiple of 64)
+      const uint32_t pw[4] = {pm.x, pm.y, pm.z, pm.w};
+#pragma unroll
+      for (int o = 0; o < SEGW; ++o) {
+        const bool ok = ((pw[o >> 2] >> (8 * (o & 3))) & 0xffu) != 0;
+        bits |= (a.start_level <= outv[o] && ok) ? (1u << o) : 0u;
+      }
+      if (a.avg_out) {
+        float4* dst = reinterpret_cast<float4*>(a.avg_out + (size_t)f * n + i0);
+#pragma unroll
+        for (int k4 = 0; k4 < SEGW / 4; ++k4) dst[k4] = make_float4(outv[4 * k4], outv[4 * k4 + 1], outv[4 * k4 + 2], outv[4 * k4 + 3]);
+      } else if (bits) {
+        float* dst = a.avg_sparse + (size_t)f * n + i0;
+#pragma unroll
+        for (int o = 0; o < SEGW; ++o)
+          if (bits & (1u << o)) dst[o] = outv[o];
+      }
+    }
+    // lanes q and q + TF hold the same frame, segments seg and seg + 1: together one 32-bit mask word
+    const uint32_t hi_bits = __shfl_down(bits, TF);
+    if ((seg & 1) == 0 && live) {
+      const uint32_t word = bits | (hi_bits << 16);
+      a.maskbits[((size_t)f * n + i0) >> 5] = word;
+      if (word) atomicAdd(&cnt[fj], __popc(word));
+    }
+  }
+  __syncthreads();
+  if (tid < TF && cnt[tid] != 0) atomicAdd(&a.counts[f0 + tid], cnt[tid]);
+}
+
+// When a batch is shorter than the ring (nframes < G-1) the oldest ring rows survive: move them up.
+__global__ void k_hist_shift(const float* __restrict__ hist_in, float* __restrict__ hist_out, int n, int keep_rows, int nframes) {
+  const size_t total = (size_t)keep_rows * n;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    hist_out[e] = hist_in[e + (size_t)nframes * n];
+  }
+}
+
+// Candidate lists (CSR) from the mask bits: one wave per frame. The frame's offset is the sum of the
+// counts of the frames before it (this path is used for nframes <= 4096). Inside the frame every lane
+// expands its mask word into an LDS list at its scanned rank, then the wave streams the list out with
+// coalesced stores — ascending bins, frames in order, deterministic.
+// counts_next (the other half of the double-buffered counters) is cleared for the next batch.
+__global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ maskbits, int words_per_row, int n, int nframes,
+                                                  const int* __restrict__ counts, int* __restrict__ counts_next,
+                                                  const float* __restrict__ avg, int cap, int* __restrict__ off_int,
+                                                  int* __restrict__ off_out, int* __restrict__ cand_idx, float* __restrict__ cand_avg) {
+  __shared__ int list[64 * 32];
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x;
+  // offset of this frame = sum of counts[0..f): 16 ints per lane per trip, all loads independent
+  int part = 0;
+  for (int base = 0; base < f; base += 1024) {
+    int v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = counts[min(base + k * 64 + lane, nframes - 1)];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) part += (base + k * 64 + lane) < f ? v[k] : 0;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+  const int begin = part;
+  const int mine = counts[f];
+  if (lane == 0) {
+    off_int[f] = begin;
+    if (off_out) off_out[f] = begin;
+    if (f == nframes - 1) {
+      off_int[nframes] = begin + mine;
+      if (off_out) off_out[nframes] = begin + mine;
+    }
+    counts_next[f] = 0;
+  }
+  if (mine == 0 || !cand_idx) return;
+  const uint32_t* row = maskbits + (size_t)f * words_per_row;
+  const float* arow = avg + (size_t)f * n;
+  int carry = begin;
+  for (int base = 0; base < words_per_row; base += 64) {
+    const int w = base + lane;
+    uint32_t bits = w < words_per_row ? row[w] : 0u;
+    const int c = __popc(bits);
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d);
+      if (lane >= d) incl += v;
+    }
+    const int total = __shfl(incl, 63);
+    if (total == 0) continue;  // wave-uniform
+    int pos = incl - c;
+    while (bits) {  // LDS stores only: nothing to wait for inside the loop
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      list[pos++] = w * 32 + b;
+    }
+    __syncthreads();  // one wave: orders the LDS writes before the reads
+    for (int p = lane; p < total; p += 64) {
+      const int i = list[p];
+      const int dst = carry + p;
+      if (dst < cap) {
+        cand_idx[dst] = i;
+        if (cand_avg) cand_avg[dst] = arow[i];
+      }
+    }
+    __syncthreads();
+    carry += total;
+  }
+}
+
+}  // namespace ss

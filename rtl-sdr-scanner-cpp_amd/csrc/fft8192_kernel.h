@@ -1,0 +1,245 @@
+// fft8192_kernel.h — the N = 8192 front end (BASELINE.json configs 1/2/4: 2.048 MS/s, 250 Hz bins).
+//
+// Same contract as k_fft_psd_lds in fft_kernels.h (Decimator + fft_v(Hamming, forward, shift) + PSD::work,
+// reference sources/radio/blocks/decimator.h:15-22, sources/radio/sdr_device.cpp:164,
+// sources/radio/blocks/psd.cpp:18-20), restructured for the CU:
+//
+//   one workgroup (256 threads = 4 waves, one per SIMD) per frame, 32 points per thread in VGPRs,
+//   8192 = 16 x 16 x 32: three register-resident Stockham passes and only TWO trips through LDS
+//   (the generic kernel makes seven), 64.5 KiB of LDS per workgroup -> two frames in flight per CU, so
+//   one frame's HBM loads overlap the other's butterflies.
+//
+//   pass 1  radix 16, Ns = 1    thread t: butterflies j = 2t, 2t+1  <- 16 x float4 global loads
+//           y[16 j + k]                               -> LDS (33-element pitch per thread, conflict-free)
+//   pass 2  radix 16, Ns = 16   thread t: butterflies j = t, t+256, twiddle W_256^((j%16) r)
+//           z[(j/16) 256 + j%16 + 16 k]               -> LDS (linear, conflict-free)
+//   pass 3  radix 32, Ns = 256  thread t: butterfly j = t, twiddle W_8192^(t r) = W_8192^(t (r&3)) * W_2048^(t (r>>2))
+//           X[t + 256 k] -> 10 log10(|X|^2 / fs) -> psd[(t + 256 k) ^ 4096]   (half rotation in the index)
+//
+// HBM traffic per frame: 64 KiB in (CF32) + 32 KiB out; window taps (32 KiB) and twiddle tables
+// (2 KiB + 20 KiB) are shared by every workgroup and stay in L2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft_kernels.h"
+
+namespace ss {
+
+// W_32^k = exp(-2 pi i k / 32), first octant is enough; the rest comes from symmetry in mulw32.
+__device__ constexpr float kC32[5] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f};
+__device__ constexpr float kS32[5] = {0.0f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654757f};
+
+// x * W_32^K for a compile-time K, with the trivial rotations free.
+template <int K>
+__device__ __forceinline__ float2 mulw32(float2 x) {
+  constexpr int k = ((K % 32) + 32) % 32;
+  if constexpr (k == 0) return x;
+  else if constexpr (k == 8) return make_float2(x.y, -x.x);
+  else if constexpr (k == 16) return make_float2(-x.x, -x.y);
+  else if constexpr (k == 24) return make_float2(-x.y, x.x);
+  else {
+    // W = c - i s with (c, s) folded into the first octant
+    constexpr int q = k / 8;       // quadrant
+    constexpr int r = k % 8;       // 1..7 inside the quadrant
+    constexpr float c0 = r <= 4 ? kC32[r] : kS32[8 - r];
+    constexpr float s0 = r <= 4 ? kS32[r] : kC32[8 - r];
+    // rotate (c0 - i s0) by (-i)^q
+    constexpr float c = q == 0 ? c0 : q == 1 ? -s0 : q == 2 ? -c0 : s0;
+    constexpr float s = q == 0 ? -s0 : q == 1 ? -c0 : q == 2 ? s0 : c0;  // imaginary part of W
+    return make_float2(x.x * c - x.y * s, x.x * s + x.y * c);
+  }
+}
+
+__device__ __forceinline__ void dft2(float2& a, float2& b) {
+  const float2 t = a;
+  a = cadd(t, b);
+  b = csub(t, b);
+}
+
+// natural order in, natural order out
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+  const float2 s0 = cadd(a0, a2), s1 = csub(a0, a2), s2 = cadd(a1, a3), s3 = cmul_mi(csub(a1, a3));
+  a0 = cadd(s0, s2);
+  a1 = cadd(s1, s3);
+  a2 = csub(s0, s2);
+  a3 = csub(s1, s3);
+}
+
+// 8-point DFT, inputs x[n] in v0..v7; output X[k] ends up in slot 2*(k&3) + (k>>2)
+__device__ __forceinline__ constexpr int slot8(int k) { return 2 * (k & 3) + (k >> 2); }
+__device__ __forceinline__ void dft8(float2& v0, float2& v1, float2& v2, float2& v3, float2& v4, float2& v5, float2& v6, float2& v7) {
+  dft4(v0, v2, v4, v6);  // n2 = 0: A[0][k1] at v[2 k1]
+  dft4(v1, v3, v5, v7);  // n2 = 1: A[1][k1] at v[2 k1 + 1]
+  v3 = mulw32<4>(v3);    // W_8^k1
+  v5 = mulw32<8>(v5);
+  v7 = mulw32<12>(v7);
+  dft2(v0, v1);  // X[k1 + 4 k2] at v[2 k1 + k2]
+  dft2(v2, v3);
+  dft2(v4, v5);
+  dft2(v6, v7);
+}
+
+// 16-point DFT in registers; X[k] ends up in slot 4*(k&3) + (k>>2)
+__device__ __forceinline__ constexpr int slot16(int k) { return 4 * (k & 3) + (k >> 2); }
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+  dft4(v[0], v[4], v[8], v[12]);  // A[n2][k1] at v[n2 + 4 k1]
+  dft4(v[1], v[5], v[9], v[13]);
+  dft4(v[2], v[6], v[10], v[14]);
+  dft4(v[3], v[7], v[11], v[15]);
+  // W_16^(n2 k1) = W_32^(2 n2 k1)
+  v[5] = mulw32<2>(v[5]);
+  v[6] = mulw32<4>(v[6]);
+  v[7] = mulw32<6>(v[7]);
+  v[9] = mulw32<4>(v[9]);
+  v[10] = mulw32<8>(v[10]);
+  v[11] = mulw32<12>(v[11]);
+  v[13] = mulw32<6>(v[13]);
+  v[14] = mulw32<12>(v[14]);
+  v[15] = mulw32<18>(v[15]);
+  dft4(v[0], v[1], v[2], v[3]);  // X[k1 + 4 k2] at v[4 k1 + k2]
+  dft4(v[4], v[5], v[6], v[7]);
+  dft4(v[8], v[9], v[10], v[11]);
+  dft4(v[12], v[13], v[14], v[15]);
+}
+
+// 32-point DFT in registers: n = n2 + 4 n1; X[k] ends up in slot (k>>3) + 4*slot8(k&7)
+__device__ __forceinline__ constexpr int slot32(int k) { return (k >> 3) + 4 * slot8(k & 7); }
+template <int N2>
+__device__ __forceinline__ void dft32_twiddle_row(float2 (&v)[32]) {
+  // v[N2 + 4*slot8(k1)] *= W_32^(N2 k1), k1 = 1..7
+  v[N2 + 4 * slot8(1)] = mulw32<N2 * 1>(v[N2 + 4 * slot8(1)]);
+  v[N2 + 4 * slot8(2)] = mulw32<N2 * 2>(v[N2 + 4 * slot8(2)]);
+  v[N2 + 4 * slot8(3)] = mulw32<N2 * 3>(v[N2 + 4 * slot8(3)]);
+  v[N2 + 4 * slot8(4)] = mulw32<N2 * 4>(v[N2 + 4 * slot8(4)]);
+  v[N2 + 4 * slot8(5)] = mulw32<N2 * 5>(v[N2 + 4 * slot8(5)]);
+  v[N2 + 4 * slot8(6)] = mulw32<N2 * 6>(v[N2 + 4 * slot8(6)]);
+  v[N2 + 4 * slot8(7)] = mulw32<N2 * 7>(v[N2 + 4 * slot8(7)]);
+}
+__device__ __forceinline__ void dft32(float2 (&v)[32]) {
+  dft8(v[0], v[4], v[8], v[12], v[16], v[20], v[24], v[28]);   // n2 = 0: A[0][k1] at v[0 + 4 slot8(k1)]
+  dft8(v[1], v[5], v[9], v[13], v[17], v[21], v[25], v[29]);
+  dft8(v[2], v[6], v[10], v[14], v[18], v[22], v[26], v[30]);
+  dft8(v[3], v[7], v[11], v[15], v[19], v[23], v[27], v[31]);
+  dft32_twiddle_row<1>(v);
+  dft32_twiddle_row<2>(v);
+  dft32_twiddle_row<3>(v);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) dft4(v[4 * s], v[4 * s + 1], v[4 * s + 2], v[4 * s + 3]);  // X[k1 + 8 k2] at v[k2 + 4 slot8(k1)]
+}
+
+// twiddle tables for this kernel (built on the host in double precision, see specscan.hip):
+//   tw2[r*16 + m]   = W_256^(m r)        r = 0..15, m = 0..15
+//   tw3a[r1*256 + t] = W_8192^(t r1)     r1 = 0..3
+//   tw3b[r2*256 + t] = W_2048^(t r2)     r2 = 0..7
+struct Fft8192Tables {
+  const float2* tw2;
+  const float2* tw3a;
+  const float2* tw3b;
+};
+
+constexpr int kFft8192LdsBytes = (8192 + 256) * 8;  // exchange 1 uses a 33-element pitch per 32 elements
+
+template <int FMT>
+__global__ __launch_bounds__(256, 2) void k_fft8192_psd(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
+                                                         Fft8192Tables tabs, float fs, float scale, float* __restrict__ psd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2* s = reinterpret_cast<float2*>(smem_raw);
+  const int t = threadIdx.x;
+  const size_t frame = blockIdx.x;
+  const size_t in_base = frame * (size_t)item_stride;
+
+  // ---------------- pass 1: radix 16, Ns = 1, butterflies j = 2t and 2t+1 ----------------
+  float2 a[16], b[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int e = 2 * t + 512 * r;
+    float2 x0, x1;
+    if constexpr (FMT == FMT_CF32) {
+      const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(iq) + in_base + e);
+      x0 = make_float2(q.x, q.y);
+      x1 = make_float2(q.z, q.w);
+    } else if constexpr (FMT == FMT_CS8) {
+      const char4 q = *reinterpret_cast<const char4*>(reinterpret_cast<const char2*>(iq) + in_base + e);
+      x0 = make_float2((float)q.x * scale, (float)q.y * scale);
+      x1 = make_float2((float)q.z * scale, (float)q.w * scale);
+    } else {
+      const uchar4 q = *reinterpret_cast<const uchar4*>(reinterpret_cast<const uchar2*>(iq) + in_base + e);
+      x0 = make_float2(((float)q.x - 127.5f) * scale, ((float)q.y - 127.5f) * scale);
+      x1 = make_float2(((float)q.z - 127.5f) * scale, ((float)q.w - 127.5f) * scale);
+    }
+    const float2 w = *reinterpret_cast<const float2*>(win + e);
+    a[r] = make_float2(x0.x * w.x, x0.y * w.x);  // volk_32fc_32f_multiply_32fc
+    b[r] = make_float2(x1.x * w.y, x1.y * w.y);
+  }
+  dft16(a);
+  dft16(b);
+  // y[16 j + k]: thread t owns y[32 t .. 32 t + 31]; LDS pitch 33 elements per thread
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    s[33 * t + k] = a[slot16(k)];
+    s[33 * t + 16 + k] = b[slot16(k)];
+  }
+  __syncthreads();
+
+  // ---------------- pass 2: radix 16, Ns = 16, butterflies j = t and t + 256 ----------------
+  {
+    const int m = t & 15;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int e0 = t + 512 * r;  // element index in y
+      const int e1 = e0 + 256;
+      float2 x0 = s[e0 + (e0 >> 5)];
+      float2 x1 = s[e1 + (e1 >> 5)];
+      if (r > 0) {
+        const float2 w = tabs.tw2[r * 16 + m];
+        x0 = cmul(x0, w);
+        x1 = cmul(x1, w);
+      }
+      a[r] = x0;
+      b[r] = x1;
+    }
+  }
+  __syncthreads();  // every read of y is done before z overwrites the buffer
+  dft16(a);
+  dft16(b);
+  {
+    // z[(j/16)*256 + j%16 + 16 k]
+    const int base0 = ((t >> 4) << 8) + (t & 15);
+    const int base1 = base0 + 4096;  // j = t + 256 -> (j/16) = t/16 + 16
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      s[base0 + 16 * k] = a[slot16(k)];
+      s[base1 + 16 * k] = b[slot16(k)];
+    }
+  }
+  __syncthreads();
+
+  // ---------------- pass 3: radix 32, Ns = 256, butterfly j = t ----------------
+  float2 v[32];
+  {
+    float2 wa[4], wb[8];
+#pragma unroll
+    for (int r1 = 1; r1 < 4; ++r1) wa[r1] = tabs.tw3a[r1 * 256 + t];
+#pragma unroll
+    for (int r2 = 1; r2 < 8; ++r2) wb[r2] = tabs.tw3b[r2 * 256 + t];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      float2 x = s[t + 256 * r];
+      const int r1 = r & 3, r2 = r >> 2;
+      if (r1 != 0 && r2 != 0) x = cmul(x, cmul(wa[r1], wb[r2]));
+      else if (r1 != 0) x = cmul(x, wa[r1]);
+      else if (r2 != 0) x = cmul(x, wb[r2]);
+      v[r] = x;
+    }
+  }
+  dft32(v);
+  float* out = psd + frame * 8192;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const int bin = t + 256 * k;
+    out[bin ^ 4096] = psd_db(v[slot32(k)], fs);
+  }
+}
+
+}  // namespace ss

@@ -18,7 +18,9 @@
 #include <vector>
 
 #include "../../include/specscan.h"
+#include "detect_fused.h"
 #include "detect_kernels.h"
+#include "fft8192_kernel.h"
 #include "fft_kernels.h"
 
 namespace {
@@ -45,6 +47,8 @@ struct ss_ctx {
   // constants
   float* d_win = nullptr;
   float2* d_tw = nullptr;
+  float2* d_tw8k = nullptr;  // tables of k_fft8192_psd: tw2[256] ++ tw3a[1024] ++ tw3b[2048]
+  bool use_fft8192 = false;
   uint8_t* d_pass = nullptr;
   bool pass_dirty = true;
   // state
@@ -52,6 +56,17 @@ struct ss_ctx {
   int frames_pushed = 0;  // Averager::m_frames, saturates at grouping_y
   int rot_frames = 0;     // rows of the previous batch still to be folded into the history rows (lazy ring rotation)
   // planes (frame-major rows of n floats)
+  // back end, fused path (grouping 21 x 21, max_batch <= 4096): ring and counters are double-buffered
+  bool fused = false;
+  float* d_hist[2] = {nullptr, nullptr};  // G-1 rel rows each; [hist_cur] is read by the next batch
+  int hist_cur = 0;
+  int* d_cnt2[2] = {nullptr, nullptr};    // per-frame candidate counts; the emit kernel clears the other half
+  int cnt_cur = 0;
+  float* d_relplane = nullptr;            // full rel plane, only when a caller asks for it (lazy)
+  int last_n_learn = 0;
+  const float* last_hist = nullptr;       // ring rows as they were before the last batch
+  float* last_thr = nullptr;
+  // back end, unfused path (any other grouping): one buffer holds the ring rows + the batch rows
   float* d_rel = nullptr;   // (G-1) history rows + max_batch rows
   float* d_hist_tmp = nullptr;
   float* d_psd = nullptr;   // internal PSD plane (used when the caller passes none)
@@ -176,7 +191,24 @@ void launch_four_step(ss_ctx* c, const void* d_iq, long long item_stride, int nf
 }
 
 template <int FMT>
+void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
+  ss::Fft8192Tables tabs{c->d_tw8k, c->d_tw8k + 256, c->d_tw8k + 256 + 1024};
+  hipEvent_t e0, e1;
+  if (prof_pair(c, &e0, &e1)) {
+    hipExtLaunchKernelGGL((ss::k_fft8192_psd<FMT>), dim3(nframes), dim3(256), ss::kFft8192LdsBytes, c->stream, e0, e1, 0, d_iq, item_stride,
+                          c->d_win, tabs, (float)c->cfg.sample_rate, c->cfg.int_scale, d_psd);
+  } else {
+    hipLaunchKernelGGL((ss::k_fft8192_psd<FMT>), dim3(nframes), dim3(256), ss::kFft8192LdsBytes, c->stream, d_iq, item_stride, c->d_win, tabs,
+                       (float)c->cfg.sample_rate, c->cfg.int_scale, d_psd);
+  }
+}
+
+template <int FMT>
 int launch_fft_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
+  if (c->use_fft8192) {
+    launch_fft8192<FMT>(c, d_iq, item_stride, nframes, d_psd);
+    return SS_OK;
+  }
   switch (c->logn) {
     case 6: launch_lds<6, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 7: launch_lds<7, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
@@ -214,19 +246,11 @@ int grid_for(size_t work_items, int block) {
   return (int)g;
 }
 
-// The chain for one batch, everything on c->stream, nothing synchronised.
-// n_learn = leading frames that belong to the noise-learning phase (decided by the caller).
-int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int n_learn, NoiseState* z, float* d_psd_out,
-              float* d_rel_out, float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
+// Back end for groupings other than 21 x 21: one simple kernel per reference stage.
+int run_backend_unfused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, NoiseState* z, float* d_rel_out, float* d_avg_out,
+                        int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
   const int n = c->n;
   const int G = c->cfg.grouping_y;
-  if (c->pass_dirty) {
-    std::vector<uint8_t> pass;
-    build_pass_mask(c, pass);
-    SS_HIP(c, hipMemcpyAsync(c->d_pass, pass.data(), pass.size(), hipMemcpyHostToDevice, c->stream));
-    SS_HIP(c, hipStreamSynchronize(c->stream));  // `pass` is pageable and dies at scope end
-    c->pass_dirty = false;
-  }
   // Fold the previous batch into the ring: history = newest G-1 rows of [history ++ previous batch].
   // Done lazily, at the start of the next batch, so that ss_read_window can still address the ring rows
   // as they were before the batch it describes (Transmission::getBestIndex, transmission.cpp:132-154).
@@ -241,10 +265,6 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     }
   }
   c->rot_frames = 0;
-  float* d_psd = d_psd_out ? d_psd_out : c->d_psd;
-  int st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
-  if (st != SS_OK) return st;
-
   float* rel_batch = c->d_rel + (size_t)(G - 1) * n;
   if (n_learn > 0) {
     hipLaunchKernelGGL(ss::k_noise_learn, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_psd, n, n_learn, z->d_thr);
@@ -264,11 +284,65 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     hipLaunchKernelGGL(ss::k_cand_write, dim3(nframes), dim3(256), 0, c->stream, c->d_mask, wpr, n, c->d_off, c->d_avg, cand_cap, d_cand_idx,
                        d_cand_avg);
   }
+  c->rot_frames = nframes;
+  return SS_OK;
+}
+
+// Back end for the reference's grouping (21 x 21): two launches, the PSD plane is read once.
+int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, NoiseState* z, float* d_rel_out, float* d_avg_out,
+                      int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
+  const int n = c->n;
+  constexpr int G = 21, GX = 21, TF = 16;
+  if (n_learn > 0) {
+    hipLaunchKernelGGL(ss::k_noise_learn, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_psd, n, n_learn, z->d_thr);
+  }
+  const float* hist_in = c->d_hist[c->hist_cur];
+  float* hist_out = c->d_hist[c->hist_cur ^ 1];
+  if (nframes < G - 1) {
+    const int keep = G - 1 - nframes;
+    hipLaunchKernelGGL(ss::k_hist_shift, dim3(grid_for((size_t)keep * n, 256)), dim3(256), 0, c->stream, hist_in, hist_out, n, keep, nframes);
+  }
+  int* counts = c->d_cnt2[c->cnt_cur];
+  int* counts_next = c->d_cnt2[c->cnt_cur ^ 1];
+  const bool keep_planes = (c->cfg.flags & SS_FLAG_KEEP_PLANES) != 0;
+  float* avg_full = d_avg_out ? d_avg_out : (keep_planes ? c->d_avg : nullptr);
+  const int tiles = ((nframes + TF - 1) / TF) * ((n + 255) / 256);
+  ss::DetectArgs da{d_psd,        z->d_thr, hist_in,   hist_out, n,         nframes,  n_learn, c->frames_pushed, c->cfg.start_level,
+                    c->d_pass,    c->d_mask, counts,    d_rel_out, avg_full, c->d_avg};
+  hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF>), dim3(tiles), dim3(256), 0, c->stream, da);
+  hipLaunchKernelGGL(ss::k_cand_emit, dim3(nframes), dim3(64), 0, c->stream, (const uint32_t*)c->d_mask, n / 32, n, nframes,
+                     (const int*)counts, counts_next, (const float*)(avg_full ? avg_full : c->d_avg), cand_cap, c->d_off, d_cand_off,
+                     (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr, d_cand_avg);
+  c->last_hist = hist_in;
+  c->hist_cur ^= 1;
+  c->cnt_cur ^= 1;
+  c->last_n_learn = n_learn;
+  c->last_thr = z->d_thr;
+  return SS_OK;
+}
+
+// The chain for one batch, everything on c->stream, nothing synchronised.
+// n_learn = leading frames that belong to the noise-learning phase (decided by the caller).
+int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int n_learn, NoiseState* z, float* d_psd_out,
+              float* d_rel_out, float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
+  const int G = c->cfg.grouping_y;
+  if (c->pass_dirty) {
+    std::vector<uint8_t> pass;
+    build_pass_mask(c, pass);
+    SS_HIP(c, hipMemcpyAsync(c->d_pass, pass.data(), pass.size(), hipMemcpyHostToDevice, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));  // `pass` is pageable and dies at scope end
+    c->pass_dirty = false;
+  }
+  float* d_psd = d_psd_out ? d_psd_out : c->d_psd;
+  int st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
+  if (st != SS_OK) return st;
+  st = c->fused ? run_backend_fused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap)
+                : run_backend_unfused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap);
+  if (st != SS_OK) return st;
   SS_HIP(c, hipGetLastError());
   c->frames_pushed = c->frames_pushed + nframes < G ? c->frames_pushed + nframes : G;
   c->last_psd = d_psd;
   c->last_n = nframes;
-  c->rot_frames = nframes;
   return SS_OK;
 }
 
@@ -311,8 +385,14 @@ void free_ctx(ss_ctx* c) {
   for (auto e : c->prof_events) (void)hipEventDestroy(e);
   (void)hipFree(c->d_win);
   (void)hipFree(c->d_tw);
+  (void)hipFree(c->d_tw8k);
   (void)hipFree(c->d_pass);
   (void)hipFree(c->d_rel);
+  (void)hipFree(c->d_hist[0]);
+  (void)hipFree(c->d_hist[1]);
+  (void)hipFree(c->d_cnt2[0]);
+  (void)hipFree(c->d_cnt2[1]);
+  (void)hipFree(c->d_relplane);
   (void)hipFree(c->d_hist_tmp);
   (void)hipFree(c->d_psd);
   (void)hipFree(c->d_avgy);
@@ -330,7 +410,36 @@ void free_ctx(ss_ctx* c) {
 
 }  // namespace
 
+// exhaustive check of div_const<21> (detect_fused.h) against the hardware IEEE division
+__global__ void k_selftest_div21(unsigned long long* mismatches) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned long long bad = 0;
+  for (unsigned long long u = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; u < (1ull << 32); u += stride) {
+    const float s = __uint_as_float((unsigned)u);
+    if (!(fabsf(s) <= 1e30f)) continue;  // NaN, inf and the overflow corner are not reachable for dB sums
+    const float q = ss::div_const<21>(s);
+    const float r = s / 21.0f;
+    if (__float_as_uint(q) != __float_as_uint(r) && !(q == 0.0f && r == 0.0f)) ++bad;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
 extern "C" {
+
+// Device self-tests of arithmetic shortcuts. which = 0: div_const<21>(s) == s / 21.0f for every float
+// |s| <= 1e30. Returns the number of mismatching inputs, or a negative ss_status.
+long long ss_selftest(int device_id, int which) {
+  if (which != 0) return SS_ERR_INVALID;
+  if (hipSetDevice(device_id) != hipSuccess) return SS_ERR_NO_DEVICE;
+  unsigned long long* d = nullptr;
+  unsigned long long h = 0;
+  if (hipMalloc(&d, sizeof(h)) != hipSuccess) return SS_ERR_HIP;
+  (void)hipMemset(d, 0, sizeof(h));
+  hipLaunchKernelGGL(k_selftest_div21, dim3(256 * 8), dim3(256), 0, 0, d);
+  const hipError_t e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  return e == hipSuccess ? (long long)h : (long long)SS_ERR_HIP;
+}
 
 void ss_default_config(ss_config* cfg, int32_t sample_rate, int32_t center_hz) {
   if (!cfg) return;
@@ -402,10 +511,24 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   CREATE_HIP(hipMalloc(&c->d_win, sizeof(float) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_tw, sizeof(float2) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_pass, (size_t)n));
-  CREATE_HIP(hipMalloc(&c->d_rel, sizeof(float) * (size_t)n * (size_t)(G - 1 + cfg->max_batch)));
-  CREATE_HIP(hipMalloc(&c->d_hist_tmp, sizeof(float) * (size_t)n * (size_t)(G > 1 ? G - 1 : 1)));
+  {
+    const char* be = getenv("SS_BACKEND");  // "unfused" forces the per-stage kernels (A/B measurements)
+    c->fused = G == 21 && cfg->grouping_x == 21 && cfg->max_batch <= 4096 && !(be && strcmp(be, "unfused") == 0);
+  }
+  if (c->fused) {
+    for (int k = 0; k < 2; ++k) {
+      CREATE_HIP(hipMalloc(&c->d_hist[k], sizeof(float) * (size_t)n * (size_t)(G - 1)));
+      CREATE_HIP(hipMemsetAsync(c->d_hist[k], 0, sizeof(float) * (size_t)n * (size_t)(G - 1), c->stream));  // Averager ctor, averager.cpp:7-12
+      CREATE_HIP(hipMalloc(&c->d_cnt2[k], sizeof(int) * (size_t)cfg->max_batch));
+      CREATE_HIP(hipMemsetAsync(c->d_cnt2[k], 0, sizeof(int) * (size_t)cfg->max_batch, c->stream));
+    }
+  } else {
+    CREATE_HIP(hipMalloc(&c->d_rel, sizeof(float) * (size_t)n * (size_t)(G - 1 + cfg->max_batch)));
+    CREATE_HIP(hipMalloc(&c->d_hist_tmp, sizeof(float) * (size_t)n * (size_t)(G > 1 ? G - 1 : 1)));
+    CREATE_HIP(hipMalloc(&c->d_avgy, plane));
+    CREATE_HIP(hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)n * (size_t)(G - 1 + cfg->max_batch), c->stream));
+  }
   CREATE_HIP(hipMalloc(&c->d_psd, plane));
-  CREATE_HIP(hipMalloc(&c->d_avgy, plane));
   CREATE_HIP(hipMalloc(&c->d_avg, plane));
   CREATE_HIP(hipMalloc(&c->d_mask, sizeof(uint32_t) * (size_t)(n / 32) * (size_t)cfg->max_batch));
   CREATE_HIP(hipMalloc(&c->d_counts, sizeof(int) * (size_t)cfg->max_batch));
@@ -427,11 +550,26 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       const double ang = -2.0 * M_PI * (double)k / (double)n;
       tw[(size_t)k] = make_float2((float)cos(ang), (float)sin(ang));
     }
+    if (n == 8192) {
+      const char* impl = getenv("SS_FFT_IMPL");  // "generic" selects the radix-4 LDS kernel (A/B measurements)
+      c->use_fft8192 = !(impl && strcmp(impl, "generic") == 0);
+      std::vector<float2> t8((size_t)(256 + 1024 + 2048));
+      auto W = [](double num, double den) {
+        const double ang = -2.0 * M_PI * num / den;
+        return make_float2((float)cos(ang), (float)sin(ang));
+      };
+      for (int r = 0; r < 16; ++r)
+        for (int m = 0; m < 16; ++m) t8[(size_t)(r * 16 + m)] = W((double)m * r, 256.0);
+      for (int r1 = 0; r1 < 4; ++r1)
+        for (int t = 0; t < 256; ++t) t8[(size_t)(256 + r1 * 256 + t)] = W((double)t * r1, 8192.0);
+      for (int r2 = 0; r2 < 8; ++r2)
+        for (int t = 0; t < 256; ++t) t8[(size_t)(256 + 1024 + r2 * 256 + t)] = W((double)t * r2, 2048.0);
+      CREATE_HIP(hipMalloc(&c->d_tw8k, sizeof(float2) * t8.size()));
+      CREATE_HIP(hipMemcpy(c->d_tw8k, t8.data(), sizeof(float2) * t8.size(), hipMemcpyHostToDevice));
+    }
     CREATE_HIP(hipMemcpy(c->d_win, win.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
   }
-  // Averager ctor: ring rows zero-filled (averager.cpp:7-12)
-  CREATE_HIP(hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)n * (size_t)(G - 1 + cfg->max_batch), c->stream));
   // 64 KiB of dynamic LDS needs no opt-in on gfx950 (160 KiB/CU), but say so explicitly for clarity
   CREATE_HIP(hipStreamSynchronize(c->stream));
 #undef CREATE_HIP
@@ -531,12 +669,20 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
   if (st != SS_OK) return st;
   const int n_learn = plan_learning(c, z, nframes, t_ms);
   const bool want_cands = cand_idx && cand_cap > 0;
-  st = run_batch(c, c->d_in, (long long)n, nframes, n_learn, z, nullptr, nullptr, nullptr, nullptr, want_cands ? c->d_cand_idx : nullptr,
-                 want_cands && cand_avg ? c->d_cand_avg : nullptr, cand_cap);
+  float* d_rel_plane = nullptr;
+  if (c->fused && rel_db) {
+    if (!c->d_relplane) SS_HIP(c, hipMalloc(&c->d_relplane, sizeof(float) * (size_t)n * (size_t)c->cfg.max_batch));
+    d_rel_plane = c->d_relplane;
+  }
+  st = run_batch(c, c->d_in, (long long)n, nframes, n_learn, z, nullptr, d_rel_plane, (c->fused && avg_db) ? c->d_avg : nullptr, nullptr,
+                 want_cands ? c->d_cand_idx : nullptr, want_cands && cand_avg ? c->d_cand_avg : nullptr, cand_cap);
   if (st != SS_OK) return st;
   const size_t plane = sizeof(float) * (size_t)n * (size_t)nframes;
   if (psd_db) SS_HIP(c, hipMemcpyAsync(psd_db, c->d_psd, plane, hipMemcpyDeviceToHost, c->stream));
-  if (rel_db) SS_HIP(c, hipMemcpyAsync(rel_db, c->d_rel + (size_t)(c->cfg.grouping_y - 1) * n, plane, hipMemcpyDeviceToHost, c->stream));
+  if (rel_db) {
+    const float* src = c->fused ? c->d_relplane : c->d_rel + (size_t)(c->cfg.grouping_y - 1) * n;
+    SS_HIP(c, hipMemcpyAsync(rel_db, src, plane, hipMemcpyDeviceToHost, c->stream));
+  }
   if (avg_db) SS_HIP(c, hipMemcpyAsync(avg_db, c->d_avg, plane, hipMemcpyDeviceToHost, c->stream));
   std::vector<int> off((size_t)nframes + 1);
   SS_HIP(c, hipMemcpyAsync(off.data(), c->d_off, sizeof(int) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, c->stream));
@@ -568,7 +714,11 @@ int ss_reset(ss_ctx* c) {  // Transmission::resetBuffers -> Averager::reset: row
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
   const int G = c->cfg.grouping_y;
-  if (G > 1) SS_HIP(c, hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)c->n * (size_t)(G - 1), c->stream));
+  if (c->fused) {
+    SS_HIP(c, hipMemsetAsync(c->d_hist[c->hist_cur], 0, sizeof(float) * (size_t)c->n * (size_t)(G - 1), c->stream));
+  } else if (G > 1) {
+    SS_HIP(c, hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)c->n * (size_t)(G - 1), c->stream));
+  }
   c->frames_pushed = 0;
   c->rot_frames = 0;
   c->last_n = 0;
@@ -592,15 +742,35 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
   const int G = c->cfg.grouping_y;
   if (lo < 0 || hi > n || lo > hi || frame >= c->last_n) return fail(c, SS_ERR_INVALID, "window out of range");
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  const size_t cnt = (size_t)(hi - lo);
+  if (c->fused && plane == SS_PLANE_REL && frame >= 0) {
+    // the fused back end never stores rel: rebuild the window as the kernel computes it,
+    // psd - thr in fp32 (noise_learner.cpp:55), or -100 for a learning frame (:49)
+    if (frame < c->last_n_learn) {
+      for (size_t k = 0; k < cnt; ++k) out[k] = SS_NO_DATA;
+      return SS_OK;
+    }
+    std::vector<float> thr(cnt);
+    SS_HIP(c, hipMemcpyAsync(out, c->last_psd + (size_t)frame * n + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
+    SS_HIP(c, hipMemcpyAsync(thr.data(), c->last_thr + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
+    SS_HIP(c, hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < cnt; ++k) out[k] = out[k] - thr[k];
+    return SS_OK;
+  }
   const float* src = nullptr;
   if (frame >= 0) {
     if (plane == SS_PLANE_PSD) src = c->last_psd + (size_t)frame * n;
-    if (plane == SS_PLANE_AVG) src = c->d_avg + (size_t)frame * n;
+    if (plane == SS_PLANE_AVG) {
+      if (c->fused && !(c->cfg.flags & SS_FLAG_KEEP_PLANES)) return fail(c, SS_ERR_INVALID, "SS_PLANE_AVG needs SS_FLAG_KEEP_PLANES at ss_create");
+      src = c->d_avg + (size_t)frame * n;
+    }
+    if (plane == SS_PLANE_REL && !c->fused) src = c->d_rel + (size_t)(G - 1 + frame) * n;
+  } else if (plane == SS_PLANE_REL && frame >= -(G - 1)) {
+    // ring rows as they were before the batch: [G-1+frame] of the ring the batch started from
+    src = c->fused ? c->last_hist + (size_t)(G - 1 + frame) * n : c->d_rel + (size_t)(G - 1 + frame) * n;
   }
-  // rel keeps [ring before the batch (G-1 rows)] ++ [batch rows] until the next batch starts
-  if (plane == SS_PLANE_REL && frame >= -(G - 1)) src = c->d_rel + (size_t)(G - 1 + frame) * n;
   if (!src) return fail(c, SS_ERR_INVALID, "bad plane/frame");
-  SS_HIP(c, hipMemcpyAsync(out, src + lo, sizeof(float) * (size_t)(hi - lo), hipMemcpyDeviceToHost, c->stream));
+  SS_HIP(c, hipMemcpyAsync(out, src + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
   SS_HIP(c, hipStreamSynchronize(c->stream));
   return SS_OK;
 }

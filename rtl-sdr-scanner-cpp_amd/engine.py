@@ -39,13 +39,15 @@ def load_library() -> C.CDLL:
         lib.ss_kernel_timing.restype = C.c_int
         lib.ss_kernel_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         lib.ss_kernel_timing_read.restype = C.c_int
+        lib.ss_selftest.argtypes = [C.c_int, C.c_int]
+        lib.ss_selftest.restype = C.c_longlong
         _lib = lib
     return _lib
 
 
 EXPORTS = ("ss_default_config", "ss_device_count", "ss_create", "ss_destroy", "ss_last_error", "ss_process",
            "ss_process_device", "ss_sync", "ss_stream", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
-           "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read")
+           "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read", "ss_selftest")
 
 
 def _ptr(t):

