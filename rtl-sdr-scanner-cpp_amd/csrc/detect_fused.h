@@ -66,6 +66,7 @@ struct DetectArgs {
   float* rel_out;
   float* avg_out;
   float* avg_sparse;
+  long long* dbg;  // diagnostic (SS_DEBUG_TIMING): per-workgroup wall_clock64 stamps {start, mid, end, class}, or null
 };
 
 // time means of one column, written into the LDS tile
@@ -88,9 +89,16 @@ __global__ __launch_bounds__(256) void k_detect_fused(DetectArgs a) {
   __shared__ int cnt[TF];
 
   const int tid = threadIdx.x;
+  long long t_start = 0, t_mid = 0;
+  if (a.dbg && tid == 0) t_start = wall_clock64();
   const int n = a.n, nframes = a.nframes;
   const int tiles_per_row = (n + TB - 1) / TB;
-  const int f0 = (blockIdx.x / tiles_per_row) * TF;
+  // Frame tiles are dispatched rotated by three: the tiles that own the ring update (end of the batch) and
+  // the ring read (start of the batch) take the slower general path, so they go first and the short
+  // straight-line tiles fill in behind them instead of leaving a tail.
+  const int nft = (nframes + TF - 1) / TF;
+  const int ft = (blockIdx.x / tiles_per_row + nft - (nft >= 3 ? 3 : 0)) % nft;
+  const int f0 = ft * TF;
   const int b0 = (blockIdx.x % tiles_per_row) * TB;
   if (tid < TF) cnt[tid] = 0;
   // block-uniform classification
@@ -98,33 +106,30 @@ __global__ __launch_bounds__(256) void k_detect_fused(DetectArgs a) {
   const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes - (G - 1));
 
   // ---------------- phase 1: time means, thread = column ----------------
-  if (steady && interior) {
-    // straight line: ROWS independent, unconditional loads per column; 276 columns over 256 threads
-    {
-      const int col = b0 - A + tid;
-      const float t = a.thr[col];
-      const float* p = a.psd + (size_t)(f0 - (G - 1)) * n + col;
-      float x[ROWS];
+  if (steady) {
+    // straight line: ROWS independent, unconditional loads per column; 276 columns over 256 threads.
+    // Columns outside the band (first / last tile of a row) read a clamped address and contribute 0.0f.
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) x[r] = p[(size_t)r * n] - t;
-      time_means_to_tile<G, TF, P>(x, &tile[tid]);
-      if (a.rel_out && tid >= A) {
+    for (int pass_c = 0; pass_c < 2; ++pass_c) {
+      const int c = pass_c * TB + tid;
+      if (pass_c == 0 || tid < 2 * A) {
+        const int col = b0 - A + c;
+        const int colc = min(max(col, 0), n - 1);
+        const bool valid = col == colc;
+        const float t = a.thr[colc];
+        const float* p = a.psd + (size_t)(f0 - (G - 1)) * n + colc;
+        float x[ROWS];
 #pragma unroll
-        for (int j = 0; j < TF; ++j) a.rel_out[(size_t)(f0 + j) * n + col] = x[G - 1 + j];
-      }
-    }
-    if (tid < 2 * A) {
-      const int c = TB + tid;
-      const int col = b0 - A + c;
-      const float t = a.thr[col];
-      const float* p = a.psd + (size_t)(f0 - (G - 1)) * n + col;
-      float x[ROWS];
+        for (int r = 0; r < ROWS; ++r) x[r] = p[(size_t)r * n] - t;
+        if (!interior) {
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) x[r] = p[(size_t)r * n] - t;
-      time_means_to_tile<G, TF, P>(x, &tile[c]);
-      if (a.rel_out && c < A + TB) {
+          for (int r = 0; r < ROWS; ++r) x[r] = valid ? x[r] : 0.0f;
+        }
+        time_means_to_tile<G, TF, P>(x, &tile[c]);
+        if (a.rel_out && valid && c >= A && c < A + TB) {
 #pragma unroll
-        for (int j = 0; j < TF; ++j) a.rel_out[(size_t)(f0 + j) * n + col] = x[G - 1 + j];
+          for (int j = 0; j < TF; ++j) a.rel_out[(size_t)(f0 + j) * n + col] = x[G - 1 + j];
+        }
       }
     }
   } else {
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(256) void k_detect_fused(DetectArgs a) {
     }
   }
   __syncthreads();
+  if (a.dbg && tid == 0) t_mid = wall_clock64();
 
   // ---------------- phase 2: frequency means + threshold, thread = (frame, 16-bin segment) ----------------
 #pragma unroll
@@ -258,6 +264,12 @@ __global__ __launch_bounds__(256) void k_detect_fused(DetectArgs a) {
   }
   __syncthreads();
   if (tid < TF && cnt[tid] != 0) atomicAdd(&a.counts[f0 + tid], cnt[tid]);
+  if (a.dbg && tid == 0) {
+    a.dbg[4 * blockIdx.x] = t_start;
+    a.dbg[4 * blockIdx.x + 1] = t_mid;
+    a.dbg[4 * blockIdx.x + 2] = wall_clock64();
+    a.dbg[4 * blockIdx.x + 3] = steady ? (interior ? 1 : 3) : 2;
+  }
 }
 
 // When a batch is shorter than the ring (nframes < G-1) the oldest ring rows survive: move them up.

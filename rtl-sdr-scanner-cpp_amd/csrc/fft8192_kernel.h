@@ -14,7 +14,7 @@
 //   pass 2  radix 16, Ns = 16   thread t: butterflies j = t, t+256, twiddle W_256^((j%16) r)
 //           z[(j/16) 256 + j%16 + 16 k]               -> LDS (linear, conflict-free)
 //   pass 3  radix 32, Ns = 256  thread t: butterfly j = t, twiddle W_8192^(t r) = W_8192^(t (r&3)) * W_2048^(t (r>>2))
-//           X[t + 256 k] -> 10 log10(|X|^2 / fs) -> psd[(t + 256 k) ^ 4096]   (half rotation in the index)
+//           X[t + 256 k] -> 10 log10(|X|^2) - 10 log10(fs) -> psd[(t + 256 k) ^ 4096]   (half rotation in the index)
 //
 // HBM traffic per frame: 64 KiB in (CF32) + 32 KiB out; window taps (32 KiB) and twiddle tables
 // (2 KiB + 20 KiB) are shared by every workgroup and stay in L2.
@@ -136,18 +136,21 @@ struct Fft8192Tables {
   const float2* tw2;
   const float2* tw3a;
   const float2* tw3b;
+  long long* dbg;  // diagnostic (SS_DEBUG_TIMING_FFT): per-workgroup s_memtime stamps of the phases, or null
 };
 
 constexpr int kFft8192LdsBytes = (8192 + 256) * 8;  // exchange 1 uses a 33-element pitch per 32 elements
 
 template <int FMT>
 __global__ __launch_bounds__(256, 2) void k_fft8192_psd(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
-                                                         Fft8192Tables tabs, float fs, float scale, float* __restrict__ psd) {
+                                                         Fft8192Tables tabs, float db_off, float scale, float* __restrict__ psd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2* s = reinterpret_cast<float2*>(smem_raw);
   const int t = threadIdx.x;
   const size_t frame = blockIdx.x;
   const size_t in_base = frame * (size_t)item_stride;
+  long long ts[8];
+  if (tabs.dbg && t == 0) ts[0] = wall_clock64();
 
   // ---------------- pass 1: radix 16, Ns = 1, butterflies j = 2t and 2t+1 ----------------
   float2 a[16], b[16];
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void k_fft8192_psd(const void* __restrict__
     a[r] = make_float2(x0.x * w.x, x0.y * w.x);  // volk_32fc_32f_multiply_32fc
     b[r] = make_float2(x1.x * w.y, x1.y * w.y);
   }
+  if (tabs.dbg && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[1] = wall_clock64(); }
   dft16(a);
   dft16(b);
   // y[16 j + k]: thread t owns y[32 t .. 32 t + 31]; LDS pitch 33 elements per thread
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(256, 2) void k_fft8192_psd(const void* __restrict__
     s[33 * t + 16 + k] = b[slot16(k)];
   }
   __syncthreads();
+  if (tabs.dbg && t == 0) ts[2] = wall_clock64();
 
   // ---------------- pass 2: radix 16, Ns = 16, butterflies j = t and t + 256 ----------------
   {
@@ -201,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_fft8192_psd(const void* __restrict__
     }
   }
   __syncthreads();  // every read of y is done before z overwrites the buffer
+  if (tabs.dbg && t == 0) ts[3] = wall_clock64();
   dft16(a);
   dft16(b);
   {
@@ -214,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void k_fft8192_psd(const void* __restrict__
     }
   }
   __syncthreads();
+  if (tabs.dbg && t == 0) ts[4] = wall_clock64();
 
   // ---------------- pass 3: radix 32, Ns = 256, butterfly j = t ----------------
   float2 v[32];
@@ -233,12 +240,19 @@ __global__ __launch_bounds__(256, 2) void k_fft8192_psd(const void* __restrict__
       v[r] = x;
     }
   }
+  if (tabs.dbg && t == 0) ts[5] = wall_clock64();
   dft32(v);
+  if (tabs.dbg && t == 0) ts[6] = wall_clock64();
   float* out = psd + frame * 8192;
 #pragma unroll
   for (int k = 0; k < 32; ++k) {
     const int bin = t + 256 * k;
-    out[bin ^ 4096] = psd_db(v[slot32(k)], fs);
+    out[bin ^ 4096] = psd_db(v[slot32(k)], db_off);
+  }
+  if (tabs.dbg && t == 0) {
+    ts[7] = wall_clock64();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tabs.dbg[8 * blockIdx.x + k] = ts[k];
   }
 }
 

@@ -41,6 +41,7 @@ struct NoiseState {  // NoiseLearner::Noise, sources/radio/blocks/noise_learner.
 struct ss_ctx {
   ss_config cfg{};
   int n = 0, logn = 0;
+  float db_off = 0.0f;  // 10*log10(fs), the constant term of PSD::work (psd.cpp:19)
   int32_t range_lo = 0, range_hi = 0;
   std::vector<int32_t> ignored;
   hipStream_t stream = nullptr;
@@ -171,10 +172,10 @@ void launch_lds(ss_ctx* c, const void* d_iq, long long item_stride, int nframes,
   hipEvent_t e0, e1;
   if (prof_pair(c, &e0, &e1)) {
     hipExtLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->stream, e0, e1, 0, d_iq,
-                          item_stride, nframes, c->d_win, c->d_tw, (float)c->cfg.sample_rate, c->cfg.int_scale, d_psd);
+                          item_stride, nframes, c->d_win, c->d_tw, c->db_off, c->cfg.int_scale, d_psd);
   } else {
     hipLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->stream, d_iq, item_stride,
-                       nframes, c->d_win, c->d_tw, (float)c->cfg.sample_rate, c->cfg.int_scale, d_psd);
+                       nframes, c->d_win, c->d_tw, c->db_off, c->cfg.int_scale, d_psd);
   }
 }
 
@@ -187,19 +188,39 @@ void launch_four_step(ss_ctx* c, const void* d_iq, long long item_stride, int nf
   hipLaunchKernelGGL((ss::k_fft_cols<LOGN1, LOGN2, FMT>), dim3(nframes * col_tiles), dim3(ss::kFftThreads), lds, c->stream, d_iq,
                      item_stride, c->d_win, c->d_tw, c->cfg.int_scale, c->d_work);
   hipLaunchKernelGGL((ss::k_fft_rows_psd<LOGN1, LOGN2>), dim3(nframes * row_tiles), dim3(ss::kFftThreads), lds, c->stream, c->d_work,
-                     c->d_tw, (float)c->cfg.sample_rate, d_psd);
+                     c->d_tw, c->db_off, d_psd);
 }
 
 template <int FMT>
 void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
-  ss::Fft8192Tables tabs{c->d_tw8k, c->d_tw8k + 256, c->d_tw8k + 256 + 1024};
+  ss::Fft8192Tables tabs{c->d_tw8k, c->d_tw8k + 256, c->d_tw8k + 256 + 1024, nullptr};
+  // development diagnostic: SS_DEBUG_TIMING_FFT=<file> dumps per-workgroup phase stamps of the 20th launch
+  static long long* s_dbg = nullptr;
+  static int s_calls = 0;
+  const char* dbg_path = getenv("SS_DEBUG_TIMING_FFT");
+  if (dbg_path && nframes <= 8192) {
+    if (!s_dbg) (void)hipMalloc(&s_dbg, sizeof(long long) * 8 * 8192);
+    tabs.dbg = s_dbg;
+  }
   hipEvent_t e0, e1;
   if (prof_pair(c, &e0, &e1)) {
     hipExtLaunchKernelGGL((ss::k_fft8192_psd<FMT>), dim3(nframes), dim3(256), ss::kFft8192LdsBytes, c->stream, e0, e1, 0, d_iq, item_stride,
-                          c->d_win, tabs, (float)c->cfg.sample_rate, c->cfg.int_scale, d_psd);
+                          c->d_win, tabs, c->db_off, c->cfg.int_scale, d_psd);
   } else {
     hipLaunchKernelGGL((ss::k_fft8192_psd<FMT>), dim3(nframes), dim3(256), ss::kFft8192LdsBytes, c->stream, d_iq, item_stride, c->d_win, tabs,
-                       (float)c->cfg.sample_rate, c->cfg.int_scale, d_psd);
+                       c->db_off, c->cfg.int_scale, d_psd);
+  }
+  if (tabs.dbg && ++s_calls == 20) {
+    std::vector<long long> h((size_t)8 * nframes);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(h.data(), s_dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen(dbg_path, "w")) {
+      for (int b = 0; b < nframes; ++b) {
+        for (int k = 0; k < 8; ++k) fprintf(fp, "%lld ", h[(size_t)8 * b + k]);
+        fprintf(fp, "\n");
+      }
+      fclose(fp);
+    }
   }
 }
 
@@ -308,8 +329,25 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   float* avg_full = d_avg_out ? d_avg_out : (keep_planes ? c->d_avg : nullptr);
   const int tiles = ((nframes + TF - 1) / TF) * ((n + 255) / 256);
   ss::DetectArgs da{d_psd,        z->d_thr, hist_in,   hist_out, n,         nframes,  n_learn, c->frames_pushed, c->cfg.start_level,
-                    c->d_pass,    c->d_mask, counts,    d_rel_out, avg_full, c->d_avg};
+                    c->d_pass,    c->d_mask, counts,    d_rel_out, avg_full, c->d_avg, nullptr};
+  // development diagnostic: SS_DEBUG_TIMING=<file> dumps per-workgroup time stamps of the 20th detect launch
+  static long long* s_dbg = nullptr;
+  static int s_calls = 0;
+  const char* dbg_path = getenv("SS_DEBUG_TIMING");
+  if (dbg_path) {
+    if (!s_dbg) (void)hipMalloc(&s_dbg, sizeof(long long) * 4 * 65536);
+    da.dbg = tiles <= 65536 ? s_dbg : nullptr;
+  }
   hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF>), dim3(tiles), dim3(256), 0, c->stream, da);
+  if (da.dbg && ++s_calls == 20) {
+    std::vector<long long> h((size_t)4 * tiles);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(h.data(), s_dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen(dbg_path, "w")) {
+      for (int b = 0; b < tiles; ++b) fprintf(fp, "%d %lld %lld %lld %lld\n", b, h[4 * b], h[4 * b + 1], h[4 * b + 2], h[4 * b + 3]);
+      fclose(fp);
+    }
+  }
   hipLaunchKernelGGL(ss::k_cand_emit, dim3(nframes), dim3(64), 0, c->stream, (const uint32_t*)c->d_mask, n / 32, n, nframes,
                      (const int*)counts, counts_next, (const float*)(avg_full ? avg_full : c->d_avg), cand_cap, c->d_off, d_cand_off,
                      (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr, d_cand_avg);
@@ -488,6 +526,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   c->cfg.window = nullptr;
   c->cfg.ignored = nullptr;
   c->n = cfg->fft_size;
+  c->db_off = (float)(10.0 * log10((double)cfg->sample_rate));
   while ((1 << c->logn) < c->n) ++c->logn;
   c->range_lo = cfg->range_lo;
   c->range_hi = cfg->range_hi;
