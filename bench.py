@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1024, help="frames per batch (BASELINE config 2: 1024)")
     ap.add_argument("--fft", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-buffer", action="store_true", help="one output set instead of two alternating ones")
+    ap.add_argument("--overlap", action="store_true", help="SS_FLAG_OVERLAP_STREAMS: FFT of batch k+1 on a second stream under the back end of batch k")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -134,18 +136,24 @@ def main():
     eng = pkg.SpectrumEngine(int(cfg["sample_rate"]), dist.band_center(cfg, band), fft_size=int(cfg["fft_size"]),
                              decim=int(cfg["decim"]), in_format=int(cfg["in_format"]), grouping_x=int(cfg["grouping_x"]),
                              grouping_y=int(cfg["grouping_y"]), start_level=cfg["start_level_mdB"] / 1000.0,
-                             learn_frames=int(cfg["learn_frames"]), max_batch=nb, device_id=local_rank)
+                             learn_frames=int(cfg["learn_frames"]), max_batch=nb, device_id=local_rank,
+                             flags=pkg.abi.SS_FLAG_OVERLAP_STREAMS if args.overlap else 0)
     iq = dist.synthetic_batch(cfg, band, nb)
     d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
-    d_psd = torch.empty((nb, n), dtype=torch.float32, device=dev)
+    # Outputs are double-buffered the way a streaming consumer would hold them: batch k writes set k & 1 while
+    # the consumer still owns set (k - 1) & 1 (and --overlap may then run the front end of batch k+1 under the
+    # back end of batch k).
     cap = nb * 1024
-    d_off = torch.zeros(nb + 1, dtype=torch.int32, device=dev)
-    d_idx = torch.empty(cap, dtype=torch.int32, device=dev)
-    d_avg = torch.empty(cap, dtype=torch.float32, device=dev)
+    outs = [dict(psd=torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
+                 idx=torch.empty(cap, dtype=torch.int32, device=dev), avg=torch.empty(cap, dtype=torch.float32, device=dev))
+            for _ in range(1 if args.single_buffer else 2)]
     torch.cuda.synchronize()
+    counter = [0]
 
     def step():
-        eng.process_device(d_iq, nb, psd=d_psd, cand_off=d_off, cand_idx=d_idx, cand_avg=d_avg)
+        o = outs[counter[0] % len(outs)]
+        counter[0] += 1
+        eng.process_device(d_iq, nb, psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
 
     for _ in range(max(args.warmup, 1)):  # first warm-up batch also absorbs the noise-learning frames
         step()
@@ -162,7 +170,7 @@ def main():
     kern_ms, launches = eng.kernel_timing_read()
     eng.kernel_timing(False)
     elapsed = dist.max_over_ranks(t1 - t0, device=dev)
-    ncand = int(d_off[-1].item())
+    ncand = int(outs[(counter[0] - 1) % len(outs)]["off"][-1].item())
 
     if rank == 0:
         samples_per_step = nb * n * world
@@ -177,8 +185,9 @@ def main():
             "config": {"workload": f"{n}-pt FFT, {fs / 1e6:.3f} MS/s, {nb}-frame batches, CF32 IQ resident in HBM, full chain "
                                    "(window+FFT+dB -> noise-relative -> 21x21 mean -> threshold -> candidate lists), "
                                    "one band per GPU",
-                       "fft_size": n, "frames_per_batch": nb, "bands": world, "candidates_per_batch": ncand},
-            "roofline": {"bound": "hbm", "kernel": "k_fft_psd_lds (load+window+FFT+dB)",
+                       "fft_size": n, "frames_per_batch": nb, "bands": world, "candidates_per_batch": ncand,
+                       "output_sets": len(outs)},
+            "roofline": {"bound": "hbm", "kernel": "k_fft8192_psd (load+window+FFT+dB)",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                          "kernel_us": round(kern_avg_s * 1e6, 2), "launches": launches, "traffic": None},

@@ -281,17 +281,28 @@ __global__ void k_hist_shift(const float* __restrict__ hist_in, float* __restric
 }
 
 // Candidate lists (CSR) from the mask bits: one wave per frame. The frame's offset is the sum of the
-// counts of the frames before it (this path is used for nframes <= 4096). Inside the frame every lane
-// expands its mask word into an LDS list at its scanned rank, then the wave streams the list out with
-// coalesced stores — ascending bins, frames in order, deterministic.
-// counts_next (the other half of the double-buffered counters) is cleared for the next batch.
+// counts of the frames before it (this path is used for nframes <= 4096). The wave pulls 256 mask words
+// per trip (one 16-byte load per lane), ranks them with one wave scan, expands the set bits into an LDS
+// list at their ranks, then streams the list out with coalesced stores — ascending bins, frames in
+// order, deterministic. counts_next (the other half of the double-buffered counters) is cleared for the
+// next batch. Everything a trip needs from global memory is requested before anything is waited for.
 __global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ maskbits, int words_per_row, int n, int nframes,
                                                   const int* __restrict__ counts, int* __restrict__ counts_next,
                                                   const float* __restrict__ avg, int cap, int* __restrict__ off_int,
                                                   int* __restrict__ off_out, int* __restrict__ cand_idx, float* __restrict__ cand_avg) {
-  __shared__ int list[64 * 32];
+  constexpr int LIST = 2048;
+  __shared__ int list[LIST];
   const int f = blockIdx.x;
   const int lane = threadIdx.x;
+  const uint32_t* row = maskbits + (size_t)f * words_per_row;
+  // first trip's mask words (words_per_row is a multiple of 2; rows of >= 256 words are 16-byte aligned)
+  const bool wide = (words_per_row & 3) == 0;
+  uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
+  if (wide) {
+    if (4 * lane < words_per_row) w4 = *reinterpret_cast<const uint4*>(row + 4 * lane);
+  } else if (lane < words_per_row) {
+    w4.x = row[lane];  // N = 64: two words per row, one per lane
+  }
   // offset of this frame = sum of counts[0..f): 16 ints per lane per trip, all loads independent
   int part = 0;
   for (int base = 0; base < f; base += 1024) {
@@ -315,13 +326,16 @@ __global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ m
     counts_next[f] = 0;
   }
   if (mine == 0 || !cand_idx) return;
-  const uint32_t* row = maskbits + (size_t)f * words_per_row;
   const float* arow = avg + (size_t)f * n;
+  const int words_per_trip = wide ? 256 : 64;
   int carry = begin;
-  for (int base = 0; base < words_per_row; base += 64) {
-    const int w = base + lane;
-    uint32_t bits = w < words_per_row ? row[w] : 0u;
-    const int c = __popc(bits);
+  for (int base = 0; base < words_per_row; base += words_per_trip) {
+    if (base > 0) {
+      w4 = make_uint4(0u, 0u, 0u, 0u);
+      if (base + 4 * lane < words_per_row) w4 = *reinterpret_cast<const uint4*>(row + base + 4 * lane);
+    }
+    const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
+    const int c = __popc(wv[0]) + __popc(wv[1]) + __popc(wv[2]) + __popc(wv[3]);
     int incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -330,22 +344,65 @@ __global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ m
     }
     const int total = __shfl(incl, 63);
     if (total == 0) continue;  // wave-uniform
-    int pos = incl - c;
-    while (bits) {  // LDS stores only: nothing to wait for inside the loop
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1;
-      list[pos++] = w * 32 + b;
-    }
-    __syncthreads();  // one wave: orders the LDS writes before the reads
-    for (int p = lane; p < total; p += 64) {
-      const int i = list[p];
-      const int dst = carry + p;
-      if (dst < cap) {
-        cand_idx[dst] = i;
-        if (cand_avg) cand_avg[dst] = arow[i];
+    const int first_word = wide ? base + 4 * lane : base + lane;
+    // rank of the first candidate of each of this lane's four words inside the trip
+    int wstart[4];
+    wstart[0] = incl - c;
+    wstart[1] = wstart[0] + __popc(wv[0]);
+    wstart[2] = wstart[1] + __popc(wv[1]);
+    wstart[3] = wstart[2] + __popc(wv[2]);
+    // expand in pieces of LIST entries (a whole row of hits does not fit the list at once)
+    for (int lo = 0; lo < total; lo += LIST) {
+      // Hits cluster in a few words (a transmission is a run of adjacent bins), so the words are expanded
+      // one per half-wave, one lane per BIT: the half-wave's 32 lanes test the 32 bits of a broadcast word
+      // and write the set ones at their ranks. No per-lane serial loop over bits.
+      const int half = lane >> 5, bit = lane & 31;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        unsigned long long nz = __ballot(wv[k] != 0u);
+        while (nz) {  // wave-uniform
+          const int l0 = __ffsll((long long)nz) - 1;
+          nz &= nz - 1;
+          int l1 = l0;
+          if (nz) {
+            l1 = __ffsll((long long)nz) - 1;
+            nz &= nz - 1;
+          }
+          const int src = half ? l1 : l0;
+          const uint32_t bits = __shfl(wv[k], src);
+          const int start = __shfl(wstart[k], src);
+          const int word = __shfl(first_word, src) + k;
+          const bool on = ((bits >> bit) & 1u) && !(half && l1 == l0);
+          const int pos = start + __popc(bits & ((1u << bit) - 1u)) - lo;
+          if (on && pos >= 0 && pos < LIST) list[pos] = word * 32 + bit;
+        }
       }
+      __syncthreads();  // one wave per block: orders the LDS writes before the reads
+      const int cnt = min(LIST, total - lo);
+      for (int p0 = 0; p0 < cnt; p0 += 256) {
+        int idx[4];
+        float av[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int p = p0 + k * 64 + lane;
+          idx[k] = p < cnt ? list[p] : 0;
+        }
+        if (cand_avg) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) av[k] = arow[idx[k]];  // four independent loads in flight
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int p = p0 + k * 64 + lane;
+          const int dst = carry + lo + p;
+          if (p < cnt && dst < cap) {
+            cand_idx[dst] = idx[k];
+            if (cand_avg) cand_avg[dst] = av[k];
+          }
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
     carry += total;
   }
 }

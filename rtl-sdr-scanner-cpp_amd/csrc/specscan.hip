@@ -44,12 +44,23 @@ struct ss_ctx {
   float db_off = 0.0f;  // 10*log10(fs), the constant term of PSD::work (psd.cpp:19)
   int32_t range_lo = 0, range_hi = 0;
   std::vector<int32_t> ignored;
-  hipStream_t stream = nullptr;
+  // Two streams: the front end (FFT + dB) of batch i+1 runs on stream_fft while the back end (noise,
+  // averaging, threshold, candidate lists) of batch i runs on stream. Events order them per batch.
+  hipStream_t stream = nullptr;      // back end + copies; the stream ss_stream() reports
+  hipStream_t stream_fft = nullptr;  // front end (only with SS_FLAG_OVERLAP_STREAMS)
+  hipStream_t fft_q = nullptr;       // where FFT launches go: stream_fft when overlapping, else stream
+  bool overlap = false;
+  hipEvent_t ev_fft[2] = {nullptr, nullptr};  // FFT of the batch in slot s has finished
+  hipEvent_t ev_det[2] = {nullptr, nullptr};  // back end of the batch in slot s has finished
+  const float* slot_psd[2] = {nullptr, nullptr};  // PSD plane each in-flight slot reads
+  unsigned long long batch_no = 0;
+  float* d_psd2 = nullptr;  // second internal PSD plane (slots alternate)
   // constants
   float* d_win = nullptr;
   float2* d_tw = nullptr;
   float2* d_tw8k = nullptr;  // tables of k_fft8192_psd: tw2[256] ++ tw3a[1024] ++ tw3b[2048]
   bool use_fft8192 = false;
+  int fft8192_variant = 0;  // 0 = eight-wave kernel (default); SS_FFT_IMPL selects the four-wave variants for A/B runs
   uint8_t* d_pass = nullptr;
   bool pass_dirty = true;
   // state
@@ -171,10 +182,10 @@ void launch_lds(ss_ctx* c, const void* d_iq, long long item_stride, int nframes,
   const size_t lds = sizeof(float2) << LOGTOT;
   hipEvent_t e0, e1;
   if (prof_pair(c, &e0, &e1)) {
-    hipExtLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->stream, e0, e1, 0, d_iq,
+    hipExtLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->fft_q, e0, e1, 0, d_iq,
                           item_stride, nframes, c->d_win, c->d_tw, c->db_off, c->cfg.int_scale, d_psd);
   } else {
-    hipLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->stream, d_iq, item_stride,
+    hipLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->fft_q, d_iq, item_stride,
                        nframes, c->d_win, c->d_tw, c->db_off, c->cfg.int_scale, d_psd);
   }
 }
@@ -185,9 +196,9 @@ void launch_four_step(ss_ctx* c, const void* d_iq, long long item_stride, int nf
   const size_t lds = sizeof(float2) << 13;
   const int col_tiles = N2 >> (13 - LOGN1);
   const int row_tiles = N1 >> (13 - LOGN2);
-  hipLaunchKernelGGL((ss::k_fft_cols<LOGN1, LOGN2, FMT>), dim3(nframes * col_tiles), dim3(ss::kFftThreads), lds, c->stream, d_iq,
+  hipLaunchKernelGGL((ss::k_fft_cols<LOGN1, LOGN2, FMT>), dim3(nframes * col_tiles), dim3(ss::kFftThreads), lds, c->fft_q, d_iq,
                      item_stride, c->d_win, c->d_tw, c->cfg.int_scale, c->d_work);
-  hipLaunchKernelGGL((ss::k_fft_rows_psd<LOGN1, LOGN2>), dim3(nframes * row_tiles), dim3(ss::kFftThreads), lds, c->stream, c->d_work,
+  hipLaunchKernelGGL((ss::k_fft_rows_psd<LOGN1, LOGN2>), dim3(nframes * row_tiles), dim3(ss::kFftThreads), lds, c->fft_q, c->d_work,
                      c->d_tw, c->db_off, d_psd);
 }
 
@@ -202,17 +213,49 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
     if (!s_dbg) (void)hipMalloc(&s_dbg, sizeof(long long) * 8 * 8192);
     tabs.dbg = s_dbg;
   }
-  hipEvent_t e0, e1;
-  if (prof_pair(c, &e0, &e1)) {
-    hipExtLaunchKernelGGL((ss::k_fft8192_psd<FMT>), dim3(nframes), dim3(256), ss::kFft8192LdsBytes, c->stream, e0, e1, 0, d_iq, item_stride,
-                          c->d_win, tabs, c->db_off, c->cfg.int_scale, d_psd);
-  } else {
-    hipLaunchKernelGGL((ss::k_fft8192_psd<FMT>), dim3(nframes), dim3(256), ss::kFft8192LdsBytes, c->stream, d_iq, item_stride, c->d_win, tabs,
-                       c->db_off, c->cfg.int_scale, d_psd);
-  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool timed = prof_pair(c, &e0, &e1);
+  auto launch = [&](auto kernel, int lds_bytes) {
+    if (timed) {
+      hipExtLaunchKernelGGL(kernel, dim3(nframes), dim3(256), lds_bytes, c->fft_q, e0, e1, 0, d_iq, item_stride, (const float*)c->d_win, tabs,
+                            c->db_off, c->cfg.int_scale, d_psd);
+    } else {
+      hipLaunchKernelGGL(kernel, dim3(nframes), dim3(256), lds_bytes, c->fft_q, d_iq, item_stride, (const float*)c->d_win, tabs, c->db_off,
+                         c->cfg.int_scale, d_psd);
+    }
+  };
+  auto launch8 = [&](auto kernel, int lds_bytes) {
+    if (timed) {
+      hipExtLaunchKernelGGL(kernel, dim3(nframes), dim3(512), lds_bytes, c->fft_q, e0, e1, 0, d_iq, item_stride, (const float*)c->d_win, tabs,
+                            c->db_off, c->cfg.int_scale, d_psd);
+    } else {
+      hipLaunchKernelGGL(kernel, dim3(nframes), dim3(512), lds_bytes, c->fft_q, d_iq, item_stride, (const float*)c->d_win, tabs, c->db_off,
+                         c->cfg.int_scale, d_psd);
+    }
+  };
+  static const int abl = getenv("SS_FFT_ABL") ? atoi(getenv("SS_FFT_ABL")) : 0;
+  if (abl == 11) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 11>, ss::kFft8192W8LdsBytes);
+  else if (abl == 12) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 12>, ss::kFft8192W8LdsBytes);
+  else if (abl == 13) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 13>, ss::kFft8192W8LdsBytes);
+  else if (abl == 14) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 14>, ss::kFft8192W8LdsBytes);
+  else if (abl == 15) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 15>, ss::kFft8192W8LdsBytes);
+  else if (abl == 16) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 16>, ss::kFft8192W8LdsBytes);
+  else if (abl == 17) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 16>, 0);
+  else if (abl == 1) launch(ss::k_fft8192_psd_split_abl<FMT, 3, 1>, ss::kFft8192SplitLdsBytes);
+  else if (abl == 2) launch(ss::k_fft8192_psd_split_abl<FMT, 3, 2>, ss::kFft8192SplitLdsBytes);
+  else if (abl == 3) launch(ss::k_fft8192_psd_split_abl<FMT, 3, 3>, ss::kFft8192SplitLdsBytes);
+  else if (abl == 4) launch(ss::k_fft8192_psd_split_abl<FMT, 3, 4>, ss::kFft8192SplitLdsBytes);
+  else if (c->fft8192_variant == 2) launch(ss::k_fft8192_psd<FMT>, ss::kFft8192LdsBytes);
+  else if (c->fft8192_variant == 3) launch(ss::k_fft8192_psd_split<FMT, 3>, ss::kFft8192SplitLdsBytes);
+  else if (c->fft8192_variant == 84) launch8(ss::k_fft8192_psd_w8<FMT, 4>, ss::kFft8192W8LdsBytes);
+  else if (c->fft8192_variant == 86) launch8(ss::k_fft8192_psd_w8<FMT, 6>, ss::kFft8192W8LdsBytes);
+  else if (c->fft8192_variant == 88) launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
+  else if (c->fft8192_variant == 44) launch(ss::k_fft8192_psd_split<FMT, 4>, ss::kFft8192SplitLdsBytes);
+  else if (tabs.dbg) launch8(ss::k_fft8192_psd_w8<FMT, 8, true>, ss::kFft8192W8LdsBytes);
+  else launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
   if (tabs.dbg && ++s_calls == 20) {
     std::vector<long long> h((size_t)8 * nframes);
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->fft_q);
     (void)hipMemcpy(h.data(), s_dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
     if (FILE* fp = fopen(dbg_path, "w")) {
       for (int b = 0; b < nframes; ++b) {
@@ -313,7 +356,8 @@ int run_backend_unfused(ss_ctx* c, const float* d_psd, int nframes, int n_learn,
 int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, NoiseState* z, float* d_rel_out, float* d_avg_out,
                       int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
   const int n = c->n;
-  constexpr int G = 21, GX = 21, TF = 16;
+  constexpr int G = 21, GX = 21;
+  static const int TF = getenv("SS_DETECT_TF") ? atoi(getenv("SS_DETECT_TF")) : 16;
   if (n_learn > 0) {
     hipLaunchKernelGGL(ss::k_noise_learn, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_psd, n, n_learn, z->d_thr);
   }
@@ -338,7 +382,8 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
     if (!s_dbg) (void)hipMalloc(&s_dbg, sizeof(long long) * 4 * 65536);
     da.dbg = tiles <= 65536 ? s_dbg : nullptr;
   }
-  hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF>), dim3(tiles), dim3(256), 0, c->stream, da);
+  if (TF == 32) hipLaunchKernelGGL((ss::k_detect_fused<G, GX, 32>), dim3(tiles), dim3(256), 0, c->stream, da);
+  else hipLaunchKernelGGL((ss::k_detect_fused<G, GX, 16>), dim3(tiles), dim3(256), 0, c->stream, da);
   if (da.dbg && ++s_calls == 20) {
     std::vector<long long> h((size_t)4 * tiles);
     (void)hipStreamSynchronize(c->stream);
@@ -371,12 +416,26 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     SS_HIP(c, hipStreamSynchronize(c->stream));  // `pass` is pageable and dies at scope end
     c->pass_dirty = false;
   }
-  float* d_psd = d_psd_out ? d_psd_out : c->d_psd;
+  const int slot = (int)(c->batch_no & 1);
+  float* d_psd = d_psd_out ? d_psd_out : (slot ? c->d_psd2 : c->d_psd);
+  if (c->overlap) {
+    // the batch that used this slot two calls ago must be done (bounds the pipeline depth at two), and the
+    // previous batch must be done too if its back end still reads the plane this FFT is about to overwrite
+    if (c->batch_no >= 2) SS_HIP(c, hipStreamWaitEvent(c->stream_fft, c->ev_det[slot], 0));
+    if (c->batch_no >= 1 && c->slot_psd[slot ^ 1] == d_psd) SS_HIP(c, hipStreamWaitEvent(c->stream_fft, c->ev_det[slot ^ 1], 0));
+  }
   int st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
   if (st != SS_OK) return st;
+  if (c->overlap) {
+    SS_HIP(c, hipEventRecord(c->ev_fft[slot], c->stream_fft));
+    SS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_fft[slot], 0));
+  }
   st = c->fused ? run_backend_fused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap)
                 : run_backend_unfused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap);
   if (st != SS_OK) return st;
+  if (c->overlap) SS_HIP(c, hipEventRecord(c->ev_det[slot], c->stream));
+  c->slot_psd[slot] = d_psd;
+  ++c->batch_no;
   SS_HIP(c, hipGetLastError());
   c->frames_pushed = c->frames_pushed + nframes < G ? c->frames_pushed + nframes : G;
   c->last_psd = d_psd;
@@ -418,7 +477,13 @@ int get_noise(ss_ctx* c, NoiseState** out) {
 void free_ctx(ss_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device_id);
+  if (c->stream_fft) (void)hipStreamSynchronize(c->stream_fft);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int k = 0; k < 2; ++k) {
+    if (c->ev_fft[k]) (void)hipEventDestroy(c->ev_fft[k]);
+    if (c->ev_det[k]) (void)hipEventDestroy(c->ev_det[k]);
+  }
+  if (c->stream_fft) (void)hipStreamDestroy(c->stream_fft);
   for (auto& z : c->noise) (void)hipFree(z.d_thr);
   for (auto e : c->prof_events) (void)hipEventDestroy(e);
   (void)hipFree(c->d_win);
@@ -433,6 +498,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_relplane);
   (void)hipFree(c->d_hist_tmp);
   (void)hipFree(c->d_psd);
+  (void)hipFree(c->d_psd2);
   (void)hipFree(c->d_avgy);
   (void)hipFree(c->d_avg);
   (void)hipFree(c->d_work);
@@ -547,6 +613,13 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   } while (0)
   CREATE_HIP(hipSetDevice(cfg->device_id));
   CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CREATE_HIP(hipStreamCreateWithFlags(&c->stream_fft, hipStreamNonBlocking));
+  c->overlap = (cfg->flags & SS_FLAG_OVERLAP_STREAMS) != 0;
+  c->fft_q = c->overlap ? c->stream_fft : c->stream;
+  for (int k = 0; k < 2; ++k) {
+    CREATE_HIP(hipEventCreateWithFlags(&c->ev_fft[k], hipEventDisableTiming));
+    CREATE_HIP(hipEventCreateWithFlags(&c->ev_det[k], hipEventDisableTiming));
+  }
   CREATE_HIP(hipMalloc(&c->d_win, sizeof(float) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_tw, sizeof(float2) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_pass, (size_t)n));
@@ -568,6 +641,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)n * (size_t)(G - 1 + cfg->max_batch), c->stream));
   }
   CREATE_HIP(hipMalloc(&c->d_psd, plane));
+  CREATE_HIP(hipMalloc(&c->d_psd2, plane));
   CREATE_HIP(hipMalloc(&c->d_avg, plane));
   CREATE_HIP(hipMalloc(&c->d_mask, sizeof(uint32_t) * (size_t)(n / 32) * (size_t)cfg->max_batch));
   CREATE_HIP(hipMalloc(&c->d_counts, sizeof(int) * (size_t)cfg->max_batch));
@@ -592,6 +666,12 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     if (n == 8192) {
       const char* impl = getenv("SS_FFT_IMPL");  // "generic" selects the radix-4 LDS kernel (A/B measurements)
       c->use_fft8192 = !(impl && strcmp(impl, "generic") == 0);
+      if (impl && strcmp(impl, "wide") == 0) c->fft8192_variant = 2;
+      if (impl && strcmp(impl, "split3") == 0) c->fft8192_variant = 3;
+      if (impl && strcmp(impl, "split4") == 0) c->fft8192_variant = 44;
+      if (impl && strcmp(impl, "w8x4") == 0) c->fft8192_variant = 84;
+      if (impl && strcmp(impl, "w8x6") == 0) c->fft8192_variant = 86;
+      if (impl && strcmp(impl, "w8x8") == 0) c->fft8192_variant = 88;
       std::vector<float2> t8((size_t)(256 + 1024 + 2048));
       auto W = [](double num, double den) {
         const double ang = -2.0 * M_PI * num / den;
@@ -625,6 +705,7 @@ void* ss_stream(ss_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int ss_sync(ss_ctx* ctx) {
   if (!ctx) return SS_ERR_INVALID;
   SS_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+  SS_HIP(ctx, hipStreamSynchronize(ctx->stream_fft));
   SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SS_OK;
 }
@@ -641,6 +722,7 @@ int ss_kernel_timing_read(ss_ctx* c, double* total_ms, int32_t* launches) {
   if (!c || !total_ms || !launches) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  SS_HIP(c, hipStreamSynchronize(c->stream_fft));
   SS_HIP(c, hipStreamSynchronize(c->stream));
   double sum = 0.0;
   for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
@@ -692,7 +774,7 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
   if (!c->d_in) SS_HIP(c, hipMalloc(&c->d_in, row_bytes * (size_t)c->cfg.max_batch));
   // Decimator: only the first N samples of each N*D item ever reach the GPU (decimator.h:15-22)
   SS_HIP(c, hipMemcpy2DAsync(c->d_in, row_bytes, iq, row_bytes * (size_t)c->cfg.decim, row_bytes, (size_t)nframes, hipMemcpyHostToDevice,
-                             c->stream));
+                             c->fft_q));
   if (cand_cap > c->cand_cap_alloc) {
     (void)hipFree(c->d_cand_idx);
     (void)hipFree(c->d_cand_avg);
@@ -717,7 +799,7 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
                  want_cands ? c->d_cand_idx : nullptr, want_cands && cand_avg ? c->d_cand_avg : nullptr, cand_cap);
   if (st != SS_OK) return st;
   const size_t plane = sizeof(float) * (size_t)n * (size_t)nframes;
-  if (psd_db) SS_HIP(c, hipMemcpyAsync(psd_db, c->d_psd, plane, hipMemcpyDeviceToHost, c->stream));
+  if (psd_db) SS_HIP(c, hipMemcpyAsync(psd_db, c->last_psd, plane, hipMemcpyDeviceToHost, c->stream));
   if (rel_db) {
     const float* src = c->fused ? c->d_relplane : c->d_rel + (size_t)(c->cfg.grouping_y - 1) * n;
     SS_HIP(c, hipMemcpyAsync(rel_db, src, plane, hipMemcpyDeviceToHost, c->stream));
