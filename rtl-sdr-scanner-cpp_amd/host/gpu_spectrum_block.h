@@ -1,0 +1,88 @@
+// gpu_spectrum_block.h — the reference-side adapter: one GNU Radio block that replaces the chain
+//   Decimator -> fft_v -> PSD -> NoiseLearner -> Transmission(front)
+// wired at sources/radio/sdr_device.cpp:161-168 of shajen/rtl-sdr-scanner-cpp, by calling libspecscan.so
+// through the C ABI of include/specscan.h. Header-only, C++17, depends on GNU Radio's sync_block only
+// (tests compile it against oracle/stubs/gnuradio/sync_block.h).
+//
+//   input  0: items of N*D gr_complex  (what stream_to_vector + Blocker deliver, sdr_device.cpp:161-162)
+//   output 0: items of N float, the raw PSD in dB (what PSD::work produced, psd.cpp:18-20) — feeds the
+//             Spectrogram side branch (sdr_device.cpp:170-171) unchanged
+//   candidates: per frame, the bins passing transmission.cpp:91 and their avg power, handed to a callback
+//             on the work() thread, in frame order — the input of Transmission::addSignals' sort (:95)
+//
+// Control calls mirror what SdrDevice does to the blocks it owns: setFrequencyRange (sdr_device.cpp:54-80)
+// -> set_frequency_range() + reset_buffers(); they are serialised against work() inside the library.
+#pragma once
+#include <gnuradio/sync_block.h>
+#include <specscan.h>
+
+#include <chrono>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+class GpuSpectrum : virtual public gr::sync_block {
+ public:
+  // frame index inside this work() call, candidate bins (ascending), their avg power in dB
+  using CandidateCallback = std::function<void(int frame, const int32_t* bins, const float* avg_db, int count)>;
+
+  GpuSpectrum(const ss_config& config, CandidateCallback on_candidates)
+      : gr::sync_block("GpuSpectrum", gr::io_signature::make(1, 1, sizeof(gr_complex) * config.fft_size * config.decim),
+                       gr::io_signature::make(1, 1, sizeof(float) * config.fft_size)),
+        m_config(config),
+        m_onCandidates(std::move(on_candidates)) {
+    // construction errors throw, like the reference's blocks (caught per device at sources/main.cpp:60-62)
+    if (ss_create(&m_config, &m_ctx) != SS_OK) {
+      throw std::runtime_error(std::string("GpuSpectrum: ") + ss_last_error(nullptr));
+    }
+    m_offsets.resize(static_cast<size_t>(m_config.max_batch) + 1);
+    m_bins.resize(static_cast<size_t>(m_config.max_batch) * 1024);
+    m_avg.resize(m_bins.size());
+    m_times.resize(static_cast<size_t>(m_config.max_batch));
+  }
+
+  ~GpuSpectrum() override { ss_destroy(m_ctx); }
+
+  GpuSpectrum(const GpuSpectrum&) = delete;
+  GpuSpectrum& operator=(const GpuSpectrum&) = delete;
+
+  int work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override {
+    const int nframes = noutput_items < m_config.max_batch ? noutput_items : m_config.max_batch;
+    // the reference's blocks read the wall clock per frame (noise_learner.cpp:18, transmission.cpp:62)
+    const auto now = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+    for (int f = 0; f < nframes; ++f) m_times[static_cast<size_t>(f)] = now;
+    const int status = ss_process(m_ctx, input_items[0], nframes, m_times.data(), static_cast<float*>(output_items[0]), nullptr, nullptr,
+                                  m_offsets.data(), m_bins.data(), m_avg.data(), static_cast<int32_t>(m_bins.size()));
+    if (status != SS_OK && status != SS_ERR_CAND_OVERFLOW) {
+      // work() has no error channel in the reference either (sdr_source.cpp:37-41 logs and exits): produce nothing
+      m_lastError = ss_last_error(m_ctx);
+      return 0;
+    }
+    if (m_onCandidates) {
+      const int32_t cap = static_cast<int32_t>(m_bins.size());
+      for (int f = 0; f < nframes; ++f) {
+        const int32_t begin = m_offsets[static_cast<size_t>(f)] < cap ? m_offsets[static_cast<size_t>(f)] : cap;
+        const int32_t end = m_offsets[static_cast<size_t>(f) + 1] < cap ? m_offsets[static_cast<size_t>(f) + 1] : cap;
+        m_onCandidates(f, m_bins.data() + begin, m_avg.data() + begin, end - begin);
+      }
+    }
+    return nframes;
+  }
+
+  // SdrDevice::setFrequencyRange's effect on the chain (sdr_device.cpp:66,74,77)
+  void setFrequencyRange(int32_t lo_hz, int32_t hi_hz) { ss_set_frequency_range(m_ctx, lo_hz, hi_hz); }
+  void resetBuffers() { ss_reset(m_ctx); }  // Transmission::resetBuffers, transmission.cpp:42-55
+  const std::string& lastError() const { return m_lastError; }
+
+ private:
+  ss_config m_config;
+  ss_ctx* m_ctx = nullptr;
+  CandidateCallback m_onCandidates;
+  std::vector<int32_t> m_offsets, m_bins;
+  std::vector<float> m_avg;
+  std::vector<int64_t> m_times;
+  std::string m_lastError;
+};
