@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--fft", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-buffer", action="store_true", help="one output set instead of two alternating ones")
+    ap.add_argument("--time-every", type=int, default=8, help="attach start/stop events to every k-th launch of the FFT kernel")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not attach per-launch events to the FFT kernel (roofline omitted)")
     ap.add_argument("--overlap", action="store_true", help="SS_FLAG_OVERLAP_STREAMS: FFT of batch k+1 on a second stream under the back end of batch k")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -146,7 +148,7 @@ def main():
     cap = nb * 1024
     outs = [dict(psd=torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
                  idx=torch.empty(cap, dtype=torch.int32, device=dev), avg=torch.empty(cap, dtype=torch.float32, device=dev))
-            for _ in range(1 if args.single_buffer else 2)]
+            for _ in range(1 if args.single_buffer else (4 if args.overlap else 2))]
     torch.cuda.synchronize()
     counter = [0]
 
@@ -158,17 +160,18 @@ def main():
     for _ in range(max(args.warmup, 1)):  # first warm-up batch also absorbs the noise-learning frames
         step()
     eng.sync()
-    eng.kernel_timing(True)
+    eng.kernel_timing(0 if args.no_kernel_timing else args.time_every)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter()
     torch.cuda.synchronize()
     dist.barrier()
     t1 = time.perf_counter()
     kern_ms, launches = eng.kernel_timing_read()
-    eng.kernel_timing(False)
+    eng.kernel_timing(0)
     elapsed = dist.max_over_ranks(t1 - t0, device=dev)
     ncand = int(outs[(counter[0] - 1) % len(outs)]["off"][-1].item())
 
@@ -186,7 +189,7 @@ def main():
                                    "(window+FFT+dB -> noise-relative -> 21x21 mean -> threshold -> candidate lists), "
                                    "one band per GPU",
                        "fft_size": n, "frames_per_batch": nb, "bands": world, "candidates_per_batch": ncand,
-                       "output_sets": len(outs)},
+                       "output_sets": len(outs), "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_fft8192_psd (load+window+FFT+dB)",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),

@@ -136,7 +136,8 @@ int ss_process_device(ss_ctx* ctx, const void* d_iq, int32_t nframes,
 int ss_sync(ss_ctx* ctx);
 void* ss_stream(ss_ctx* ctx); /* the hipStream_t ss_process_device enqueues on */
 
-/* Measurement aid (bench.py): when enabled, every launch of the dominant kernel (fused load + window +
+/* Measurement aid (bench.py): when enabled (enable = 1: every launch, enable = k > 1: every k-th launch, to keep
+ * the ~4 us the two event packets cost out of most steps), a launch of the dominant kernel (fused load + window +
  * FFT + dB) carries its own start/stop events on the context's stream; ss_kernel_timing_read
  * synchronises the stream, returns the summed device time in ms and the number of timed launches,
  * and clears the tally. Replaces the reference's PerformanceLogger::kick (sources/performance_logger.cpp:9-22,

@@ -40,10 +40,10 @@ __device__ __forceinline__ float div_const(float s) {
   return fmaf(e, r, q0);
 }
 
-template <int G, int GX, int TF>
+template <int G, int GX, int TF, int TB_ = 256>
 struct DetectTile {
   static constexpr int A = GX / 2;
-  static constexpr int TB = 256;
+  static constexpr int TB = TB_;           // bins per tile = threads per workgroup
   static constexpr int P = TB + 2 * A;     // tile pitch in floats (276 for GX = 21: rows stay 16-byte aligned)
   static constexpr int ROWS = G - 1 + TF;  // rel rows a column needs
   static constexpr int SEGW = 16;          // bins per phase-2 thread
@@ -81,9 +81,9 @@ __device__ __forceinline__ void time_means_to_tile(const float (&x)[G - 1 + TF],
   }
 }
 
-template <int G, int GX, int TF>
-__global__ __launch_bounds__(256) void k_detect_fused(DetectArgs a) {
-  using T = DetectTile<G, GX, TF>;
+template <int G, int GX, int TF, int TB_ = 256>
+__global__ __launch_bounds__(TB_) void k_detect_fused(DetectArgs a) {
+  using T = DetectTile<G, GX, TF, TB_>;
   constexpr int A = T::A, TB = T::TB, P = T::P, ROWS = T::ROWS, SEGW = T::SEGW, NSEG = T::NSEG, YW = T::YW;
   __shared__ __attribute__((aligned(16))) float tile[TF * P];
   __shared__ int cnt[TF];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_detect_fused(DetectArgs a) {
   } else {
     // general path: ring rows from before the batch, learning frames, averager warm-up, ragged batch end,
     // band edges, and the ring update. Rows are walked one at a time (few tiles take this path).
-    for (int c = tid; c < P; c += 256) {
+    for (int c = tid; c < P; c += TB) {
       const int col = b0 - A + c;
       if (col < 0 || col >= n) {
         for (int j = 0; j < TF; ++j) tile[j * P + c] = 0.0f;  // outside the band: contributes exactly nothing to the clipped window sums
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_detect_fused(DetectArgs a) {
 
   // ---------------- phase 2: frequency means + threshold, thread = (frame, 16-bin segment) ----------------
 #pragma unroll
-  for (int q0 = 0; q0 < TF * NSEG; q0 += 256) {
+  for (int q0 = 0; q0 < TF * NSEG; q0 += TB) {
     const int q = q0 + tid;
     const int fj = q % TF;
     const int seg = q / TF;

@@ -689,6 +689,118 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
   }
 }
 
+
+// Eight-wave kernel, whole-complex (float2) LDS exchanges: 68 KiB of LDS per workgroup (two frames in flight per
+// CU, two rounds of workgroups per 1024-frame launch), three barriers instead of seven, and a 128-VGPR budget
+// that lets every table value (pass-2 and pass-3 twiddles) be requested at the top of the kernel next to the IQ
+// loads, so no table load sits behind a barrier.
+constexpr int kFft8192W8WideLdsBytes = (8192 + 512) * 8;
+
+template <int FMT>
+__global__ __launch_bounds__(512, 4) void k_fft8192_psd_w8wide(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
+                                                                Fft8192Tables tabs, float db_off, float scale, float* __restrict__ psd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float2* s = reinterpret_cast<float2*>(smem_raw);
+  const int t = threadIdx.x;
+  const size_t frame = blockIdx.x;
+  const size_t in_base = frame * (size_t)item_stride;
+  const int lane = t & 63;
+  const int h = lane >> 5;
+  const int j = ((t >> 6) << 5) + (lane & 31);
+
+  // ---------------- all global reads of the frame up front: IQ, window, twiddles ----------------
+  float2 a[16];
+  float w[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int e = t + 512 * r;
+    a[r] = load_iq<FMT>(iq, in_base + e, scale);
+    w[r] = win[e];
+  }
+  float2 tw2[16];
+  {
+    const int m = t & 15;
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tw2[r] = tabs.tw2[r * 16 + m];
+  }
+  const float2 wa0 = tabs.tw3a[h * 256 + j];
+  const float2 wa1 = tabs.tw3a[(2 + h) * 256 + j];
+  float2 wb[8];
+#pragma unroll
+  for (int q2 = 1; q2 < 8; ++q2) wb[q2] = tabs.tw3b[q2 * 256 + j];
+
+  // ---------------- pass 1: radix 16, Ns = 1, butterfly j = t ----------------
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = make_float2(a[r].x * w[r], a[r].y * w[r]);  // volk_32fc_32f_multiply_32fc
+  dft16(a);
+  // exchange 1: y[16 t + k] at element 17 t + k
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s[17 * t + k] = a[slot16(k)];
+  __syncthreads();
+  // ---------------- pass 2: radix 16, Ns = 16, butterfly j = t ----------------
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int e = t + 512 * r;
+    a[r] = s[e + (e >> 4)];
+  }
+#pragma unroll
+  for (int r = 1; r < 16; ++r) a[r] = cmul(a[r], tw2[r]);
+  dft16(a);
+  __syncthreads();  // every read of y is done before z overwrites the buffer
+  // exchange 2: z[(t/16)*256 + t%16 + 16 k]; pass 3 lane (w, l) reads z[j + 256 (2q + h)]
+  {
+    const int zbase = ((t >> 4) << 8) + (t & 15);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s[zbase + 16 * k] = a[slot16(k)];
+  }
+  __syncthreads();
+  {
+    const int rbase = j + 256 * h;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = s[rbase + 512 * q];
+  }
+  // ---------------- pass 3: radix 32, Ns = 256, butterfly j shared by lanes l and l + 32 ----------------
+  a[0] = cmul(a[0], wa0);
+  a[1] = cmul(a[1], wa1);
+#pragma unroll
+  for (int q2 = 1; q2 < 8; ++q2) {
+    a[2 * q2] = cmul(a[2 * q2], cmul(wa0, wb[q2]));
+    a[2 * q2 + 1] = cmul(a[2 * q2 + 1], cmul(wa1, wb[q2]));
+  }
+  dft16(a);  // A_h[k] in slot16(k)
+  const bool odd = h != 0;
+  float2 u[16];
+  u[0] = a[slot16(0)];
+  u[1] = mulw32_if<1>(a[slot16(1)], odd);
+  u[2] = mulw32_if<2>(a[slot16(2)], odd);
+  u[3] = mulw32_if<3>(a[slot16(3)], odd);
+  u[4] = mulw32_if<4>(a[slot16(4)], odd);
+  u[5] = mulw32_if<5>(a[slot16(5)], odd);
+  u[6] = mulw32_if<6>(a[slot16(6)], odd);
+  u[7] = mulw32_if<7>(a[slot16(7)], odd);
+  u[8] = mulw32_if<8>(a[slot16(8)], odd);
+  u[9] = mulw32_if<9>(a[slot16(9)], odd);
+  u[10] = mulw32_if<10>(a[slot16(10)], odd);
+  u[11] = mulw32_if<11>(a[slot16(11)], odd);
+  u[12] = mulw32_if<12>(a[slot16(12)], odd);
+  u[13] = mulw32_if<13>(a[slot16(13)], odd);
+  u[14] = mulw32_if<14>(a[slot16(14)], odd);
+  u[15] = mulw32_if<15>(a[slot16(15)], odd);
+  float* out = psd + frame * 8192;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].x), __float_as_uint(u[k + 8].x), false, false);
+    const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].y), __float_as_uint(u[k + 8].y), false, false);
+    const float2 e = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
+    const float2 o = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
+    const int kk = k + 8 * h;
+    const int bin0 = j + 256 * kk;
+    const int bin1 = bin0 + 256 * 16;
+    out[bin0 ^ 4096] = psd_db(cadd(e, o), db_off);
+    out[bin1 ^ 4096] = psd_db(csub(e, o), db_off);
+  }
+}
+
 // Timing-only ablations of k_fft8192_psd_w8 (wrong results by construction; SS_FFT_ABL=11..15):
 //   11 = no HBM input loads, 12 = no LDS exchanges/barriers, 13 = no HBM stores, 14 = no window/twiddle loads, 15 = no butterflies
 template <int FMT, int WAVES_PER_SIMD, int ABL>

@@ -50,11 +50,12 @@ struct ss_ctx {
   hipStream_t stream_fft = nullptr;  // front end (only with SS_FLAG_OVERLAP_STREAMS)
   hipStream_t fft_q = nullptr;       // where FFT launches go: stream_fft when overlapping, else stream
   bool overlap = false;
-  hipEvent_t ev_fft[2] = {nullptr, nullptr};  // FFT of the batch in slot s has finished
-  hipEvent_t ev_det[2] = {nullptr, nullptr};  // back end of the batch in slot s has finished
-  const float* slot_psd[2] = {nullptr, nullptr};  // PSD plane each in-flight slot reads
+  static constexpr int kSlots = 4;             // batches in flight when overlapping (ring of slots)
+  hipEvent_t ev_fft[kSlots] = {};              // FFT of the batch in slot s has finished
+  hipEvent_t ev_det[kSlots] = {};              // back end of the batch in slot s has finished
+  const float* slot_psd[kSlots] = {};          // PSD plane the back end of slot s reads
   unsigned long long batch_no = 0;
-  float* d_psd2 = nullptr;  // second internal PSD plane (slots alternate)
+  float* d_psd_ring[kSlots] = {};              // internal PSD planes, one per slot ([0] aliases d_psd), lazily allocated
   // constants
   float* d_win = nullptr;
   float2* d_tw = nullptr;
@@ -98,6 +99,8 @@ struct ss_ctx {
   // optional per-launch timing of the dominant (FFT+PSD) kernel: start/stop events attached to the
   // dispatch itself (hipExtLaunchKernelGGL), read back by ss_kernel_timing_read
   bool prof_on = false;
+  int prof_every = 1;       // attach events to every prof_every-th launch only (the event packets cost ~4 us of GPU timeline each)
+  unsigned prof_seen = 0;
   std::vector<hipEvent_t> prof_events;  // pairs
   size_t prof_used = 0;
   std::mutex mtx;
@@ -160,6 +163,7 @@ NoiseState* noise_for(ss_ctx* c, int32_t center) {
 // next start/stop event pair for a timed launch, or false when timing is off / the pool is exhausted
 bool prof_pair(ss_ctx* c, hipEvent_t* a, hipEvent_t* b) {
   if (!c->prof_on) return false;
+  if ((c->prof_seen++ % (unsigned)c->prof_every) != 0) return false;
   if (c->prof_used + 2 > c->prof_events.size()) {
     if (c->prof_events.size() >= 2 * 8192) return false;
     hipEvent_t e0, e1;
@@ -247,6 +251,7 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
   else if (abl == 4) launch(ss::k_fft8192_psd_split_abl<FMT, 3, 4>, ss::kFft8192SplitLdsBytes);
   else if (c->fft8192_variant == 2) launch(ss::k_fft8192_psd<FMT>, ss::kFft8192LdsBytes);
   else if (c->fft8192_variant == 3) launch(ss::k_fft8192_psd_split<FMT, 3>, ss::kFft8192SplitLdsBytes);
+  else if (c->fft8192_variant == 80) launch8(ss::k_fft8192_psd_w8wide<FMT>, ss::kFft8192W8WideLdsBytes);
   else if (c->fft8192_variant == 84) launch8(ss::k_fft8192_psd_w8<FMT, 4>, ss::kFft8192W8LdsBytes);
   else if (c->fft8192_variant == 86) launch8(ss::k_fft8192_psd_w8<FMT, 6>, ss::kFft8192W8LdsBytes);
   else if (c->fft8192_variant == 88) launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
@@ -371,7 +376,9 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   int* counts_next = c->d_cnt2[c->cnt_cur ^ 1];
   const bool keep_planes = (c->cfg.flags & SS_FLAG_KEEP_PLANES) != 0;
   float* avg_full = d_avg_out ? d_avg_out : (keep_planes ? c->d_avg : nullptr);
-  const int tiles = ((nframes + TF - 1) / TF) * ((n + 255) / 256);
+  static const int TB = getenv("SS_DETECT_TB") ? atoi(getenv("SS_DETECT_TB")) : 256;
+  const int tb = (TB == 128 && n >= 128) ? 128 : 256;
+  const int tiles = ((nframes + TF - 1) / TF) * ((n + tb - 1) / tb);
   ss::DetectArgs da{d_psd,        z->d_thr, hist_in,   hist_out, n,         nframes,  n_learn, c->frames_pushed, c->cfg.start_level,
                     c->d_pass,    c->d_mask, counts,    d_rel_out, avg_full, c->d_avg, nullptr};
   // development diagnostic: SS_DEBUG_TIMING=<file> dumps per-workgroup time stamps of the 20th detect launch
@@ -383,6 +390,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
     da.dbg = tiles <= 65536 ? s_dbg : nullptr;
   }
   if (TF == 32) hipLaunchKernelGGL((ss::k_detect_fused<G, GX, 32>), dim3(tiles), dim3(256), 0, c->stream, da);
+  else if (tb == 128) hipLaunchKernelGGL((ss::k_detect_fused<G, GX, 16, 128>), dim3(tiles), dim3(128), 0, c->stream, da);
   else hipLaunchKernelGGL((ss::k_detect_fused<G, GX, 16>), dim3(tiles), dim3(256), 0, c->stream, da);
   if (da.dbg && ++s_calls == 20) {
     std::vector<long long> h((size_t)4 * tiles);
@@ -416,13 +424,25 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     SS_HIP(c, hipStreamSynchronize(c->stream));  // `pass` is pageable and dies at scope end
     c->pass_dirty = false;
   }
-  const int slot = (int)(c->batch_no & 1);
-  float* d_psd = d_psd_out ? d_psd_out : (slot ? c->d_psd2 : c->d_psd);
+  constexpr int S = ss_ctx::kSlots;
+  const int slot = c->overlap ? (int)(c->batch_no % S) : 0;
+  float* d_psd = d_psd_out;
+  if (!d_psd) {
+    if (slot == 0) {
+      d_psd = c->d_psd;
+    } else {
+      if (!c->d_psd_ring[slot]) SS_HIP(c, hipMalloc(&c->d_psd_ring[slot], sizeof(float) * (size_t)c->n * (size_t)c->cfg.max_batch));
+      d_psd = c->d_psd_ring[slot];
+    }
+  }
   if (c->overlap) {
-    // the batch that used this slot two calls ago must be done (bounds the pipeline depth at two), and the
-    // previous batch must be done too if its back end still reads the plane this FFT is about to overwrite
-    if (c->batch_no >= 2) SS_HIP(c, hipStreamWaitEvent(c->stream_fft, c->ev_det[slot], 0));
-    if (c->batch_no >= 1 && c->slot_psd[slot ^ 1] == d_psd) SS_HIP(c, hipStreamWaitEvent(c->stream_fft, c->ev_det[slot ^ 1], 0));
+    // The front end runs ahead of the back end by up to S-1 batches. It must not overwrite a PSD plane an
+    // unfinished back end still reads: wait for the batch that used this slot S calls ago, and for any younger
+    // batch that was given the same plane (a caller that rotates fewer than S output sets).
+    for (int back = 1; back <= S && (unsigned long long)back <= c->batch_no; ++back) {
+      const int s2 = (int)((c->batch_no - back) % S);
+      if (back == S || c->slot_psd[s2] == d_psd) SS_HIP(c, hipStreamWaitEvent(c->stream_fft, c->ev_det[s2], 0));
+    }
   }
   int st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
   if (st != SS_OK) return st;
@@ -479,7 +499,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipSetDevice(c->cfg.device_id);
   if (c->stream_fft) (void)hipStreamSynchronize(c->stream_fft);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < ss_ctx::kSlots; ++k) {
     if (c->ev_fft[k]) (void)hipEventDestroy(c->ev_fft[k]);
     if (c->ev_det[k]) (void)hipEventDestroy(c->ev_det[k]);
   }
@@ -498,7 +518,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_relplane);
   (void)hipFree(c->d_hist_tmp);
   (void)hipFree(c->d_psd);
-  (void)hipFree(c->d_psd2);
+  for (int k = 1; k < ss_ctx::kSlots; ++k) (void)hipFree(c->d_psd_ring[k]);
   (void)hipFree(c->d_avgy);
   (void)hipFree(c->d_avg);
   (void)hipFree(c->d_work);
@@ -616,7 +636,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   CREATE_HIP(hipStreamCreateWithFlags(&c->stream_fft, hipStreamNonBlocking));
   c->overlap = (cfg->flags & SS_FLAG_OVERLAP_STREAMS) != 0;
   c->fft_q = c->overlap ? c->stream_fft : c->stream;
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < ss_ctx::kSlots; ++k) {
     CREATE_HIP(hipEventCreateWithFlags(&c->ev_fft[k], hipEventDisableTiming));
     CREATE_HIP(hipEventCreateWithFlags(&c->ev_det[k], hipEventDisableTiming));
   }
@@ -641,7 +661,6 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)n * (size_t)(G - 1 + cfg->max_batch), c->stream));
   }
   CREATE_HIP(hipMalloc(&c->d_psd, plane));
-  CREATE_HIP(hipMalloc(&c->d_psd2, plane));
   CREATE_HIP(hipMalloc(&c->d_avg, plane));
   CREATE_HIP(hipMalloc(&c->d_mask, sizeof(uint32_t) * (size_t)(n / 32) * (size_t)cfg->max_batch));
   CREATE_HIP(hipMalloc(&c->d_counts, sizeof(int) * (size_t)cfg->max_batch));
@@ -669,6 +688,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       if (impl && strcmp(impl, "wide") == 0) c->fft8192_variant = 2;
       if (impl && strcmp(impl, "split3") == 0) c->fft8192_variant = 3;
       if (impl && strcmp(impl, "split4") == 0) c->fft8192_variant = 44;
+      if (impl && strcmp(impl, "w8wide") == 0) c->fft8192_variant = 80;
       if (impl && strcmp(impl, "w8x4") == 0) c->fft8192_variant = 84;
       if (impl && strcmp(impl, "w8x6") == 0) c->fft8192_variant = 86;
       if (impl && strcmp(impl, "w8x8") == 0) c->fft8192_variant = 88;
@@ -714,6 +734,8 @@ int ss_kernel_timing(ss_ctx* c, int enable) {
   if (!c) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
   c->prof_on = enable != 0;
+  c->prof_every = enable > 1 ? enable : 1;
+  c->prof_seen = 0;
   c->prof_used = 0;
   return SS_OK;
 }

@@ -76,8 +76,9 @@ class SpectrumEngine(abi.Chain):
     def sync(self):
         self._check(self._lib.ss_sync(self._h))
 
-    def kernel_timing(self, enable: bool):
-        self._check(self._lib.ss_kernel_timing(self._h, 1 if enable else 0))
+    def kernel_timing(self, every: int):
+        """0 = off, 1 = time every launch of the FFT+PSD kernel, k > 1 = every k-th launch."""
+        self._check(self._lib.ss_kernel_timing(self._h, int(every)))
 
     def kernel_timing_read(self):
         """(total device ms, launches) of the timed FFT+PSD launches since the last read."""

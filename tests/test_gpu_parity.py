@@ -254,7 +254,7 @@ def test_overlapped_streams_give_identical_results():
     want = [plain.process(iq[k * nb:(k + 1) * nb], want=("psd",)) for k in range(5)]
     dev = torch.device("cuda:0")
     d_iq = torch.from_numpy(iq.view(np.float32)).to(dev).reshape(5, nb, 2 * n)
-    for nsets in (2, 1):
+    for nsets in (5, 2, 1):
         eng = pkg.SpectrumEngine(fs, center, flags=pkg.abi.SS_FLAG_OVERLAP_STREAMS, **kw)
         sets = [dict(psd=torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
                      idx=torch.empty(nb * n, dtype=torch.int32, device=dev)) for _ in range(nsets)]
@@ -262,16 +262,15 @@ def test_overlapped_streams_give_identical_results():
         got = []
         for k in range(5):
             o = sets[k % nsets]
-            eng.process_device(d_iq[k], nb, psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"])
-            if nsets == 1 or k % 2 == 1:  # a consumer drains the sets it owns
+            if nsets < 5 and k >= nsets:  # a consumer drains a set before handing it back
                 eng.sync()
-                for kk in ([k] if nsets == 1 else [k - 1, k]):
-                    oo = sets[kk % nsets]
-                    got.append((kk, oo["psd"].cpu().numpy().copy(), oo["off"].cpu().numpy().copy(), oo["idx"].cpu().numpy().copy()))
+                kk = k - nsets
+                got.append((kk, o["psd"].cpu().numpy().copy(), o["off"].cpu().numpy().copy(), o["idx"].cpu().numpy().copy()))
+            eng.process_device(d_iq[k], nb, psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"])
         eng.sync()
-        if nsets == 2:
-            oo = sets[0]
-            got.append((4, oo["psd"].cpu().numpy().copy(), oo["off"].cpu().numpy().copy(), oo["idx"].cpu().numpy().copy()))
+        for kk in range(max(0, 5 - nsets), 5):
+            oo = sets[kk % nsets]
+            got.append((kk, oo["psd"].cpu().numpy().copy(), oo["off"].cpu().numpy().copy(), oo["idx"].cpu().numpy().copy()))
         assert sorted(g[0] for g in got) == [0, 1, 2, 3, 4]
         for kk, psd, off, idx in got:
             np.testing.assert_array_equal(psd, want[kk]["psd"])
