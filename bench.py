@@ -111,7 +111,6 @@ def main():
     ap.add_argument("--single-buffer", action="store_true", help="one output set instead of two alternating ones")
     ap.add_argument("--time-every", type=int, default=8, help="attach start/stop events to every k-th launch of the FFT kernel")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not attach per-launch events to the FFT kernel (roofline omitted)")
-    ap.add_argument("--overlap", action="store_true", help="SS_FLAG_OVERLAP_STREAMS: FFT of batch k+1 on a second stream under the back end of batch k")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -138,17 +137,15 @@ def main():
     eng = pkg.SpectrumEngine(int(cfg["sample_rate"]), dist.band_center(cfg, band), fft_size=int(cfg["fft_size"]),
                              decim=int(cfg["decim"]), in_format=int(cfg["in_format"]), grouping_x=int(cfg["grouping_x"]),
                              grouping_y=int(cfg["grouping_y"]), start_level=cfg["start_level_mdB"] / 1000.0,
-                             learn_frames=int(cfg["learn_frames"]), max_batch=nb, device_id=local_rank,
-                             flags=pkg.abi.SS_FLAG_OVERLAP_STREAMS if args.overlap else 0)
+                             learn_frames=int(cfg["learn_frames"]), max_batch=nb, device_id=local_rank)
     iq = dist.synthetic_batch(cfg, band, nb)
     d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
     # Outputs are double-buffered the way a streaming consumer would hold them: batch k writes set k & 1 while
-    # the consumer still owns set (k - 1) & 1 (and --overlap may then run the front end of batch k+1 under the
-    # back end of batch k).
+    # the consumer still owns set (k - 1) & 1.
     cap = nb * 1024
     outs = [dict(psd=torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
                  idx=torch.empty(cap, dtype=torch.int32, device=dev), avg=torch.empty(cap, dtype=torch.float32, device=dev))
-            for _ in range(1 if args.single_buffer else (4 if args.overlap else 2))]
+            for _ in range(1 if args.single_buffer else 2)]
     torch.cuda.synchronize()
     counter = [0]
 

@@ -65,11 +65,6 @@ typedef enum ss_plane {
 /* ss_config.flags: keep the full avg plane of every batch on the device so that ss_read_window can serve
  * SS_PLANE_AVG (the host-side signal tracker needs it); costs 4 B/sample of extra HBM writes. */
 #define SS_FLAG_KEEP_PLANES 1u
-/* Run the front end (FFT + dB) of batch k+1 on a second stream under the back end of batch k; needs the
- * caller to alternate output buffers between consecutive ss_process_device calls (with the same buffers
- * the engine orders the two and nothing is gained). Off by default: on ROCm 7.2 a cross-stream event
- * dependency costs ~14 us on MI355X, more than the overlap returns at 1024-frame batches. */
-#define SS_FLAG_OVERLAP_STREAMS 2u
 
 #define SS_NO_DATA (-100.0f) /* setNoData sentinel, sources/utils/radio_utils.cpp:72-76 */
 

@@ -44,18 +44,8 @@ struct ss_ctx {
   float db_off = 0.0f;  // 10*log10(fs), the constant term of PSD::work (psd.cpp:19)
   int32_t range_lo = 0, range_hi = 0;
   std::vector<int32_t> ignored;
-  // Two streams: the front end (FFT + dB) of batch i+1 runs on stream_fft while the back end (noise,
-  // averaging, threshold, candidate lists) of batch i runs on stream. Events order them per batch.
-  hipStream_t stream = nullptr;      // back end + copies; the stream ss_stream() reports
-  hipStream_t stream_fft = nullptr;  // front end (only with SS_FLAG_OVERLAP_STREAMS)
-  hipStream_t fft_q = nullptr;       // where FFT launches go: stream_fft when overlapping, else stream
-  bool overlap = false;
-  static constexpr int kSlots = 4;             // batches in flight when overlapping (ring of slots)
-  hipEvent_t ev_fft[kSlots] = {};              // FFT of the batch in slot s has finished
-  hipEvent_t ev_det[kSlots] = {};              // back end of the batch in slot s has finished
-  const float* slot_psd[kSlots] = {};          // PSD plane the back end of slot s reads
+  hipStream_t stream = nullptr;  // every kernel and copy of this chain is ordered on this stream
   unsigned long long batch_no = 0;
-  float* d_psd_ring[kSlots] = {};              // internal PSD planes, one per slot ([0] aliases d_psd), lazily allocated
   // constants
   float* d_win = nullptr;
   float2* d_tw = nullptr;
@@ -186,10 +176,10 @@ void launch_lds(ss_ctx* c, const void* d_iq, long long item_stride, int nframes,
   const size_t lds = sizeof(float2) << LOGTOT;
   hipEvent_t e0, e1;
   if (prof_pair(c, &e0, &e1)) {
-    hipExtLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->fft_q, e0, e1, 0, d_iq,
+    hipExtLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->stream, e0, e1, 0, d_iq,
                           item_stride, nframes, c->d_win, c->d_tw, c->db_off, c->cfg.int_scale, d_psd);
   } else {
-    hipLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->fft_q, d_iq, item_stride,
+    hipLaunchKernelGGL((ss::k_fft_psd_lds<LOGN, LOGTOT, FMT>), dim3(blocks), dim3(ss::kFftThreads), lds, c->stream, d_iq, item_stride,
                        nframes, c->d_win, c->d_tw, c->db_off, c->cfg.int_scale, d_psd);
   }
 }
@@ -200,9 +190,9 @@ void launch_four_step(ss_ctx* c, const void* d_iq, long long item_stride, int nf
   const size_t lds = sizeof(float2) << 13;
   const int col_tiles = N2 >> (13 - LOGN1);
   const int row_tiles = N1 >> (13 - LOGN2);
-  hipLaunchKernelGGL((ss::k_fft_cols<LOGN1, LOGN2, FMT>), dim3(nframes * col_tiles), dim3(ss::kFftThreads), lds, c->fft_q, d_iq,
+  hipLaunchKernelGGL((ss::k_fft_cols<LOGN1, LOGN2, FMT>), dim3(nframes * col_tiles), dim3(ss::kFftThreads), lds, c->stream, d_iq,
                      item_stride, c->d_win, c->d_tw, c->cfg.int_scale, c->d_work);
-  hipLaunchKernelGGL((ss::k_fft_rows_psd<LOGN1, LOGN2>), dim3(nframes * row_tiles), dim3(ss::kFftThreads), lds, c->fft_q, c->d_work,
+  hipLaunchKernelGGL((ss::k_fft_rows_psd<LOGN1, LOGN2>), dim3(nframes * row_tiles), dim3(ss::kFftThreads), lds, c->stream, c->d_work,
                      c->d_tw, c->db_off, d_psd);
 }
 
@@ -221,19 +211,19 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
   const bool timed = prof_pair(c, &e0, &e1);
   auto launch = [&](auto kernel, int lds_bytes) {
     if (timed) {
-      hipExtLaunchKernelGGL(kernel, dim3(nframes), dim3(256), lds_bytes, c->fft_q, e0, e1, 0, d_iq, item_stride, (const float*)c->d_win, tabs,
+      hipExtLaunchKernelGGL(kernel, dim3(nframes), dim3(256), lds_bytes, c->stream, e0, e1, 0, d_iq, item_stride, (const float*)c->d_win, tabs,
                             c->db_off, c->cfg.int_scale, d_psd);
     } else {
-      hipLaunchKernelGGL(kernel, dim3(nframes), dim3(256), lds_bytes, c->fft_q, d_iq, item_stride, (const float*)c->d_win, tabs, c->db_off,
+      hipLaunchKernelGGL(kernel, dim3(nframes), dim3(256), lds_bytes, c->stream, d_iq, item_stride, (const float*)c->d_win, tabs, c->db_off,
                          c->cfg.int_scale, d_psd);
     }
   };
   auto launch8 = [&](auto kernel, int lds_bytes) {
     if (timed) {
-      hipExtLaunchKernelGGL(kernel, dim3(nframes), dim3(512), lds_bytes, c->fft_q, e0, e1, 0, d_iq, item_stride, (const float*)c->d_win, tabs,
+      hipExtLaunchKernelGGL(kernel, dim3(nframes), dim3(512), lds_bytes, c->stream, e0, e1, 0, d_iq, item_stride, (const float*)c->d_win, tabs,
                             c->db_off, c->cfg.int_scale, d_psd);
     } else {
-      hipLaunchKernelGGL(kernel, dim3(nframes), dim3(512), lds_bytes, c->fft_q, d_iq, item_stride, (const float*)c->d_win, tabs, c->db_off,
+      hipLaunchKernelGGL(kernel, dim3(nframes), dim3(512), lds_bytes, c->stream, d_iq, item_stride, (const float*)c->d_win, tabs, c->db_off,
                          c->cfg.int_scale, d_psd);
     }
   };
@@ -260,7 +250,7 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
   else launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
   if (tabs.dbg && ++s_calls == 20) {
     std::vector<long long> h((size_t)8 * nframes);
-    (void)hipStreamSynchronize(c->fft_q);
+    (void)hipStreamSynchronize(c->stream);
     (void)hipMemcpy(h.data(), s_dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
     if (FILE* fp = fopen(dbg_path, "w")) {
       for (int b = 0; b < nframes; ++b) {
@@ -424,37 +414,12 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     SS_HIP(c, hipStreamSynchronize(c->stream));  // `pass` is pageable and dies at scope end
     c->pass_dirty = false;
   }
-  constexpr int S = ss_ctx::kSlots;
-  const int slot = c->overlap ? (int)(c->batch_no % S) : 0;
-  float* d_psd = d_psd_out;
-  if (!d_psd) {
-    if (slot == 0) {
-      d_psd = c->d_psd;
-    } else {
-      if (!c->d_psd_ring[slot]) SS_HIP(c, hipMalloc(&c->d_psd_ring[slot], sizeof(float) * (size_t)c->n * (size_t)c->cfg.max_batch));
-      d_psd = c->d_psd_ring[slot];
-    }
-  }
-  if (c->overlap) {
-    // The front end runs ahead of the back end by up to S-1 batches. It must not overwrite a PSD plane an
-    // unfinished back end still reads: wait for the batch that used this slot S calls ago, and for any younger
-    // batch that was given the same plane (a caller that rotates fewer than S output sets).
-    for (int back = 1; back <= S && (unsigned long long)back <= c->batch_no; ++back) {
-      const int s2 = (int)((c->batch_no - back) % S);
-      if (back == S || c->slot_psd[s2] == d_psd) SS_HIP(c, hipStreamWaitEvent(c->stream_fft, c->ev_det[s2], 0));
-    }
-  }
+  float* d_psd = d_psd_out ? d_psd_out : c->d_psd;
   int st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
   if (st != SS_OK) return st;
-  if (c->overlap) {
-    SS_HIP(c, hipEventRecord(c->ev_fft[slot], c->stream_fft));
-    SS_HIP(c, hipStreamWaitEvent(c->stream, c->ev_fft[slot], 0));
-  }
   st = c->fused ? run_backend_fused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap)
                 : run_backend_unfused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap);
   if (st != SS_OK) return st;
-  if (c->overlap) SS_HIP(c, hipEventRecord(c->ev_det[slot], c->stream));
-  c->slot_psd[slot] = d_psd;
   ++c->batch_no;
   SS_HIP(c, hipGetLastError());
   c->frames_pushed = c->frames_pushed + nframes < G ? c->frames_pushed + nframes : G;
@@ -497,13 +462,7 @@ int get_noise(ss_ctx* c, NoiseState** out) {
 void free_ctx(ss_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device_id);
-  if (c->stream_fft) (void)hipStreamSynchronize(c->stream_fft);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (int k = 0; k < ss_ctx::kSlots; ++k) {
-    if (c->ev_fft[k]) (void)hipEventDestroy(c->ev_fft[k]);
-    if (c->ev_det[k]) (void)hipEventDestroy(c->ev_det[k]);
-  }
-  if (c->stream_fft) (void)hipStreamDestroy(c->stream_fft);
   for (auto& z : c->noise) (void)hipFree(z.d_thr);
   for (auto e : c->prof_events) (void)hipEventDestroy(e);
   (void)hipFree(c->d_win);
@@ -518,7 +477,6 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_relplane);
   (void)hipFree(c->d_hist_tmp);
   (void)hipFree(c->d_psd);
-  for (int k = 1; k < ss_ctx::kSlots; ++k) (void)hipFree(c->d_psd_ring[k]);
   (void)hipFree(c->d_avgy);
   (void)hipFree(c->d_avg);
   (void)hipFree(c->d_work);
@@ -633,13 +591,6 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   } while (0)
   CREATE_HIP(hipSetDevice(cfg->device_id));
   CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  CREATE_HIP(hipStreamCreateWithFlags(&c->stream_fft, hipStreamNonBlocking));
-  c->overlap = (cfg->flags & SS_FLAG_OVERLAP_STREAMS) != 0;
-  c->fft_q = c->overlap ? c->stream_fft : c->stream;
-  for (int k = 0; k < ss_ctx::kSlots; ++k) {
-    CREATE_HIP(hipEventCreateWithFlags(&c->ev_fft[k], hipEventDisableTiming));
-    CREATE_HIP(hipEventCreateWithFlags(&c->ev_det[k], hipEventDisableTiming));
-  }
   CREATE_HIP(hipMalloc(&c->d_win, sizeof(float) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_tw, sizeof(float2) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_pass, (size_t)n));
@@ -725,7 +676,6 @@ void* ss_stream(ss_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int ss_sync(ss_ctx* ctx) {
   if (!ctx) return SS_ERR_INVALID;
   SS_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
-  SS_HIP(ctx, hipStreamSynchronize(ctx->stream_fft));
   SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SS_OK;
 }
@@ -744,7 +694,6 @@ int ss_kernel_timing_read(ss_ctx* c, double* total_ms, int32_t* launches) {
   if (!c || !total_ms || !launches) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
-  SS_HIP(c, hipStreamSynchronize(c->stream_fft));
   SS_HIP(c, hipStreamSynchronize(c->stream));
   double sum = 0.0;
   for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
@@ -796,7 +745,7 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
   if (!c->d_in) SS_HIP(c, hipMalloc(&c->d_in, row_bytes * (size_t)c->cfg.max_batch));
   // Decimator: only the first N samples of each N*D item ever reach the GPU (decimator.h:15-22)
   SS_HIP(c, hipMemcpy2DAsync(c->d_in, row_bytes, iq, row_bytes * (size_t)c->cfg.decim, row_bytes, (size_t)nframes, hipMemcpyHostToDevice,
-                             c->fft_q));
+                             c->stream));
   if (cand_cap > c->cand_cap_alloc) {
     (void)hipFree(c->d_cand_idx);
     (void)hipFree(c->d_cand_avg);

@@ -242,42 +242,6 @@ def test_device_resident_entry_point_matches_host_entry_point():
     np.testing.assert_array_equal(cav[:total].cpu().numpy(), host["cand_avg"])
 
 
-def test_overlapped_streams_give_identical_results():
-    """SS_FLAG_OVERLAP_STREAMS: front end of batch k+1 on a second stream while the back end of batch k runs, outputs
-    alternating between two sets — and the hazard case where the caller reuses one set. Same bits as the plain engine."""
-    import torch
-    n, fs, center, nb = 8192, 2_048_000, 145_000_000, 64
-    band = pkg.synth.SyntheticBand(n, seed=19, on_frame=40, off_frame=300)
-    iq = band.frames_cf32(5 * nb)
-    kw = dict(fft_size=n, decim=1, learn_frames=20, max_batch=nb)
-    plain = pkg.SpectrumEngine(fs, center, **kw)
-    want = [plain.process(iq[k * nb:(k + 1) * nb], want=("psd",)) for k in range(5)]
-    dev = torch.device("cuda:0")
-    d_iq = torch.from_numpy(iq.view(np.float32)).to(dev).reshape(5, nb, 2 * n)
-    for nsets in (5, 2, 1):
-        eng = pkg.SpectrumEngine(fs, center, flags=pkg.abi.SS_FLAG_OVERLAP_STREAMS, **kw)
-        sets = [dict(psd=torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
-                     idx=torch.empty(nb * n, dtype=torch.int32, device=dev)) for _ in range(nsets)]
-        torch.cuda.synchronize()
-        got = []
-        for k in range(5):
-            o = sets[k % nsets]
-            if nsets < 5 and k >= nsets:  # a consumer drains a set before handing it back
-                eng.sync()
-                kk = k - nsets
-                got.append((kk, o["psd"].cpu().numpy().copy(), o["off"].cpu().numpy().copy(), o["idx"].cpu().numpy().copy()))
-            eng.process_device(d_iq[k], nb, psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"])
-        eng.sync()
-        for kk in range(max(0, 5 - nsets), 5):
-            oo = sets[kk % nsets]
-            got.append((kk, oo["psd"].cpu().numpy().copy(), oo["off"].cpu().numpy().copy(), oo["idx"].cpu().numpy().copy()))
-        assert sorted(g[0] for g in got) == [0, 1, 2, 3, 4]
-        for kk, psd, off, idx in got:
-            np.testing.assert_array_equal(psd, want[kk]["psd"])
-            np.testing.assert_array_equal(off, want[kk]["cand_off"])
-            np.testing.assert_array_equal(idx[:off[-1]], want[kk]["cand_idx"])
-
-
 def test_two_contexts_are_independent(oracle_mod):
     n, fs = 1024, 256_000
     a = pkg.SpectrumEngine(fs, 140_000_000, fft_size=n, decim=1, learn_frames=10, max_batch=64)
