@@ -37,5 +37,22 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HOST_DIR, "libspecscan_host.so")
+
+
+def build_host_lib(force: bool = False, verbose: bool = False) -> str:
+    """g++ -> host/libspecscan_host.so: the host-side signal tracker (no GPU code)."""
+    src = os.path.join(HOST_DIR, "signal_tracker.cpp")
+    hdr = os.path.join(HOST_DIR, "signal_tracker.h")
+    if force or not os.path.exists(HOST_LIB) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(HOST_LIB):
+        cmd = [shutil.which("g++") or "g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wpedantic", "-Werror", "-o", HOST_LIB, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=HOST_DIR)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
+    print(build_host_lib(force=True, verbose=True))

@@ -49,6 +49,27 @@ def chain_case(name, n, fs, seed, nframes, dt_ms, ignored=(), retune_at=None):
     print(name, "frames", nframes, "candidates", int(off[-1]))
 
 
+def tracker_case(name, n, fs, seed, nframes, dt_ms, min_ms, timeout_ms):
+    """Per-frame output of the reference's Transmission/Signal bookkeeping: the notified (shift Hz, flush) list and
+    the keys of m_signals."""
+    center = 145_000_000
+    band = pkg.synth.SyntheticBand(n, seed=seed, on_frame=70, off_frame=190, comb_width=max(8, n // 32))
+    iq = band.frames_cf32(nframes)
+    t = (1_000 + dt_ms * np.arange(nframes)).astype(np.int64)
+    O.ref().orc_set_fft_backend(0)
+    ref = O.RefChain(n, fs, center - fs // 2, center + fs // 2, min_time_ms=min_ms, timeout_ms=timeout_ms)
+    r = ref.process(iq, t)
+    tx_off = np.zeros(nframes + 1, np.int32)
+    tx_off[1:] = np.cumsum([len(x) for x in r["tx"]])
+    sig_off = np.zeros(nframes + 1, np.int32)
+    sig_off[1:] = np.cumsum([len(x) for x in r["signals"]])
+    tx = np.concatenate([x.reshape(-1, 2) for x in r["tx"]]).astype(np.int32)
+    sig = np.concatenate(r["signals"]).astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), iq=iq, t_ms=t, tx_off=tx_off, tx=tx, sig_off=sig_off, sig=sig, n=n, fs=fs,
+                        center=center, min_ms=min_ms, timeout_ms=timeout_ms)
+    print(name, "frames", nframes, "transmission entries", int(tx_off[-1]))
+
+
 if __name__ == "__main__":
     if not O.have_ref():
         sys.exit("oracle/_ref is not built (needs /root/reference): run make -C oracle")
@@ -57,3 +78,4 @@ if __name__ == "__main__":
     chain_case("ref_chain_n256_ignored", 256, 64000, seed=4, nframes=140, dt_ms=40,
                ignored=[145_000_000 + 9000, 145_000_000 + 13000])
     chain_case("ref_chain_n256_retune", 256, 64000, seed=5, nframes=220, dt_ms=40, retune_at=100)
+    tracker_case("ref_tracker_n256", 256, 64000, seed=6, nframes=300, dt_ms=40, min_ms=800, timeout_ms=1200)

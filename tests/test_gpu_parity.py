@@ -242,6 +242,29 @@ def test_device_resident_entry_point_matches_host_entry_point():
     np.testing.assert_array_equal(cav[:total].cpu().numpy(), host["cand_avg"])
 
 
+def test_tracker_on_engine_planes_follows_the_reference(oracle_mod):
+    """End of the drop-in: engine planes + candidates -> host-side tracker -> the Scanner's (shift Hz, flush) list.
+    The tracker itself is bit-exact against the reference on identical planes (tests/test_signal_tracker.py); fed
+    with the engine's planes (equal to the oracle's within the fp32 FFT rounding floor) it must report the same
+    transmissions at the same tuned frequencies; a start or stop may move by one frame when a smoothed value sits
+    on the threshold."""
+    n, fs, center, nframes, dt = 1024, 256_000, 145_000_000, 330, 40
+    band = pkg.synth.SyntheticBand(n, seed=34, on_frame=70, off_frame=190, comb_width=32)
+    iq = band.frames_cf32(nframes)
+    t = (1_000 + dt * np.arange(nframes)).astype(np.int64)
+    kw = dict(fft_size=n, decim=1, max_batch=128)
+    eng, orc = pkg.SpectrumEngine(fs, center, **kw), oracle_mod.oracle_chain(fs, center, **kw)
+    got, ref = _run(eng, iq, 128, t_ms=t), _run(orc, iq, 128, t_ms=t)
+    tk = dict(min_time_ms=400, timeout_ms=600)
+    a = pkg.tracker.SignalTracker(n, fs, **tk).process_batch(t, got["avg"], got["rel"], got["cand_off"], got["cand_idx"])
+    b = pkg.tracker.SignalTracker(n, fs, **tk).process_batch(t, ref["avg"], ref["rel"], ref["cand_off"], ref["cand_idx"])
+    same = sum(np.array_equal(a[f][0], b[f][0]) for f in range(nframes))
+    assert same >= nframes - 4, f"only {same} of {nframes} frames notify the same list"
+    shifts_a = {int(s) for f in range(nframes) for s in a[f][0][:, 0]}
+    shifts_b = {int(s) for f in range(nframes) for s in b[f][0][:, 0]}
+    assert shifts_a == shifts_b and len(shifts_b) >= 4
+
+
 def test_two_contexts_are_independent(oracle_mod):
     n, fs = 1024, 256_000
     a = pkg.SpectrumEngine(fs, 140_000_000, fft_size=n, decim=1, learn_frames=10, max_batch=64)
