@@ -119,11 +119,16 @@ def main():
     import rtl_sdr_scanner_cpp_amd as pkg
     from rtl_sdr_scanner_cpp_amd import dist
 
-    rank, local_rank, world = dist.init("nccl")
+    # RCCL ("nccl") over xGMI in production; SS_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box
+    # with fewer GPUs than ranks (ranks then share devices, results are functional only)
+    backend = os.environ.get("SS_DIST_BACKEND", "nccl")
+    rank, local_rank, world = dist.init(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    device_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     n, fs, nb = args.fft, 2_048_000 * (args.fft // 8192 if args.fft >= 8192 else 1), args.frames
     cfg0 = None
@@ -131,13 +136,13 @@ def main():
         cfg0 = dict(fft_size=n, sample_rate=fs, decim=1, in_format=pkg.abi.SS_FMT_CF32, grouping_x=21, grouping_y=21,
                     start_level_mdB=8000, learn_frames=100, learn_ms=2000, max_batch=nb, band0_center=140_000_000,
                     band_spacing=2_000_000, n_bands=world, seed=0)
-    cfg = dist.broadcast_config(cfg0, device=dev)  # the only collective of the whole job (RCCL, < 1 KiB)
+    cfg = dist.broadcast_config(cfg0, device=coll_dev)  # the only collective of the whole job (RCCL, < 1 KiB)
     band = dist.bands_for_rank(int(cfg["n_bands"]), rank, world)[0]
 
     eng = pkg.SpectrumEngine(int(cfg["sample_rate"]), dist.band_center(cfg, band), fft_size=int(cfg["fft_size"]),
                              decim=int(cfg["decim"]), in_format=int(cfg["in_format"]), grouping_x=int(cfg["grouping_x"]),
                              grouping_y=int(cfg["grouping_y"]), start_level=cfg["start_level_mdB"] / 1000.0,
-                             learn_frames=int(cfg["learn_frames"]), max_batch=nb, device_id=local_rank)
+                             learn_frames=int(cfg["learn_frames"]), max_batch=nb, device_id=device_index)
     iq = dist.synthetic_batch(cfg, band, nb)
     d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
     # Outputs are double-buffered the way a streaming consumer would hold them: batch k writes set k & 1 while
@@ -169,7 +174,7 @@ def main():
     t1 = time.perf_counter()
     kern_ms, launches = eng.kernel_timing_read()
     eng.kernel_timing(0)
-    elapsed = dist.max_over_ranks(t1 - t0, device=dev)
+    elapsed = dist.max_over_ranks(t1 - t0, device=coll_dev)
     ncand = int(outs[(counter[0] - 1) % len(outs)]["off"][-1].item())
 
     if rank == 0:
