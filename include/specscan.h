@@ -65,6 +65,9 @@ typedef enum ss_plane {
 /* ss_config.flags: keep the full avg plane of every batch on the device so that ss_read_window can serve
  * SS_PLANE_AVG (the host-side signal tracker needs it); costs 4 B/sample of extra HBM writes. */
 #define SS_FLAG_KEEP_PLANES 1u
+/* Also run the Spectrogram side branch (sources/radio/blocks/spectrogram.cpp): accumulate the bin-decimated raw
+ * PSD per centre frequency; read it back with ss_spectrogram_read. */
+#define SS_FLAG_SPECTROGRAM 2u
 
 #define SS_NO_DATA (-100.0f) /* setNoData sentinel, sources/utils/radio_utils.cpp:72-76 */
 
@@ -156,6 +159,14 @@ int ss_reset_noise(ss_ctx* ctx);
  * negative down to -(grouping_y-1) for SS_PLANE_REL, addressing the averager ring rows that
  * Transmission::getBestIndex walks (transmission.cpp:132-154). */
 int ss_read_window(ss_ctx* ctx, int32_t plane, int32_t frame, int32_t lo, int32_t hi, float* out);
+
+/* Spectrogram side branch (needs SS_FLAG_SPECTROGRAM). ss_spectrogram_size: number of output bins,
+ * min(16384, getFft(fs, 1000)) (spectrogram.cpp:14), 0 when disabled. ss_spectrogram_read: what Spectrogram::send
+ * publishes (spectrogram.cpp:62-75, minus its 1000 ms gate and the MQTT framing of data_controller.cpp:44-57):
+ * out[j] = int8(sum[j]/count) for the current centre frequency, container cleared; mean_out (nullable) gets the
+ * float before the conversion. Returns the number of frames accumulated (0 = nothing to send) or < 0. */
+int ss_spectrogram_size(const ss_ctx* ctx);
+int ss_spectrogram_read(ss_ctx* ctx, int8_t* out, float* mean_out);
 
 /* Learned ceiling for the current centre frequency: N floats, -FLT_MAX where nothing was learned.
  * Returns 1 if learning is complete, 0 if still learning, <0 on error. */

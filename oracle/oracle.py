@@ -57,6 +57,12 @@ def lib() -> C.CDLL:
         L.orc_averager_row.argtypes = [C.c_void_p, C.c_int]
         L.orc_averager_row.restype = c_float_p
         L.orc_stage_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.orc_spectrogram_create.argtypes = [C.c_int, C.c_int32]
+        L.orc_spectrogram_create.restype = C.c_void_p
+        L.orc_spectrogram_destroy.argtypes = [C.c_void_p]
+        L.orc_spectrogram_size.argtypes = [C.c_void_p]
+        L.orc_spectrogram_process.argtypes = [C.c_void_p, c_float_p]
+        L.orc_spectrogram_send.argtypes = [C.c_void_p, C.POINTER(C.c_int8), c_float_p]
     return _lib
 
 

@@ -774,6 +774,60 @@ int orc_read_noise(orc_ctx* c, float* thr) {
   return z->ready ? 1 : 0;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Spectrogram side branch — sources/radio/blocks/spectrogram.cpp. Fed with the raw PSD rows (PSD::work
+ * output, before the noise subtraction: the branch is wired psd -> spectrogram at sdr_device.cpp:170-171).
+ * ---------------------------------------------------------------------------------------------- */
+struct orc_spectrogram {
+  int in_size, out_size, factor; /* m_inputSize, m_outputSize, m_decimatorFactor (spectrogram.cpp:13-15) */
+  float* sum;                    /* Container::m_sum */
+  int counter;                   /* Container::m_counter */
+};
+
+orc_spectrogram* orc_spectrogram_create(int in_size, int32_t sample_rate) {
+  orc_spectrogram* g = (orc_spectrogram*)calloc(1, sizeof(*g));
+  const int pref = orc_get_fft(sample_rate, 1000); /* SPECTROGRAM_PREFERRED_MAX_STEP, config.h:36 */
+  g->in_size = in_size;
+  g->out_size = pref < 16384 ? pref : 16384; /* SPECTROGRAM_MAX_FFT, config.h:37; spectrogram.cpp:14 */
+  if (g->out_size > in_size) g->out_size = in_size;
+  g->factor = in_size / g->out_size;
+  g->sum = (float*)calloc((size_t)g->out_size, sizeof(float));
+  return g;
+}
+void orc_spectrogram_destroy(orc_spectrogram* g) {
+  if (!g) return;
+  free(g->sum);
+  free(g);
+}
+int orc_spectrogram_size(const orc_spectrogram* g) { return g->out_size; }
+
+/* Spectrogram::process — spectrogram.cpp:45-60 */
+void orc_spectrogram_process(orc_spectrogram* g, const float* data) {
+  if (g->factor == 1) {
+    for (int i = 0; i < g->out_size; ++i) g->sum[i] += data[i];
+  } else {
+    for (int i = 0; i < g->out_size; ++i) {
+      float sum = 0.0f;
+      for (int j = 0; j < g->factor; ++j) sum += data[i * g->factor + j];
+      g->sum[i] += sum / g->factor; /* float / int */
+    }
+  }
+  g->counter++;
+}
+
+/* Spectrogram::send without the 1000 ms gate — spectrogram.cpp:66-72: int8 = float -> int8 conversion of sum/count */
+int orc_spectrogram_send(orc_spectrogram* g, int8_t* out, float* mean_out) {
+  const int count = g->counter;
+  for (int j = 0; j < g->out_size; ++j) {
+    const float v = g->sum[j] / g->counter;
+    if (mean_out) mean_out[j] = v;
+    out[j] = (int8_t)v;
+  }
+  memset(g->sum, 0, sizeof(float) * (size_t)g->out_size);
+  g->counter = 0;
+  return count;
+}
+
 void orc_stage_seconds(orc_ctx* c, double out[6]) {
   for (int i = 0; i < 6; ++i) {
     out[i] = c->stage[i];

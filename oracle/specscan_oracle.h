@@ -63,6 +63,15 @@ const float* orc_averager_average(const orc_averager* a);
 /* row 0 = oldest ... group_size-1 = newest (the deque order of Averager::data()) */
 const float* orc_averager_row(const orc_averager* a, int row);
 
+/* Spectrogram side branch (sources/radio/blocks/spectrogram.cpp), fed with raw PSD rows. */
+typedef struct orc_spectrogram orc_spectrogram;
+orc_spectrogram* orc_spectrogram_create(int in_size, int32_t sample_rate);
+void orc_spectrogram_destroy(orc_spectrogram* g);
+int orc_spectrogram_size(const orc_spectrogram* g);
+void orc_spectrogram_process(orc_spectrogram* g, const float* psd_row);
+/* returns the number of accumulated frames; out = int8(sum/count), mean_out (nullable) = the float before conversion */
+int orc_spectrogram_send(orc_spectrogram* g, int8_t* out, float* mean_out);
+
 /* ---- the chain behind the same boundary as ss_* ---- */
 void orc_default_config(ss_config* cfg, int32_t sample_rate, int32_t center_hz);
 int orc_create(const ss_config* cfg, orc_ctx** out);

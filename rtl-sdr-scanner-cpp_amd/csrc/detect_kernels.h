@@ -210,6 +210,33 @@ __global__ __launch_bounds__(256) void k_cand_write(const uint32_t* __restrict__
   }
 }
 
+// Spectrogram side branch — sources/radio/blocks/spectrogram.cpp:45-60: every frame adds the mean of `m`
+// adjacent PSD bins to an accumulator per output bin. Two deterministic steps: a partial sum per chunk of frames
+// (frames in order, the m bins in ascending order, then / m as the reference does), then the chunks in order.
+__global__ __launch_bounds__(256) void k_spec_partial(const float* __restrict__ psd, int n, int nframes, int m, int out_n, int chunk,
+                                                      float* __restrict__ partial) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= out_n) return;
+  const int f0 = blockIdx.y * chunk;
+  const int f1 = min(nframes, f0 + chunk);
+  float acc = 0.0f;
+  for (int f = f0; f < f1; ++f) {
+    const float* p = psd + (size_t)f * n + (size_t)j * m;
+    float s = 0.0f;
+    for (int k = 0; k < m; ++k) s += p[k];
+    acc += (m == 1) ? s : s / (float)m;  // spectrogram.cpp:48 / :52-57
+  }
+  partial[(size_t)blockIdx.y * out_n + j] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_spec_combine(const float* __restrict__ partial, int nchunks, int out_n, float* __restrict__ sum) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= out_n) return;
+  float acc = sum[j];
+  for (int c = 0; c < nchunks; ++c) acc += partial[(size_t)c * out_n + j];
+  sum[j] = acc;
+}
+
 // Keep the newest G-1 rows of [history ++ batch] as the next history (the averager ring).
 __global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, size_t count4) {
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < count4; e += (size_t)gridDim.x * blockDim.x) {

@@ -27,6 +27,12 @@ namespace {
 
 thread_local char g_create_err[512] = "";
 
+struct SpecState {  // Spectrogram::Container, sources/radio/blocks/spectrogram.h:10-16, one per centre frequency
+  int32_t center = 0;
+  float* d_sum = nullptr;
+  int count = 0;
+};
+
 struct NoiseState {  // NoiseLearner::Noise, sources/radio/blocks/noise_learner.h:11-20, one per centre frequency
   int32_t center = 0;
   float* d_thr = nullptr;
@@ -56,6 +62,10 @@ struct ss_ctx {
   bool pass_dirty = true;
   // state
   std::vector<NoiseState> noise;
+  // spectrogram side branch (SS_FLAG_SPECTROGRAM)
+  int spec_n = 0, spec_m = 0;  // output bins, input bins per output bin (spectrogram.cpp:14-15)
+  std::vector<SpecState> spec;
+  float* d_spec_partial = nullptr;
   int frames_pushed = 0;  // Averager::m_frames, saturates at grouping_y
   int rot_frames = 0;     // rows of the previous batch still to be folded into the history rows (lazy ring rotation)
   // planes (frame-major rows of n floats)
@@ -402,6 +412,31 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   return SS_OK;
 }
 
+// Spectrogram::work/process for a batch (spectrogram.cpp:29-60): the container of the current centre frequency
+// accumulates the bin-decimated raw PSD of every frame.
+int spectrogram_accumulate(ss_ctx* c, const float* d_psd, int nframes) {
+  const int32_t center = (c->range_lo + c->range_hi) / 2;
+  SpecState* g = nullptr;
+  for (auto& s : c->spec)
+    if (s.center == center) g = &s;
+  if (!g) {
+    SpecState ns;
+    ns.center = center;
+    SS_HIP(c, hipMalloc(&ns.d_sum, sizeof(float) * (size_t)c->spec_n));
+    SS_HIP(c, hipMemsetAsync(ns.d_sum, 0, sizeof(float) * (size_t)c->spec_n, c->stream));
+    c->spec.push_back(ns);
+    g = &c->spec.back();
+  }
+  constexpr int kChunk = 32;
+  const int nchunks = (nframes + kChunk - 1) / kChunk;
+  const dim3 grid((c->spec_n + 255) / 256, nchunks);
+  hipLaunchKernelGGL(ss::k_spec_partial, grid, dim3(256), 0, c->stream, d_psd, c->n, nframes, c->spec_m, c->spec_n, kChunk, c->d_spec_partial);
+  hipLaunchKernelGGL(ss::k_spec_combine, dim3((c->spec_n + 255) / 256), dim3(256), 0, c->stream, (const float*)c->d_spec_partial, nchunks,
+                     c->spec_n, g->d_sum);
+  g->count += nframes;
+  return SS_OK;
+}
+
 // The chain for one batch, everything on c->stream, nothing synchronised.
 // n_learn = leading frames that belong to the noise-learning phase (decided by the caller).
 int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int n_learn, NoiseState* z, float* d_psd_out,
@@ -417,6 +452,10 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
   float* d_psd = d_psd_out ? d_psd_out : c->d_psd;
   int st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
   if (st != SS_OK) return st;
+  if (c->spec_n > 0) {
+    st = spectrogram_accumulate(c, d_psd, nframes);
+    if (st != SS_OK) return st;
+  }
   st = c->fused ? run_backend_fused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap)
                 : run_backend_unfused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap);
   if (st != SS_OK) return st;
@@ -464,6 +503,8 @@ void free_ctx(ss_ctx* c) {
   (void)hipSetDevice(c->cfg.device_id);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& z : c->noise) (void)hipFree(z.d_thr);
+  for (auto& g : c->spec) (void)hipFree(g.d_sum);
+  (void)hipFree(c->d_spec_partial);
   for (auto e : c->prof_events) (void)hipEventDestroy(e);
   (void)hipFree(c->d_win);
   (void)hipFree(c->d_tw);
@@ -616,6 +657,16 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   CREATE_HIP(hipMalloc(&c->d_mask, sizeof(uint32_t) * (size_t)(n / 32) * (size_t)cfg->max_batch));
   CREATE_HIP(hipMalloc(&c->d_counts, sizeof(int) * (size_t)cfg->max_batch));
   CREATE_HIP(hipMalloc(&c->d_off, sizeof(int) * ((size_t)cfg->max_batch + 1)));
+  if (cfg->flags & SS_FLAG_SPECTROGRAM) {
+    // output size rule of the Spectrogram block: min(SPECTROGRAM_MAX_FFT, getFft(fs, SPECTROGRAM_PREFERRED_MAX_STEP)),
+    // sources/radio/blocks/spectrogram.cpp:14, config.h:36-37
+    int out_n = get_fft(cfg->sample_rate, 1000);
+    if (out_n > 16384) out_n = 16384;
+    if (out_n > n) out_n = n;
+    c->spec_n = out_n;
+    c->spec_m = n / out_n;
+    CREATE_HIP(hipMalloc(&c->d_spec_partial, sizeof(float) * (size_t)out_n * (size_t)((cfg->max_batch + 31) / 32)));
+  }
   if (c->logn > 13) CREATE_HIP(hipMalloc(&c->d_work, sizeof(float2) * (size_t)n * (size_t)cfg->max_batch));
 
   // window: caller's taps or gr::fft::window::hamming(N) (sdr_device.cpp:164; GNU Radio's definition:
@@ -865,6 +916,36 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
   SS_HIP(c, hipMemcpyAsync(out, src + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
   SS_HIP(c, hipStreamSynchronize(c->stream));
   return SS_OK;
+}
+
+int ss_spectrogram_size(const ss_ctx* c) { return c ? c->spec_n : 0; }
+
+// Spectrogram::send without its 1000 ms gate (spectrogram.cpp:62-75): out[j] = int8(sum[j] / count) — the C++
+// float -> int8 conversion, i.e. truncation toward zero — for the current centre frequency; the container is
+// cleared. mean_out (nullable) receives the float before conversion. Returns the number of frames that were
+// accumulated (0: nothing to send, out untouched), or a negative status.
+int ss_spectrogram_read(ss_ctx* c, int8_t* out, float* mean_out) {
+  if (!c || !out) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  if (c->spec_n == 0) return fail(c, SS_ERR_INVALID, "spectrogram not enabled (SS_FLAG_SPECTROGRAM)");
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  const int32_t center = (c->range_lo + c->range_hi) / 2;
+  SpecState* g = nullptr;
+  for (auto& s : c->spec)
+    if (s.center == center) g = &s;
+  if (!g || g->count == 0) return 0;
+  std::vector<float> sum((size_t)c->spec_n);
+  SS_HIP(c, hipMemcpyAsync(sum.data(), g->d_sum, sizeof(float) * sum.size(), hipMemcpyDeviceToHost, c->stream));
+  SS_HIP(c, hipMemsetAsync(g->d_sum, 0, sizeof(float) * sum.size(), c->stream));
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  const int count = g->count;
+  for (int j = 0; j < c->spec_n; ++j) {
+    const float v = sum[(size_t)j] / count;  // container.m_sum[j] / container.m_counter (float / int)
+    if (mean_out) mean_out[j] = v;
+    out[j] = (int8_t)v;
+  }
+  g->count = 0;
+  return count;
 }
 
 int ss_read_noise(ss_ctx* c, float* thr) {

@@ -39,6 +39,10 @@ def load_library() -> C.CDLL:
         lib.ss_kernel_timing.restype = C.c_int
         lib.ss_kernel_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         lib.ss_kernel_timing_read.restype = C.c_int
+        lib.ss_spectrogram_size.argtypes = [C.c_void_p]
+        lib.ss_spectrogram_size.restype = C.c_int
+        lib.ss_spectrogram_read.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.POINTER(C.c_float)]
+        lib.ss_spectrogram_read.restype = C.c_int
         lib.ss_selftest.argtypes = [C.c_int, C.c_int]
         lib.ss_selftest.restype = C.c_longlong
         _lib = lib
@@ -47,7 +51,7 @@ def load_library() -> C.CDLL:
 
 EXPORTS = ("ss_default_config", "ss_device_count", "ss_create", "ss_destroy", "ss_last_error", "ss_process",
            "ss_process_device", "ss_sync", "ss_stream", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
-           "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read", "ss_selftest")
+           "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read")
 
 
 def _ptr(t):
@@ -75,6 +79,16 @@ class SpectrumEngine(abi.Chain):
 
     def sync(self):
         self._check(self._lib.ss_sync(self._h))
+
+    def spectrogram_read(self):
+        """(int8 spectrogram row, float means, frames accumulated) for the current centre; clears the accumulator."""
+        size = self._lib.ss_spectrogram_size(self._h)
+        out = np.zeros(size, np.int8)
+        mean = np.zeros(size, np.float32)
+        cnt = self._lib.ss_spectrogram_read(self._h, out.ctypes.data_as(C.POINTER(C.c_int8)), mean.ctypes.data_as(C.POINTER(C.c_float)))
+        if cnt < 0:
+            self._check(cnt)
+        return out, mean, cnt
 
     def kernel_timing(self, every: int):
         """0 = off, 1 = time every launch of the FFT+PSD kernel, k > 1 = every k-th launch."""

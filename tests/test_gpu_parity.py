@@ -278,3 +278,36 @@ def test_two_contexts_are_independent(oracle_mod):
     ob = oracle_mod.oracle_chain(fs, 142_000_000, fft_size=n, decim=1, learn_frames=10, max_batch=64).process(xb)
     check_plane("a", np.concatenate([ra1["avg"], ra2["avg"]]), oa["avg"])
     check_plane("b", np.concatenate([rb1["avg"], rb2["avg"]]), ob["avg"])
+
+
+def test_spectrogram_side_branch(oracle_mod):
+    """Spectrogram::process/send (spectrogram.cpp:45-75) on the raw PSD: bin-decimated mean accumulated over frames,
+    published as int8 by the C++ float -> int8 conversion. The float means agree to 1e-4 dB; the int8 bytes are
+    identical wherever the reference's own mean is not within 1e-3 of an integer (there truncation decides)."""
+    import ctypes as C
+    n, fs, center = 8192, 2_048_000, 145_000_000
+    band = pkg.synth.SyntheticBand(n, seed=51, on_frame=20, off_frame=90)
+    iq = band.frames_cf32(150)
+    eng = pkg.SpectrumEngine(fs, center, fft_size=n, decim=1, learn_frames=10, max_batch=64, flags=pkg.abi.SS_FLAG_SPECTROGRAM)
+    orc = oracle_mod.oracle_chain(fs, center, fft_size=n, decim=1, learn_frames=10, max_batch=64)
+    L = oracle_mod.lib()
+    g = L.orc_spectrogram_create(n, fs)
+    size = L.orc_spectrogram_size(g)
+    assert size == 2048 and eng._lib.ss_spectrogram_size(eng._h) == size
+    for a, b in ((0, 64), (64, 100), (100, 150)):  # two "send" intervals, ragged batches
+        got_planes = eng.process(iq[a:b], want=("psd",))
+        ref_planes = orc.process(iq[a:b], want=("psd",))
+        for row in ref_planes["psd"]:
+            L.orc_spectrogram_process(g, row.ctypes.data_as(C.POINTER(C.c_float)))
+        if b in (100, 150):
+            want8, wantf = np.zeros(size, np.int8), np.zeros(size, np.float32)
+            cnt_ref = L.orc_spectrogram_send(g, want8.ctypes.data_as(C.POINTER(C.c_int8)), wantf.ctypes.data_as(C.POINTER(C.c_float)))
+            got8, gotf, cnt = eng.spectrogram_read()
+            assert cnt == cnt_ref == (100 if b == 100 else 50)
+            assert np.max(np.abs(gotf - wantf)) < 1e-4 * 60
+            frac = np.abs(wantf - np.trunc(wantf))
+            decided = (frac > 1e-3) & (frac < 1 - 1e-3)
+            np.testing.assert_array_equal(got8[decided], want8[decided])
+            assert decided.mean() > 0.99
+    assert eng.spectrogram_read()[2] == 0  # nothing accumulated since the last send
+    L.orc_spectrogram_destroy(g)
