@@ -141,6 +141,8 @@ struct Fft8192Tables {
 
 constexpr int kFft8192LdsBytes = (8192 + 256) * 8;  // exchange 1 uses a 33-element pitch per 32 elements
 
+// Four-wave variant (256 threads, 32 points per thread, float2 exchanges, 66 KiB LDS, ~14 KiB of straight-line code):
+// kept as the A/B reference for the eight-wave kernel below (SS_FFT_IMPL=wide).
 template <int FMT>
 __global__ __launch_bounds__(256, 2) void k_fft8192_psd(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
                                                          Fft8192Tables tabs, float db_off, float scale, float* __restrict__ psd) {
@@ -256,289 +258,10 @@ __global__ __launch_bounds__(256, 2) void k_fft8192_psd(const void* __restrict__
   }
 }
 
-constexpr int kFft8192SplitLdsBytes = (8192 + 256) * 4;  // one fp32 plane at a time
-
-// Same transform with the two LDS exchanges done one fp32 plane at a time (real parts, then imaginary
-// parts): 33 KiB of LDS per workgroup instead of 66 KiB, so three or four frames are in flight per CU
-// instead of two — more waves to cover HBM latency, barriers and the dependent-issue stalls of a single
-// wave per SIMD. Costs four extra barriers and b32 instead of b64 LDS accesses per frame.
-template <int FMT, int WAVES_PER_SIMD>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_fft8192_psd_split(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
-                                                         Fft8192Tables tabs, float db_off, float scale, float* __restrict__ psd) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* s = reinterpret_cast<float*>(smem_raw);  // one fp32 plane (re, then im) of the 8192 points
-  const int t = threadIdx.x;
-  const size_t frame = blockIdx.x;
-  const size_t in_base = frame * (size_t)item_stride;
-  long long ts[8];
-  if (tabs.dbg && t == 0) ts[0] = wall_clock64();
-
-  // ---------------- pass 1: radix 16, Ns = 1, butterflies j = 2t and 2t+1 ----------------
-  float2 a[16], b[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e = 2 * t + 512 * r;
-    float2 x0, x1;
-    if constexpr (FMT == FMT_CF32) {
-      const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(iq) + in_base + e);
-      x0 = make_float2(q.x, q.y);
-      x1 = make_float2(q.z, q.w);
-    } else if constexpr (FMT == FMT_CS8) {
-      const char4 q = *reinterpret_cast<const char4*>(reinterpret_cast<const char2*>(iq) + in_base + e);
-      x0 = make_float2((float)q.x * scale, (float)q.y * scale);
-      x1 = make_float2((float)q.z * scale, (float)q.w * scale);
-    } else {
-      const uchar4 q = *reinterpret_cast<const uchar4*>(reinterpret_cast<const uchar2*>(iq) + in_base + e);
-      x0 = make_float2(((float)q.x - 127.5f) * scale, ((float)q.y - 127.5f) * scale);
-      x1 = make_float2(((float)q.z - 127.5f) * scale, ((float)q.w - 127.5f) * scale);
-    }
-    const float2 w = *reinterpret_cast<const float2*>(win + e);
-    a[r] = make_float2(x0.x * w.x, x0.y * w.x);  // volk_32fc_32f_multiply_32fc
-    b[r] = make_float2(x1.x * w.y, x1.y * w.y);
-  }
-  if (tabs.dbg && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[1] = wall_clock64(); }
-  dft16(a);
-  dft16(b);
-  // y[16 j + k]: thread t owns y[32 t .. 32 t + 31]; LDS pitch 33 words per thread. The real parts of all
-  // 8192 points go through the 33 KiB buffer first, then the imaginary parts.
-  float2 a2[16], b2[16];
-  const int m = t & 15;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    s[33 * t + k] = a[slot16(k)].x;
-    s[33 * t + 16 + k] = b[slot16(k)].x;
-  }
-  __syncthreads();
-  if (tabs.dbg && t == 0) ts[2] = wall_clock64();
-  // ---------------- pass 2: radix 16, Ns = 16, butterflies j = t and t + 256 ----------------
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e0 = t + 512 * r, e1 = e0 + 256;
-    a2[r].x = s[e0 + (e0 >> 5)];
-    b2[r].x = s[e1 + (e1 >> 5)];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    s[33 * t + k] = a[slot16(k)].y;
-    s[33 * t + 16 + k] = b[slot16(k)].y;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e0 = t + 512 * r, e1 = e0 + 256;
-    a2[r].y = s[e0 + (e0 >> 5)];
-    b2[r].y = s[e1 + (e1 >> 5)];
-  }
-#pragma unroll
-  for (int r = 1; r < 16; ++r) {
-    const float2 w = tabs.tw2[r * 16 + m];
-    a2[r] = cmul(a2[r], w);
-    b2[r] = cmul(b2[r], w);
-  }
-  __syncthreads();  // every read of y is done before z overwrites the buffer
-  if (tabs.dbg && t == 0) ts[3] = wall_clock64();
-  dft16(a2);
-  dft16(b2);
-  float2 v[32];
-  {
-    // z[(j/16)*256 + j%16 + 16 k], real plane then imaginary plane
-    const int base0 = ((t >> 4) << 8) + (t & 15);
-    const int base1 = base0 + 4096;  // j = t + 256 -> (j/16) = t/16 + 16
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      s[base0 + 16 * k] = a2[slot16(k)].x;
-      s[base1 + 16 * k] = b2[slot16(k)].x;
-    }
-    __syncthreads();
-    if (tabs.dbg && t == 0) ts[4] = wall_clock64();
-    // ---------------- pass 3: radix 32, Ns = 256, butterfly j = t ----------------
-#pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].x = s[t + 256 * r];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      s[base0 + 16 * k] = a2[slot16(k)].y;
-      s[base1 + 16 * k] = b2[slot16(k)].y;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].y = s[t + 256 * r];
-    float2 wa[4], wb[8];
-#pragma unroll
-    for (int r1 = 1; r1 < 4; ++r1) wa[r1] = tabs.tw3a[r1 * 256 + t];
-#pragma unroll
-    for (int r2 = 1; r2 < 8; ++r2) wb[r2] = tabs.tw3b[r2 * 256 + t];
-#pragma unroll
-    for (int r = 1; r < 32; ++r) {
-      const int r1 = r & 3, r2 = r >> 2;
-      if (r1 != 0 && r2 != 0) v[r] = cmul(v[r], cmul(wa[r1], wb[r2]));
-      else if (r1 != 0) v[r] = cmul(v[r], wa[r1]);
-      else v[r] = cmul(v[r], wb[r2]);
-    }
-  }
-  if (tabs.dbg && t == 0) ts[5] = wall_clock64();
-  dft32(v);
-  if (tabs.dbg && t == 0) ts[6] = wall_clock64();
-  float* out = psd + frame * 8192;
-#pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    const int bin = t + 256 * k;
-    out[bin ^ 4096] = psd_db(v[slot32(k)], db_off);
-  }
-  if (tabs.dbg && t == 0) {
-    ts[7] = wall_clock64();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tabs.dbg[8 * blockIdx.x + k] = ts[k];
-  }
-}
-
-
-// Timing-only ablations of k_fft8192_psd_split (wrong results by construction; SS_FFT_ABL=1..4, development aid):
-//   1 = no HBM input loads, 2 = no LDS exchanges/barriers, 3 = no HBM stores, 4 = no window/twiddle table loads
-template <int FMT, int WAVES_PER_SIMD, int ABL>
-__global__ __launch_bounds__(256, WAVES_PER_SIMD) void k_fft8192_psd_split_abl(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
-                                                         Fft8192Tables tabs, float db_off, float scale, float* __restrict__ psd) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* s = reinterpret_cast<float*>(smem_raw);  // one fp32 plane (re, then im) of the 8192 points
-  const int t = threadIdx.x;
-  const size_t frame = blockIdx.x;
-  const size_t in_base = frame * (size_t)item_stride;
-  long long ts[8];
-  if (tabs.dbg && t == 0) ts[0] = wall_clock64();
-
-  // ---------------- pass 1: radix 16, Ns = 1, butterflies j = 2t and 2t+1 ----------------
-  float2 a[16], b[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e = 2 * t + 512 * r;
-    float2 x0, x1;
-    if constexpr (ABL == 1) {
-      x0 = make_float2(e * 1e-4f, scale);
-      x1 = make_float2(scale, e * 2e-4f);
-    } else if constexpr (FMT == FMT_CF32) {
-      const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(iq) + in_base + e);
-      x0 = make_float2(q.x, q.y);
-      x1 = make_float2(q.z, q.w);
-    } else if constexpr (FMT == FMT_CS8) {
-      const char4 q = *reinterpret_cast<const char4*>(reinterpret_cast<const char2*>(iq) + in_base + e);
-      x0 = make_float2((float)q.x * scale, (float)q.y * scale);
-      x1 = make_float2((float)q.z * scale, (float)q.w * scale);
-    } else {
-      const uchar4 q = *reinterpret_cast<const uchar4*>(reinterpret_cast<const uchar2*>(iq) + in_base + e);
-      x0 = make_float2(((float)q.x - 127.5f) * scale, ((float)q.y - 127.5f) * scale);
-      x1 = make_float2(((float)q.z - 127.5f) * scale, ((float)q.w - 127.5f) * scale);
-    }
-    const float2 w = ABL == 4 ? make_float2(scale, db_off) : *reinterpret_cast<const float2*>(win + e);
-    a[r] = make_float2(x0.x * w.x, x0.y * w.x);  // volk_32fc_32f_multiply_32fc
-    b[r] = make_float2(x1.x * w.y, x1.y * w.y);
-  }
-  if (tabs.dbg && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[1] = wall_clock64(); }
-  dft16(a);
-  dft16(b);
-  // y[16 j + k]: thread t owns y[32 t .. 32 t + 31]; LDS pitch 33 words per thread. The real parts of all
-  // 8192 points go through the 33 KiB buffer first, then the imaginary parts.
-  float2 a2[16], b2[16];
-  const int m = t & 15;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    s[33 * t + k] = a[slot16(k)].x;
-    s[33 * t + 16 + k] = b[slot16(k)].x;
-  }
-  if (ABL != 2) __syncthreads();
-  if (tabs.dbg && t == 0) ts[2] = wall_clock64();
-  // ---------------- pass 2: radix 16, Ns = 16, butterflies j = t and t + 256 ----------------
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e0 = t + 512 * r, e1 = e0 + 256;
-    a2[r].x = s[e0 + (e0 >> 5)];
-    b2[r].x = s[e1 + (e1 >> 5)];
-  }
-  if (ABL != 2) __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    s[33 * t + k] = a[slot16(k)].y;
-    s[33 * t + 16 + k] = b[slot16(k)].y;
-  }
-  if (ABL != 2) __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e0 = t + 512 * r, e1 = e0 + 256;
-    a2[r].y = s[e0 + (e0 >> 5)];
-    b2[r].y = s[e1 + (e1 >> 5)];
-  }
-#pragma unroll
-  for (int r = 1; r < 16; ++r) {
-    const float2 w = ABL == 4 ? make_float2(scale * r, db_off) : tabs.tw2[r * 16 + m];
-    a2[r] = cmul(a2[r], w);
-    b2[r] = cmul(b2[r], w);
-  }
-  if (ABL != 2) __syncthreads();  // every read of y is done before z overwrites the buffer
-  if (tabs.dbg && t == 0) ts[3] = wall_clock64();
-  dft16(a2);
-  dft16(b2);
-  float2 v[32];
-  {
-    // z[(j/16)*256 + j%16 + 16 k], real plane then imaginary plane
-    const int base0 = ((t >> 4) << 8) + (t & 15);
-    const int base1 = base0 + 4096;  // j = t + 256 -> (j/16) = t/16 + 16
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      s[base0 + 16 * k] = a2[slot16(k)].x;
-      s[base1 + 16 * k] = b2[slot16(k)].x;
-    }
-    if (ABL != 2) __syncthreads();
-    if (tabs.dbg && t == 0) ts[4] = wall_clock64();
-    // ---------------- pass 3: radix 32, Ns = 256, butterfly j = t ----------------
-#pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].x = s[t + 256 * r];
-    if (ABL != 2) __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      s[base0 + 16 * k] = a2[slot16(k)].y;
-      s[base1 + 16 * k] = b2[slot16(k)].y;
-    }
-    if (ABL != 2) __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 32; ++r) v[r].y = s[t + 256 * r];
-    float2 wa[4], wb[8];
-#pragma unroll
-    for (int r1 = 1; r1 < 4; ++r1) wa[r1] = ABL == 4 ? make_float2(scale * r1, db_off) : tabs.tw3a[r1 * 256 + t];
-#pragma unroll
-    for (int r2 = 1; r2 < 8; ++r2) wb[r2] = ABL == 4 ? make_float2(scale, db_off * r2) : tabs.tw3b[r2 * 256 + t];
-#pragma unroll
-    for (int r = 1; r < 32; ++r) {
-      const int r1 = r & 3, r2 = r >> 2;
-      if (r1 != 0 && r2 != 0) v[r] = cmul(v[r], cmul(wa[r1], wb[r2]));
-      else if (r1 != 0) v[r] = cmul(v[r], wa[r1]);
-      else v[r] = cmul(v[r], wb[r2]);
-    }
-  }
-  if (tabs.dbg && t == 0) ts[5] = wall_clock64();
-  dft32(v);
-  if (tabs.dbg && t == 0) ts[6] = wall_clock64();
-  float* out = psd + frame * 8192;
-#pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    const int bin = t + 256 * k;
-    const float r_ = psd_db(v[slot32(k)], db_off);
-    if (ABL != 3 || r_ == 12345.678f) out[bin ^ 4096] = r_;
-  }
-  if (tabs.dbg && t == 0) {
-    ts[7] = wall_clock64();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tabs.dbg[8 * blockIdx.x + k] = ts[k];
-  }
-}
-
-
-
-
 // =================================================================================================
-// Eight-wave variant: 512 threads, 16 points per thread. The 256-thread kernels above are bound by the
-// dependent-issue latency of one long instruction stream per SIMD (ablating their HBM loads, stores,
-// table loads or barriers changes their time by < 10 %); halving the per-thread work doubles the waves
-// that cover each other's stalls at the same LDS footprint.
+// Eight-wave kernel (the default): 512 threads, 16 points per thread. Half the per-thread work of the four-wave
+// variant, 7 KiB of code instead of 14 (instruction fetch falls off a cliff between 8 and 16 KiB of hot code,
+// scripts/ubench/ifetch2), 64 VGPRs and 34 KiB of LDS: four frames and 32 waves per CU.
 //
 //   pass 1  radix 16, Ns = 1    thread t: butterfly j = t            <- 16 x 8-byte global loads
 //           y[16 j + k]                      -> LDS plane, 17-word pitch per thread (conflict-free)
@@ -686,241 +409,6 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
     ts[5] = wall_clock64();
 #pragma unroll
     for (int k = 0; k < (DBG ? 8 : 1); ++k) tabs.dbg[8 * blockIdx.x + k] = ts[k];
-  }
-}
-
-
-// Eight-wave kernel, whole-complex (float2) LDS exchanges: 68 KiB of LDS per workgroup (two frames in flight per
-// CU, two rounds of workgroups per 1024-frame launch), three barriers instead of seven, and a 128-VGPR budget
-// that lets every table value (pass-2 and pass-3 twiddles) be requested at the top of the kernel next to the IQ
-// loads, so no table load sits behind a barrier.
-constexpr int kFft8192W8WideLdsBytes = (8192 + 512) * 8;
-
-template <int FMT>
-__global__ __launch_bounds__(512, 4) void k_fft8192_psd_w8wide(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
-                                                                Fft8192Tables tabs, float db_off, float scale, float* __restrict__ psd) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float2* s = reinterpret_cast<float2*>(smem_raw);
-  const int t = threadIdx.x;
-  const size_t frame = blockIdx.x;
-  const size_t in_base = frame * (size_t)item_stride;
-  const int lane = t & 63;
-  const int h = lane >> 5;
-  const int j = ((t >> 6) << 5) + (lane & 31);
-
-  // ---------------- all global reads of the frame up front: IQ, window, twiddles ----------------
-  float2 a[16];
-  float w[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e = t + 512 * r;
-    a[r] = load_iq<FMT>(iq, in_base + e, scale);
-    w[r] = win[e];
-  }
-  float2 tw2[16];
-  {
-    const int m = t & 15;
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tw2[r] = tabs.tw2[r * 16 + m];
-  }
-  const float2 wa0 = tabs.tw3a[h * 256 + j];
-  const float2 wa1 = tabs.tw3a[(2 + h) * 256 + j];
-  float2 wb[8];
-#pragma unroll
-  for (int q2 = 1; q2 < 8; ++q2) wb[q2] = tabs.tw3b[q2 * 256 + j];
-
-  // ---------------- pass 1: radix 16, Ns = 1, butterfly j = t ----------------
-#pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = make_float2(a[r].x * w[r], a[r].y * w[r]);  // volk_32fc_32f_multiply_32fc
-  dft16(a);
-  // exchange 1: y[16 t + k] at element 17 t + k
-#pragma unroll
-  for (int k = 0; k < 16; ++k) s[17 * t + k] = a[slot16(k)];
-  __syncthreads();
-  // ---------------- pass 2: radix 16, Ns = 16, butterfly j = t ----------------
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e = t + 512 * r;
-    a[r] = s[e + (e >> 4)];
-  }
-#pragma unroll
-  for (int r = 1; r < 16; ++r) a[r] = cmul(a[r], tw2[r]);
-  dft16(a);
-  __syncthreads();  // every read of y is done before z overwrites the buffer
-  // exchange 2: z[(t/16)*256 + t%16 + 16 k]; pass 3 lane (w, l) reads z[j + 256 (2q + h)]
-  {
-    const int zbase = ((t >> 4) << 8) + (t & 15);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) s[zbase + 16 * k] = a[slot16(k)];
-  }
-  __syncthreads();
-  {
-    const int rbase = j + 256 * h;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) a[q] = s[rbase + 512 * q];
-  }
-  // ---------------- pass 3: radix 32, Ns = 256, butterfly j shared by lanes l and l + 32 ----------------
-  a[0] = cmul(a[0], wa0);
-  a[1] = cmul(a[1], wa1);
-#pragma unroll
-  for (int q2 = 1; q2 < 8; ++q2) {
-    a[2 * q2] = cmul(a[2 * q2], cmul(wa0, wb[q2]));
-    a[2 * q2 + 1] = cmul(a[2 * q2 + 1], cmul(wa1, wb[q2]));
-  }
-  dft16(a);  // A_h[k] in slot16(k)
-  const bool odd = h != 0;
-  float2 u[16];
-  u[0] = a[slot16(0)];
-  u[1] = mulw32_if<1>(a[slot16(1)], odd);
-  u[2] = mulw32_if<2>(a[slot16(2)], odd);
-  u[3] = mulw32_if<3>(a[slot16(3)], odd);
-  u[4] = mulw32_if<4>(a[slot16(4)], odd);
-  u[5] = mulw32_if<5>(a[slot16(5)], odd);
-  u[6] = mulw32_if<6>(a[slot16(6)], odd);
-  u[7] = mulw32_if<7>(a[slot16(7)], odd);
-  u[8] = mulw32_if<8>(a[slot16(8)], odd);
-  u[9] = mulw32_if<9>(a[slot16(9)], odd);
-  u[10] = mulw32_if<10>(a[slot16(10)], odd);
-  u[11] = mulw32_if<11>(a[slot16(11)], odd);
-  u[12] = mulw32_if<12>(a[slot16(12)], odd);
-  u[13] = mulw32_if<13>(a[slot16(13)], odd);
-  u[14] = mulw32_if<14>(a[slot16(14)], odd);
-  u[15] = mulw32_if<15>(a[slot16(15)], odd);
-  float* out = psd + frame * 8192;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].x), __float_as_uint(u[k + 8].x), false, false);
-    const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].y), __float_as_uint(u[k + 8].y), false, false);
-    const float2 e = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
-    const float2 o = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
-    const int kk = k + 8 * h;
-    const int bin0 = j + 256 * kk;
-    const int bin1 = bin0 + 256 * 16;
-    out[bin0 ^ 4096] = psd_db(cadd(e, o), db_off);
-    out[bin1 ^ 4096] = psd_db(csub(e, o), db_off);
-  }
-}
-
-// Timing-only ablations of k_fft8192_psd_w8 (wrong results by construction; SS_FFT_ABL=11..15):
-//   11 = no HBM input loads, 12 = no LDS exchanges/barriers, 13 = no HBM stores, 14 = no window/twiddle loads, 15 = no butterflies
-template <int FMT, int WAVES_PER_SIMD, int ABL>
-__global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8_abl(const void* __restrict__ iq, long long item_stride,
-                                                                          const float* __restrict__ win, Fft8192Tables tabs, float db_off,
-                                                                          float scale, float* __restrict__ psd) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (ABL == 16) {  // empty workgroup: launch + LDS allocation cost only
-    if (scale == 12345.678f) psd[threadIdx.x] = smem_raw[threadIdx.x];
-    return;
-  }
-  float* s = reinterpret_cast<float*>(smem_raw);
-  const int t = threadIdx.x;
-  const size_t frame = blockIdx.x;
-  const size_t in_base = frame * (size_t)item_stride;
-
-  // ---------------- pass 1: radix 16, Ns = 1, butterfly j = t ----------------
-  float2 a[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e = t + 512 * r;
-    const float2 x = ABL == 11 ? make_float2(e * 1e-4f, scale) : load_iq<FMT>(iq, in_base + e, scale);
-    const float w = ABL == 14 ? db_off : win[e];
-    a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
-  }
-  if (ABL != 15) dft16(a);
-  float2 c[16];
-  // exchange 1: y[16 t + k] at word 17 t + k
-#pragma unroll
-  for (int k = 0; k < 16; ++k) if (ABL != 12) s[17 * t + k] = a[slot16(k)].x;
-  if (ABL != 12) __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e = t + 512 * r;
-    c[r].x = ABL == 12 ? a[r].x + e : s[e + (e >> 4)];
-  }
-  if (ABL != 12) __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) if (ABL != 12) s[17 * t + k] = a[slot16(k)].y;
-  if (ABL != 12) __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e = t + 512 * r;
-    c[r].y = ABL == 12 ? a[r].y + e : s[e + (e >> 4)];
-  }
-  // ---------------- pass 2: radix 16, Ns = 16, butterfly j = t ----------------
-  {
-    const int m = t & 15;
-#pragma unroll
-    for (int r = 1; r < 16; ++r) c[r] = cmul(c[r], ABL == 14 ? make_float2(scale * r, db_off) : tabs.tw2[r * 16 + m]);
-  }
-  if (ABL != 15) dft16(c);
-  if (ABL != 12) __syncthreads();  // every read of y is done before z overwrites the plane
-  // exchange 2: z[(t/16)*256 + t%16 + 16 k]; pass 3 lane (w, l) reads z[j + 256 (2q + h)], j = 32 w + (l & 31), h = l >> 5
-  const int zbase = ((t >> 4) << 8) + (t & 15);
-  const int lane = t & 63;
-  const int h = lane >> 5;
-  const int j = ((t >> 6) << 5) + (lane & 31);
-  const int rbase = j + 256 * h;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) if (ABL != 12) s[zbase + 16 * k] = c[slot16(k)].x;
-  if (ABL != 12) __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) a[q].x = ABL == 12 ? c[q].x + rbase : s[rbase + 512 * q];
-  if (ABL != 12) __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) if (ABL != 12) s[zbase + 16 * k] = c[slot16(k)].y;
-  if (ABL != 12) __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) a[q].y = ABL == 12 ? c[q].y + rbase : s[rbase + 512 * q];
-
-  // ---------------- pass 3: radix 32, Ns = 256, butterfly j shared by lanes l and l + 32 ----------------
-  // twiddle of input r = 2q + h:  W_8192^(j r) = W_8192^(j (r & 3)) * W_2048^(j (r >> 2)),  r & 3 = 2 (q & 1) + h,  r >> 2 = q >> 1
-  {
-    const float2 wa0 = ABL == 14 ? make_float2(scale, db_off) : tabs.tw3a[h * 256 + j];        // r & 3 = h      (h = 0: W^0 = 1)
-    const float2 wa1 = ABL == 14 ? make_float2(db_off, scale) : tabs.tw3a[(2 + h) * 256 + j];  // r & 3 = 2 + h
-    a[0] = cmul(a[0], wa0);
-    a[1] = cmul(a[1], wa1);
-#pragma unroll
-    for (int q2 = 1; q2 < 8; ++q2) {
-      const float2 wb = ABL == 14 ? make_float2(scale * q2, db_off) : tabs.tw3b[q2 * 256 + j];
-      a[2 * q2] = cmul(a[2 * q2], cmul(wa0, wb));
-      a[2 * q2 + 1] = cmul(a[2 * q2 + 1], cmul(wa1, wb));
-    }
-  }
-  if (ABL != 15) dft16(a);  // A_h[k] in slot16(k)
-  const bool odd = h != 0;
-  float2 u[16];  // u[k] = A_even[k] on the low half-wave, W_32^k A_odd[k] on the high half-wave
-  u[0] = a[slot16(0)];
-  u[1] = mulw32_if<1>(a[slot16(1)], odd);
-  u[2] = mulw32_if<2>(a[slot16(2)], odd);
-  u[3] = mulw32_if<3>(a[slot16(3)], odd);
-  u[4] = mulw32_if<4>(a[slot16(4)], odd);
-  u[5] = mulw32_if<5>(a[slot16(5)], odd);
-  u[6] = mulw32_if<6>(a[slot16(6)], odd);
-  u[7] = mulw32_if<7>(a[slot16(7)], odd);
-  u[8] = mulw32_if<8>(a[slot16(8)], odd);
-  u[9] = mulw32_if<9>(a[slot16(9)], odd);
-  u[10] = mulw32_if<10>(a[slot16(10)], odd);
-  u[11] = mulw32_if<11>(a[slot16(11)], odd);
-  u[12] = mulw32_if<12>(a[slot16(12)], odd);
-  u[13] = mulw32_if<13>(a[slot16(13)], odd);
-  u[14] = mulw32_if<14>(a[slot16(14)], odd);
-  u[15] = mulw32_if<15>(a[slot16(15)], odd);
-  float* out = psd + frame * 8192;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    // v_permlane32_swap(vdst, src): lanes 32..63 of vdst <-> lanes 0..31 of src. With vdst = u[k], src = u[k+8]:
-    //   low half:  (e, o) = (own u[k] = A_even[k],          partner's u[k]   = W^k A_odd[k])
-    //   high half: (e, o) = (partner's u[k+8] = A_even[k+8], own u[k+8]      = W^(k+8) A_odd[k+8])
-    const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].x), __float_as_uint(u[k + 8].x), false, false);
-    const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].y), __float_as_uint(u[k + 8].y), false, false);
-    const float2 e = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
-    const float2 o = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
-    const int kk = k + 8 * h;                 // this lane's output index k (0..15)
-    const int bin0 = j + 256 * kk;            // X[kk]
-    const int bin1 = bin0 + 256 * 16;         // X[kk + 16]
-    const float r0_ = psd_db(cadd(e, o), db_off), r1_ = psd_db(csub(e, o), db_off);
-    if (ABL != 13 || r0_ == 12345.678f) out[bin0 ^ 4096] = r0_;
-    if (ABL != 13 || r1_ == 12345.678f) out[bin1 ^ 4096] = r1_;
   }
 }
 

@@ -56,8 +56,9 @@ __device__ __forceinline__ float psd_db(float2 x, float db_off) {
 // In place: every thread first pulls all its inputs into registers, barrier, then scatters.
 //   thread butterfly j:  v[r] = s[j + r*M/R] * W_M^(r*(j mod Ns)*M/(Ns*R));  DFT_R(v);
 //                        s[(j/Ns)*Ns*R + (j mod Ns) + r*Ns] = v[r]
-// tw = W_TW^k table (TW >= M, power of two), tw_shift = log2(TW / M).
-template <int LOGM, int LOGTOT, int LOGNS, int R>
+// tw = W_TW^k table (TW >= M, power of two), tw_shift = log2(TW / M). BS = element stride between sub-FFTs
+// (M, or M + 1 to keep column-wise tile accesses off a single LDS bank).
+template <int LOGM, int LOGTOT, int LOGNS, int R, int BS = (1 << LOGM)>
 __device__ __forceinline__ void stockham_pass(float2* __restrict__ s, const float2* __restrict__ tw, int tw_shift, int tid) {
   constexpr int M = 1 << LOGM;
   constexpr int TOT = 1 << LOGTOT;
@@ -76,7 +77,7 @@ __device__ __forceinline__ void stockham_pass(float2* __restrict__ s, const floa
       const int m = j & (NS - 1);
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float2 x = s[b * M + j + r * BPF];
+        float2 x = s[b * BS + j + r * BPF];
         if (LOGNS > 0 && r > 0) {
           // W_M^(r*m*M/(NS*R)) = W_TW^((r*m) << (LOGM - LOGNS - LOGR + tw_shift))
           const float2 w = tw[(r * m) << (LOGM - LOGNS - LOGR + tw_shift)];
@@ -95,7 +96,7 @@ __device__ __forceinline__ void stockham_pass(float2* __restrict__ s, const floa
       const int j = g % BPF;
       const int m = j & (NS - 1);
       const int j0 = ((j >> LOGNS) << (LOGNS + LOGR)) + m;
-      float2* o = s + b * M + j0;
+      float2* o = s + b * BS + j0;
       if constexpr (R == 4) {
         const float2 a0 = cadd(v[q][0], v[q][2]);
         const float2 a1 = csub(v[q][0], v[q][2]);
@@ -115,15 +116,15 @@ __device__ __forceinline__ void stockham_pass(float2* __restrict__ s, const floa
 }
 
 // All passes of a size-M FFT: radix 4 while at least two bits remain, then one radix-2 pass.
-template <int LOGM, int LOGTOT, int LOGNS = 0>
+template <int LOGM, int LOGTOT, int LOGNS = 0, int BS = (1 << LOGM)>
 __device__ __forceinline__ void stockham_fft(float2* __restrict__ s, const float2* __restrict__ tw, int tw_shift, int tid) {
   if constexpr (LOGNS < LOGM) {
     if constexpr (LOGM - LOGNS >= 2) {
-      stockham_pass<LOGM, LOGTOT, LOGNS, 4>(s, tw, tw_shift, tid);
-      stockham_fft<LOGM, LOGTOT, LOGNS + 2>(s, tw, tw_shift, tid);
+      stockham_pass<LOGM, LOGTOT, LOGNS, 4, BS>(s, tw, tw_shift, tid);
+      stockham_fft<LOGM, LOGTOT, LOGNS + 2, BS>(s, tw, tw_shift, tid);
     } else {
-      stockham_pass<LOGM, LOGTOT, LOGNS, 2>(s, tw, tw_shift, tid);
-      stockham_fft<LOGM, LOGTOT, LOGNS + 1>(s, tw, tw_shift, tid);
+      stockham_pass<LOGM, LOGTOT, LOGNS, 2, BS>(s, tw, tw_shift, tid);
+      stockham_fft<LOGM, LOGTOT, LOGNS + 1, BS>(s, tw, tw_shift, tid);
     }
   }
 }
@@ -192,7 +193,9 @@ __global__ __launch_bounds__(kFftThreads) void k_fft_cols(const void* __restrict
   const int f = blockIdx.x / tiles_per_frame;
   const int c0 = (blockIdx.x % tiles_per_frame) * C;
   const size_t in_base = (size_t)f * (size_t)item_stride;
-  // LDS layout: column c is the contiguous sub-FFT  s[c*N1 + n1]
+  // LDS layout: column c is the sub-FFT s[c*BS + n1], BS = N1 + 1: adjacent lanes hold adjacent columns, and the odd
+  // stride spreads them over all banks (with BS = N1 every lane of a wave would hit the same bank)
+  constexpr int BS = N1 + 1;
 #pragma unroll 4
   for (int e = tid; e < TOT; e += kFftThreads) {
     const int c = e & (C - 1);  // fastest in memory: adjacent lanes read adjacent n2
@@ -202,10 +205,10 @@ __global__ __launch_bounds__(kFftThreads) void k_fft_cols(const void* __restrict
     const float w = win[n];
     x.x *= w;
     x.y *= w;
-    s[c * N1 + n1] = x;
+    s[c * BS + n1] = x;
   }
   __syncthreads();
-  stockham_fft<LOGN1, 13>(s, tw, LOGN - LOGN1, tid);
+  stockham_fft<LOGN1, 13, 0, BS>(s, tw, LOGN - LOGN1, tid);
   float2* wf = work + (size_t)f * (1 << LOGN);
 #pragma unroll 4
   for (int e = tid; e < TOT; e += kFftThreads) {
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(kFftThreads) void k_fft_cols(const void* __restrict
     const int k1 = e >> LOGC;
     const int n2 = c0 + c;
     const float2 t = tw[(size_t)n2 * k1];  // W_N^(n2*k1), n2*k1 < N
-    wf[k1 * N2 + n2] = cmul(s[c * N1 + k1], t);
+    wf[k1 * N2 + n2] = cmul(s[c * BS + k1], t);
   }
 }
 
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(kFftThreads) void k_fft_rows_psd(const float2* __re
   constexpr int LOGRW = 13 - LOGN2;  // rows (k1 values) per tile
   constexpr int RW = 1 << LOGRW;
   constexpr int TOT = 1 << 13;
+  constexpr int BS = N2 + 1;  // row r is the sub-FFT s[r*BS + n2]; the odd stride keeps the row-fastest read-out off one bank
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float2* s = reinterpret_cast<float2*>(smem_raw);
   const int tid = threadIdx.x;
@@ -234,17 +238,17 @@ __global__ __launch_bounds__(kFftThreads) void k_fft_rows_psd(const float2* __re
   const float2* wf = work + (size_t)f * N;
 #pragma unroll 4
   for (int e = tid; e < TOT; e += kFftThreads) {
-    s[e] = wf[(size_t)r0 * N2 + e];  // rows r0..r0+RW-1 are contiguous in work
+    s[(e >> LOGN2) * BS + (e & (N2 - 1))] = wf[(size_t)r0 * N2 + e];  // rows r0..r0+RW-1 are contiguous in work
   }
   __syncthreads();
-  stockham_fft<LOGN2, 13>(s, tw, LOGN - LOGN2, tid);
+  stockham_fft<LOGN2, 13, 0, BS>(s, tw, LOGN - LOGN2, tid);
   float* out = psd + (size_t)f * N;
 #pragma unroll 4
   for (int e = tid; e < TOT; e += kFftThreads) {
     const int r = e & (RW - 1);  // fastest: adjacent lanes write adjacent k1 -> adjacent output bins
     const int k2 = e >> LOGRW;
     const int k = (r0 + r) + N1 * k2;
-    out[k ^ (N >> 1)] = psd_db(s[r * N2 + k2], db_off);
+    out[k ^ (N >> 1)] = psd_db(s[r * BS + k2], db_off);
   }
 }
 

@@ -57,7 +57,7 @@ struct ss_ctx {
   float2* d_tw = nullptr;
   float2* d_tw8k = nullptr;  // tables of k_fft8192_psd: tw2[256] ++ tw3a[1024] ++ tw3b[2048]
   bool use_fft8192 = false;
-  int fft8192_variant = 0;  // 0 = eight-wave kernel (default); SS_FFT_IMPL selects the four-wave variants for A/B runs
+  int fft8192_variant = 0;  // 0 = eight-wave kernel (default); 2 = four-wave variant (SS_FFT_IMPL=wide, A/B runs)
   uint8_t* d_pass = nullptr;
   bool pass_dirty = true;
   // state
@@ -197,7 +197,7 @@ void launch_lds(ss_ctx* c, const void* d_iq, long long item_stride, int nframes,
 template <int LOGN1, int LOGN2, int FMT>
 void launch_four_step(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
   constexpr int N1 = 1 << LOGN1, N2 = 1 << LOGN2;
-  const size_t lds = sizeof(float2) << 13;
+  const size_t lds = sizeof(float2) * ((1 << 13) + 128);  // 8192 points + one pad element per sub-FFT (at most 128 of them)
   const int col_tiles = N2 >> (13 - LOGN1);
   const int row_tiles = N1 >> (13 - LOGN2);
   hipLaunchKernelGGL((ss::k_fft_cols<LOGN1, LOGN2, FMT>), dim3(nframes * col_tiles), dim3(ss::kFftThreads), lds, c->stream, d_iq,
@@ -237,25 +237,7 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
                          c->cfg.int_scale, d_psd);
     }
   };
-  static const int abl = getenv("SS_FFT_ABL") ? atoi(getenv("SS_FFT_ABL")) : 0;
-  if (abl == 11) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 11>, ss::kFft8192W8LdsBytes);
-  else if (abl == 12) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 12>, ss::kFft8192W8LdsBytes);
-  else if (abl == 13) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 13>, ss::kFft8192W8LdsBytes);
-  else if (abl == 14) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 14>, ss::kFft8192W8LdsBytes);
-  else if (abl == 15) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 15>, ss::kFft8192W8LdsBytes);
-  else if (abl == 16) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 16>, ss::kFft8192W8LdsBytes);
-  else if (abl == 17) launch8(ss::k_fft8192_psd_w8_abl<FMT, 8, 16>, 0);
-  else if (abl == 1) launch(ss::k_fft8192_psd_split_abl<FMT, 3, 1>, ss::kFft8192SplitLdsBytes);
-  else if (abl == 2) launch(ss::k_fft8192_psd_split_abl<FMT, 3, 2>, ss::kFft8192SplitLdsBytes);
-  else if (abl == 3) launch(ss::k_fft8192_psd_split_abl<FMT, 3, 3>, ss::kFft8192SplitLdsBytes);
-  else if (abl == 4) launch(ss::k_fft8192_psd_split_abl<FMT, 3, 4>, ss::kFft8192SplitLdsBytes);
-  else if (c->fft8192_variant == 2) launch(ss::k_fft8192_psd<FMT>, ss::kFft8192LdsBytes);
-  else if (c->fft8192_variant == 3) launch(ss::k_fft8192_psd_split<FMT, 3>, ss::kFft8192SplitLdsBytes);
-  else if (c->fft8192_variant == 80) launch8(ss::k_fft8192_psd_w8wide<FMT>, ss::kFft8192W8WideLdsBytes);
-  else if (c->fft8192_variant == 84) launch8(ss::k_fft8192_psd_w8<FMT, 4>, ss::kFft8192W8LdsBytes);
-  else if (c->fft8192_variant == 86) launch8(ss::k_fft8192_psd_w8<FMT, 6>, ss::kFft8192W8LdsBytes);
-  else if (c->fft8192_variant == 88) launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
-  else if (c->fft8192_variant == 44) launch(ss::k_fft8192_psd_split<FMT, 4>, ss::kFft8192SplitLdsBytes);
+  if (c->fft8192_variant == 2) launch(ss::k_fft8192_psd<FMT>, ss::kFft8192LdsBytes);
   else if (tabs.dbg) launch8(ss::k_fft8192_psd_w8<FMT, 8, true>, ss::kFft8192W8LdsBytes);
   else launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
   if (tabs.dbg && ++s_calls == 20) {
@@ -361,8 +343,7 @@ int run_backend_unfused(ss_ctx* c, const float* d_psd, int nframes, int n_learn,
 int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, NoiseState* z, float* d_rel_out, float* d_avg_out,
                       int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
   const int n = c->n;
-  constexpr int G = 21, GX = 21;
-  static const int TF = getenv("SS_DETECT_TF") ? atoi(getenv("SS_DETECT_TF")) : 16;
+  constexpr int G = 21, GX = 21, TF = 16, TB = 256;  // measured against 32-frame and 128-bin tiles: 16 x 256 is fastest
   if (n_learn > 0) {
     hipLaunchKernelGGL(ss::k_noise_learn, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_psd, n, n_learn, z->d_thr);
   }
@@ -376,9 +357,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   int* counts_next = c->d_cnt2[c->cnt_cur ^ 1];
   const bool keep_planes = (c->cfg.flags & SS_FLAG_KEEP_PLANES) != 0;
   float* avg_full = d_avg_out ? d_avg_out : (keep_planes ? c->d_avg : nullptr);
-  static const int TB = getenv("SS_DETECT_TB") ? atoi(getenv("SS_DETECT_TB")) : 256;
-  const int tb = (TB == 128 && n >= 128) ? 128 : 256;
-  const int tiles = ((nframes + TF - 1) / TF) * ((n + tb - 1) / tb);
+  const int tiles = ((nframes + TF - 1) / TF) * ((n + TB - 1) / TB);
   ss::DetectArgs da{d_psd,        z->d_thr, hist_in,   hist_out, n,         nframes,  n_learn, c->frames_pushed, c->cfg.start_level,
                     c->d_pass,    c->d_mask, counts,    d_rel_out, avg_full, c->d_avg, nullptr};
   // development diagnostic: SS_DEBUG_TIMING=<file> dumps per-workgroup time stamps of the 20th detect launch
@@ -389,9 +368,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
     if (!s_dbg) (void)hipMalloc(&s_dbg, sizeof(long long) * 4 * 65536);
     da.dbg = tiles <= 65536 ? s_dbg : nullptr;
   }
-  if (TF == 32) hipLaunchKernelGGL((ss::k_detect_fused<G, GX, 32>), dim3(tiles), dim3(256), 0, c->stream, da);
-  else if (tb == 128) hipLaunchKernelGGL((ss::k_detect_fused<G, GX, 16, 128>), dim3(tiles), dim3(128), 0, c->stream, da);
-  else hipLaunchKernelGGL((ss::k_detect_fused<G, GX, 16>), dim3(tiles), dim3(256), 0, c->stream, da);
+  hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB>), dim3(tiles), dim3(TB), 0, c->stream, da);
   if (da.dbg && ++s_calls == 20) {
     std::vector<long long> h((size_t)4 * tiles);
     (void)hipStreamSynchronize(c->stream);
@@ -688,12 +665,6 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       const char* impl = getenv("SS_FFT_IMPL");  // "generic" selects the radix-4 LDS kernel (A/B measurements)
       c->use_fft8192 = !(impl && strcmp(impl, "generic") == 0);
       if (impl && strcmp(impl, "wide") == 0) c->fft8192_variant = 2;
-      if (impl && strcmp(impl, "split3") == 0) c->fft8192_variant = 3;
-      if (impl && strcmp(impl, "split4") == 0) c->fft8192_variant = 44;
-      if (impl && strcmp(impl, "w8wide") == 0) c->fft8192_variant = 80;
-      if (impl && strcmp(impl, "w8x4") == 0) c->fft8192_variant = 84;
-      if (impl && strcmp(impl, "w8x6") == 0) c->fft8192_variant = 86;
-      if (impl && strcmp(impl, "w8x8") == 0) c->fft8192_variant = 88;
       std::vector<float2> t8((size_t)(256 + 1024 + 2048));
       auto W = [](double num, double den) {
         const double ang = -2.0 * M_PI * num / den;
