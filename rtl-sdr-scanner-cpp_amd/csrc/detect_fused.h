@@ -9,18 +9,23 @@
 //   avgXY    = centred GX-bin mean of avgY, window clipped at the band edges         sources/utils/utils.cpp:31-53
 //   hit      = start_level <= avgXY && pass(i)                                       sources/radio/blocks/transmission.cpp:91
 //
-// Tiling: one workgroup = TF frames x 256 bins.
-//   phase 1: thread = column. The G-1+TF rel values of the column sit in registers; each time mean is a
-//            fixed-order G-term sum, oldest frame first (independent of how frames are split into
-//            batches, bit for bit: tests/test_gpu_fullsize.py).
+// Tiling: one workgroup = TF frames x 256 bins. Frame tiles are aligned to the ABSOLUTE frame index (frames
+// since the last reset), not to the batch: tile boundaries, and with them every rounding below, do not depend
+// on how the frame stream is cut into batches (bit for bit: tests/test_gpu_fullsize.py). A batch that starts
+// in the middle of a tile re-reads the tile's earlier rows from the ring, which therefore holds
+// H = G-1 + TF-1 rows instead of the Averager's G-1.
+//   phase 1: thread = column. The G-1+TF rel values of the column sit in registers. The first time mean of
+//            the tile is a fixed-order G-term sum, oldest frame first; the next TF-1 slide it the way the
+//            reference's Averager does (sum -= oldest row; sum += new row, averager.cpp:14-25,40-50) —
+//            restarted every TF frames, so the drift of the reference's never-re-zeroed sum cannot build up.
 //   the avgY tile goes through LDS once and changes owner
 //   phase 2: thread = (frame, 16-bin segment). 36 avgY values in registers; the first window of the
 //            segment is a fixed-order GX-term sum, the next 15 slide it the way the reference does
 //            (sum -= leaving bin; sum += entering bin, utils.cpp:39-48) — restarted every 16 bins, so the
 //            drift of the reference's whole-row running sum never builds up.
-// Interior tiles of a steady-state batch (no ring rows, no learning frames, no band edge) take a
-// straight-line path; the few edge tiles take a general path that also maintains the averager ring
-// (the newest G-1 rel rows go to hist_out).
+// Tiles of a steady-state batch (no ring rows, no learning frames, all TF frames inside the batch) take a
+// straight-line path; the few others take a general path. The tiles that hold the newest H frames of the
+// batch also write them to hist_out, the ring the next batch starts from.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -46,6 +51,7 @@ struct DetectTile {
   static constexpr int TB = TB_;           // bins per tile = threads per workgroup
   static constexpr int P = TB + 2 * A;     // tile pitch in floats (276 for GX = 21: rows stay 16-byte aligned)
   static constexpr int ROWS = G - 1 + TF;  // rel rows a column needs
+  static constexpr int H = G - 1 + TF - 1; // ring rows kept between batches (a tile may start TF-1 frames before the batch)
   static constexpr int SEGW = 16;          // bins per phase-2 thread
   static constexpr int NSEG = TB / SEGW;   // 16
   static constexpr int YW = SEGW + 2 * A;  // 36 avgY values per phase-2 thread
@@ -59,6 +65,7 @@ struct DetectArgs {
   const float* hist_in;
   float* hist_out;
   int n, nframes, n_learn, pushed_before;
+  int shift;  // (frames since reset, before this batch) mod TF: tile t covers batch frames [t*TF - shift, t*TF - shift + TF)
   float start_level;
   const uint8_t* pass;
   uint32_t* maskbits;
@@ -69,22 +76,33 @@ struct DetectArgs {
   long long* dbg;  // diagnostic (SS_DEBUG_TIMING): per-workgroup wall_clock64 stamps {start, mid, end, class}, or null
 };
 
-// time means of one column, written into the LDS tile
-template <int G, int TF, int P>
-__device__ __forceinline__ void time_means_to_tile(const float (&x)[G - 1 + TF], float* __restrict__ tile_col) {
+// plane[row][byte offset coff]: block-uniform row base (scalar registers) + one 32-bit per-thread offset
+__device__ __forceinline__ void store_row(float* plane, int row, int n, uint32_t coff, float v) {
+  *reinterpret_cast<float*>(reinterpret_cast<char*>(plane + (size_t)row * n) + coff) = v;
+}
+
+// time means of one column's tile, written into the LDS tile: direct sum for the tile's first frame, then the
+// Averager's own update. frames_seen = Averager::m_frames after the tile's first frame (warm-up: -100 until G).
+template <int G, int TF, int P, bool WARMUP>
+__device__ __forceinline__ void time_means_to_tile(const float (&x)[G - 1 + TF], float* __restrict__ tile_col, int frames_seen) {
+  float sum = 0.0f;
+#pragma unroll
+  for (int g = 0; g < G; ++g) sum += x[g];  // oldest first
 #pragma unroll
   for (int j = 0; j < TF; ++j) {
-    float sum = 0.0f;
-#pragma unroll
-    for (int g = 0; g < G; ++g) sum += x[j + g];  // oldest first
-    tile_col[j * P] = div_const<G>(sum);           // m_sum[i] / m_groupSize
+    if (j > 0) {
+      sum -= x[j - 1];      // Averager::subtract(front)
+      sum += x[j + G - 1];  // Averager::add(new row)
+    }
+    const float m = div_const<G>(sum);  // m_sum[i] / m_groupSize
+    tile_col[j * P] = (!WARMUP || frames_seen + j >= G) ? m : kNoData;  // Averager::updateAverage: m_groupSize <= m_frames
   }
 }
 
 template <int G, int GX, int TF, int TB_ = 256>
 __global__ __launch_bounds__(TB_) void k_detect_fused(DetectArgs a) {
   using T = DetectTile<G, GX, TF, TB_>;
-  constexpr int A = T::A, TB = T::TB, P = T::P, ROWS = T::ROWS, SEGW = T::SEGW, NSEG = T::NSEG, YW = T::YW;
+  constexpr int A = T::A, TB = T::TB, P = T::P, ROWS = T::ROWS, H = T::H, SEGW = T::SEGW, NSEG = T::NSEG, YW = T::YW;
   __shared__ __attribute__((aligned(16))) float tile[TF * P];
   __shared__ int cnt[TF];
 
@@ -93,17 +111,18 @@ __global__ __launch_bounds__(TB_) void k_detect_fused(DetectArgs a) {
   if (a.dbg && tid == 0) t_start = wall_clock64();
   const int n = a.n, nframes = a.nframes;
   const int tiles_per_row = (n + TB - 1) / TB;
-  // Frame tiles are dispatched rotated by three: the tiles that own the ring update (end of the batch) and
-  // the ring read (start of the batch) take the slower general path, so they go first and the short
-  // straight-line tiles fill in behind them instead of leaving a tail.
-  const int nft = (nframes + TF - 1) / TF;
-  const int ft = (blockIdx.x / tiles_per_row + nft - (nft >= 3 ? 3 : 0)) % nft;
-  const int f0 = ft * TF;
+  // Frame tiles are dispatched rotated by one: the ragged last tile and the tiles that read ring rows take the
+  // slower general path, so they go first and the straight-line tiles fill in behind them instead of leaving a tail.
+  const int nft = (nframes + a.shift + TF - 1) / TF;
+  const int ft = (blockIdx.x / tiles_per_row + nft - 1) % nft;
+  const int f0 = ft * TF - a.shift;  // batch-relative frame of the tile's first row of outputs; may be negative
   const int b0 = (blockIdx.x % tiles_per_row) * TB;
   if (tid < TF) cnt[tid] = 0;
   // block-uniform classification
   const bool interior = (b0 - A >= 0) && (b0 + TB + A <= n);
-  const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes - (G - 1));
+  const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes);
+  const int first_hist = nframes - H;  // batch frames >= first_hist become the ring rows [frame - first_hist]
+  const bool writes_hist = f0 + TF > first_hist;
 
   // ---------------- phase 1: time means, thread = column ----------------
   if (steady) {
@@ -117,73 +136,75 @@ __global__ __launch_bounds__(TB_) void k_detect_fused(DetectArgs a) {
         const int colc = min(max(col, 0), n - 1);
         const bool valid = col == colc;
         const float t = a.thr[colc];
-        const float* p = a.psd + (size_t)(f0 - (G - 1)) * n + colc;
+        // block-uniform row base (scalar registers) + one 32-bit per-thread byte offset
+        const char* p = reinterpret_cast<const char*>(a.psd + (size_t)(f0 - (G - 1)) * n);
+        const uint32_t coff = (uint32_t)colc * 4u;
         float x[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) x[r] = p[(size_t)r * n] - t;
+        for (int r = 0; r < ROWS; ++r) x[r] = *reinterpret_cast<const float*>(p + (size_t)r * n * 4 + coff) - t;
         if (!interior) {
 #pragma unroll
           for (int r = 0; r < ROWS; ++r) x[r] = valid ? x[r] : 0.0f;
         }
-        time_means_to_tile<G, TF, P>(x, &tile[c]);
-        if (a.rel_out && valid && c >= A && c < A + TB) {
+        time_means_to_tile<G, TF, P, false>(x, &tile[c], 0);
+        if (valid && c >= A && c < A + TB) {
+          if (a.rel_out) {
 #pragma unroll
-          for (int j = 0; j < TF; ++j) a.rel_out[(size_t)(f0 + j) * n + col] = x[G - 1 + j];
+            for (int j = 0; j < TF; ++j) store_row(a.rel_out, f0 + j, n, coff, x[G - 1 + j]);
+          }
+          if (writes_hist) {
+#pragma unroll
+            for (int j = 0; j < TF; ++j)
+              if (f0 + j >= first_hist) store_row(a.hist_out, f0 + j - first_hist, n, coff, x[G - 1 + j]);
+          }
         }
       }
     }
   } else {
-    // general path: ring rows from before the batch, learning frames, averager warm-up, ragged batch end,
-    // band edges, and the ring update. Rows are walked one at a time (few tiles take this path).
-    for (int c = tid; c < P; c += TB) {
+    // general path: ring rows from before the batch, learning frames, averager warm-up, ragged batch end.
+    // Same arithmetic as above on the same values, so a frame's result does not depend on the path.
+    // (two straight passes over the 276 columns, not a loop: a loop makes the compiler hoist all 36 row
+    // pointers out of it and spill scalar registers)
+#pragma unroll
+    for (int pass_c = 0; pass_c < 2; ++pass_c) {
+      const int c = pass_c * TB + tid;
       const int col = b0 - A + c;
-      if (col < 0 || col >= n) {
+      if (pass_c == 1 && tid >= 2 * A) {
+        // nothing: 276 columns over 256 threads
+      } else if (col < 0 || col >= n) {
+#pragma unroll
         for (int j = 0; j < TF; ++j) tile[j * P + c] = 0.0f;  // outside the band: contributes exactly nothing to the clipped window sums
-        continue;
-      }
-      const bool main_col = c >= A && c < A + TB;
-      const float t = a.thr[col];
-      const int first_hist = nframes - (G - 1);  // newest G-1 frames of this batch become the ring
-      // all loads first, unconditional, on clamped (always legal) addresses: independent and in flight
-      // together; a branch around each load would serialise them on s_waitcnt
-      float x[ROWS];
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r) {
-        const int fr = f0 - (G - 1) + r;  // frame inside the batch; negative = ring rows from before it
-        x[r] = a.psd[(size_t)min(max(fr, 0), nframes - 1) * n + col];
-      }
-      float h[G - 1];
-      if (f0 < G - 1) {  // block-uniform: only the first tiles of a batch see ring rows
-#pragma unroll
-        for (int r = 0; r < G - 1; ++r) h[r] = a.hist_in[(size_t)min(f0 + r, G - 2) * n + col];
       } else {
+        const bool main_col = c >= A && c < A + TB;
+        const float t = a.thr[col];
+        // all loads first, unconditional, on always-legal addresses: independent and in flight together; a
+        // branch around each load would serialise them on s_waitcnt. The row pointer is block-uniform:
+        // frames before the batch come from the ring (row H + frame), frames past its end are clamped.
+        const uint32_t coff = (uint32_t)col * 4u;
+        float x[ROWS];
 #pragma unroll
-        for (int r = 0; r < G - 1; ++r) h[r] = 0.0f;
-      }
+        for (int r = 0; r < ROWS; ++r) {
+          const int fr = f0 - (G - 1) + r;
+          const float* src = fr < 0 ? a.hist_in + (size_t)max(H + fr, 0) * n : a.psd + (size_t)min(fr, nframes - 1) * n;
+          x[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + coff);
+        }
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) {
-        const int fr = f0 - (G - 1) + r;
-        float v = fr < a.n_learn ? kNoData : x[r] - t;  // noise_learner.cpp:49 / :55
-        if (r < G - 1) v = fr < 0 ? h[r] : v;
-        x[r] = fr < nframes ? v : 0.0f;
-      }
-      if (main_col) {
+        for (int r = 0; r < ROWS; ++r) {
+          const int fr = f0 - (G - 1) + r;
+          const float v = fr < a.n_learn ? kNoData : x[r] - t;  // noise_learner.cpp:49 / :55
+          x[r] = fr < 0 ? x[r] : (fr < nframes ? v : 0.0f);     // ring rows already hold rel values
+        }
+        if (main_col) {
 #pragma unroll
-        for (int j = 0; j < TF; ++j) {
-          const int fr = f0 + j;
-          if (fr < nframes) {
-            if (a.rel_out) a.rel_out[(size_t)fr * n + col] = x[G - 1 + j];
-            if (fr >= first_hist) a.hist_out[(size_t)(fr - first_hist) * n + col] = x[G - 1 + j];
+          for (int j = 0; j < TF; ++j) {
+            const int fr = f0 + j;
+            if (fr >= 0 && fr < nframes) {
+              if (a.rel_out) store_row(a.rel_out, fr, n, coff, x[G - 1 + j]);
+              if (fr >= first_hist) store_row(a.hist_out, fr - first_hist, n, coff, x[G - 1 + j]);
+            }
           }
         }
-      }
-#pragma unroll
-      for (int j = 0; j < TF; ++j) {
-        float sum = 0.0f;
-#pragma unroll
-        for (int g = 0; g < G; ++g) sum += x[j + g];
-        const bool warm = a.pushed_before + f0 + j + 1 >= G;  // Averager::updateAverage: m_groupSize <= m_frames
-        tile[j * P + c] = warm ? div_const<G>(sum) : kNoData;
+        time_means_to_tile<G, TF, P, true>(x, &tile[c], a.pushed_before + f0 + 1);
       }
     }
   }
@@ -198,7 +219,7 @@ __global__ __launch_bounds__(TB_) void k_detect_fused(DetectArgs a) {
     const int seg = q / TF;
     const int f = f0 + fj;
     const int i0 = b0 + seg * SEGW;  // first bin of the segment
-    const bool live = f < nframes && i0 < n;
+    const bool live = f >= 0 && f < nframes && i0 < n;
     uint32_t bits = 0;
     if (live) {
       float outv[SEGW];
@@ -272,7 +293,7 @@ __global__ __launch_bounds__(TB_) void k_detect_fused(DetectArgs a) {
   }
 }
 
-// When a batch is shorter than the ring (nframes < G-1) the oldest ring rows survive: move them up.
+// When a batch is shorter than the ring (nframes < H) the oldest ring rows survive: move them up.
 __global__ void k_hist_shift(const float* __restrict__ hist_in, float* __restrict__ hist_out, int n, int keep_rows, int nframes) {
   const size_t total = (size_t)keep_rows * n;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {

@@ -27,6 +27,10 @@ namespace {
 
 thread_local char g_create_err[512] = "";
 
+// fused back end (grouping 21 x 21): frames per tile, and the ring rows kept between batches
+constexpr int kFusedTF = 16;
+constexpr int kHistRows = ss::DetectTile<21, 21, kFusedTF, 256>::H;  // 35
+
 struct SpecState {  // Spectrogram::Container, sources/radio/blocks/spectrogram.h:10-16, one per centre frequency
   int32_t center = 0;
   float* d_sum = nullptr;
@@ -71,8 +75,9 @@ struct ss_ctx {
   // planes (frame-major rows of n floats)
   // back end, fused path (grouping 21 x 21, max_batch <= 4096): ring and counters are double-buffered
   bool fused = false;
-  float* d_hist[2] = {nullptr, nullptr};  // G-1 rel rows each; [hist_cur] is read by the next batch
+  float* d_hist[2] = {nullptr, nullptr};  // kHistRows rel rows each (newest last); [hist_cur] is read by the next batch
   int hist_cur = 0;
+  long long abs_frames = 0;               // frames since the last reset: frame tiles are aligned to this index
   int* d_cnt2[2] = {nullptr, nullptr};    // per-frame candidate counts; the emit kernel clears the other half
   int cnt_cur = 0;
   float* d_relplane = nullptr;            // full rel plane, only when a caller asks for it (lazy)
@@ -343,23 +348,26 @@ int run_backend_unfused(ss_ctx* c, const float* d_psd, int nframes, int n_learn,
 int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, NoiseState* z, float* d_rel_out, float* d_avg_out,
                       int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
   const int n = c->n;
-  constexpr int G = 21, GX = 21, TF = 16, TB = 256;  // measured against 32-frame and 128-bin tiles: 16 x 256 is fastest
+  constexpr int G = 21, GX = 21, TF = kFusedTF, TB = 256;  // measured against 32-frame and 128-bin tiles: 16 x 256 is fastest
+  constexpr int H = kHistRows;
+  static_assert(H == ss::DetectTile<G, GX, TF, TB>::H, "ring depth");
   if (n_learn > 0) {
     hipLaunchKernelGGL(ss::k_noise_learn, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_psd, n, n_learn, z->d_thr);
   }
   const float* hist_in = c->d_hist[c->hist_cur];
   float* hist_out = c->d_hist[c->hist_cur ^ 1];
-  if (nframes < G - 1) {
-    const int keep = G - 1 - nframes;
+  if (nframes < H) {
+    const int keep = H - nframes;
     hipLaunchKernelGGL(ss::k_hist_shift, dim3(grid_for((size_t)keep * n, 256)), dim3(256), 0, c->stream, hist_in, hist_out, n, keep, nframes);
   }
   int* counts = c->d_cnt2[c->cnt_cur];
   int* counts_next = c->d_cnt2[c->cnt_cur ^ 1];
   const bool keep_planes = (c->cfg.flags & SS_FLAG_KEEP_PLANES) != 0;
   float* avg_full = d_avg_out ? d_avg_out : (keep_planes ? c->d_avg : nullptr);
-  const int tiles = ((nframes + TF - 1) / TF) * ((n + TB - 1) / TB);
-  ss::DetectArgs da{d_psd,        z->d_thr, hist_in,   hist_out, n,         nframes,  n_learn, c->frames_pushed, c->cfg.start_level,
-                    c->d_pass,    c->d_mask, counts,    d_rel_out, avg_full, c->d_avg, nullptr};
+  const int shift = (int)(c->abs_frames % TF);
+  const int tiles = ((nframes + shift + TF - 1) / TF) * ((n + TB - 1) / TB);
+  ss::DetectArgs da{d_psd, z->d_thr,           hist_in,   hist_out,  n,      nframes,   n_learn,  c->frames_pushed,
+                    shift, c->cfg.start_level, c->d_pass, c->d_mask, counts, d_rel_out, avg_full, c->d_avg,         nullptr};
   // development diagnostic: SS_DEBUG_TIMING=<file> dumps per-workgroup time stamps of the 20th detect launch
   static long long* s_dbg = nullptr;
   static int s_calls = 0;
@@ -439,6 +447,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
   ++c->batch_no;
   SS_HIP(c, hipGetLastError());
   c->frames_pushed = c->frames_pushed + nframes < G ? c->frames_pushed + nframes : G;
+  c->abs_frames += nframes;
   c->last_psd = d_psd;
   c->last_n = nframes;
   return SS_OK;
@@ -618,8 +627,8 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   }
   if (c->fused) {
     for (int k = 0; k < 2; ++k) {
-      CREATE_HIP(hipMalloc(&c->d_hist[k], sizeof(float) * (size_t)n * (size_t)(G - 1)));
-      CREATE_HIP(hipMemsetAsync(c->d_hist[k], 0, sizeof(float) * (size_t)n * (size_t)(G - 1), c->stream));  // Averager ctor, averager.cpp:7-12
+      CREATE_HIP(hipMalloc(&c->d_hist[k], sizeof(float) * (size_t)n * (size_t)kHistRows));
+      CREATE_HIP(hipMemsetAsync(c->d_hist[k], 0, sizeof(float) * (size_t)n * (size_t)kHistRows, c->stream));  // Averager ctor, averager.cpp:7-12
       CREATE_HIP(hipMalloc(&c->d_cnt2[k], sizeof(int) * (size_t)cfg->max_batch));
       CREATE_HIP(hipMemsetAsync(c->d_cnt2[k], 0, sizeof(int) * (size_t)cfg->max_batch, c->stream));
     }
@@ -829,11 +838,12 @@ int ss_reset(ss_ctx* c) {  // Transmission::resetBuffers -> Averager::reset: row
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
   const int G = c->cfg.grouping_y;
   if (c->fused) {
-    SS_HIP(c, hipMemsetAsync(c->d_hist[c->hist_cur], 0, sizeof(float) * (size_t)c->n * (size_t)(G - 1), c->stream));
+    SS_HIP(c, hipMemsetAsync(c->d_hist[c->hist_cur], 0, sizeof(float) * (size_t)c->n * (size_t)kHistRows, c->stream));
   } else if (G > 1) {
     SS_HIP(c, hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)c->n * (size_t)(G - 1), c->stream));
   }
   c->frames_pushed = 0;
+  c->abs_frames = 0;
   c->rot_frames = 0;
   c->last_n = 0;
   return SS_OK;
@@ -880,8 +890,8 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
     }
     if (plane == SS_PLANE_REL && !c->fused) src = c->d_rel + (size_t)(G - 1 + frame) * n;
   } else if (plane == SS_PLANE_REL && frame >= -(G - 1)) {
-    // ring rows as they were before the batch: [G-1+frame] of the ring the batch started from
-    src = c->fused ? c->last_hist + (size_t)(G - 1 + frame) * n : c->d_rel + (size_t)(G - 1 + frame) * n;
+    // ring rows as they were before the batch: the ring's newest row is frame -1
+    src = c->fused ? c->last_hist + (size_t)(kHistRows + frame) * n : c->d_rel + (size_t)(G - 1 + frame) * n;
   }
   if (!src) return fail(c, SS_ERR_INVALID, "bad plane/frame");
   SS_HIP(c, hipMemcpyAsync(out, src + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));

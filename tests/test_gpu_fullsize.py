@@ -22,7 +22,7 @@ def test_batch_split_invariance(batch):
     work() calls (noise ceiling, averager ring, frame counter) is exactly what a bigger batch sees."""
     kw = dict(fft_size=N, decim=1, learn_frames=100, max_batch=B)
     whole = pkg.SpectrumEngine(FS, CENTER, **kw).process(batch)
-    for sizes in ([256] * 4, [1, 99, 100, 7, 13, 804]):
+    for sizes in ([256] * 4, [1, 99, 100, 7, 13, 804], [3, 5, 2, 30, 40, 17, 36, 35, 856]):
         eng = pkg.SpectrumEngine(FS, CENTER, **kw)
         pos, outs = 0, []
         for s in sizes:
