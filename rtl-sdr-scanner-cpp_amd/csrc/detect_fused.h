@@ -100,7 +100,7 @@ __device__ __forceinline__ void time_means_to_tile(const float (&x)[G - 1 + TF],
 }
 
 template <int G, int GX, int TF, int TB_ = 256>
-__global__ __launch_bounds__(TB_) void k_detect_fused(DetectArgs a) {
+__global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k_detect_fused(DetectArgs a) {
   using T = DetectTile<G, GX, TF, TB_>;
   constexpr int A = T::A, TB = T::TB, P = T::P, ROWS = T::ROWS, H = T::H, SEGW = T::SEGW, NSEG = T::NSEG, YW = T::YW;
   __shared__ __attribute__((aligned(16))) float tile[TF * P];
