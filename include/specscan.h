@@ -172,6 +172,39 @@ int ss_spectrogram_read(ss_ctx* ctx, int8_t* out, float* mean_out);
  * Returns 1 if learning is complete, 0 if still learning, <0 on error. */
 int ss_read_noise(ss_ctx* ctx, float* thr);
 
+/* ---- pipelined host feeding (replay front end) ------------------------------------------------
+ * ss_process is synchronous, as a GNU Radio work() has to be (the scheduler owns the buffers only during the
+ * call). A source that owns its buffers — a file being replayed (the reference's own raw dumps,
+ * sources/utils/radio_utils.cpp:78-84, sources/radio/sdr_device.cpp:173-181), or a SoapySDR readStream loop
+ * (sources/radio/blocks/sdr_source.cpp:63-93) writing straight into pinned memory — can do better: the feed owns
+ * `depth` slots of pinned staging; while batch k runs, batch k+1 crosses PCIe on a copy stream and the caller
+ * fills k+2. Batches go through the chain strictly in submission order, with the same state as ss_process.
+ *
+ *   ss_feed_acquire  -> pinned buffer for up to max_batch frames of N samples (in_format), already decimated
+ *                       (first N samples of each N*decim item, sources/radio/blocks/decimator.h:15-22)
+ *   ss_feed_submit   -> async H2D + the chain + async D2H of the results; returns at once
+ *   ss_feed_collect  -> oldest submitted batch; blocks until it is done. Pointers are pinned host memory owned
+ *                       by the feed, valid until that slot is handed out again by ss_feed_acquire.
+ * Returns SS_ERR_INVALID from acquire when every slot is submitted-and-uncollected (collect first), and from
+ * collect when nothing is pending. Not to be mixed with ss_process on the same context while batches are pending. */
+typedef struct ss_feed ss_feed;
+typedef struct ss_feed_result {
+  int32_t nframes;
+  int32_t status;          /* SS_OK, or SS_ERR_CAND_OVERFLOW (cand_off exact, lists truncated to cand_cap) */
+  int64_t user_tag;        /* the tag given to ss_feed_submit */
+  const int32_t* cand_off; /* nframes + 1 */
+  const int32_t* cand_idx; /* min(cand_off[nframes], cand_cap) */
+  const float* cand_avg;
+  const float* psd_db;     /* nframes * N when the feed was created with want_psd, else NULL */
+} ss_feed_result;
+
+int ss_feed_create(ss_ctx* ctx, int32_t depth, int32_t cand_cap, int32_t want_psd, ss_feed** out);
+void ss_feed_destroy(ss_feed* feed);
+int ss_feed_acquire(ss_feed* feed, void** frames);
+int ss_feed_submit(ss_feed* feed, int32_t nframes, const int64_t* t_ms, int64_t user_tag);
+int ss_feed_collect(ss_feed* feed, ss_feed_result* out);
+int ss_feed_pending(const ss_feed* feed);
+
 #ifdef __cplusplus
 }
 #endif

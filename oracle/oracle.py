@@ -94,6 +94,8 @@ def ref() -> C.CDLL:
         R.ref_get_max_index.argtypes = [c_float_p, C.c_int, C.c_int, C.c_int]
         R.ref_get_fft.argtypes = [C.c_int, C.c_int]
         R.ref_get_tuned_frequency.argtypes = [C.c_int, C.c_int]
+        R.ref_get_raw_file_name.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        R.ref_get_raw_file_name.restype = C.c_int
         R.ref_contains_with_margin.argtypes = [c_int32_p, C.c_int, C.c_int, C.c_int, c_int32_p]
         R.ref_most_frequent_value.argtypes = [c_int32_p, C.c_int]
         R.ref_psd.argtypes = [c_float_p, c_float_p, C.c_int, C.c_int]

@@ -256,6 +256,13 @@ void ref_average(const float* in, float* out, int size, int group) { average(in,
 int ref_get_max_index(const float* data, int size, int index, int group) { return getMaxIndex(data, size, index, group); }
 int ref_get_fft(int sample_rate, int max_step) { return getFft(sample_rate, max_step); }
 int ref_get_tuned_frequency(int f, int step) { return getTunedFrequency(f, step); }
+// getRawFileName (utils/radio_utils.cpp:78-84) reads the wall clock itself: the caller compares within one second
+int ref_get_raw_file_name(const char* label, const char* extension, int frequency, int sample_rate, char* out, int cap) {
+  const std::string s = getRawFileName(label, extension, frequency, sample_rate);
+  if ((int)s.size() + 1 > cap) return -1;
+  memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
 int ref_contains_with_margin(const int* keys, int nkeys, int index, int margin, int* found) {
   std::map<int, bool> m;
   for (int i = 0; i < nkeys; ++i) m[keys[i]] = false;

@@ -32,6 +32,11 @@ class SsConfig(C.Structure):
     ]
 
 
+class SsFeedResult(C.Structure):  # ss_feed_result, include/specscan.h
+    _fields_ = [("nframes", C.c_int32), ("status", C.c_int32), ("user_tag", C.c_int64), ("cand_off", C.POINTER(C.c_int32)),
+                ("cand_idx", C.POINTER(C.c_int32)), ("cand_avg", C.POINTER(C.c_float)), ("psd_db", C.POINTER(C.c_float))]
+
+
 class SpecscanError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"specscan status {status}: {message}")

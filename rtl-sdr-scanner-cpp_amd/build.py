@@ -42,11 +42,12 @@ HOST_LIB = os.path.join(HOST_DIR, "libspecscan_host.so")
 
 
 def build_host_lib(force: bool = False, verbose: bool = False) -> str:
-    """g++ -> host/libspecscan_host.so: the host-side signal tracker (no GPU code)."""
-    src = os.path.join(HOST_DIR, "signal_tracker.cpp")
-    hdr = os.path.join(HOST_DIR, "signal_tracker.h")
-    if force or not os.path.exists(HOST_LIB) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(HOST_LIB):
-        cmd = [shutil.which("g++") or "g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wpedantic", "-Werror", "-o", HOST_LIB, src]
+    """g++ -> host/libspecscan_host.so: the host-side signal tracker and the raw dump files (no GPU code)."""
+    srcs = [os.path.join(HOST_DIR, f) for f in ("signal_tracker.cpp", "raw_file.cpp")]
+    deps = srcs + [os.path.join(HOST_DIR, f) for f in ("signal_tracker.h", "raw_file.h")]
+    if force or not os.path.exists(HOST_LIB) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(HOST_LIB):
+        cmd = [shutil.which("g++") or "g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wpedantic", "-Werror", "-o", HOST_LIB,
+               *srcs]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=HOST_DIR)

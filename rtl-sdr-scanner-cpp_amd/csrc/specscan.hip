@@ -944,3 +944,198 @@ int ss_read_noise(ss_ctx* c, float* thr) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined host feeding (include/specscan.h): pinned staging slots, H2D on a copy stream, the chain on
+// the context's stream, exact-size candidate read-back on a third stream at collect time.
+// ------------------------------------------------------------------------------------------------
+struct ss_feed_slot {
+  void* h_in = nullptr;  // pinned
+  void* d_in = nullptr;
+  int32_t* h_off = nullptr;  // pinned
+  int32_t* h_idx = nullptr;
+  float* h_avg = nullptr;
+  float* h_psd = nullptr;
+  int32_t* d_off = nullptr;
+  int32_t* d_idx = nullptr;
+  float* d_avg = nullptr;
+  hipEvent_t ev_h2d = nullptr, ev_done = nullptr;
+  int nframes = 0;
+  int64_t tag = 0;
+  int state = 0;  // 0 free, 1 acquired (being filled), 2 submitted
+};
+
+struct ss_feed {
+  ss_ctx* c = nullptr;
+  int depth = 0, cand_cap = 0;
+  bool want_psd = false;
+  std::vector<ss_feed_slot> slots;
+  int next_acquire = 0, next_collect = 0, pending = 0, acquired = -1;
+  hipStream_t copy_stream = nullptr, d2h_stream = nullptr;
+};
+
+namespace {
+void feed_free(ss_feed* f) {
+  if (!f) return;
+  for (auto& s : f->slots) {
+    if (s.h_in) (void)hipHostFree(s.h_in);
+    if (s.h_off) (void)hipHostFree(s.h_off);
+    if (s.h_idx) (void)hipHostFree(s.h_idx);
+    if (s.h_avg) (void)hipHostFree(s.h_avg);
+    if (s.h_psd) (void)hipHostFree(s.h_psd);
+    (void)hipFree(s.d_in);
+    (void)hipFree(s.d_off);
+    (void)hipFree(s.d_idx);
+    (void)hipFree(s.d_avg);
+    if (s.ev_h2d) (void)hipEventDestroy(s.ev_h2d);
+    if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+  }
+  if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
+  if (f->d2h_stream) (void)hipStreamDestroy(f->d2h_stream);
+  delete f;
+}
+}  // namespace
+
+extern "C" {
+
+int ss_feed_create(ss_ctx* c, int32_t depth, int32_t cand_cap, int32_t want_psd, ss_feed** out) {
+  if (!c || !out) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  if (depth < 2 || depth > 8 || cand_cap < 0) return fail(c, SS_ERR_INVALID, "feed depth %d (2..8) / cand_cap %d", depth, cand_cap);
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  ss_feed* f = new ss_feed;
+  f->c = c;
+  f->depth = depth;
+  f->cand_cap = cand_cap;
+  f->want_psd = want_psd != 0;
+  f->slots.resize((size_t)depth);
+  const size_t in_bytes = in_bytes_per_sample(c->cfg.in_format) * (size_t)c->n * (size_t)c->cfg.max_batch;
+  const size_t plane = sizeof(float) * (size_t)c->n * (size_t)c->cfg.max_batch;
+  const size_t ncand = (size_t)(cand_cap > 0 ? cand_cap : 1);
+#define FEED_HIP(call)                                                              \
+  do {                                                                              \
+    hipError_t e_ = (call);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      feed_free(f);                                                                 \
+      return fail(c, SS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));    \
+    }                                                                               \
+  } while (0)
+  FEED_HIP(hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking));
+  FEED_HIP(hipStreamCreateWithFlags(&f->d2h_stream, hipStreamNonBlocking));
+  for (auto& s : f->slots) {
+    FEED_HIP(hipHostMalloc(&s.h_in, in_bytes, hipHostMallocDefault));
+    FEED_HIP(hipMalloc(&s.d_in, in_bytes));
+    FEED_HIP(hipHostMalloc((void**)&s.h_off, sizeof(int32_t) * ((size_t)c->cfg.max_batch + 1), hipHostMallocDefault));
+    FEED_HIP(hipHostMalloc((void**)&s.h_idx, sizeof(int32_t) * ncand, hipHostMallocDefault));
+    FEED_HIP(hipHostMalloc((void**)&s.h_avg, sizeof(float) * ncand, hipHostMallocDefault));
+    if (f->want_psd) FEED_HIP(hipHostMalloc((void**)&s.h_psd, plane, hipHostMallocDefault));
+    FEED_HIP(hipMalloc(&s.d_off, sizeof(int32_t) * ((size_t)c->cfg.max_batch + 1)));
+    FEED_HIP(hipMalloc(&s.d_idx, sizeof(int32_t) * ncand));
+    FEED_HIP(hipMalloc(&s.d_avg, sizeof(float) * ncand));
+    FEED_HIP(hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming));
+    FEED_HIP(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+  }
+#undef FEED_HIP
+  *out = f;
+  return SS_OK;
+}
+
+void ss_feed_destroy(ss_feed* f) {
+  if (!f) return;
+  {
+    std::lock_guard<std::mutex> lock(f->c->mtx);
+    (void)hipSetDevice(f->c->cfg.device_id);
+    (void)hipStreamSynchronize(f->copy_stream);
+    (void)hipStreamSynchronize(f->c->stream);
+    (void)hipStreamSynchronize(f->d2h_stream);
+  }
+  feed_free(f);
+}
+
+int ss_feed_pending(const ss_feed* f) { return f ? f->pending : 0; }
+
+int ss_feed_acquire(ss_feed* f, void** frames) {
+  if (!f || !frames) return SS_ERR_INVALID;
+  ss_ctx* c = f->c;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  if (f->acquired >= 0) {  // acquiring twice without a submit hands out the same buffer
+    *frames = f->slots[(size_t)f->acquired].h_in;
+    return SS_OK;
+  }
+  ss_feed_slot& s = f->slots[(size_t)f->next_acquire];
+  if (s.state != 0) return fail(c, SS_ERR_INVALID, "no free feed slot: collect a batch first");
+  s.state = 1;
+  f->acquired = f->next_acquire;
+  f->next_acquire = (f->next_acquire + 1) % f->depth;
+  *frames = s.h_in;
+  return SS_OK;
+}
+
+int ss_feed_submit(ss_feed* f, int32_t nframes, const int64_t* t_ms, int64_t user_tag) {
+  if (!f) return SS_ERR_INVALID;
+  ss_ctx* c = f->c;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  if (f->acquired < 0) return fail(c, SS_ERR_INVALID, "ss_feed_submit without ss_feed_acquire");
+  if (nframes <= 0) return fail(c, SS_ERR_INVALID, "nframes %d", nframes);
+  if (nframes > c->cfg.max_batch) return fail(c, SS_ERR_BATCH, "nframes %d > max_batch %d", nframes, c->cfg.max_batch);
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  ss_feed_slot& s = f->slots[(size_t)f->acquired];
+  const int n = c->n;
+  const size_t row_bytes = in_bytes_per_sample(c->cfg.in_format) * (size_t)n;
+  SS_HIP(c, hipMemcpyAsync(s.d_in, s.h_in, row_bytes * (size_t)nframes, hipMemcpyHostToDevice, f->copy_stream));
+  SS_HIP(c, hipEventRecord(s.ev_h2d, f->copy_stream));
+  SS_HIP(c, hipStreamWaitEvent(c->stream, s.ev_h2d, 0));
+  NoiseState* z = nullptr;
+  int st = get_noise(c, &z);
+  if (st != SS_OK) return st;
+  const int n_learn = plan_learning(c, z, nframes, t_ms);
+  const bool want_cands = f->cand_cap > 0;
+  st = run_batch(c, s.d_in, (long long)n, nframes, n_learn, z, nullptr, nullptr, nullptr, s.d_off, want_cands ? s.d_idx : nullptr,
+                 want_cands ? s.d_avg : nullptr, f->cand_cap);
+  if (st != SS_OK) return st;
+  SS_HIP(c, hipMemcpyAsync(s.h_off, s.d_off, sizeof(int32_t) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, c->stream));
+  if (f->want_psd) SS_HIP(c, hipMemcpyAsync(s.h_psd, c->last_psd, sizeof(float) * (size_t)n * (size_t)nframes, hipMemcpyDeviceToHost, c->stream));
+  SS_HIP(c, hipEventRecord(s.ev_done, c->stream));
+  s.nframes = nframes;
+  s.tag = user_tag;
+  s.state = 2;
+  f->acquired = -1;
+  ++f->pending;
+  return SS_OK;
+}
+
+int ss_feed_collect(ss_feed* f, ss_feed_result* out) {
+  if (!f || !out) return SS_ERR_INVALID;
+  ss_ctx* c = f->c;
+  ss_feed_slot* s = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(c->mtx);
+    if (f->pending == 0) return fail(c, SS_ERR_INVALID, "ss_feed_collect: nothing pending");
+    s = &f->slots[(size_t)f->next_collect];
+  }
+  // wait outside the lock: a producer thread may acquire / submit the next slots meanwhile
+  hipError_t e = hipEventSynchronize(s->ev_done);
+  std::lock_guard<std::mutex> lock(c->mtx);
+  if (e != hipSuccess) return fail(c, SS_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(e));
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  const int total = s->h_off[s->nframes];
+  const int ncopy = total < f->cand_cap ? total : f->cand_cap;
+  if (ncopy > 0) {
+    SS_HIP(c, hipMemcpyAsync(s->h_idx, s->d_idx, sizeof(int32_t) * (size_t)ncopy, hipMemcpyDeviceToHost, f->d2h_stream));
+    SS_HIP(c, hipMemcpyAsync(s->h_avg, s->d_avg, sizeof(float) * (size_t)ncopy, hipMemcpyDeviceToHost, f->d2h_stream));
+    SS_HIP(c, hipStreamSynchronize(f->d2h_stream));
+  }
+  out->nframes = s->nframes;
+  out->status = (f->cand_cap > 0 && total > f->cand_cap) ? SS_ERR_CAND_OVERFLOW : SS_OK;
+  out->user_tag = s->tag;
+  out->cand_off = s->h_off;
+  out->cand_idx = s->h_idx;
+  out->cand_avg = s->h_avg;
+  out->psd_db = f->want_psd ? s->h_psd : nullptr;
+  s->state = 0;
+  f->next_collect = (f->next_collect + 1) % f->depth;
+  --f->pending;
+  return SS_OK;
+}
+
+}  // extern "C"

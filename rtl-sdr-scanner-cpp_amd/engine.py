@@ -45,13 +45,26 @@ def load_library() -> C.CDLL:
         lib.ss_spectrogram_read.restype = C.c_int
         lib.ss_selftest.argtypes = [C.c_int, C.c_int]
         lib.ss_selftest.restype = C.c_longlong
+        lib.ss_feed_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        lib.ss_feed_create.restype = C.c_int
+        lib.ss_feed_destroy.argtypes = [C.c_void_p]
+        lib.ss_feed_destroy.restype = None
+        lib.ss_feed_acquire.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.ss_feed_acquire.restype = C.c_int
+        lib.ss_feed_submit.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_int64]
+        lib.ss_feed_submit.restype = C.c_int
+        lib.ss_feed_collect.argtypes = [C.c_void_p, C.POINTER(abi.SsFeedResult)]
+        lib.ss_feed_collect.restype = C.c_int
+        lib.ss_feed_pending.argtypes = [C.c_void_p]
+        lib.ss_feed_pending.restype = C.c_int
         _lib = lib
     return _lib
 
 
 EXPORTS = ("ss_default_config", "ss_device_count", "ss_create", "ss_destroy", "ss_last_error", "ss_process",
            "ss_process_device", "ss_sync", "ss_stream", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
-           "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read")
+           "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read",
+           "ss_feed_create", "ss_feed_destroy", "ss_feed_acquire", "ss_feed_submit", "ss_feed_collect", "ss_feed_pending")
 
 
 def _ptr(t):
@@ -99,3 +112,68 @@ class SpectrumEngine(abi.Chain):
         ms, cnt = C.c_double(), C.c_int32()
         self._check(self._lib.ss_kernel_timing_read(self._h, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+
+    def feed(self, depth: int = 3, cand_cap: int = 1 << 20, want_psd: bool = False) -> "Feed":
+        """Pipelined host feeding (ss_feed_*): pinned staging slots, H2D overlapped with the chain."""
+        return Feed(self, depth, cand_cap, want_psd)
+
+
+class Feed:
+    """ss_feed_* of include/specscan.h: ``acquire()`` a pinned numpy view, fill it, ``submit(nframes)``,
+    ``collect()`` results in submission order. Views returned by ``collect`` live in the feed's pinned memory and
+    are valid until the slot is acquired again (copy what must outlive that)."""
+
+    def __init__(self, engine: SpectrumEngine, depth: int, cand_cap: int, want_psd: bool):
+        self._e, self._lib = engine, engine._lib
+        self.cand_cap = int(cand_cap)
+        h = C.c_void_p()
+        engine._check(self._lib.ss_feed_create(engine._h, int(depth), int(cand_cap), int(bool(want_psd)), C.byref(h)))
+        self._h = h
+        cfg = engine.cfg
+        self._shape = (cfg.max_batch, cfg.fft_size) if cfg.in_format == abi.SS_FMT_CF32 else (cfg.max_batch, cfg.fft_size, 2)
+        self._dtype = {abi.SS_FMT_CF32: np.complex64, abi.SS_FMT_CS8: np.int8, abi.SS_FMT_CU8: np.uint8}[cfg.in_format]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ss_feed_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def pending(self) -> int:
+        return int(self._lib.ss_feed_pending(self._h))
+
+    def acquire(self) -> np.ndarray:
+        """[max_batch, N] complex64 (or [max_batch, N, 2] int8/uint8) view of the next free pinned slot: frames
+        already decimated (the first N samples of each N*D item)."""
+        p = C.c_void_p()
+        self._e._check(self._lib.ss_feed_acquire(self._h, C.byref(p)))
+        nbytes = int(np.prod(self._shape)) * np.dtype(self._dtype).itemsize
+        buf = (C.c_char * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=self._dtype).reshape(self._shape)
+
+    def submit(self, nframes: int, t_ms=None, tag: int = 0):
+        tp = None
+        if t_ms is not None:
+            t = np.ascontiguousarray(t_ms, dtype=np.int64)
+            tp = t.ctypes.data_as(C.POINTER(C.c_int64))
+        self._e._check(self._lib.ss_feed_submit(self._h, int(nframes), tp, int(tag)))
+
+    def collect(self) -> dict:
+        r = abi.SsFeedResult()
+        self._e._check(self._lib.ss_feed_collect(self._h, C.byref(r)))
+        nf = r.nframes
+        off = np.ctypeslib.as_array(r.cand_off, shape=(nf + 1,))
+        total = min(int(off[nf]), self.cand_cap)
+        out = {"nframes": nf, "status": r.status, "tag": r.user_tag, "cand_off": off,
+               "cand_idx": np.ctypeslib.as_array(r.cand_idx, shape=(max(total, 1),))[:total],
+               "cand_avg": np.ctypeslib.as_array(r.cand_avg, shape=(max(total, 1),))[:total]}
+        if r.psd_db:
+            out["psd"] = np.ctypeslib.as_array(r.psd_db, shape=(nf, self._e.n))
+        return out
