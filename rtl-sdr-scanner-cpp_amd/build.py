@@ -47,7 +47,7 @@ def build_host_lib(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + [os.path.join(HOST_DIR, f) for f in ("signal_tracker.h", "raw_file.h")]
     if force or not os.path.exists(HOST_LIB) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(HOST_LIB):
         cmd = [shutil.which("g++") or "g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wpedantic", "-Werror", "-o", HOST_LIB,
-               *srcs]
+               *srcs, "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=HOST_DIR)

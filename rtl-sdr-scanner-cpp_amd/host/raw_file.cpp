@@ -83,4 +83,12 @@ int srf_reader_read_frames(void* reader, void* out, int max_frames) {
     return -3;
   }
 }
+int srf_reader_read_frames_parallel(void* reader, void* out, int max_frames, int threads) {
+  if (!reader || !out || max_frames < 0) return -1;
+  try {
+    return static_cast<RawIqReader*>(reader)->readFramesParallel(out, max_frames, threads);
+  } catch (const std::exception&) {
+    return -3;
+  }
+}
 }

@@ -22,7 +22,10 @@
 #include <ctime>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 namespace specscan {
 
@@ -191,6 +194,38 @@ class RawIqReader {
   int64_t position() const { return m_pos; }
   size_t frameBytes() const { return rawBytesPerValue(m_kind) * (size_t)m_n; }
 
+  // The same with the copy out of the page cache spread over `threads` readers (pread on disjoint ranges): one
+  // thread moves ~20 GB/s, less than the PCIe link behind it takes. Adjacent frames (decim 1) only; falls back otherwise.
+  int readFramesParallel(void* out, int max_frames, int threads) {
+    const int64_t want = std::min<int64_t>(max_frames, m_items - m_pos);
+    const size_t fb = frameBytes();
+    if (m_decim != 1 || threads <= 1 || want * (int64_t)fb < (int64_t)(8u << 20)) return readFrames(out, max_frames);
+    const int fd = fileno(m_file);
+    const int64_t base = m_pos * (int64_t)fb, total = want * (int64_t)fb;
+    std::vector<std::thread> pool;
+    std::vector<int> ok((size_t)threads, 1);
+    for (int k = 0; k < threads; ++k) {
+      const int64_t lo = total * k / threads, hi = total * (k + 1) / threads;
+      pool.emplace_back([=, &ok] {
+        int64_t done = lo;
+        while (done < hi) {
+          const ssize_t got = pread(fd, static_cast<char*>(out) + done, (size_t)(hi - done), (off_t)(base + done));
+          if (got <= 0) {
+            ok[(size_t)k] = 0;
+            return;
+          }
+          done += got;
+        }
+      });
+    }
+    for (auto& t : pool) t.join();
+    for (int v : ok)
+      if (!v) throw std::runtime_error("read failed");
+    m_pos += want;
+    if (fseeko(m_file, (off_t)(m_pos * (int64_t)fb), SEEK_SET) != 0) throw std::runtime_error("seek failed");
+    return (int)want;
+  }
+
   // Up to max_frames frames of N samples, contiguous in `out`; returns how many (0 at the end of the file).
   int readFrames(void* out, int max_frames) {
     int done = 0;
@@ -239,4 +274,5 @@ void* srf_reader_open(const char* path, int kind, int fft_size, int decim);
 void srf_reader_close(void* reader);
 int64_t srf_reader_items(void* reader);
 int srf_reader_read_frames(void* reader, void* out, int max_frames);
+int srf_reader_read_frames_parallel(void* reader, void* out, int max_frames, int threads);
 }

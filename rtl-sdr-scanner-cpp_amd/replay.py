@@ -49,6 +49,8 @@ def _lib():
         lib.srf_reader_items.restype = C.c_int64
         lib.srf_reader_read_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.srf_reader_read_frames.restype = C.c_int
+        lib.srf_reader_read_frames_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        lib.srf_reader_read_frames_parallel.restype = C.c_int
         lib._srf_bound = True
     return lib
 
@@ -129,9 +131,10 @@ class RawIqReader:
         self.kind, self.n = kind, fft_size
         self.items = int(self._lib.srf_reader_items(self._h))
 
-    def read_into(self, frames: np.ndarray, max_frames: int) -> int:
-        """Fills ``frames`` (C-contiguous, at least max_frames frames) with the next frames; returns how many (0 = end)."""
-        n = self._lib.srf_reader_read_frames(self._h, frames.ctypes.data, int(max_frames))
+    def read_into(self, frames: np.ndarray, max_frames: int, threads: int = 1) -> int:
+        """Fills ``frames`` (C-contiguous, at least max_frames frames) with the next frames; returns how many (0 = end).
+        threads > 1 spreads the copy out of the page cache over that many readers."""
+        n = self._lib.srf_reader_read_frames_parallel(self._h, frames.ctypes.data, int(max_frames), int(threads))
         if n < 0:
             raise OSError("raw IQ read failed")
         return n
@@ -178,7 +181,7 @@ def engine_overrides_for(info: RawFileInfo) -> dict:
 
 
 def replay_file(engine, path: str, kind: int | None = None, batch: int | None = None, depth: int = 3, cand_cap: int = 1 << 20,
-                want_psd: bool = False, frame_period_ms: float | None = None, stats: ReplayStats | None = None):
+                want_psd: bool = False, frame_period_ms: float | None = None, stats: ReplayStats | None = None, read_threads: int = 4):
     """Generator: streams the dump through ``engine`` (a SpectrumEngine whose in_format matches the file) and yields
     one result dict per batch, in order (copies: safe to keep). A reader thread fills pinned slots; up to ``depth - 1``
     batches are in flight behind the one being read.
@@ -209,7 +212,7 @@ def replay_file(engine, path: str, kind: int | None = None, batch: int | None = 
                 free.acquire()
                 buf = feed.acquire()
                 t0 = time.perf_counter()
-                got = reader.read_into(buf, batch)
+                got = reader.read_into(buf, batch, read_threads)
                 st.read_seconds += time.perf_counter() - t0
                 if got == 0:
                     break

@@ -132,3 +132,21 @@ def test_reader_rejects_power_files(tmp_path):
     np.zeros(16, np.float32).tofile(p)
     with pytest.raises(OSError):
         replay.RawIqReader(str(p), replay.KIND_F32, 16)
+
+
+def test_parallel_read_equals_sequential(tmp_path):
+    """readFramesParallel (pread on disjoint ranges) returns the same frames as the single-stream read, including
+    the short last batch."""
+    n, items = 4096, 700  # 22 MiB of cf32: above the size where the parallel path engages
+    rng = np.random.default_rng(5)
+    data = rng.integers(0, 2**31, size=(items * n + 11, 2), dtype=np.int64).astype(np.float32).view(np.complex64).reshape(-1)
+    path = tmp_path / "full_20250307_090501_144500000_2048000_fc.raw"
+    data.tofile(path)
+    a = replay.RawIqReader(str(path), replay.KIND_CF32, n)
+    b = replay.RawIqReader(str(path), replay.KIND_CF32, n)
+    buf_a, buf_b = np.empty((300, n), np.complex64), np.empty((300, n), np.complex64)
+    for want in (300, 300, 100, 0):
+        ga = a.read_into(buf_a, 300, threads=1)
+        gb = b.read_into(buf_b, 300, threads=4)
+        assert ga == gb == want
+        np.testing.assert_array_equal(buf_a[:ga].view(np.uint64), buf_b[:gb].view(np.uint64))
