@@ -54,6 +54,25 @@ def build_host_lib(force: bool = False, verbose: bool = False) -> str:
     return HOST_LIB
 
 
+REPLAY_TOOL = os.path.join(HOST_DIR, "specscan_replay")
+
+
+def build_replay_tool(force: bool = False, verbose: bool = False) -> str:
+    """g++ -> host/specscan_replay: the C++ replay host (host/replay_main.cpp) linked against libspecscan.so."""
+    src = os.path.join(HOST_DIR, "replay_main.cpp")
+    deps = [src, os.path.join(HOST_DIR, "raw_file.h"), os.path.join(HERE, "..", "include", "specscan.h"), LIB]
+    if force or not os.path.exists(REPLAY_TOOL) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(REPLAY_TOOL):
+        build_lib()
+        cmd = [shutil.which("g++") or "g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Wpedantic", "-Werror",
+               "-I" + os.path.join(HERE, "..", "include"), "-o", REPLAY_TOOL, src, "-L" + CSRC, "-lspecscan", "-Wl,-rpath,$ORIGIN/../csrc",
+               "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib"), "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=HOST_DIR)
+    return REPLAY_TOOL
+
+
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
     print(build_host_lib(force=True, verbose=True))
+    print(build_replay_tool(force=True, verbose=True))

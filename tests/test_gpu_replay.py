@@ -117,3 +117,32 @@ def test_feed_slot_discipline():
     feed.submit(3, tag=7)
     assert feed.collect()["tag"] == 101 and feed.collect()["nframes"] == 3 and feed.pending == 0
     feed.close()
+
+
+def test_cpp_replay_host_matches_python_path(tmp_path):
+    """host/specscan_replay — a C++ program on the C ABI alone — replays the same dump: same candidate total, and its
+    `_power.raw` (the reference's DEBUG_SAVE_FULL_POWER dump, sdr_device.cpp:173-176) equals the PSD plane bit for bit."""
+    import json
+    import os
+    import subprocess
+    tool = pkg.build.build_replay_tool()
+    n, nframes, batch, learn = 2048, 180, 64, 25
+    band = pkg.synth.SyntheticBand(n, seed=13, on_frame=learn + 5, off_frame=nframes - 3)
+    iq = band.frames_cf32(nframes)
+    path = _write_dump(tmp_path, iq, replay.KIND_CF32)
+    out_dir = tmp_path / "power"
+    out_dir.mkdir()
+    r = subprocess.run([tool, path, "--fft", str(n), "--decim", "1", "--batch", str(batch), "--learn-frames", str(learn),
+                        "--power-dir", str(out_dir)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    eng = pkg.SpectrumEngine(FS, CENTER, fft_size=n, decim=1, learn_frames=learn, max_batch=batch)
+    want = _concat(list(replay.replay_file(eng, path, batch=batch, want_psd=True)))
+    assert (rep["frames"], rep["batches"], rep["candidates"]) == (nframes, -(-nframes // batch), int(want["cand_off"][-1]))
+    files = os.listdir(out_dir)
+    assert files == ["full_20250307_090501_%d_%d_power.raw" % (CENTER, FS)]
+    power = np.fromfile(out_dir / files[0], np.float32).reshape(-1, n)
+    np.testing.assert_array_equal(power, want["psd"])
+    # usage errors and bad names do not reach the GPU
+    assert subprocess.run([tool], capture_output=True).returncode == 2
+    assert subprocess.run([tool, str(tmp_path / "nonsense.bin")], capture_output=True).returncode == 2
