@@ -281,7 +281,10 @@ __device__ __forceinline__ float2 mulw32_if(float2 x, bool on) {
   return on ? y : x;
 }
 
-template <int FMT, int WAVES_PER_SIMD, bool DBG = false>
+// ABLATE (diagnostic, SS_FFT_ABLATE): 1 = memory traffic only (same loads and store count, no transform), 2 = transform
+// only (no global loads, stores never execute). Measured at 1024 / 4096 frames per launch: full 26.1 / 90.7 us,
+// memory only 19.2 / 72.3 us, transform only 16.7 / 48.6 us — see DESIGN.md.
+template <int FMT, int WAVES_PER_SIMD, bool DBG = false, int ABLATE = 0>
 __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const void* __restrict__ iq, long long item_stride,
                                                                           const float* __restrict__ win, Fft8192Tables tabs, float db_off,
                                                                           float scale, float* __restrict__ psd) {
@@ -301,10 +304,16 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
     const float2 x = load_iq<FMT>(iq, in_base + e, scale);
     const float w = win[e];
     a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
+    if constexpr (ABLATE == 2) a[r] = make_float2(__int_as_float(0x3f800000 + e), db_off * (float)r);  // no global loads
   }
   if constexpr (DBG) if (t == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ts[1] = wall_clock64();
+  }
+  if constexpr (ABLATE == 1) {  // memory traffic only: same loads, same number of stores, no transform
+#pragma unroll
+    for (int r = 0; r < 16; ++r) psd[frame * 8192 + t + 512 * r] = a[r].x + a[r].y;
+    return;
   }
   dft16(a);
   float2 c[16];
@@ -400,8 +409,15 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
     const int kk = k + 8 * h;                 // this lane's output index k (0..15)
     const int bin0 = j + 256 * kk;            // X[kk]
     const int bin1 = bin0 + 256 * 16;         // X[kk + 16]
-    out[bin0 ^ 4096] = psd_db(cadd(e, o), db_off);
-    out[bin1 ^ 4096] = psd_db(csub(e, o), db_off);
+    if constexpr (ABLATE == 2) {  // compute only: the stores stay in the program but never execute
+      if (scale == 12345.0f) {
+        out[bin0 ^ 4096] = psd_db(cadd(e, o), db_off);
+        out[bin1 ^ 4096] = psd_db(csub(e, o), db_off);
+      }
+    } else {
+      out[bin0 ^ 4096] = psd_db(cadd(e, o), db_off);
+      out[bin1 ^ 4096] = psd_db(csub(e, o), db_off);
+    }
   }
   if constexpr (DBG) if (t == 0) {
     ts[4] = wall_clock64();

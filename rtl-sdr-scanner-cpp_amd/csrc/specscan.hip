@@ -244,7 +244,12 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
   };
   if (c->fft8192_variant == 2) launch(ss::k_fft8192_psd<FMT>, ss::kFft8192LdsBytes);
   else if (tabs.dbg) launch8(ss::k_fft8192_psd_w8<FMT, 8, true>, ss::kFft8192W8LdsBytes);
-  else launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
+  else {
+    static const int ablate = getenv("SS_FFT_ABLATE") ? atoi(getenv("SS_FFT_ABLATE")) : 0;
+    if (ablate == 1) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 1>, ss::kFft8192W8LdsBytes);
+    else if (ablate == 2) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 2>, ss::kFft8192W8LdsBytes);
+    else launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
+  }
   if (tabs.dbg && ++s_calls == 20) {
     std::vector<long long> h((size_t)8 * nframes);
     (void)hipStreamSynchronize(c->stream);
