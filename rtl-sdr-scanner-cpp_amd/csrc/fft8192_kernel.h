@@ -423,6 +423,12 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
     ts[4] = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ts[5] = wall_clock64();
+    // where the workgroup ran: HW_ID (wave, SIMD, CU, SH, SE) and XCC_ID, for dispatch-order analysis
+    unsigned hw_id = 0, xcc_id = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    ts[6] = hw_id;
+    ts[7] = xcc_id;
 #pragma unroll
     for (int k = 0; k < (DBG ? 8 : 1); ++k) tabs.dbg[8 * blockIdx.x + k] = ts[k];
   }
