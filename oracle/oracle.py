@@ -63,7 +63,74 @@ def lib() -> C.CDLL:
         L.orc_spectrogram_size.argtypes = [C.c_void_p]
         L.orc_spectrogram_process.argtypes = [C.c_void_p, c_float_p]
         L.orc_spectrogram_send.argtypes = [C.c_void_p, C.POINTER(C.c_int8), c_float_p]
+        # channeliser oracle (channelizer_oracle.h)
+        c_int_p = C.POINTER(C.c_int)
+        L.cho_resampler_factors.argtypes = [C.c_int32, C.c_int32, C.c_int, c_int_p, c_int_p, C.c_int]
+        L.cho_design_taps.argtypes = [C.c_int, C.c_int, c_float_p, C.c_int]
+        L.cho_create.argtypes = [C.c_int32, C.c_int32, C.c_int]
+        L.cho_create.restype = C.c_void_p
+        L.cho_destroy.argtypes = [C.c_void_p]
+        L.cho_stage_count.argtypes = [C.c_void_p]
+        L.cho_stage_info.argtypes = [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p]
+        L.cho_set_shift.argtypes = [C.c_void_p, C.c_int32]
+        L.cho_process.argtypes = [C.c_void_p, c_float_p, C.c_int, c_float_p, C.POINTER(C.c_int8), C.c_int]
+        L.cho_transmission_payload.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_int8), C.c_int, C.POINTER(C.c_uint8), C.c_int]
     return _lib
+
+
+def resampler_factors(sample_rate: int, bandwidth: int, threshold: int = 125, which: str = "oracle"):
+    """getResamplersFactors as a list of (interpolation, decimation); which = "oracle" (restated) or "ref" (the reference's own code)."""
+    a, b = (C.c_int * 16)(), (C.c_int * 16)()
+    fn = lib().cho_resampler_factors if which == "oracle" else ref().ref_get_resamplers_factors
+    n = fn(sample_rate, bandwidth, threshold, a, b, 16)
+    return [(a[i], b[i]) for i in range(n)]
+
+
+def design_taps(interp: int, decim: int) -> np.ndarray:
+    n = lib().cho_design_taps(interp, decim, None, 0)
+    t = np.zeros(n, np.float32)
+    lib().cho_design_taps(interp, decim, fp(t), n)
+    return t
+
+
+class ChannelizerOracle:
+    """One recording slot of the reference's Recorder, restated (channelizer_oracle.c)."""
+
+    def __init__(self, sample_rate: int, bandwidth: int, threshold: int = 125):
+        self._h = lib().cho_create(sample_rate, bandwidth, threshold)
+        self.sample_rate, self.bandwidth = sample_rate, bandwidth
+        n = lib().cho_stage_count(self._h)
+        self.stages = []
+        for s in range(n):
+            i, d, t = C.c_int(), C.c_int(), C.c_int()
+            lib().cho_stage_info(self._h, s, C.byref(i), C.byref(d), C.byref(t))
+            self.stages.append((i.value, d.value, t.value))
+
+    def set_shift(self, shift_hz: int):
+        lib().cho_set_shift(self._h, int(shift_hz))
+
+    def process(self, iq: np.ndarray):
+        """iq: complex64 [n]. Returns (cf32 output, int8 [m, 2] output)."""
+        x = np.ascontiguousarray(iq, dtype=np.complex64)
+        cap = x.size + 16
+        for i, d, _ in self.stages:
+            cap = cap * i // d + 16
+        out = np.zeros(cap, np.complex64)
+        i8 = np.zeros((cap, 2), np.int8)
+        m = lib().cho_process(self._h, x.view(np.float32).ctypes.data_as(c_float_p), x.size, out.view(np.float32).ctypes.data_as(c_float_p),
+                              i8.ctypes.data_as(C.POINTER(C.c_int8)), cap)
+        return out[:m], i8[:m]
+
+    def close(self):
+        if self._h:
+            lib().cho_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def have_ref() -> bool:
@@ -96,6 +163,7 @@ def ref() -> C.CDLL:
         R.ref_get_tuned_frequency.argtypes = [C.c_int, C.c_int]
         R.ref_get_raw_file_name.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
         R.ref_get_raw_file_name.restype = C.c_int
+        R.ref_get_resamplers_factors.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
         R.ref_contains_with_margin.argtypes = [c_int32_p, C.c_int, C.c_int, C.c_int, c_int32_p]
         R.ref_most_frequent_value.argtypes = [c_int32_p, C.c_int]
         R.ref_psd.argtypes = [c_float_p, c_float_p, C.c_int, C.c_int]

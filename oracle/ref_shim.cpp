@@ -256,6 +256,15 @@ void ref_average(const float* in, float* out, int size, int group) { average(in,
 int ref_get_max_index(const float* data, int size, int index, int group) { return getMaxIndex(data, size, index, group); }
 int ref_get_fft(int sample_rate, int max_step) { return getFft(sample_rate, max_step); }
 int ref_get_tuned_frequency(int f, int step) { return getTunedFrequency(f, step); }
+// getResamplersFactors (utils/radio_utils.cpp:128-152): pairs (interpolation, decimation)
+int ref_get_resamplers_factors(int sample_rate, int bandwidth, int threshold, int* interp, int* decim, int cap) {
+  const auto r = getResamplersFactors(sample_rate, bandwidth, threshold);
+  for (size_t i = 0; i < r.size() && (int)i < cap; ++i) {
+    interp[i] = r[i].first;
+    decim[i] = r[i].second;
+  }
+  return (int)r.size();
+}
 // getRawFileName (utils/radio_utils.cpp:78-84) reads the wall clock itself: the caller compares within one second
 int ref_get_raw_file_name(const char* label, const char* extension, int frequency, int sample_rate, char* out, int cap) {
   const std::string s = getRawFileName(label, extension, frequency, sample_rate);
