@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -149,6 +150,9 @@ struct Stage {
   int max_in = 0, max_out = 0;
   int tile = 64;        // outputs per workgroup
   int lds_floats2 = 0;  // LDS elements a tile needs at most
+  // first stage with interpolation 1: the polyphase-by-branch kernel (k_chan_dec)
+  bool fast = false;
+  int logg = 6, passes = 1, waves = 4;
 };
 
 struct Slot {
@@ -171,6 +175,8 @@ struct sc_ctx {
   Slot slots[SC_MAX_CHANNELS];
   float2* d_hist0 = nullptr;  // first stage: per slot the newest nt-1 ROTATED samples
   long long hist0_stride = 0;
+  float2* d_ptab = nullptr;  // k_chan_dec: per slot exp(2*pi*i*k*df), rebuilt by sc_start
+  long long ptab_stride = 0;
   // host-entry staging
   float2* d_in = nullptr;
   int8_t* d_out_i8 = nullptr;
@@ -206,6 +212,8 @@ struct ChanArgs {
   const float2* in_buf;  // !ROTATE: per slot [hist (nt-1) | new]
   long long in_stride;
   const float* arm;
+  const float2* ptab;  // decimating fast path: per slot exp(2*pi*i*k*df), k = 0 .. ptab_stride-1
+  long long ptab_stride;
   int interp, decim, nt, tile;
   float2* next_buf;  // outputs for the next stage (written after its history), or null
   long long next_stride;
@@ -321,6 +329,150 @@ __global__ __launch_bounds__(256) void k_chan_stage(ChanArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// First stage, interpolation 1 (every configuration the reference's defaults produce): polyphase by branch.
+//   y[m] = sum_b sum_a h[D a + b] * x[p(m - a) - b],   p(m) = skip + m D,   b = 0..D-1,   a = 0..32
+// (GNU Radio's default design always has ceil(ntaps / D) = 33 taps per branch: ntaps = 32.8 D.)
+// A lane owns one branch b and R = 16 consecutive outputs: it pulls the 48 samples x[p(m0 + k - 32) - b] of its
+// branch out of LDS once (3 LDS reads per output instead of 33), holds its 33 taps in registers, and runs 16 x 33
+// complex-by-real multiply-adds; the D branch sums of every output are then added across the lanes of a group with a
+// halving butterfly (32 shuffles for the 32 partial values of a lane, not 32 x log2 D). Groups of 8/16/32/64 lanes
+// cover D <= 64; for D up to 128 a lane takes branches b and b + 64. The rotator is applied while the samples are
+// staged: phase(n) = P(n_lo) * T[n - n_lo] with T[k] = exp(2 pi i k df) tabulated per slot when the shift is set
+// (two roundings per sample, independent of where tiles and calls fall).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kDecA = 33, kDecR = 16;
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+__global__ void k_chan_ptab(float2* __restrict__ tab, int n, double df) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) tab[k] = phase_of(0.0, df, k);
+}
+
+template <int LOGG, int PASSES>
+__global__ __launch_bounds__(256) void k_chan_dec(ChanArgs a) {
+  constexpr int GL = 1 << LOGG, G = 64 / GL, A = kDecA, R = kDecR, W = A - 1 + R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char chan_smem[];
+  float2* lds = reinterpret_cast<float2*>(chan_smem);
+  const int s = blockIdx.y;
+  const int nout = a.nout[s];
+  const int tile_out = (int)(blockDim.x >> 6) * G * R;
+  const int m0 = blockIdx.x * tile_out;
+  if (m0 >= nout) return;
+  const int slot = a.slot[s];
+  const int D = a.decim, ntaps = a.nt, h = a.nt - 1;
+  const int tcount = min(tile_out, nout - m0);
+  const int p_first = a.skip0[s] + m0 * D;  // interpolation 1: the arm counter is always 0
+  const int p_last = p_first + (tcount - 1) * D;
+  const int n_lo = p_first - (A * D - 1);  // oldest sample any lane touches (taps beyond ntaps are zero)
+  const int span = p_last - n_lo + 1;
+  const float2 P0 = phase_of(a.f0[s], a.df[s], n_lo);
+  const float2* ptab = a.ptab + (size_t)slot * a.ptab_stride;
+  if (n_lo >= 0) {
+    // every sample of the span is in this call's input: eight independent, unconditional (clamped) loads per thread in
+    // flight at a time — a load, its arithmetic and its store per loop trip would serialise on the memory latency
+    const float2* src = a.in_raw + n_lo;
+    for (int base = 0; base < span; base += 8 * (int)blockDim.x) {
+      float2 xv[8], tv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = min(base + u * (int)blockDim.x + (int)threadIdx.x, span - 1);
+        xv[u] = src[idx];
+        tv[u] = ptab[idx];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * (int)blockDim.x + (int)threadIdx.x;
+        if (idx < span) lds[idx] = rotate(xv[u], cmulf(P0, tv[u]));
+      }
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < span; idx += blockDim.x) {
+      const int n = n_lo + idx;
+      float2 v = make_float2(0.0f, 0.0f);
+      if (n >= 0) v = rotate(a.in_raw[n], cmulf(P0, ptab[idx]));
+      else if (n >= -h) v = a.hist0[(size_t)slot * a.hist0_stride + (h + n)];
+      lds[idx] = v;
+    }
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lg = lane & (GL - 1), g = lane >> LOGG;
+  const int blk = wave * G + g;  // this group's block of R outputs inside the tile
+  float v[2 * R];
+#pragma unroll
+  for (int i = 0; i < 2 * R; ++i) v[i] = 0.0f;
+  if (blk * R < tcount) {
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+      const int b = lg + 64 * pass;
+      const bool live = b < D;
+      const int bc = min(b, D - 1);
+      float H[A];
+#pragma unroll
+      for (int t = 0; t < A; ++t) {
+        const int k = D * t + bc;
+        const float tap = a.arm[min(k, ntaps - 1)];
+        H[t] = (live && k < ntaps) ? tap : 0.0f;
+      }
+      // w[k] = x[p(m_blk + k - 32) - b]: LDS index of k = 0 is (p_first - n_lo) + blk*R*D - 32 D - b, then steps of D
+      const int i0 = (A * D - 1) + blk * R * D - (A - 1) * D - bc;
+      float2 w[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) w[k] = lds[min(i0 + k * D, span - 1)];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int t = 0; t < A; ++t) {
+          v[2 * r] = fmaf(w[A - 1 + r - t].x, H[t], v[2 * r]);
+          v[2 * r + 1] = fmaf(w[A - 1 + r - t].y, H[t], v[2 * r + 1]);
+        }
+      }
+    }
+  }
+  // add the branch sums across the GL lanes of the group: halve the value set while doubling what each value has seen
+  constexpr int S = LOGG - 1;
+  int base = 0;
+#pragma unroll
+  for (int st = 0; st < S; ++st) {
+    const int cnt = R >> st;      // values kept after this stage (of 2R, R, ...)
+    const int bit = GL >> (st + 1);
+    const bool hi = (lane & bit) != 0;
+    // bitwise selects (one v_bfi_b32 each): a ?: on two array elements gets turned into a runtime index into the
+    // register array, i.e. a compare/select chain over all 32 values per access
+    const uint32_t mh = hi ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < cnt; ++i) {
+      const uint32_t lo_v = __float_as_uint(v[i]), hi_v = __float_as_uint(v[i + cnt]);
+      const float send = __uint_as_float((lo_v & mh) | (hi_v & ~mh));
+      const float keep = __uint_as_float((hi_v & mh) | (lo_v & ~mh));
+      v[i] = keep + __shfl_xor(send, bit);
+    }
+    base += hi ? cnt : 0;
+  }
+  constexpr int CNT = (2 * R) >> S;  // values a lane holds now; lanes l and l^1 hold the same ones
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) v[i] += __shfl_xor(v[i], 1);
+  if ((lane & 1) == 0) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+      const int idx = base + i;  // 2 r + component
+      const int r = idx >> 1, comp = idx & 1;
+      const int m = m0 + blk * R + r;
+      if (blk * R + r < tcount) {
+        const float y = v[i];
+        if (a.next_buf) reinterpret_cast<float*>(a.next_buf + (size_t)slot * a.next_stride + a.next_hist + m)[comp] = y;
+        if (m < a.cap) {
+          if (a.out_cf32) reinterpret_cast<float*>(a.out_cf32 + (size_t)slot * a.cap + m)[comp] = y;
+          if (a.out_i8) a.out_i8[((size_t)slot * a.cap + m) * 2 + comp] = to_i8(y, a.pack_scale);
+        }
+      }
+    }
+  }
+}
+
 // After a call: the newest h samples of [history | new samples] become the history. One workgroup per slot, staged
 // through LDS because source and destination overlap when fewer than h samples arrived.
 template <bool ROTATE>
@@ -366,6 +518,7 @@ void free_sc(sc_ctx* c) {
     (void)hipFree(st.d_buf);
   }
   (void)hipFree(c->d_hist0);
+  (void)hipFree(c->d_ptab);
   (void)hipFree(c->d_in);
   (void)hipFree(c->d_out_i8);
   (void)hipFree(c->d_out_cf32);
@@ -393,6 +546,8 @@ int run_stages(sc_ctx* c, const float2* d_iq, int nsamples, int8_t* d_out_i8, fl
     a.in_buf = st.d_buf;
     a.in_stride = st.buf_stride;
     a.arm = st.d_arm;
+    a.ptab = c->d_ptab;
+    a.ptab_stride = c->ptab_stride;
     a.interp = st.interp;
     a.decim = st.decim;
     a.nt = st.nt;
@@ -417,7 +572,16 @@ int run_stages(sc_ctx* c, const float2* d_iq, int nsamples, int8_t* d_out_i8, fl
       max_out = a.nout[s] > max_out ? a.nout[s] : max_out;
     }
     const size_t lds_bytes = sizeof(float2) * (size_t)st.lds_floats2;
-    if (max_out > 0) {
+    if (max_out > 0 && k == 0 && st.fast) {
+      const dim3 grid((unsigned)((max_out + st.tile - 1) / st.tile), (unsigned)a.nslots), block((unsigned)(64 * st.waves));
+      switch (st.logg * 2 + (st.passes - 1)) {
+        case 6: hipLaunchKernelGGL((k_chan_dec<3, 1>), grid, block, lds_bytes, c->stream, a); break;
+        case 8: hipLaunchKernelGGL((k_chan_dec<4, 1>), grid, block, lds_bytes, c->stream, a); break;
+        case 10: hipLaunchKernelGGL((k_chan_dec<5, 1>), grid, block, lds_bytes, c->stream, a); break;
+        case 12: hipLaunchKernelGGL((k_chan_dec<6, 1>), grid, block, lds_bytes, c->stream, a); break;
+        default: hipLaunchKernelGGL((k_chan_dec<6, 2>), grid, block, lds_bytes, c->stream, a); break;
+      }
+    } else if (max_out > 0) {
       const dim3 grid((unsigned)((max_out + st.tile - 1) / st.tile), (unsigned)a.nslots);
       if (k == 0) hipLaunchKernelGGL(k_chan_stage<true>, grid, dim3(256), lds_bytes, c->stream, a);
       else hipLaunchKernelGGL(k_chan_stage<false>, grid, dim3(256), lds_bytes, c->stream, a);
@@ -511,6 +675,29 @@ int sc_create(const sc_config* cfg, sc_ctx** out) {
       }
       st.tile /= 2;
     }
+    // first stage, interpolation 1, at most 33 taps per branch (GNU Radio's design always gives 33): branch kernel
+    const char* force_generic = getenv("SC_GENERIC");  // A/B measurements
+    if (c->stages.empty() && st.interp == 1 && st.decim <= 128 && st.ntaps <= kDecA * st.decim && !(force_generic && force_generic[0] == '1')) {
+      const int generic_tile = st.tile, generic_lds = st.lds_floats2;
+      st.fast = true;
+      st.passes = st.decim > 64 ? 2 : 1;
+      st.logg = 3;
+      while ((1 << st.logg) < st.decim && st.logg < 6) ++st.logg;
+      const int groups = 64 >> st.logg;
+      for (st.waves = 4; st.waves >= 1; st.waves /= 2) {
+        st.tile = st.waves * groups * kDecR;
+        st.lds_floats2 = (st.tile - 1) * st.decim + kDecA * st.decim;
+        if ((long long)st.lds_floats2 * (long long)sizeof(float2) <= 64 * 1024) break;
+      }
+      if (st.waves < 1) {
+        st.fast = false;
+        st.waves = 4;
+        st.tile = generic_tile;
+        st.lds_floats2 = generic_lds;
+      } else {
+        c->ptab_stride = st.lds_floats2;
+      }
+    }
     if ((long long)st.lds_floats2 * (long long)sizeof(float2) > 64 * 1024 || (long long)(st.nt - 1) * (long long)sizeof(float2) > 64 * 1024) {
       sc_fail(nullptr, SS_ERR_INVALID, "resampler %d/%d needs %d taps per arm: does not fit the LDS tile", st.interp, st.decim, st.nt);
       free_sc(c);
@@ -531,6 +718,10 @@ int sc_create(const sc_config* cfg, sc_ctx** out) {
   c->hist0_stride = c->stages[0].nt > 1 ? c->stages[0].nt - 1 : 1;
   SC_CREATE_HIP(hipMalloc(&c->d_hist0, sizeof(float2) * (size_t)c->hist0_stride * (size_t)cfg->channels));
   SC_CREATE_HIP(hipMemsetAsync(c->d_hist0, 0, sizeof(float2) * (size_t)c->hist0_stride * (size_t)cfg->channels, c->stream));
+  if (c->ptab_stride > 0) {
+    SC_CREATE_HIP(hipMalloc(&c->d_ptab, sizeof(float2) * (size_t)c->ptab_stride * (size_t)cfg->channels));
+    SC_CREATE_HIP(hipMemsetAsync(c->d_ptab, 0, sizeof(float2) * (size_t)c->ptab_stride * (size_t)cfg->channels, c->stream));
+  }
   SC_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chan_stage<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   SC_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chan_stage<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   SC_CREATE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chan_keep<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -588,6 +779,12 @@ int sc_start(sc_ctx* c, int32_t channel, int32_t shift_hz) {
   sl.inc_re = re / mag;
   sl.inc_im = im / mag;
   sl.df = atan2((double)sl.inc_im, (double)sl.inc_re) / (2.0 * M_PI);  // what one multiplication by the fp32 increment turns the phase by
+  if (c->d_ptab) {
+    SC_HIP(c, hipSetDevice(c->cfg.device_id));
+    const int n = (int)c->ptab_stride;
+    hipLaunchKernelGGL(k_chan_ptab, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->d_ptab + (size_t)channel * c->ptab_stride, n, sl.df);
+    SC_HIP(c, hipGetLastError());
+  }
   sl.active = true;
   return SS_OK;
 }
