@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/specscan.h"
@@ -62,6 +63,16 @@ struct ss_ctx {
   float2* d_tw8k = nullptr;  // tables of k_fft8192_psd: tw2[256] ++ tw3a[1024] ++ tw3b[2048]
   bool use_fft8192 = false;
   int fft8192_variant = 0;  // 0 = eight-wave kernel (default); 2 = four-wave variant (SS_FFT_IMPL=wide, A/B runs)
+  // development diagnostics, read from the environment once at ss_create and owned by the context:
+  //   SS_DEBUG_TIMING_FFT=<file> / SS_DEBUG_TIMING=<file>: per-workgroup clock stamps of the 20th FFT / detect launch
+  //   SS_FFT_ABLATE=1|2: memory-only / transform-only variant of the 8192-point kernel (profiles/README.md)
+  struct Diag {
+    std::string fft_stamp_path, detect_stamp_path;
+    long long* d_fft_stamps = nullptr;     // 8 stamps x up to 8192 workgroups
+    long long* d_detect_stamps = nullptr;  // 4 stamps x up to 65536 workgroups
+    int fft_calls = 0, detect_calls = 0;
+    int fft_ablate = 0;
+  } diag;
   uint8_t* d_pass = nullptr;
   bool pass_dirty = true;
   // state
@@ -214,14 +225,7 @@ void launch_four_step(ss_ctx* c, const void* d_iq, long long item_stride, int nf
 template <int FMT>
 void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
   ss::Fft8192Tables tabs{c->d_tw8k, c->d_tw8k + 256, c->d_tw8k + 256 + 1024, nullptr};
-  // development diagnostic: SS_DEBUG_TIMING_FFT=<file> dumps per-workgroup phase stamps of the 20th launch
-  static long long* s_dbg = nullptr;
-  static int s_calls = 0;
-  const char* dbg_path = getenv("SS_DEBUG_TIMING_FFT");
-  if (dbg_path && nframes <= 8192) {
-    if (!s_dbg) (void)hipMalloc(&s_dbg, sizeof(long long) * 8 * 8192);
-    tabs.dbg = s_dbg;
-  }
+  if (c->diag.d_fft_stamps && nframes <= 8192) tabs.dbg = c->diag.d_fft_stamps;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool timed = prof_pair(c, &e0, &e1);
   auto launch = [&](auto kernel, int lds_bytes) {
@@ -245,16 +249,16 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
   if (c->fft8192_variant == 2) launch(ss::k_fft8192_psd<FMT>, ss::kFft8192LdsBytes);
   else if (tabs.dbg) launch8(ss::k_fft8192_psd_w8<FMT, 8, true>, ss::kFft8192W8LdsBytes);
   else {
-    static const int ablate = getenv("SS_FFT_ABLATE") ? atoi(getenv("SS_FFT_ABLATE")) : 0;
+    const int ablate = c->diag.fft_ablate;
     if (ablate == 1) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 1>, ss::kFft8192W8LdsBytes);
     else if (ablate == 2) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 2>, ss::kFft8192W8LdsBytes);
     else launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
   }
-  if (tabs.dbg && ++s_calls == 20) {
+  if (tabs.dbg && ++c->diag.fft_calls == 20) {
     std::vector<long long> h((size_t)8 * nframes);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipMemcpy(h.data(), s_dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-    if (FILE* fp = fopen(dbg_path, "w")) {
+    (void)hipMemcpy(h.data(), c->diag.d_fft_stamps, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen(c->diag.fft_stamp_path.c_str(), "w")) {
       for (int b = 0; b < nframes; ++b) {
         for (int k = 0; k < 8; ++k) fprintf(fp, "%lld ", h[(size_t)8 * b + k]);
         fprintf(fp, "\n");
@@ -373,20 +377,13 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   const int tiles = ((nframes + shift + TF - 1) / TF) * ((n + TB - 1) / TB);
   ss::DetectArgs da{d_psd, z->d_thr,           hist_in,   hist_out,  n,      nframes,   n_learn,  c->frames_pushed,
                     shift, c->cfg.start_level, c->d_pass, c->d_mask, counts, d_rel_out, avg_full, c->d_avg,         nullptr};
-  // development diagnostic: SS_DEBUG_TIMING=<file> dumps per-workgroup time stamps of the 20th detect launch
-  static long long* s_dbg = nullptr;
-  static int s_calls = 0;
-  const char* dbg_path = getenv("SS_DEBUG_TIMING");
-  if (dbg_path) {
-    if (!s_dbg) (void)hipMalloc(&s_dbg, sizeof(long long) * 4 * 65536);
-    da.dbg = tiles <= 65536 ? s_dbg : nullptr;
-  }
+  if (c->diag.d_detect_stamps && tiles <= 65536) da.dbg = c->diag.d_detect_stamps;
   hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB>), dim3(tiles), dim3(TB), 0, c->stream, da);
-  if (da.dbg && ++s_calls == 20) {
+  if (da.dbg && ++c->diag.detect_calls == 20) {
     std::vector<long long> h((size_t)4 * tiles);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipMemcpy(h.data(), s_dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-    if (FILE* fp = fopen(dbg_path, "w")) {
+    (void)hipMemcpy(h.data(), c->diag.d_detect_stamps, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen(c->diag.detect_stamp_path.c_str(), "w")) {
       for (int b = 0; b < tiles; ++b) fprintf(fp, "%d %lld %lld %lld %lld\n", b, h[4 * b], h[4 * b + 1], h[4 * b + 2], h[4 * b + 3]);
       fclose(fp);
     }
@@ -502,6 +499,8 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_tw8k);
   (void)hipFree(c->d_pass);
   (void)hipFree(c->d_rel);
+  (void)hipFree(c->diag.d_fft_stamps);
+  (void)hipFree(c->diag.d_detect_stamps);
   (void)hipFree(c->d_hist[0]);
   (void)hipFree(c->d_hist[1]);
   (void)hipFree(c->d_cnt2[0]);
@@ -626,6 +625,15 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   CREATE_HIP(hipMalloc(&c->d_win, sizeof(float) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_tw, sizeof(float2) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_pass, (size_t)n));
+  if (const char* pth = getenv("SS_DEBUG_TIMING_FFT")) {
+    c->diag.fft_stamp_path = pth;
+    CREATE_HIP(hipMalloc(&c->diag.d_fft_stamps, sizeof(long long) * 8 * 8192));
+  }
+  if (const char* pth = getenv("SS_DEBUG_TIMING")) {
+    c->diag.detect_stamp_path = pth;
+    CREATE_HIP(hipMalloc(&c->diag.d_detect_stamps, sizeof(long long) * 4 * 65536));
+  }
+  if (const char* ab = getenv("SS_FFT_ABLATE")) c->diag.fft_ablate = atoi(ab);
   {
     const char* be = getenv("SS_BACKEND");  // "unfused" forces the per-stage kernels (A/B measurements)
     c->fused = G == 21 && cfg->grouping_x == 21 && cfg->max_batch <= 4096 && !(be && strcmp(be, "unfused") == 0);
@@ -1057,7 +1065,11 @@ void ss_feed_destroy(ss_feed* f) {
   feed_free(f);
 }
 
-int ss_feed_pending(const ss_feed* f) { return f ? f->pending : 0; }
+int ss_feed_pending(const ss_feed* f) {
+  if (!f) return 0;
+  std::lock_guard<std::mutex> lock(f->c->mtx);
+  return f->pending;
+}
 
 int ss_feed_acquire(ss_feed* f, void** frames) {
   if (!f || !frames) return SS_ERR_INVALID;
