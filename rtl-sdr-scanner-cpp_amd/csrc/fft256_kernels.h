@@ -1,0 +1,134 @@
+// fft256_kernels.h — four-step front end for N >= 65536 built on 256-point FFTs held in registers
+// (BASELINE.json configs 3 and 5: 65536 points at 20 MS/s, 2^20 points at 61.44 MS/s).
+//
+// Same contract as k_fft_cols / k_fft_rows_psd in fft_kernels.h (Decimator + fft_v(Hamming, forward, shift) + PSD::work:
+// reference sources/radio/blocks/decimator.h:15-22, sources/radio/sdr_device.cpp:164, sources/radio/blocks/psd.cpp:18-20):
+//   N = 256 * N2,  n = n1 * N2 + n2,  k = k1 + 256 * k2
+//   step A (k_fft_cols256):  for every n2 the 256-point FFT over n1, times W_N^(n2 k1)  -> work[k1 * N2 + n2]
+//   step B:  for every k1 the N2-point FFT over n2 -> X[k1 + 256 k2] -> dB
+//            N2 = 256: k_fft_rows256_psd below;  other N2: the generic k_fft_rows_psd<8, log2 N2>
+//
+// A 256-point FFT is two radix-16 passes (the 16-point DFT of fft8192_kernel.h) with ONE exchange, done one fp32 plane
+// at a time through a 17-word pitch per thread exactly like the first exchange of the 8192-point kernel: the generic
+// kernels make four radix-4 trips of the whole tile through LDS with two barriers each.
+//
+// k_fft_cols256: workgroup = 512 threads = 32 columns x 256 rows = 8192 points. Thread (q = t % 32, j = t / 32): column
+// n2 = c0 + q, rows n1 = j + 16 r. Lanes run along n2, so every global load and every store of a wave is two 256-byte
+// runs; no transposition is needed on the way out (work[k1 * N2 + n2] is n2-fastest too).
+//   pass 1: Y[16 j + k] = DFT16_r( x[j + 16 r] )                    -> LDS word q * 273 + 17 j + k
+//   pass 2: X[j + 16 k] = DFT16_r'( Y[j + 16 r'] W_256^(r' j) )     <- LDS word q * 273 + 17 r' + j
+// k_fft_rows256_psd: workgroup = 512 threads = 32 rows (k1) x 256 points. Thread (rho = t / 16, j = t % 16): lanes run
+// along n2 inside a row (work is n2-fastest). The dB values go through LDS once more so that the store runs along k1,
+// the fastest index of the output bin k1 + 256 k2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft8192_kernel.h"
+#include "fft_kernels.h"
+
+namespace ss {
+
+// words per 256-point FFT in the exchange plane (16 threads x 17-word pitch = 272): the columns kernel, whose lanes run
+// over 32 different FFTs, adds one so that the FFTs start on different banks; the rows kernel, whose 16-lane groups
+// belong to 4 FFTs, keeps 272 = 16 mod 32 so that consecutive FFTs use complementary bank halves
+constexpr int kFft256PitchCols = 273, kFft256PitchRows = 272;
+constexpr int kFft256LdsBytes = 32 * kFft256PitchCols * 4;  // one fp32 plane of 32 FFTs: 34 944 bytes
+constexpr int kFft256RowsLdsBytes = 256 * 33 * 4;           // rows kernel read-out plane [k2][rho], 33-word pitch: 33 792 bytes
+
+// the two register passes of 32 independent 256-point FFTs; `fft` = which of the 32, `j` = butterfly 0..15
+template <int PITCH>
+__device__ __forceinline__ void fft256_passes(float2 (&a)[16], float2 (&c)[16], float* __restrict__ s, const float2* __restrict__ tw256, int fft,
+                                              int j) {
+  dft16(a);
+  float* plane = s + fft * PITCH;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) plane[17 * j + k] = a[slot16(k)].x;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r].x = plane[17 * r + j];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) plane[17 * j + k] = a[slot16(k)].y;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float2 v = make_float2(c[r].x, plane[17 * r + j]);
+    c[r] = r == 0 ? v : cmul(v, tw256[r * 16 + j]);  // W_256^(r j), applied as the second plane arrives
+  }
+  dft16(c);  // X[j + 16 k] in c[slot16(k)]
+}
+
+template <int FMT>
+__global__ __launch_bounds__(512, 6) void k_fft_cols256(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
+                                                        const float2* __restrict__ tw256, const float2* __restrict__ twc, float scale,
+                                                        float2* __restrict__ work, int logn2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s = reinterpret_cast<float*>(smem_raw);
+  const int t = threadIdx.x;
+  const int q = t & 31, j = t >> 5;
+  const int n2size = 1 << logn2;
+  const int tiles_per_frame = n2size >> 5;
+  const int f = blockIdx.x / tiles_per_frame;
+  const int n2 = ((blockIdx.x % tiles_per_frame) << 5) + q;
+  // sample n = (j + 16 r) N2 + n2: block-uniform part (frame, 16 r N2) in scalar registers, per-thread part one 32-bit offset
+  constexpr uint32_t kInBytes = FMT == FMT_CF32 ? 8u : 2u;
+  const char* in_frame = reinterpret_cast<const char*>(iq) + (size_t)f * (size_t)item_stride * kInBytes;
+  const char* win_b = reinterpret_cast<const char*>(win);
+  const uint32_t tn = ((uint32_t)j << logn2) + (uint32_t)n2;
+  float2 a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const size_t un = (size_t)(16 * r) << logn2;
+    const float2 x = load_iq<FMT>(in_frame + un * kInBytes + tn * kInBytes, 0, scale);
+    const float w = *reinterpret_cast<const float*>(win_b + un * 4 + tn * 4u);
+    a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
+  }
+  float2 c[16];
+  fft256_passes<kFft256PitchCols>(a, c, s, tw256, q, j);
+  // step-A twiddle W_N^(n2 k1), k1 = j + 16 k, as W_N^(n2 j) * W_N^(16 n2 k) from two tables laid out [j][n2] and [k][n2]:
+  // the lanes of a wave (consecutive n2) read consecutive entries (a gather from the N-entry table W_N^m at m = n2 k1
+  // costs as much as the whole transform). work[k1 * N2 + n2]: block-uniform base + one 32-bit offset per access.
+  char* wf = reinterpret_cast<char*>(work + ((size_t)f << (8 + logn2)));
+  const char* t1 = reinterpret_cast<const char*>(twc);
+  const char* t2 = reinterpret_cast<const char*>(twc + ((size_t)16 << logn2));
+  const float2 tj = *reinterpret_cast<const float2*>(t1 + 8u * (((uint32_t)j << logn2) + (uint32_t)n2));
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t k1 = (uint32_t)(j + 16 * k);
+    float2 y = cmul(c[slot16(k)], tj);
+    if (k > 0) y = cmul(y, *reinterpret_cast<const float2*>(t2 + 8u * (((uint32_t)k << logn2) + (uint32_t)n2)));
+    *reinterpret_cast<float2*>(wf + 8u * ((k1 << logn2) + (uint32_t)n2)) = y;
+  }
+}
+
+__global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __restrict__ work, const float2* __restrict__ tw256, float db_off,
+                                                            float* __restrict__ psd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s = reinterpret_cast<float*>(smem_raw);
+  const int t = threadIdx.x;
+  const int rho = t >> 4, j = t & 15;
+  const int f = blockIdx.x >> 3;          // 256 rows per frame, 32 per workgroup
+  const int r0 = (blockIdx.x & 7) << 5;
+  const float2* row = work + ((size_t)f << 16) + ((size_t)(r0 + rho) << 8);
+  float2 a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = row[j + 16 * r];
+  float2 c[16];
+  fft256_passes<kFft256PitchRows>(a, c, s, tw256, rho, j);
+  __syncthreads();  // the exchange plane is reused for the read-out
+  // dB values to LDS at [k2][rho] (33-word pitch), then out along k1
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s[(j + 16 * k) * 33 + rho] = psd_db(c[slot16(k)], db_off);
+  __syncthreads();
+  float* out = psd + ((size_t)f << 16);
+  const int rr = t & 31, kb = t >> 5;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k2 = kb + 16 * i;
+    // fft_v shift=true: X[k] lands at k ^ (N/2)
+    out[((r0 + rr) + (k2 << 8)) ^ 32768] = s[k2 * 33 + rr];
+  }
+}
+
+}  // namespace ss

@@ -21,6 +21,7 @@
 #include "../../include/specscan.h"
 #include "detect_fused.h"
 #include "detect_kernels.h"
+#include "fft256_kernels.h"
 #include "fft8192_kernel.h"
 #include "fft_kernels.h"
 
@@ -102,6 +103,9 @@ struct ss_ctx {
   float* d_avgy = nullptr;
   float* d_avg = nullptr;
   float2* d_work = nullptr;  // four-step intermediate (N > 8192)
+  float2* d_tw256 = nullptr; // W_256^(m r), r*16 + m: second pass of the 256-point register FFTs (N >= 65536)
+  float2* d_tw_cols = nullptr;  // N >= 65536: step-A twiddle factored for k_fft_cols256, [j][n2] W_N^(n2 j) then [k][n2] W_N^(16 n2 k)
+  bool use_fft256 = false;
   uint32_t* d_mask = nullptr;
   int* d_counts = nullptr;
   int* d_off = nullptr;
@@ -222,6 +226,23 @@ void launch_four_step(ss_ctx* c, const void* d_iq, long long item_stride, int nf
                      c->d_tw, c->db_off, d_psd);
 }
 
+// N >= 65536: N = 256 x N2. Columns: 256-point register FFTs; rows: the same for N2 = 256, the generic LDS kernel otherwise.
+template <int LOGN2, int FMT>
+void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
+  constexpr int N2 = 1 << LOGN2;
+  hipLaunchKernelGGL((ss::k_fft_cols256<FMT>), dim3(nframes * (N2 / 32)), dim3(512), ss::kFft256LdsBytes, c->stream, d_iq, item_stride,
+                     (const float*)c->d_win, (const float2*)c->d_tw256, (const float2*)c->d_tw_cols, c->cfg.int_scale, c->d_work, LOGN2);
+  if constexpr (LOGN2 == 8) {
+    hipLaunchKernelGGL(ss::k_fft_rows256_psd, dim3(nframes * 8), dim3(512), ss::kFft256LdsBytes, c->stream, (const float2*)c->d_work,
+                       (const float2*)c->d_tw256, c->db_off, d_psd);
+  } else {
+    const size_t lds = sizeof(float2) * ((1 << 13) + 128);
+    const int row_tiles = 256 >> (13 - LOGN2);
+    hipLaunchKernelGGL((ss::k_fft_rows_psd<8, LOGN2>), dim3(nframes * row_tiles), dim3(ss::kFftThreads), lds, c->stream, c->d_work,
+                       c->d_tw, c->db_off, d_psd);
+  }
+}
+
 template <int FMT>
 void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
   ss::Fft8192Tables tabs{c->d_tw8k, c->d_tw8k + 256, c->d_tw8k + 256 + 1024, nullptr};
@@ -285,11 +306,11 @@ int launch_fft_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nfram
     case 13: launch_lds<13, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 14: launch_four_step<7, 7, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 15: launch_four_step<7, 8, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
-    case 16: launch_four_step<8, 8, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
-    case 17: launch_four_step<8, 9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
-    case 18: launch_four_step<9, 9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
-    case 19: launch_four_step<9, 10, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
-    case 20: launch_four_step<10, 10, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 16: c->use_fft256 ? launch_four_step256<8, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<8, 8, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 17: c->use_fft256 ? launch_four_step256<9, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<8, 9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 18: c->use_fft256 ? launch_four_step256<10, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<9, 9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 19: c->use_fft256 ? launch_four_step256<11, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<9, 10, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 20: c->use_fft256 ? launch_four_step256<12, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<10, 10, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     default: return fail(c, SS_ERR_INVALID, "fft_size 2^%d unsupported", c->logn);
   }
   return SS_OK;
@@ -511,6 +532,8 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_avgy);
   (void)hipFree(c->d_avg);
   (void)hipFree(c->d_work);
+  (void)hipFree(c->d_tw256);
+  (void)hipFree(c->d_tw_cols);
   (void)hipFree(c->d_mask);
   (void)hipFree(c->d_counts);
   (void)hipFree(c->d_off);
@@ -682,6 +705,30 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     for (int k = 0; k < n; ++k) {
       const double ang = -2.0 * M_PI * (double)k / (double)n;
       tw[(size_t)k] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    if (n >= 65536) {
+      const char* impl = getenv("SS_FFT_IMPL");  // "generic" keeps the LDS radix-4 four-step kernels (A/B measurements)
+      c->use_fft256 = !(impl && strcmp(impl, "generic") == 0);
+      std::vector<float2> t256(256);
+      for (int r = 0; r < 16; ++r)
+        for (int m = 0; m < 16; ++m) {
+          const double ang = -2.0 * M_PI * (double)(m * r) / 256.0;
+          t256[(size_t)(r * 16 + m)] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+      CREATE_HIP(hipMalloc(&c->d_tw256, sizeof(float2) * t256.size()));
+      CREATE_HIP(hipMemcpy(c->d_tw256, t256.data(), sizeof(float2) * t256.size(), hipMemcpyHostToDevice));
+      {
+        const int n2size = n / 256;
+        std::vector<float2> tc((size_t)32 * (size_t)n2size);
+        for (int i = 0; i < 16; ++i)
+          for (int n2 = 0; n2 < n2size; ++n2) {
+            const double a1 = -2.0 * M_PI * ((double)n2 * i) / (double)n, a2 = -2.0 * M_PI * (16.0 * (double)n2 * i) / (double)n;
+            tc[(size_t)i * n2size + n2] = make_float2((float)cos(a1), (float)sin(a1));
+            tc[(size_t)(16 + i) * n2size + n2] = make_float2((float)cos(a2), (float)sin(a2));
+          }
+        CREATE_HIP(hipMalloc(&c->d_tw_cols, sizeof(float2) * tc.size()));
+        CREATE_HIP(hipMemcpy(c->d_tw_cols, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
+      }
     }
     if (n == 8192) {
       const char* impl = getenv("SS_FFT_IMPL");  // "generic" selects the radix-4 LDS kernel (A/B measurements)

@@ -19,9 +19,10 @@ BAND = 1e-3  # dB
 def eps_fft(n):
     """Worst-case amplitude DIFFERENCE of two fp32 FFTs on a weak bin, in units of the spectrum RMS. Each
     fp32 FFT is off from fp64 by ~1.5e-7*RMS rms and, at worst over weak bins, by 0.6e-6 (N=2^10), 1.1e-6
-    (2^13), 2e-6 (2^16), 5e-6 (2^20) — measured alike for the oracle's radix-2, MKL's FFTW interface
-    (tests/test_oracle_fft.py) and the HIP kernels (scripts/fft_accuracy.py). Two of them differ by up to twice that."""
-    return max(0.8e-6, 2.2e-6 * (n / 8192.0) ** 0.3)
+    (2^13), 2.2e-6 (2^16), 3.2e-6 (2^17), 4.3e-6 (2^20) — measured alike for the oracle's radix-2, MKL's FFTW
+    interface (tests/test_oracle_fft.py) and the HIP kernels, generic and register-pass alike
+    (scripts/fft_accuracy.py). Two of them differ by up to twice that."""
+    return max(0.8e-6, 2.6e-6 * (n / 8192.0) ** 0.35)
 
 
 def floor_tolerance(ref_psd):
