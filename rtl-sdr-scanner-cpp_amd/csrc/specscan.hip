@@ -226,7 +226,7 @@ void launch_four_step(ss_ctx* c, const void* d_iq, long long item_stride, int nf
                      c->d_tw, c->db_off, d_psd);
 }
 
-// N >= 65536: N = 256 x N2. Columns: 256-point register FFTs; rows: the same for N2 = 256, the generic LDS kernel otherwise.
+// N >= 16384: N = 256 x N2. Columns: 256-point register FFTs; rows: the same for N2 = 256, the generic LDS kernel otherwise.
 template <int LOGN2, int FMT>
 void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
   constexpr int N2 = 1 << LOGN2;
@@ -304,8 +304,8 @@ int launch_fft_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nfram
     case 11: launch_lds<11, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 12: launch_lds<12, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 13: launch_lds<13, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
-    case 14: launch_four_step<7, 7, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
-    case 15: launch_four_step<7, 8, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 14: c->use_fft256 ? launch_four_step256<6, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<7, 7, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 15: c->use_fft256 ? launch_four_step256<7, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<7, 8, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 16: c->use_fft256 ? launch_four_step256<8, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<8, 8, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 17: c->use_fft256 ? launch_four_step256<9, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<8, 9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 18: c->use_fft256 ? launch_four_step256<10, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<9, 9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
@@ -706,7 +706,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       const double ang = -2.0 * M_PI * (double)k / (double)n;
       tw[(size_t)k] = make_float2((float)cos(ang), (float)sin(ang));
     }
-    if (n >= 65536) {
+    if (n >= 16384) {
       const char* impl = getenv("SS_FFT_IMPL");  // "generic" keeps the LDS radix-4 four-step kernels (A/B measurements)
       c->use_fft256 = !(impl && strcmp(impl, "generic") == 0);
       std::vector<float2> t256(256);

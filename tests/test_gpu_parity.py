@@ -62,6 +62,7 @@ CASES = [
     (8192, 2_048_000, 1, "cf32", 96, 48, 24, 5),
     (8192, 2_048_000, 5, "cu8", 70, 70, 21, 6),
     (16384, 4_096_000, 1, "cf32", 64, 30, 10, 7),
+    (32768, 6_000_000, 1, "cu8", 60, 24, 8, 10),    # 256 x 128 four-step (what getFft picks for a 6 MS/s Airspy)
     (65536, 20_000_000, 1, "cs8", 56, 25, 6, 8),
     (131072, 20_000_000, 1, "cf32", 40, 20, 4, 9),  # what getFft(20 MS/s, 250) picks: the reference's HackRF regime
 ]
