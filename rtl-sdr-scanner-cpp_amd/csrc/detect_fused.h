@@ -305,10 +305,10 @@ __global__ void k_hist_shift(const float* __restrict__ hist_in, float* __restric
 // counts of the frames before it (this path is used for nframes <= 4096). The wave pulls 256 mask words
 // per trip (one 16-byte load per lane), ranks them with one wave scan, expands the set bits into an LDS
 // list at their ranks, then streams the list out with coalesced stores — ascending bins, frames in
-// order, deterministic. counts_next (the other half of the double-buffered counters) is cleared for the
-// next batch. Everything a trip needs from global memory is requested before anything is waited for.
+// order, deterministic. counts_next (the other half of the double-buffered counters, last used by the previous
+// batch with clear_n frames) is cleared for the next batch. Everything a trip needs from global memory is requested before anything is waited for.
 __global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ maskbits, int words_per_row, int n, int nframes,
-                                                  const int* __restrict__ counts, int* __restrict__ counts_next,
+                                                  const int* __restrict__ counts, int* __restrict__ counts_next, int clear_n,
                                                   const float* __restrict__ avg, int cap, int* __restrict__ off_int,
                                                   int* __restrict__ off_out, int* __restrict__ cand_idx, float* __restrict__ cand_avg) {
   constexpr int LIST = 2048;
@@ -344,7 +344,8 @@ __global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ m
       off_int[nframes] = begin + mine;
       if (off_out) off_out[nframes] = begin + mine;
     }
-    counts_next[f] = 0;
+    // the other half of the double-buffered counters held the PREVIOUS batch (clear_n frames, possibly more than this one)
+    for (int g = f; g < clear_n; g += nframes) counts_next[g] = 0;
   }
   if (mine == 0 || !cand_idx) return;
   const float* arow = avg + (size_t)f * n;

@@ -92,6 +92,7 @@ struct ss_ctx {
   long long abs_frames = 0;               // frames since the last reset: frame tiles are aligned to this index
   int* d_cnt2[2] = {nullptr, nullptr};    // per-frame candidate counts; the emit kernel clears the other half
   int cnt_cur = 0;
+  int cnt_frames[2] = {0, 0};             // how many entries of each half may be non-zero
   float* d_relplane = nullptr;            // full rel plane, only when a caller asks for it (lazy)
   int last_n_learn = 0;
   const float* last_hist = nullptr;       // ring rows as they were before the last batch
@@ -410,10 +411,13 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
     }
   }
   hipLaunchKernelGGL(ss::k_cand_emit, dim3(nframes), dim3(64), 0, c->stream, (const uint32_t*)c->d_mask, n / 32, n, nframes,
-                     (const int*)counts, counts_next, (const float*)(avg_full ? avg_full : c->d_avg), cand_cap, c->d_off, d_cand_off,
+                     (const int*)counts, counts_next, c->cnt_frames[c->cnt_cur ^ 1], (const float*)(avg_full ? avg_full : c->d_avg), cand_cap,
+                     c->d_off, d_cand_off,
                      (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr, d_cand_avg);
   c->last_hist = hist_in;
   c->hist_cur ^= 1;
+  c->cnt_frames[c->cnt_cur] = nframes;   // this half now holds nframes counts (read by the emit above, cleared by the next one)
+  c->cnt_frames[c->cnt_cur ^ 1] = 0;     // just cleared
   c->cnt_cur ^= 1;
   c->last_n_learn = n_learn;
   c->last_thr = z->d_thr;
