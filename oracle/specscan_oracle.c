@@ -686,6 +686,7 @@ int orc_process(orc_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms
     orc_averager_push(c->avgr, c->rel_row);
     double t4 = now_s();
     c->stage[3] += t4 - t3;
+    memset(c->avg_row, 0, sizeof(float) * (size_t)n); /* std::vector<float> avgPower(size, 0.0), transmission.cpp:60: with GROUPING_X = 1 average() never writes the last bin */
     orc_average(orc_averager_average(c->avgr), c->avg_row, n, c->cfg.grouping_x);
     double t5 = now_s();
     c->stage[4] += t5 - t4;

@@ -109,7 +109,10 @@ __global__ __launch_bounds__(256) void k_freq_mean_detect(const float* __restric
     const int lo = max(0, i - a), hi = min(n - 1, i + a);
     float s = 0.0f;
     for (int k = lo; k <= hi; ++k) s += row[k - b0 + a];
-    const float v = s / (float)(hi - lo + 1);  // sum / count: float / int
+    float v = s / (float)(hi - lo + 1);  // sum / count: float / int
+    // average() walks i < size + a - 1 (utils.cpp:39): with a group of one (a = 0) it never reaches the last bin, which
+    // keeps the 0.0 its caller initialised it with (transmission.cpp:60)
+    if (a == 0 && i == n - 1) v = 0.0f;
     avg[(size_t)f * n + i] = v;
     if (avg_out) avg_out[(size_t)f * n + i] = v;
     hit = (start_level <= v) && pass[i];

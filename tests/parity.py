@@ -94,7 +94,7 @@ def propagated_floor(floor, gy=21, gx=21):
     return (cx[:, r + 1] - cx[:, l]) / (r - l + 1)[None, :]
 
 
-def check_all(got, ref, start_level=8.0):
+def check_all(got, ref, start_level=8.0, gy=21, gx=21):
     floor = floor_tolerance(ref["psd"]) if "psd" in ref else None
     errs = {}
     for k in ("psd", "rel", "avg"):
@@ -104,7 +104,7 @@ def check_all(got, ref, start_level=8.0):
             else:
                 extra = running_sum_drift(ref[k].shape[1])[None, :]
                 if floor is not None:
-                    extra = extra + propagated_floor(floor)
+                    extra = extra + propagated_floor(floor, gy, gx)
             errs[k] = check_plane(k, got[k], ref[k], extra)
     if floor is not None:  # the allowance must stay an exception: almost every bin is held to ~1e-4 x |ref|
         assert (floor > 1e-3).mean() < 0.10 and (floor > 1e-2).mean() < 0.005

@@ -61,3 +61,55 @@ def test_random_scenario(oracle_mod, seed):
     errs, ncand, ndc = check_all(got, ref)
     assert ndc <= max(2, ncand // 100), (seed, ncand, ndc)
     assert ncand > 0 or n < 512, (seed, n, fmt)  # the 48-bin combs of the generator are too wide for the smallest sizes
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SS_FUZZ_SEEDS2", "10"))))
+def test_random_scenario_variants(oracle_mod, seed):
+    """The same with the less travelled options mixed in: wall-clock learning (per-frame timestamps), groupings other
+    than 21 x 21 (the unfused back end), a caller that asks for no planes or only some, a small candidate capacity
+    (SS_ERR_CAND_OVERFLOW keeps cand_off exact), and zero-length calls."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([256, 512, 1024, 2048]))
+    fs = n * 250
+    center = 433_000_000
+    nframes = int(rng.integers(120, 200))
+    gy, gx = [(21, 21), (21, 21), (5, 7), (21, 5), (3, 21), (1, 1)][int(rng.integers(0, 6))]
+    use_clock = rng.random() < 0.5
+    period = float(rng.choice([10.0, 20.0, 33.3]))
+    learn = int(rng.integers(10, 30))
+    max_batch = int(rng.choice([16, 64, 128]))
+    band = pkg.synth.SyntheticBand(n, seed=900 + seed, on_frame=(110 if use_clock and period < 30 else 75) if use_clock else learn + 3,
+                                   off_frame=nframes - 4)
+    iq = band.frames_cf32(nframes)
+    kw = dict(fft_size=n, decim=1, learn_frames=learn, max_batch=max_batch, grouping_x=gx, grouping_y=gy)
+    if use_clock:
+        kw["learn_ms"] = 1500
+    eng, orc = pkg.SpectrumEngine(fs, center, **kw), oracle_mod.oracle_chain(fs, center, **kw)
+    t_all = np.round(np.arange(nframes) * period).astype(np.int64) + 1_700_000_000_000
+    want = [("psd", "rel", "avg"), ("avg",), (), ("psd", "avg")][int(rng.integers(0, 4))]
+    small_cap = rng.random() < 0.3
+    pos, pairs = 0, []
+    while pos < nframes:
+        size = int(min(nframes - pos, rng.integers(0, max_batch + 1)))  # zero-length calls allowed
+        t = t_all[pos:pos + size] if use_clock else None
+        cap = 5 if small_cap else None
+        g = eng.process(iq[pos:pos + size], t_ms=t, want=want, cand_cap=cap)
+        o = orc.process(iq[pos:pos + size], t_ms=t, want=("psd", "rel", "avg"), cand_cap=cap)
+        assert g["status"] == o["status"], (seed, pos, g["status"], o["status"])
+        pairs.append((g, o))
+        pos += size
+    got = {k: np.concatenate([g[k] for g, _ in pairs]) for k in want}
+    ref = {k: np.concatenate([o[k] for _, o in pairs]) for k in ("psd", "rel", "avg")}
+    for key in ("cand_idx", "cand_avg"):
+        got[key] = np.concatenate([g[key] for g, _ in pairs])
+        ref[key] = np.concatenate([o[key] for _, o in pairs])
+    cg = np.concatenate([np.diff(g["cand_off"]) for g, _ in pairs])
+    co = np.concatenate([np.diff(o["cand_off"]) for _, o in pairs])
+    if small_cap:
+        # lists are truncated per call; the per-frame counts stay exact (up to the start_level band)
+        assert np.abs(cg - co).sum() <= max(2, int(co.sum()) // 100)
+        return
+    got["cand_off"] = np.concatenate([[0], np.cumsum(cg)]).astype(np.int32)
+    ref["cand_off"] = np.concatenate([[0], np.cumsum(co)]).astype(np.int32)
+    errs, ncand, ndc = check_all(got, ref, gy=gy, gx=gx)
+    assert ndc <= max(2, ncand // 100), (seed, ncand, ndc)
