@@ -113,3 +113,77 @@ def test_random_scenario_variants(oracle_mod, seed):
     ref["cand_off"] = np.concatenate([[0], np.cumsum(co)]).astype(np.int32)
     errs, ncand, ndc = check_all(got, ref, gy=gy, gx=gx)
     assert ndc <= max(2, ncand // 100), (seed, ncand, ndc)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SS_FUZZ_SEEDS3", "8"))))
+def test_entry_points_agree(seed):
+    """The three ways into the chain — ss_process (host buffers), ss_process_device (HBM buffers), ss_feed_* (pinned,
+    pipelined) — give the same bits on the same random stream and call sizes; ss_read_window returns what the planes
+    hold (rows before the batch included)."""
+    import torch
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([512, 1024, 4096, 8192]))
+    fs, center = n * 250, 145_000_000
+    nframes = int(rng.integers(100, 180))
+    learn = int(rng.integers(8, 30))
+    max_batch = int(rng.choice([16, 48, 64]))
+    decim = int(rng.choice([1, 1, 3]))
+    band = pkg.synth.SyntheticBand(n, decim=decim, seed=300 + seed, on_frame=learn + 3, off_frame=nframes - 4)
+    iq = band.frames_cf32(nframes)
+    kw = dict(fft_size=n, decim=decim, learn_frames=learn, max_batch=max_batch)
+    host = pkg.SpectrumEngine(fs, center, flags=pkg.abi.SS_FLAG_KEEP_PLANES, **kw)
+    devc = pkg.SpectrumEngine(fs, center, **kw)
+    fed = pkg.SpectrumEngine(fs, center, **kw)
+    feed = fed.feed(depth=3, cand_cap=max_batch * n, want_psd=True)
+    dev = torch.device("cuda:0")
+    sizes, pos = [], 0
+    while pos < nframes:
+        s_ = int(min(nframes - pos, rng.integers(1, max_batch + 1)))
+        sizes.append(s_)
+        pos += s_
+    pos, pending = 0, []
+    for s_ in sizes:
+        chunk = iq[pos:pos + s_]
+        h = host.process(chunk)
+        # device entry point
+        d_iq = torch.from_numpy(chunk.view(np.float32).copy()).to(dev)
+        d_psd = torch.empty((s_, n), dtype=torch.float32, device=dev)
+        d_avg = torch.empty((s_, n), dtype=torch.float32, device=dev)
+        d_off = torch.zeros(s_ + 1, dtype=torch.int32, device=dev)
+        d_idx = torch.zeros(s_ * n, dtype=torch.int32, device=dev)
+        d_cav = torch.zeros(s_ * n, dtype=torch.float32, device=dev)
+        devc.process_device(d_iq, s_, psd=d_psd, avg=d_avg, cand_off=d_off, cand_idx=d_idx, cand_avg=d_cav)
+        devc.sync()
+        off = d_off.cpu().numpy()
+        np.testing.assert_array_equal(off, h["cand_off"])
+        np.testing.assert_array_equal(d_psd.cpu().numpy(), h["psd"])
+        np.testing.assert_array_equal(d_avg.cpu().numpy(), h["avg"])
+        np.testing.assert_array_equal(d_idx.cpu().numpy()[: off[-1]], h["cand_idx"])
+        np.testing.assert_array_equal(d_cav.cpu().numpy()[: off[-1]], h["cand_avg"])
+        # pipelined feed: submit now, compare when collected
+        buf = feed.acquire()
+        buf[:s_] = chunk.reshape(s_, -1)[:, :n]  # already decimated: the first N samples of each item
+        feed.submit(s_, tag=pos)
+        pending.append((pos, h))
+        if feed.pending == 3 or pos + s_ == nframes:
+            while pending:
+                p0, hh = pending.pop(0)
+                r = feed.collect()
+                assert r["tag"] == p0
+                np.testing.assert_array_equal(r["cand_off"], hh["cand_off"])
+                np.testing.assert_array_equal(r["cand_idx"], hh["cand_idx"])
+                np.testing.assert_array_equal(r["cand_avg"], hh["cand_avg"])
+                np.testing.assert_array_equal(r["psd"], hh["psd"])
+        # windows of the planes the host context kept, a few random ones per call
+        for _ in range(3):
+            f = int(rng.integers(0, s_))
+            lo = int(rng.integers(0, n - 1))
+            hi = int(rng.integers(lo + 1, min(n, lo + 200) + 1))
+            for plane, key in ((pkg.abi.SS_PLANE_PSD, "psd"), (pkg.abi.SS_PLANE_REL, "rel"), (pkg.abi.SS_PLANE_AVG, "avg")):
+                np.testing.assert_array_equal(host.read_window(plane, f, lo, hi), h[key][f, lo:hi])
+        if pos > 0:  # ring rows: frame -k is the k-th newest frame before this call (what getBestIndex walks back over)
+            k = int(rng.integers(1, min(20, pos) + 1))
+            np.testing.assert_array_equal(host.read_window(pkg.abi.SS_PLANE_REL, -k, 0, n), all_rel[pos - k])
+        all_rel = h["rel"] if pos == 0 else np.concatenate([all_rel, h["rel"]])
+        pos += s_
+    feed.close()
