@@ -202,3 +202,59 @@ def test_argument_errors():
     with pytest.raises(pkg.abi.SpecscanError):
         Channelizer(2_048_000, 32_000, channels=17)
     assert ch.process(np.zeros(100, np.complex64)) == {}
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SC_FUZZ_SEEDS", "8"))))
+def test_random_recording_sessions(seed):
+    """Random sample rates / bandwidths (single and multi stage, interpolating stages included), random slots starting,
+    stopping and restarting on other shifts at random times, random call sizes: every slot against its own oracle chain
+    fed exactly the samples it was recording for."""
+    rng = np.random.default_rng(4000 + seed)
+    fs, bw = [(2_048_000, 32_000), (2_048_000, 16_000), (1_024_000, 20_000), (1_000_000, 16_000), (2_400_000, 32_000),
+              (250_000, 25_000), (1_024_000, 16_000), (2_000_000, 20_000)][int(rng.integers(0, 8))]
+    nslots = int(rng.integers(1, 5))
+    n = int(rng.integers(60_000, 160_000))
+    carriers = [float(rng.integers(-fs // 3, fs // 3)) for _ in range(3)]
+    x = _stream(n, fs, carriers, seed=seed)
+    ch = Channelizer(fs, bw, channels=nslots, max_samples=1 << 16)
+    oracles = [oracle.ChannelizerOracle(fs, bw) for _ in range(nslots)]
+    active = [False] * nslots
+    segs = [[] for _ in range(nslots)]  # per slot: list of (got_cf32, ref_cf32) per recording session
+    cur = [None] * nslots
+    pos = 0
+    while pos < n:
+        for k in range(nslots):  # random control events between calls
+            r = rng.random()
+            if not active[k] and r < 0.35:
+                sh = int(rng.choice(carriers) + rng.integers(-2000, 2000))
+                ch.start(k, sh)
+                oracles[k].set_shift(sh)
+                active[k] = True
+                cur[k] = ([], [])
+            elif active[k] and r < 0.08:
+                ch.stop(k)
+                active[k] = False
+                segs[k].append(cur[k])
+                cur[k] = None
+        size = int(min(n - pos, rng.integers(1, 1 << 16)))
+        out = ch.process(x[pos:pos + size])
+        assert sorted(out) == [k for k in range(nslots) if active[k]]
+        for k in out:
+            y, _i8 = oracles[k].process(x[pos:pos + size])
+            assert len(out[k][1]) == len(y), (seed, k, len(out[k][1]), len(y))
+            cur[k][0].append(out[k][1])
+            cur[k][1].append(y)
+        pos += size
+    for k in range(nslots):
+        if cur[k] is not None:
+            segs[k].append(cur[k])
+        for got, ref in segs[k]:
+            if not got:
+                continue
+            g, r = np.concatenate(got), np.concatenate(ref)
+            if len(r) < 40 or np.abs(r).max() < 1e-3:
+                continue
+            # every session restarts from the state the previous one left (phase, histories): compare modulo the creep
+            resid, slope = _decreep(g, r, fs / bw)
+            assert resid < 3e-4 and abs(slope) < 1e-7, (seed, k, len(r), resid, slope)
+    ch.close()
