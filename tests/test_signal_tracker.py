@@ -73,3 +73,53 @@ def test_reset_clears_signals_and_ring(oracle_mod):
     tr.reset()
     tx, sig = tr.process_frame(1040, np.full(n, -100.0, np.float32), np.full(n, -100.0, np.float32), np.zeros(0, np.int32))
     assert len(sig) == 0 and len(tx) == 0
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SS_TRACKER_SEEDS", "10"))))
+def test_tracker_matches_reference_on_random_traffic(ref_mod, seed):
+    """Random bursts (position, width, level, start, duration — overlapping, adjacent, re-appearing inside the margin of an
+    old signal), random frame period, timeouts, tuning step and recording bandwidth: the tracker against the reference's own
+    compiled Transmission/Signal on every frame."""
+    O = ref_mod
+    rng = np.random.default_rng(600 + seed)
+    n = int(rng.choice([256, 512, 1024]))
+    fs = n * 250
+    center, nframes = 145_000_000, int(rng.integers(260, 420))
+    dt = int(rng.choice([20, 40, 55]))
+    min_ms, timeout_ms = int(rng.choice([0, 300, 2000])), int(rng.choice([60, 500, 2000]))
+    step = int(rng.choice([2500, 1000, 12500]))
+    bandwidth = int(rng.choice([8000, 16000, 32000]))
+    sigma = 0.05
+    x = (rng.standard_normal((nframes, n)) + 1j * rng.standard_normal((nframes, n))) * sigma
+    k = np.arange(n)
+    amp = pkg.synth.comb_amplitude(n, sigma)
+    nburst = int(rng.integers(3, 9))
+    for _ in range(nburst):
+        c0 = int(rng.integers(30, n - 30))
+        width = int(rng.integers(6, 40))
+        level = amp * float(rng.uniform(0.6, 2.0))
+        start = int(rng.integers(50, nframes - 60))
+        stop = min(nframes, start + int(rng.integers(5, 150)))
+        bins = np.arange(c0 - width // 2, c0 + width // 2)
+        for f in range(start, stop):
+            ph = rng.uniform(0, 2 * np.pi, size=len(bins))
+            tone = np.exp(2j * np.pi * ((bins - n // 2)[:, None] * k[None, :]) / n + 1j * ph[:, None]).sum(axis=0)
+            x[f] += level * tone
+    iq = x.astype(np.complex64)
+    t = (5_000 + dt * np.arange(nframes)).astype(np.int64)
+    O.ref().orc_set_fft_backend(0)
+    O.lib().orc_set_fft_backend(0)
+    ref = O.RefChain(n, fs, center - fs // 2, center + fs // 2, min_time_ms=min_ms, timeout_ms=timeout_ms, tuning_step=step, bandwidth=bandwidth)
+    want = ref.process(iq, t)
+    ch = O.oracle_chain(fs, center, fft_size=n, decim=1, max_batch=nframes)
+    r = ch.process(iq, t_ms=t)
+    tr = pkg.tracker.SignalTracker(n, fs, min_time_ms=min_ms, timeout_ms=timeout_ms, tuning_step=step, bandwidth=bandwidth)
+    got = tr.process_batch(t, r["avg"], r["rel"], r["cand_off"], r["cand_idx"])
+    total = 0
+    for f in range(nframes):
+        tx, sig = got[f]
+        np.testing.assert_array_equal(tx, want["tx"][f], err_msg=f"seed {seed} frame {f}")
+        np.testing.assert_array_equal(sig, want["signals"][f], err_msg=f"seed {seed} frame {f}")
+        total += len(sig)
+    if total == 0:
+        pytest.skip("this draw produced no detection (bursts too short for the 21-frame mean)")
