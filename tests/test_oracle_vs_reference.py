@@ -81,6 +81,46 @@ def test_oracle_matches_live_reference(ref_mod, n, fs, seed):
         np.testing.assert_array_equal(idx[off[f]:off[f + 1]], r["cands"][f])
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SS_ORACLE_SEEDS", "8"))))
+def test_oracle_matches_live_reference_on_random_runs(ref_mod, seed):
+    """Random size, frame period, ignored ranges, call sizes and a retune with reset at a random frame: the restated chain
+    against the reference's own compiled PSD / NoiseLearner / Transmission, bit for bit, frame by frame."""
+    O = ref_mod
+    rng = np.random.default_rng(300 + seed)
+    n = int(rng.choice([64, 128, 256, 512, 1024]))
+    fs = n * int(rng.choice([125, 250, 500]))
+    center = 433_000_000
+    nframes = int(rng.integers(140, 260))
+    dt = int(rng.choice([15, 40, 70]))
+    band = pkg.synth.SyntheticBand(n, seed=700 + seed, on_frame=int(2000 / dt) + 12, off_frame=nframes - 5, comb_width=max(8, n // 24))
+    iq = band.frames_cf32(nframes)
+    t = (9_000 + dt * np.arange(nframes)).astype(np.int64)
+    ignored = ()
+    if rng.random() < 0.6:
+        lo = center + int(rng.integers(-fs // 3, fs // 4))
+        ignored = (lo, lo + fs // 16)
+    retune_at = int(rng.integers(nframes // 2, nframes - 40)) if rng.random() < 0.5 else None
+    chunk = int(rng.choice([1, 5, 33, 64]))
+    O.ref().orc_set_fft_backend(0)
+    ref = O.RefChain(n, fs, center - fs // 2, center + fs // 2, ignored=ignored)
+    parts = []
+    if retune_at is None:
+        parts.append(ref.process(iq, t))
+    else:
+        parts.append(ref.process(iq[:retune_at], t[:retune_at]))
+        ref.set_range(center + fs - fs // 2, center + fs + fs // 2)  # SdrDevice::setFrequencyRange + Transmission::resetBuffers
+        ref.reset()
+        parts.append(ref.process(iq[retune_at:], t[retune_at:]))
+    r = {k: np.concatenate([p_[k] for p_ in parts]) for k in ("psd", "rel", "avg")}
+    cands = [c for p_ in parts for c in p_["cands"]]
+    psd, rel, avg, off, idx, _ = _run_oracle(O, iq, t, n, fs, center, ignored, retune_at, chunk)
+    np.testing.assert_array_equal(psd, r["psd"])
+    np.testing.assert_array_equal(rel, r["rel"])
+    np.testing.assert_array_equal(avg, r["avg"])
+    for f in range(nframes):
+        np.testing.assert_array_equal(idx[off[f]:off[f + 1]], cands[f], err_msg=f"seed {seed} frame {f}")
+
+
 def test_frame_count_learning_equals_timestamp_learning(oracle_mod):
     """learn_frames = k is the same as timestamps that complete NOISE_LEARNING_TIME on frame k."""
     O = oracle_mod
