@@ -302,7 +302,7 @@ __global__ void k_hist_shift(const float* __restrict__ hist_in, float* __restric
 }
 
 // Candidate lists (CSR) from the mask bits: one wave per frame. The frame's offset is the sum of the
-// counts of the frames before it (this path is used for nframes <= 4096). The wave pulls 256 mask words
+// counts of the frames before it (16 counts per lane per trip of 1024 frames). The wave pulls 256 mask words
 // per trip (one 16-byte load per lane), ranks them with one wave scan, expands the set bits into an LDS
 // list at their ranks, then streams the list out with coalesced stores — ascending bins, frames in
 // order, deterministic. counts_next (the other half of the double-buffered counters, last used by the previous

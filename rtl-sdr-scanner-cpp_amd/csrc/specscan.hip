@@ -85,7 +85,7 @@ struct ss_ctx {
   int frames_pushed = 0;  // Averager::m_frames, saturates at grouping_y
   int rot_frames = 0;     // rows of the previous batch still to be folded into the history rows (lazy ring rotation)
   // planes (frame-major rows of n floats)
-  // back end, fused path (grouping 21 x 21, max_batch <= 4096): ring and counters are double-buffered
+  // back end, fused path (grouping 21 x 21, max_batch <= 65536): ring and counters are double-buffered
   bool fused = false;
   float* d_hist[2] = {nullptr, nullptr};  // kHistRows rel rows each (newest last); [hist_cur] is read by the next batch
   int hist_cur = 0;
@@ -663,7 +663,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   if (const char* ab = getenv("SS_FFT_ABLATE")) c->diag.fft_ablate = atoi(ab);
   {
     const char* be = getenv("SS_BACKEND");  // "unfused" forces the per-stage kernels (A/B measurements)
-    c->fused = G == 21 && cfg->grouping_x == 21 && cfg->max_batch <= 4096 && !(be && strcmp(be, "unfused") == 0);
+    c->fused = G == 21 && cfg->grouping_x == 21 && cfg->max_batch <= 65536 && !(be && strcmp(be, "unfused") == 0);
   }
   if (c->fused) {
     for (int k = 0; k < 2; ++k) {

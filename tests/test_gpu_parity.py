@@ -58,6 +58,7 @@ CASES = [
     (64, 16_000, 1, "cf32", 120, 17, 20, 1),
     (1024, 256_000, 1, "cf32", 150, 64, 30, 2),
     (2048, 512_000, 3, "cf32", 90, 32, 25, 3),
+    (512, 128_000, 1, "cf32", 5000, 5000, 40, 12),  # one long call: more frames than wave slots, per-frame offsets beyond one scan trip
     (4096, 1_024_000, 1, "cs8", 80, 80, 22, 4),
     (8192, 2_048_000, 1, "cf32", 96, 48, 24, 5),
     (8192, 2_048_000, 5, "cu8", 70, 70, 21, 6),
