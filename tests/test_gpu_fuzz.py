@@ -187,3 +187,61 @@ def test_entry_points_agree(seed):
         all_rel = h["rel"] if pos == 0 else np.concatenate([all_rel, h["rel"]])
         pos += s_
     feed.close()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SS_FUZZ_SEEDS4", "6"))))
+def test_random_spectrogram_sessions(oracle_mod, seed):
+    """The spectrogram side branch under random sizes (its output size follows min(16384, getFft(fs, 1000))), call sizes,
+    send times and a retune (the accumulator is per centre frequency, spectrogram.cpp:29-60)."""
+    import ctypes as C
+    rng = np.random.default_rng(12000 + seed)
+    n = int(rng.choice([1024, 4096, 8192, 16384]))
+    fs = n * int(rng.choice([125, 250]))
+    center = 100_000_000
+    nframes = int(rng.integers(80, 160))
+    max_batch = int(rng.choice([8, 32, 64]))
+    band = pkg.synth.SyntheticBand(n, seed=77 + seed, on_frame=20, off_frame=nframes - 5)
+    iq = band.frames_cf32(nframes)
+    kw = dict(fft_size=n, decim=1, learn_frames=10, max_batch=max_batch)
+    eng = pkg.SpectrumEngine(fs, center, flags=pkg.abi.SS_FLAG_SPECTROGRAM, **kw)
+    orc = oracle_mod.oracle_chain(fs, center, **kw)
+    L = oracle_mod.lib()
+    accs = {}  # centre -> oracle accumulator (the reference keeps one container per centre frequency)
+
+    def acc_for(c):
+        if c not in accs:
+            accs[c] = L.orc_spectrogram_create(n, fs)
+        return accs[c]
+
+    size = L.orc_spectrogram_size(acc_for(center))
+    assert eng._lib.ss_spectrogram_size(eng._h) == size
+    cur = center
+    retune_at = int(rng.integers(30, nframes - 30)) if rng.random() < 0.6 else -1
+    pos = sends = 0
+    while pos < nframes:
+        s_ = int(min(nframes - pos, rng.integers(1, max_batch + 1)))
+        if pos <= retune_at < pos + s_:
+            s_ = max(1, retune_at - pos) if retune_at > pos else s_
+        if pos == retune_at:
+            cur = center + fs
+            for c in (eng, orc):
+                c.set_frequency_range(cur - fs // 2, cur + fs // 2)
+                c.reset()
+        eng.process(iq[pos:pos + s_], want=())
+        for row in orc.process(iq[pos:pos + s_], want=("psd",))["psd"]:
+            L.orc_spectrogram_process(acc_for(cur), row.ctypes.data_as(C.POINTER(C.c_float)))
+        pos += s_
+        if rng.random() < 0.25 or pos == nframes:
+            want8, wantf = np.zeros(size, np.int8), np.zeros(size, np.float32)
+            cnt_ref = L.orc_spectrogram_send(acc_for(cur), want8.ctypes.data_as(C.POINTER(C.c_int8)), wantf.ctypes.data_as(C.POINTER(C.c_float)))
+            got8, gotf, cnt = eng.spectrogram_read()
+            assert cnt == cnt_ref, (seed, pos, cnt, cnt_ref)
+            if cnt:
+                sends += 1
+                assert np.max(np.abs(gotf - wantf)) < 1e-4 * 60
+                frac = np.abs(wantf - np.trunc(wantf))
+                decided = (frac > 1e-3) & (frac < 1 - 1e-3)
+                np.testing.assert_array_equal(got8[decided], want8[decided])
+    assert sends >= 1
+    for g in accs.values():
+        L.orc_spectrogram_destroy(g)
