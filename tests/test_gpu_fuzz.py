@@ -13,11 +13,14 @@ pytestmark = pytest.mark.gpu
 
 def _scenario(seed):
     rng = np.random.default_rng(1000 + seed)
-    n = int(rng.choice([64, 128, 256, 512, 1024, 2048, 4096]))
+    sizes = [64, 128, 256, 512, 1024, 2048, 4096]
+    if seed % 4 == 3:  # every fourth draw: the register-kernel sizes (8192-point kernel, 256-column four-step)
+        sizes = [8192, 16384, 32768, 65536]
+    n = int(rng.choice(sizes))
     decim = int(rng.choice([1, 1, 2, 5]))
     fmt = str(rng.choice(["cf32", "cf32", "cs8", "cu8"]))
     fs = int(n * rng.choice([200, 250, 125]))
-    nframes = int(rng.integers(90, 220))
+    nframes = int(rng.integers(90, 220)) if n <= 8192 else int(rng.integers(60, 110))
     learn = int(rng.integers(5, 40))
     max_batch = int(rng.choice([8, 16, 64, 256]))
     return rng, n, decim, fmt, fs, nframes, learn, max_batch
@@ -60,7 +63,7 @@ def test_random_scenario(oracle_mod, seed):
     got, ref = cat(outs_g), cat(outs_o)
     errs, ncand, ndc = check_all(got, ref)
     assert ndc <= max(2, ncand // 100), (seed, ncand, ndc)
-    assert ncand > 0 or n < 512, (seed, n, fmt)  # the 48-bin combs of the generator are too wide for the smallest sizes
+    assert ncand > 0 or n < 512 or n > 8192, (seed, n, fmt)  # the generator is tuned for 512..8192 points
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SS_FUZZ_SEEDS2", "10"))))
