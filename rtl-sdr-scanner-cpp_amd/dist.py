@@ -80,3 +80,35 @@ def synthetic_batch(cfg: dict, band: int, nframes: int) -> np.ndarray:
     b = synth.SyntheticBand(int(cfg["fft_size"]), decim=int(cfg["decim"]), seed=int(cfg["seed"]) + band,
                             on_frame=int(cfg["learn_frames"]) + 30, off_frame=nframes - 50)
     return b.frames_cf32(nframes)
+
+
+def scan_frame_range(chain, frames, lo: int, hi: int, learn_frames: int, max_batch: int, align: int = 16, halo: int = 20):
+    """One rank's share of a recorded band, frames [lo, hi) of ``frames`` ([nframes, N*D] items), with no exchange between
+    ranks (BASELINE config 5): every rank first runs the learning prefix [0, learn_frames) itself so that
+    all ranks hold the same noise ceiling, resets the averager, and re-reads a halo before its range — the 20 frames the
+    21-frame mean needs (GROUPING_Y - 1), extended back to a multiple of ``align`` frames so that the engine's frame tiles
+    (which restart their sliding sums every 16 frames since the last reset) fall where they fall in a single-rank run. The
+    outputs of halo frames are dropped. Returns per-frame candidate lists for [lo, hi), bit-identical to a single-rank scan
+    for every frame past the averager's warm-up (lo >= learn_frames + halo)."""
+    if lo >= hi:
+        return []
+    pos = 0
+    while pos < learn_frames:  # noise ceiling: identical on every rank
+        n = min(max_batch, learn_frames - pos)
+        chain.process(frames[pos:pos + n], want=())
+        pos += n
+    start = max(learn_frames, ((lo - halo) // align) * align)
+    if start > learn_frames:
+        chain.reset()  # Averager::reset: ring and frame counter to zero; the engine's tile origin moves to `start`
+    # frames of the range that lie inside the learning prefix never have candidates (noise_learner.cpp:45-51)
+    out = [np.zeros(0, np.int32) for _ in range(max(0, min(hi, learn_frames) - lo))]
+    pos = start
+    while pos < hi:
+        n = min(max_batch, hi - pos)
+        r = chain.process(frames[pos:pos + n], want=())
+        off, idx = r["cand_off"], r["cand_idx"]
+        for f in range(n):
+            if pos + f >= max(lo, learn_frames):
+                out.append(idx[off[f]:off[f + 1]].copy())
+        pos += n
+    return out

@@ -35,6 +35,16 @@ WORKER = textwrap.dedent("""
     mine = time.perf_counter() - t0 + (0.25 if rank == 1 else 0.0)
     out["mine"], out["max"] = mine, dist.max_over_ranks(mine)
     out["frames"] = dist.frame_ranges(1000, rank, world, 20)
+    # frame-range sharding of ONE band (SURVEY.md 8e-2): this rank's contiguous range with a re-read halo, no exchange
+    nfr = 400
+    rec = dist.synthetic_batch(cfg, 0, nfr)
+    mk = lambda: O.oracle_chain(int(cfg["sample_rate"]), dist.band_center(cfg, 0), fft_size=int(cfg["fft_size"]), decim=1,
+                                learn_frames=int(cfg["learn_frames"]), max_batch=128, start_level=cfg["start_level_mdB"] / 1000.0)
+    _, lo, hi = dist.frame_ranges(nfr, rank, world, 20)
+    mine_lists = dist.scan_frame_range(mk(), rec, lo, hi, int(cfg["learn_frames"]), 128)
+    whole = dist.scan_frame_range(mk(), rec, 0, nfr, int(cfg["learn_frames"]), 128)
+    same = sum(int(np.array_equal(a, b)) for a, b in zip(mine_lists, whole[lo:hi]))
+    out["shard"] = {"lo": lo, "hi": hi, "frames_equal": same, "cands": int(sum(len(c) for c in mine_lists))}
     print("RESULT " + json.dumps(out), flush=True)
 """)
 
@@ -66,3 +76,9 @@ def test_two_rank_band_sharding_over_gloo(oracle_mod, tmp_path):
     assert all(v > 0 for r in res for v in r["cands"].values())  # every band was really scanned
     assert abs(res[0]["max"] - res[1]["max"]) < 1e-9 and res[0]["max"] >= max(res[0]["mine"], res[1]["mine"]) - 1e-9
     assert res[0]["frames"] == [0, 0, 500] and res[1]["frames"] == [480, 500, 1000]  # 20-frame halo re-read, no exchange
+    # the two ranges tile the recording, and every rank reproduces the single-rank lists of its frames (the oracle's
+    # never-re-zeroed running sums may flip a bin at the threshold when restarted from a halo: allow a handful)
+    assert (res[0]["shard"]["lo"], res[0]["shard"]["hi"], res[1]["shard"]["lo"], res[1]["shard"]["hi"]) == (0, 200, 200, 400)
+    for r in res:
+        assert r["shard"]["frames_equal"] >= (r["shard"]["hi"] - r["shard"]["lo"]) - 3, r["shard"]
+    assert res[0]["shard"]["cands"] + res[1]["shard"]["cands"] > 500

@@ -65,3 +65,25 @@ def test_tone_lands_on_shifted_bin():
     iq = np.exp(2j * np.pi * ks[:, None] * n[None, :] / N).astype(np.complex64)
     psd = eng.process(iq, want=("psd",))["psd"]
     np.testing.assert_array_equal(np.argmax(psd, axis=1), (N // 2 + ks) % N)
+
+
+def test_frame_range_sharding_equals_single_rank():
+    """BASELINE config 5's sharding: ranks scan contiguous frame ranges of one band with a re-read halo
+    and no exchange. Simulated here rank by rank on one GPU: the union of the ranks' candidate lists is the single-rank
+    scan, bit for bit."""
+    n, fs, center = 8192, 2_048_000, 145_000_000
+    nframes, learn, world = 1500, 100, 4
+    band = pkg.synth.SyntheticBand(n, seed=33, on_frame=150, off_frame=1400)
+    frames = band.frames_cf32(nframes)
+    kw = dict(fft_size=n, decim=1, learn_frames=learn, max_batch=256)
+    single = pkg.dist.scan_frame_range(pkg.SpectrumEngine(fs, center, **kw), frames, 0, nframes, learn, 256)
+    assert len(single) == nframes and sum(len(c) for c in single) > 100_000
+    got = []
+    for rank in range(world):
+        _, lo, hi = pkg.dist.frame_ranges(nframes, rank, world, 20)
+        part = pkg.dist.scan_frame_range(pkg.SpectrumEngine(fs, center, **kw), frames, lo, hi, learn, 256)
+        assert len(part) == hi - lo
+        got.extend(part)
+    assert len(got) == nframes
+    for f in range(nframes):
+        np.testing.assert_array_equal(got[f], single[f], err_msg=f"frame {f}")
