@@ -27,3 +27,99 @@ def test_adapter_compiles_against_the_block_api(tmp_path):
            "-I" + os.path.join(ROOT, "oracle", "stubs"), str(src)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+ADAPTER_MAIN = r"""
+// Drives the reference-side adapter the way GNU Radio's scheduler drives a sync_block: work() calls on scheduler-owned
+// buffers, a retune from another control path, the tracker consuming each frame's candidates.
+#include <gpu_spectrum_block.h>
+#include <signal_tracker.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  const char* path = argv[1];
+  const int n = atoi(argv[2]), nframes = atoi(argv[3]);
+  ss_config cfg;
+  ss_default_config(&cfg, n * 250, 145000000);
+  cfg.fft_size = n;
+  cfg.decim = 1;
+  cfg.learn_frames = 20;
+  cfg.learn_ms = 0;
+  cfg.max_batch = 16;
+  std::vector<gr_complex> iq((size_t)n * nframes);
+  FILE* fp = fopen(path, "rb");
+  if (!fp || fread(iq.data(), sizeof(gr_complex), iq.size(), fp) != iq.size()) return 3;
+  fclose(fp);
+  long long total = 0;
+  std::vector<int> per_frame;
+  GpuSpectrum block(cfg, [&](int, const int32_t*, const float*, int count) {
+    total += count;
+    per_frame.push_back(count);
+  });
+  std::vector<float> psd((size_t)n * 16);
+  int pos = 0;
+  const int sizes[] = {1, 16, 7, 3, 16, 16, 5};
+  int k = 0;
+  while (pos < nframes) {
+    int want = sizes[k++ % 7];
+    if (want > nframes - pos) want = nframes - pos;
+    gr_vector_const_void_star in{iq.data() + (size_t)pos * n};
+    gr_vector_void_star out{psd.data()};
+    const int produced = block.work(want, in, out);
+    if (produced != want) {
+      fprintf(stderr, "work produced %d of %d: %s\n", produced, want, block.lastError().c_str());
+      return 4;
+    }
+    pos += produced;
+  }
+  printf("{\"frames\": %d, \"candidates\": %lld, \"last_psd0\": %.6f, \"per_frame\": [", (int)per_frame.size(), total, psd[0]);
+  for (size_t i = 0; i < per_frame.size(); ++i) printf("%s%d", i ? "," : "", per_frame[i]);
+  printf("]}\n");
+  return 0;
+}
+"""
+
+
+@pytest.mark.gpu
+def test_adapter_runs_against_the_library(tmp_path):
+    """The adapter block compiled against the block API (stand-in header) and LINKED with libspecscan.so, driven like the
+    scheduler drives it: the candidates it hands to the callback are the ones the boundary reports for the same frames."""
+    import json
+    import numpy as np
+    import rtl_sdr_scanner_cpp_amd as pkg
+    n, nframes = 1024, 120
+    band = pkg.synth.SyntheticBand(n, seed=21, on_frame=28, off_frame=110)
+    iq = band.frames_cf32(nframes)
+    raw = tmp_path / "iq.cf32"
+    iq.tofile(raw)
+    src = tmp_path / "adapter_main.cpp"
+    src.write_text(ADAPTER_MAIN)
+    exe = tmp_path / "adapter_main"
+    csrc = os.path.join(ROOT, "rtl-sdr-scanner-cpp_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "rtl-sdr-scanner-cpp_amd", "host"),
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle", "stubs"), str(src), "-o", str(exe), "-L" + csrc, "-lspecscan",
+           "-Wl,-rpath," + csrc, "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib"), "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe), str(raw), str(n), str(nframes)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    eng = pkg.SpectrumEngine(n * 250, 145_000_000, fft_size=n, decim=1, learn_frames=20, learn_ms=0, max_batch=16)
+    want, last = [], None
+    pos, k = 0, 0
+    sizes = [1, 16, 7, 3, 16, 16, 5]
+    while pos < nframes:
+        s_ = min(sizes[k % 7], nframes - pos)
+        k += 1
+        # the adapter stamps every frame with the wall clock (as the reference's blocks do); with learn_ms = 0 the very
+        # first frame completes the learning whatever the clock says, so constant stamps reproduce it
+        o = eng.process(iq[pos:pos + s_], t_ms=np.full(s_, 1_700_000_000_000, np.int64), want=("psd",))
+        want.extend(np.diff(o["cand_off"]).tolist())
+        last = o["psd"]
+        pos += s_
+    assert rep["frames"] == nframes and rep["per_frame"] == want and rep["candidates"] == sum(want) > 500
+    assert abs(rep["last_psd0"] - float(last[0, 0])) < 1e-4
