@@ -10,11 +10,18 @@
 //   candidates: per frame, the bins passing transmission.cpp:91 and their avg power, handed to a callback
 //             on the work() thread, in frame order — the input of Transmission::addSignals' sort (:95)
 //
+// Optionally the block also runs the host-side remainder of Transmission (enableTracker): every frame's avg / rel rows and
+// candidates go through specscan::SignalTracker (host/signal_tracker.h) and the resulting std::vector<FrequencyFlush> —
+// what Transmission::process hands to m_notification.notify (transmission.cpp:67) — goes to a callback, so that the
+// Scanner thread (sources/scanner.cpp:36-64) sees exactly the interface it sees today.
+//
 // Control calls mirror what SdrDevice does to the blocks it owns: setFrequencyRange (sdr_device.cpp:54-80)
 // -> set_frequency_range() + reset_buffers(); they are serialised against work() inside the library.
 #pragma once
 #include <gnuradio/sync_block.h>
 #include <specscan.h>
+
+#include "signal_tracker.h"
 
 #include <chrono>
 #include <cstdint>
@@ -49,13 +56,27 @@ class GpuSpectrum : virtual public gr::sync_block {
   GpuSpectrum(const GpuSpectrum&) = delete;
   GpuSpectrum& operator=(const GpuSpectrum&) = delete;
 
+  using TransmissionCallback = std::function<void(const std::vector<specscan::FrequencyFlush>&)>;
+  using Clock = std::function<int64_t()>;  // milliseconds; the reference's getTime() (utils/utils.cpp:14)
+
+  // Run Transmission's signal bookkeeping on every frame and report what Notification::notify would receive.
+  void enableTracker(const specscan::TrackerConfig& config, TransmissionCallback on_transmissions) {
+    m_tracker = std::make_unique<specscan::SignalTracker>(config);
+    m_onTransmissions = std::move(on_transmissions);
+    m_rel.resize(static_cast<size_t>(m_config.max_batch) * static_cast<size_t>(m_config.fft_size));
+    m_avgPlane.resize(m_rel.size());
+  }
+  void setClock(Clock clock) { m_clock = std::move(clock); }
+
   int work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override {
     const int nframes = noutput_items < m_config.max_batch ? noutput_items : m_config.max_batch;
     // the reference's blocks read the wall clock per frame (noise_learner.cpp:18, transmission.cpp:62)
-    const auto now = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+    const int64_t now = m_clock ? m_clock()
+                                : std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
     for (int f = 0; f < nframes; ++f) m_times[static_cast<size_t>(f)] = now;
-    const int status = ss_process(m_ctx, input_items[0], nframes, m_times.data(), static_cast<float*>(output_items[0]), nullptr, nullptr,
-                                  m_offsets.data(), m_bins.data(), m_avg.data(), static_cast<int32_t>(m_bins.size()));
+    const int status = ss_process(m_ctx, input_items[0], nframes, m_times.data(), static_cast<float*>(output_items[0]),
+                                  m_tracker ? m_rel.data() : nullptr, m_tracker ? m_avgPlane.data() : nullptr, m_offsets.data(), m_bins.data(),
+                                  m_avg.data(), static_cast<int32_t>(m_bins.size()));
     if (status != SS_OK && status != SS_ERR_CAND_OVERFLOW) {
       // work() has no error channel in the reference either (sdr_source.cpp:37-41 logs and exits): produce nothing
       m_lastError = ss_last_error(m_ctx);
@@ -69,12 +90,26 @@ class GpuSpectrum : virtual public gr::sync_block {
         m_onCandidates(f, m_bins.data() + begin, m_avg.data() + begin, end - begin);
       }
     }
+    if (m_tracker) {
+      const int32_t cap = static_cast<int32_t>(m_bins.size());
+      const size_t n = static_cast<size_t>(m_config.fft_size);
+      for (int f = 0; f < nframes; ++f) {
+        const int32_t begin = m_offsets[static_cast<size_t>(f)] < cap ? m_offsets[static_cast<size_t>(f)] : cap;
+        const int32_t end = m_offsets[static_cast<size_t>(f) + 1] < cap ? m_offsets[static_cast<size_t>(f) + 1] : cap;
+        const auto& tx = m_tracker->processFrame(now, m_avgPlane.data() + static_cast<size_t>(f) * n, m_rel.data() + static_cast<size_t>(f) * n,
+                                                 m_bins.data() + begin, end - begin);
+        if (m_onTransmissions) m_onTransmissions(tx);
+      }
+    }
     return nframes;
   }
 
   // SdrDevice::setFrequencyRange's effect on the chain (sdr_device.cpp:66,74,77)
   void setFrequencyRange(int32_t lo_hz, int32_t hi_hz) { ss_set_frequency_range(m_ctx, lo_hz, hi_hz); }
-  void resetBuffers() { ss_reset(m_ctx); }  // Transmission::resetBuffers, transmission.cpp:42-55
+  void resetBuffers() {  // Transmission::resetBuffers, transmission.cpp:42-55: signals cleared, averager reset
+    ss_reset(m_ctx);
+    if (m_tracker) m_tracker->reset();
+  }
   const std::string& lastError() const { return m_lastError; }
 
  private:
@@ -85,4 +120,8 @@ class GpuSpectrum : virtual public gr::sync_block {
   std::vector<float> m_avg;
   std::vector<int64_t> m_times;
   std::string m_lastError;
+  std::unique_ptr<specscan::SignalTracker> m_tracker;
+  TransmissionCallback m_onTransmissions;
+  Clock m_clock;
+  std::vector<float> m_rel, m_avgPlane;
 };

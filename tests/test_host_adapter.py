@@ -60,6 +60,17 @@ int main(int argc, char** argv) {
     total += count;
     per_frame.push_back(count);
   });
+  // Transmission's bookkeeping on top, with an injected clock: 40 ms per frame, read once per work() call
+  int clock_pos = 0;
+  block.setClock([&] { return (int64_t)(1000 + 40 * clock_pos); });
+  specscan::TrackerConfig tc;
+  tc.fft_size = n;
+  tc.sample_rate = n * 250;
+  tc.group_size = 128;  // ceil(32000 / 250)
+  tc.min_time_ms = 200;
+  tc.timeout_ms = 400;
+  std::vector<std::vector<specscan::FrequencyFlush>> tx_per_frame;
+  block.enableTracker(tc, [&](const std::vector<specscan::FrequencyFlush>& tx) { tx_per_frame.push_back(tx); });
   std::vector<float> psd((size_t)n * 16);
   int pos = 0;
   const int sizes[] = {1, 16, 7, 3, 16, 16, 5};
@@ -69,6 +80,7 @@ int main(int argc, char** argv) {
     if (want > nframes - pos) want = nframes - pos;
     gr_vector_const_void_star in{iq.data() + (size_t)pos * n};
     gr_vector_void_star out{psd.data()};
+    clock_pos = pos;
     const int produced = block.work(want, in, out);
     if (produced != want) {
       fprintf(stderr, "work produced %d of %d: %s\n", produced, want, block.lastError().c_str());
@@ -78,6 +90,12 @@ int main(int argc, char** argv) {
   }
   printf("{\"frames\": %d, \"candidates\": %lld, \"last_psd0\": %.6f, \"per_frame\": [", (int)per_frame.size(), total, psd[0]);
   for (size_t i = 0; i < per_frame.size(); ++i) printf("%s%d", i ? "," : "", per_frame[i]);
+  printf("], \"tx\": [");
+  for (size_t i = 0; i < tx_per_frame.size(); ++i) {
+    printf("%s[", i ? "," : "");
+    for (size_t k = 0; k < tx_per_frame[i].size(); ++k) printf("%s[%d,%d]", k ? "," : "", tx_per_frame[i][k].shift_hz, (int)tx_per_frame[i][k].flush);
+    printf("]");
+  }
   printf("]}\n");
   return 0;
 }
@@ -101,7 +119,7 @@ def test_adapter_runs_against_the_library(tmp_path):
     exe = tmp_path / "adapter_main"
     csrc = os.path.join(ROOT, "rtl-sdr-scanner-cpp_amd", "csrc")
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "rtl-sdr-scanner-cpp_amd", "host"),
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle", "stubs"), str(src), "-o", str(exe), "-L" + csrc, "-lspecscan",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle", "stubs"), str(src), os.path.join(ROOT, "rtl-sdr-scanner-cpp_amd", "host", "signal_tracker.cpp"), "-o", str(exe), "-L" + csrc, "-lspecscan",
            "-Wl,-rpath," + csrc, "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib"), "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -109,12 +127,17 @@ def test_adapter_runs_against_the_library(tmp_path):
     assert r.returncode == 0, r.stderr
     rep = json.loads(r.stdout.strip().splitlines()[-1])
     eng = pkg.SpectrumEngine(n * 250, 145_000_000, fft_size=n, decim=1, learn_frames=20, learn_ms=0, max_batch=16)
-    want, last = [], None
+    eng2 = pkg.SpectrumEngine(n * 250, 145_000_000, fft_size=n, decim=1, learn_frames=20, learn_ms=0, max_batch=16)
+    want, last, want_tx = [], None, []
     pos, k = 0, 0
     sizes = [1, 16, 7, 3, 16, 16, 5]
+    trk = pkg.tracker.SignalTracker(n, n * 250, group_size=128, min_time_ms=200, timeout_ms=400)
     while pos < nframes:
         s_ = min(sizes[k % 7], nframes - pos)
         k += 1
+        full = eng2.process(iq[pos:pos + s_], t_ms=np.full(s_, 1_700_000_000_000, np.int64))
+        for tx, _sig in trk.process_batch(np.full(s_, 1000 + 40 * pos, np.int64), full["avg"], full["rel"], full["cand_off"], full["cand_idx"]):
+            want_tx.append(np.asarray(tx).reshape(-1, 2).tolist())
         # the adapter stamps every frame with the wall clock (as the reference's blocks do); with learn_ms = 0 the very
         # first frame completes the learning whatever the clock says, so constant stamps reproduce it
         o = eng.process(iq[pos:pos + s_], t_ms=np.full(s_, 1_700_000_000_000, np.int64), want=("psd",))
@@ -123,3 +146,5 @@ def test_adapter_runs_against_the_library(tmp_path):
         pos += s_
     assert rep["frames"] == nframes and rep["per_frame"] == want and rep["candidates"] == sum(want) > 500
     assert abs(rep["last_psd0"] - float(last[0, 0])) < 1e-4
+    # and the list Notification::notify would receive, frame by frame: tuned shifts (Hz) and flush flags
+    assert rep["tx"] == want_tx and sum(len(t) for t in want_tx) > 50 and any(f for t in want_tx for _, f in t)
