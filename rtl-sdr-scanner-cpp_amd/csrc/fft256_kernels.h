@@ -102,32 +102,59 @@ __global__ __launch_bounds__(512, 6) void k_fft_cols256(const void* __restrict__
   }
 }
 
+// Rows of 256 points spaced row_stride apart: N2 = 256 (row_stride 256, nsub 1) directly after the columns pass, or
+// N2 = 256 A after k_fft_sub_dft (row_stride N2, nsub = A sub-rows c per row). Output bin of X_row[d] is
+// k1 + 256 c + 256 nsub d; a workgroup takes 32 consecutive k1 of one c so that stores run along k1.
 __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __restrict__ work, const float2* __restrict__ tw256, float db_off,
-                                                            float* __restrict__ psd) {
+                                                            float* __restrict__ psd, int logn, int lognsub) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s = reinterpret_cast<float*>(smem_raw);
   const int t = threadIdx.x;
   const int rho = t >> 4, j = t & 15;
-  const int f = blockIdx.x >> 3;          // 256 rows per frame, 32 per workgroup
+  // blockIdx = ((f * nsub) + c) * 8 + k1 tile
   const int r0 = (blockIdx.x & 7) << 5;
-  const float2* row = work + ((size_t)f << 16) + ((size_t)(r0 + rho) << 8);
+  const int c = (blockIdx.x >> 3) & ((1 << lognsub) - 1);
+  const int f = blockIdx.x >> (3 + lognsub);
+  const int log_row = 8 + lognsub;  // log2 of the row stride
+  const float2* row = work + ((size_t)f << logn) + ((size_t)(r0 + rho) << log_row) + ((size_t)c << 8);
   float2 a[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = row[j + 16 * r];
-  float2 c[16];
-  fft256_passes<kFft256PitchRows>(a, c, s, tw256, rho, j);
+  float2 cc[16];
+  fft256_passes<kFft256PitchRows>(a, cc, s, tw256, rho, j);
   __syncthreads();  // the exchange plane is reused for the read-out
-  // dB values to LDS at [k2][rho] (33-word pitch), then out along k1
+  // dB values to LDS at [d][rho] (33-word pitch), then out along k1
 #pragma unroll
-  for (int k = 0; k < 16; ++k) s[(j + 16 * k) * 33 + rho] = psd_db(c[slot16(k)], db_off);
+  for (int k = 0; k < 16; ++k) s[(j + 16 * k) * 33 + rho] = psd_db(cc[slot16(k)], db_off);
   __syncthreads();
-  float* out = psd + ((size_t)f << 16);
+  float* out = psd + ((size_t)f << logn);
   const int rr = t & 31, kb = t >> 5;
+  const int half = 1 << (logn - 1);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const int k2 = kb + 16 * i;
+    const int d = kb + 16 * i;
     // fft_v shift=true: X[k] lands at k ^ (N/2)
-    out[((r0 + rr) + (k2 << 8)) ^ 32768] = s[k2 * 33 + rr];
+    out[((r0 + rr) + (c << 8) + (d << log_row)) ^ half] = s[d * 33 + rr];
+  }
+}
+
+// N2 = 256 A (A = 8, 16): first half of the row FFTs, in place. n2 = 256 a + b, k2 = c + A d:
+//   V[k1][c][b] = W_N2^(b c) * sum_a work[k1][256 a + b] W_A^(a c)
+// One thread per (frame, k1, b): A loads and A stores at a stride of 256 elements, lanes along b (2 KiB runs). The
+// 256-point FFTs over b that finish the job are k_fft_rows256_psd with nsub = A.
+template <int A>
+__global__ __launch_bounds__(256) void k_fft_sub_dft(float2* __restrict__ work, const float2* __restrict__ twsub /* [c][b] W_N2^(b c) */) {
+  const int b = threadIdx.x;
+  float2* row = work + (size_t)blockIdx.x * (256 * A) + b;  // blockIdx = f * 256 + k1: rows are contiguous in work
+  float2 v[A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) v[a] = row[256 * a];
+  if constexpr (A == 16) dft16(v);
+  else dft8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+#pragma unroll
+  for (int c = 0; c < A; ++c) {
+    const float2 y = A == 16 ? v[slot16(c)] : v[slot8(c)];
+    row[256 * c] = c == 0 ? y : cmul(y, twsub[c * 256 + b]);
   }
 }
 

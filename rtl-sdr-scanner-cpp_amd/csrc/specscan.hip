@@ -105,6 +105,7 @@ struct ss_ctx {
   float* d_avg = nullptr;
   float2* d_work = nullptr;  // four-step intermediate (N > 8192)
   float2* d_tw256 = nullptr; // W_256^(m r), r*16 + m: second pass of the 256-point register FFTs (N >= 65536)
+  float2* d_tw_sub = nullptr;   // N = 2^19, 2^20: [c][b] W_N2^(b c) for k_fft_sub_dft (N2 = N / 256 = 256 A)
   float2* d_tw_cols = nullptr;  // N >= 65536: step-A twiddle factored for k_fft_cols256, [j][n2] W_N^(n2 j) then [k][n2] W_N^(16 n2 k)
   bool use_fft256 = false;
   uint32_t* d_mask = nullptr;
@@ -235,12 +236,25 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
                      (const float*)c->d_win, (const float2*)c->d_tw256, (const float2*)c->d_tw_cols, c->cfg.int_scale, c->d_work, LOGN2);
   if constexpr (LOGN2 == 8) {
     hipLaunchKernelGGL(ss::k_fft_rows256_psd, dim3(nframes * 8), dim3(512), ss::kFft256LdsBytes, c->stream, (const float2*)c->d_work,
-                       (const float2*)c->d_tw256, c->db_off, d_psd);
+                       (const float2*)c->d_tw256, c->db_off, d_psd, 16, 0);
   } else {
-    const size_t lds = sizeof(float2) * ((1 << 13) + 128);
-    const int row_tiles = 256 >> (13 - LOGN2);
-    hipLaunchKernelGGL((ss::k_fft_rows_psd<8, LOGN2>), dim3(nframes * row_tiles), dim3(ss::kFftThreads), lds, c->stream, c->d_work,
-                       c->d_tw, c->db_off, d_psd);
+    bool done = false;
+    if constexpr (LOGN2 >= 11) {
+      if (c->d_tw_sub) {
+        // rows of 256 A points (A = 8, 16) as an in-place radix-A step over the stride-256 index, then 256-point rows
+        constexpr int A = 1 << (LOGN2 - 8);
+        hipLaunchKernelGGL((ss::k_fft_sub_dft<A>), dim3(nframes * 256), dim3(256), 0, c->stream, c->d_work, (const float2*)c->d_tw_sub);
+        hipLaunchKernelGGL(ss::k_fft_rows256_psd, dim3(nframes * A * 8), dim3(512), ss::kFft256LdsBytes, c->stream, (const float2*)c->d_work,
+                           (const float2*)c->d_tw256, c->db_off, d_psd, 8 + LOGN2, LOGN2 - 8);
+        done = true;
+      }
+    }
+    if (!done) {
+      const size_t lds = sizeof(float2) * ((1 << 13) + 128);
+      const int row_tiles = 256 >> (13 - LOGN2);
+      hipLaunchKernelGGL((ss::k_fft_rows_psd<8, LOGN2>), dim3(nframes * row_tiles), dim3(ss::kFftThreads), lds, c->stream, c->d_work, c->d_tw,
+                         c->db_off, d_psd);
+    }
   }
 }
 
@@ -538,6 +552,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_work);
   (void)hipFree(c->d_tw256);
   (void)hipFree(c->d_tw_cols);
+  (void)hipFree(c->d_tw_sub);
   (void)hipFree(c->d_mask);
   (void)hipFree(c->d_counts);
   (void)hipFree(c->d_off);
@@ -732,6 +747,17 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
           }
         CREATE_HIP(hipMalloc(&c->d_tw_cols, sizeof(float2) * tc.size()));
         CREATE_HIP(hipMemcpy(c->d_tw_cols, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
+        if (n2size >= 2048 && !(getenv("SS_FFT_SUB") && getenv("SS_FFT_SUB")[0] == '0')) {
+          const int A = n2size / 256;
+          std::vector<float2> ts((size_t)A * 256);
+          for (int cc = 0; cc < A; ++cc)
+            for (int b = 0; b < 256; ++b) {
+              const double ang = -2.0 * M_PI * ((double)b * cc) / (double)n2size;
+              ts[(size_t)cc * 256 + b] = make_float2((float)cos(ang), (float)sin(ang));
+            }
+          CREATE_HIP(hipMalloc(&c->d_tw_sub, sizeof(float2) * ts.size()));
+          CREATE_HIP(hipMemcpy(c->d_tw_sub, ts.data(), sizeof(float2) * ts.size(), hipMemcpyHostToDevice));
+        }
       }
     }
     if (n == 8192) {
