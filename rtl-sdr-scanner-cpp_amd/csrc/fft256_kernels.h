@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
   }
 }
 
-// N2 = 256 A (A = 8, 16): first half of the row FFTs, in place. n2 = 256 a + b, k2 = c + A d:
+// N2 = 256 A (A = 2, 4, 8, 16): first half of the row FFTs, in place. n2 = 256 a + b, k2 = c + A d:
 //   V[k1][c][b] = W_N2^(b c) * sum_a work[k1][256 a + b] W_A^(a c)
 // One thread per (frame, k1, b): A loads and A stores at a stride of 256 elements, lanes along b (2 KiB runs). The
 // 256-point FFTs over b that finish the job are k_fft_rows256_psd with nsub = A.
@@ -150,10 +150,12 @@ __global__ __launch_bounds__(256) void k_fft_sub_dft(float2* __restrict__ work, 
 #pragma unroll
   for (int a = 0; a < A; ++a) v[a] = row[256 * a];
   if constexpr (A == 16) dft16(v);
-  else dft8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+  else if constexpr (A == 8) dft8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+  else if constexpr (A == 4) dft4(v[0], v[1], v[2], v[3]);
+  else dft2(v[0], v[1]);
 #pragma unroll
   for (int c = 0; c < A; ++c) {
-    const float2 y = A == 16 ? v[slot16(c)] : v[slot8(c)];
+    const float2 y = A == 16 ? v[slot16(c)] : A == 8 ? v[slot8(c)] : v[c];
     row[256 * c] = c == 0 ? y : cmul(y, twsub[c * 256 + b]);
   }
 }

@@ -239,7 +239,7 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
                        (const float2*)c->d_tw256, c->db_off, d_psd, 16, 0);
   } else {
     bool done = false;
-    if constexpr (LOGN2 >= 11) {
+    if constexpr (LOGN2 >= 9) {
       if (c->d_tw_sub) {
         // rows of 256 A points (A = 8, 16) as an in-place radix-A step over the stride-256 index, then 256-point rows
         constexpr int A = 1 << (LOGN2 - 8);
@@ -747,7 +747,8 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
           }
         CREATE_HIP(hipMalloc(&c->d_tw_cols, sizeof(float2) * tc.size()));
         CREATE_HIP(hipMemcpy(c->d_tw_cols, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
-        if (n2size >= 2048 && !(getenv("SS_FFT_SUB") && getenv("SS_FFT_SUB")[0] == '0')) {
+        const char* sub_env = getenv("SS_FFT_SUB");  // A/B: "0" never, "1" whenever N2 > 256
+        if (n2size > 256 && (sub_env ? sub_env[0] == '1' : n2size >= 2048)) {
           const int A = n2size / 256;
           std::vector<float2> ts((size_t)A * 256);
           for (int cc = 0; cc < A; ++cc)
