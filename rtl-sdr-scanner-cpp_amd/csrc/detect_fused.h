@@ -293,7 +293,8 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
   }
 }
 
-// When a batch is shorter than the ring (nframes < H) the oldest ring rows survive: move them up.
+// Row copy used when the sliding ring window reaches the end of its buffer and moves back to the front
+// (source and destination never overlap: the buffer holds at least three windows).
 __global__ void k_hist_shift(const float* __restrict__ hist_in, float* __restrict__ hist_out, int n, int keep_rows, int nframes) {
   const size_t total = (size_t)keep_rows * n;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {

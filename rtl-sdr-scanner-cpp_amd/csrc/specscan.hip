@@ -87,8 +87,12 @@ struct ss_ctx {
   // planes (frame-major rows of n floats)
   // back end, fused path (grouping 21 x 21, max_batch <= 65536): ring and counters are double-buffered
   bool fused = false;
-  float* d_hist[2] = {nullptr, nullptr};  // kHistRows rel rows each (newest last); [hist_cur] is read by the next batch
-  int hist_cur = 0;
+  // Averager ring: the newest kHistRows rel rows (newest last) are a WINDOW [hist_start, hist_start + kHistRows) of a
+  // longer buffer. A batch shorter than the ring appends its rows behind the window and the window slides (nothing is
+  // copied until the buffer's end is reached); a longer batch writes a fresh window clear of the one it reads.
+  float* d_hist = nullptr;
+  int hist_rows = 0;   // capacity in rows
+  int hist_start = 0;
   long long abs_frames = 0;               // frames since the last reset: frame tiles are aligned to this index
   int* d_cnt2[2] = {nullptr, nullptr};    // per-frame candidate counts; the emit kernel clears the other half
   int cnt_cur = 0;
@@ -399,12 +403,18 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   if (n_learn > 0) {
     hipLaunchKernelGGL(ss::k_noise_learn, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_psd, n, n_learn, z->d_thr);
   }
-  const float* hist_in = c->d_hist[c->hist_cur];
-  float* hist_out = c->d_hist[c->hist_cur ^ 1];
-  if (nframes < H) {
-    const int keep = H - nframes;
-    hipLaunchKernelGGL(ss::k_hist_shift, dim3(grid_for((size_t)keep * n, 256)), dim3(256), 0, c->stream, hist_in, hist_out, n, keep, nframes);
+  // The kernel writes the batch's newest min(nframes, H) rel rows to the LAST rows of hist_out[0..H).
+  if (nframes < H && c->hist_start + H + nframes > c->hist_rows) {
+    // end of the buffer: move the window to the front once (rare: every (hist_rows - H) / nframes batches)
+    hipLaunchKernelGGL(ss::k_hist_shift, dim3(grid_for((size_t)H * n, 256)), dim3(256), 0, c->stream,
+                       (const float*)(c->d_hist + (size_t)c->hist_start * n), c->d_hist, n, H, 0);
+    c->hist_start = 0;
   }
+  const float* hist_in = c->d_hist + (size_t)c->hist_start * n;
+  int next_start;
+  if (nframes < H) next_start = c->hist_start + nframes;  // old rows [nframes, H) stay where they are, new ones land behind them
+  else next_start = c->hist_start >= H ? 0 : c->hist_start + H;  // a whole new window, clear of the one being read
+  float* hist_out = c->d_hist + (size_t)next_start * n;
   int* counts = c->d_cnt2[c->cnt_cur];
   int* counts_next = c->d_cnt2[c->cnt_cur ^ 1];
   const bool keep_planes = (c->cfg.flags & SS_FLAG_KEEP_PLANES) != 0;
@@ -429,7 +439,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
                      c->d_off, d_cand_off,
                      (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr, d_cand_avg);
   c->last_hist = hist_in;
-  c->hist_cur ^= 1;
+  c->hist_start = next_start;
   c->cnt_frames[c->cnt_cur] = nframes;   // this half now holds nframes counts (read by the emit above, cleared by the next one)
   c->cnt_frames[c->cnt_cur ^ 1] = 0;     // just cleared
   c->cnt_cur ^= 1;
@@ -540,8 +550,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_rel);
   (void)hipFree(c->diag.d_fft_stamps);
   (void)hipFree(c->diag.d_detect_stamps);
-  (void)hipFree(c->d_hist[0]);
-  (void)hipFree(c->d_hist[1]);
+  (void)hipFree(c->d_hist);
   (void)hipFree(c->d_cnt2[0]);
   (void)hipFree(c->d_cnt2[1]);
   (void)hipFree(c->d_relplane);
@@ -681,9 +690,17 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     c->fused = G == 21 && cfg->grouping_x == 21 && cfg->max_batch <= 65536 && !(be && strcmp(be, "unfused") == 0);
   }
   if (c->fused) {
+    {
+      // ring capacity: at least three windows (a long batch needs a free one next to the one it reads), more when rows
+      // are small, so that short batches slide for a long time before the window is moved back to the front
+      long long rows = (64ll << 20) / ((long long)n * 4);
+      if (rows < 3 * kHistRows) rows = 3 * kHistRows;
+      if (rows > 64 * kHistRows) rows = 64 * kHistRows;
+      c->hist_rows = (int)rows;
+      CREATE_HIP(hipMalloc(&c->d_hist, sizeof(float) * (size_t)n * (size_t)rows));
+      CREATE_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(float) * (size_t)n * (size_t)kHistRows, c->stream));  // Averager ctor, averager.cpp:7-12
+    }
     for (int k = 0; k < 2; ++k) {
-      CREATE_HIP(hipMalloc(&c->d_hist[k], sizeof(float) * (size_t)n * (size_t)kHistRows));
-      CREATE_HIP(hipMemsetAsync(c->d_hist[k], 0, sizeof(float) * (size_t)n * (size_t)kHistRows, c->stream));  // Averager ctor, averager.cpp:7-12
       CREATE_HIP(hipMalloc(&c->d_cnt2[k], sizeof(int) * (size_t)cfg->max_batch));
       CREATE_HIP(hipMemsetAsync(c->d_cnt2[k], 0, sizeof(int) * (size_t)cfg->max_batch, c->stream));
     }
@@ -929,7 +946,8 @@ int ss_reset(ss_ctx* c) {  // Transmission::resetBuffers -> Averager::reset: row
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
   const int G = c->cfg.grouping_y;
   if (c->fused) {
-    SS_HIP(c, hipMemsetAsync(c->d_hist[c->hist_cur], 0, sizeof(float) * (size_t)c->n * (size_t)kHistRows, c->stream));
+    c->hist_start = 0;
+    SS_HIP(c, hipMemsetAsync(c->d_hist, 0, sizeof(float) * (size_t)c->n * (size_t)kHistRows, c->stream));
   } else if (G > 1) {
     SS_HIP(c, hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)c->n * (size_t)(G - 1), c->stream));
   }
