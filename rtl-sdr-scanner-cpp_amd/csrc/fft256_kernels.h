@@ -60,7 +60,7 @@ __device__ __forceinline__ void fft256_passes(float2 (&a)[16], float2 (&c)[16], 
 }
 
 template <int FMT>
-__global__ __launch_bounds__(512, 6) void k_fft_cols256(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
+__global__ __launch_bounds__(512, 5) void k_fft_cols256(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
                                                         const float2* __restrict__ tw256, const float2* __restrict__ twc, float scale,
                                                         float2* __restrict__ work, int logn2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -135,6 +135,67 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
     const int d = kb + 16 * i;
     // fft_v shift=true: X[k] lands at k ^ (N/2)
     out[((r0 + rr) + (c << 8) + (d << log_row)) ^ half] = s[d * 33 + rr];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// N = 4096 (what getFft picks for 0.5 < fs <= 1.024 MS/s), two frames per workgroup of 512 threads, in registers:
+//   n = 16 m + q:  X[k' + 256 kap] = sum_q W_16^(q kap) * W_4096^(q k') * Z_q[k'],   Z_q = FFT256 over m of x[16 m + q]
+// Thread t (frame = t / 256, q = t % 16, j = (t / 16) % 16) loads x[(t % 256) + 256 r] — consecutive threads, consecutive
+// samples — which is exactly element m = j + 16 r of sub-sequence q, runs the two register passes of fft256_passes
+// (32 sub-FFTs per workgroup), then the Z values change owner through LDS ([q][k'] planes, 257-word pitch) so that
+// thread (frame, k' = t % 256) holds Z_0..15[k'], applies W_4096^(q k') from a [q][k'] table and finishes with one more
+// 16-point DFT. Stores run along k'. Three 16-point DFTs and two exchanges: the shape of the 8192-point kernel.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFft4096LdsBytes = 32 * 273 * 4;  // >= 2 frames x 16 x 257 words for the second exchange
+
+template <int FMT>
+__global__ __launch_bounds__(512, 4) void k_fft4096_psd(const void* __restrict__ iq, long long item_stride, int nframes,
+                                                        const float* __restrict__ win, const float2* __restrict__ tw256,
+                                                        const float2* __restrict__ tw4096 /* [q][k'] W_4096^(q k') */, float db_off, float scale,
+                                                        float* __restrict__ psd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s = reinterpret_cast<float*>(smem_raw);
+  const int t = threadIdx.x;
+  const int fr = t >> 8, tt = t & 255;
+  const int q = t & 15, j = (t >> 4) & 15;
+  int frame = 2 * blockIdx.x + fr;
+  const bool live = frame < nframes;
+  if (!live) frame = nframes - 1;  // odd frame count: the second half recomputes the last frame and does not store
+  const size_t in_base = (size_t)frame * (size_t)item_stride;
+  float2 a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = tt + 256 * r;
+    const float2 x = load_iq<FMT>(iq, in_base + n, scale);
+    const float w = win[n];
+    a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
+  }
+  float2 c[16];
+  fft256_passes<kFft256PitchCols>(a, c, s, tw256, (fr << 4) | q, j);  // Z_q[j + 16 k] in c[slot16(k)]
+  __syncthreads();
+  // second exchange: Z_q[k'] to word (fr * 16 + q) * 257 + k'; thread (fr, k' = tt) reads its 16 q's
+  float* zp = s + ((fr << 4) | q) * 257 + j;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) zp[16 * k] = c[slot16(k)].x;
+  __syncthreads();
+  const float* zr = s + (fr << 4) * 257 + tt;
+#pragma unroll
+  for (int qq = 0; qq < 16; ++qq) a[qq].x = zr[qq * 257];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) zp[16 * k] = c[slot16(k)].y;
+  __syncthreads();
+#pragma unroll
+  for (int qq = 0; qq < 16; ++qq) {
+    const float2 v = make_float2(a[qq].x, zr[qq * 257]);
+    a[qq] = qq == 0 ? v : cmul(v, tw4096[qq * 256 + tt]);  // W_4096^(q k')
+  }
+  dft16(a);  // X[k' + 256 kap] in a[slot16(kap)]
+  if (live) {
+    float* out = psd + (size_t)frame * 4096;
+#pragma unroll
+    for (int kap = 0; kap < 16; ++kap) out[(tt + 256 * kap) ^ 2048] = psd_db(a[slot16(kap)], db_off);  // fft_v shift=true
   }
 }
 
