@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1024, help="frames per batch (BASELINE config 2: 1024)")
     ap.add_argument("--fft", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fmt", default="cf32", choices=["cf32", "cs8", "cu8"], help="IQ sample format in HBM (the headline is cf32)")
     ap.add_argument("--single-buffer", action="store_true", help="one output set instead of two alternating ones")
     ap.add_argument("--time-every", type=int, default=8, help="attach start/stop events to every k-th launch of the FFT kernel")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not attach per-launch events to the FFT kernel (roofline omitted)")
@@ -133,7 +134,7 @@ def main():
     n, fs, nb = args.fft, 2_048_000 * (args.fft // 8192 if args.fft >= 8192 else 1), args.frames
     cfg0 = None
     if rank == 0:
-        cfg0 = dict(fft_size=n, sample_rate=fs, decim=1, in_format=pkg.abi.SS_FMT_CF32, grouping_x=21, grouping_y=21,
+        cfg0 = dict(fft_size=n, sample_rate=fs, decim=1, in_format={"cf32": 0, "cs8": 1, "cu8": 2}[args.fmt], grouping_x=21, grouping_y=21,
                     start_level_mdB=8000, learn_frames=100, learn_ms=2000, max_batch=nb, band0_center=140_000_000,
                     band_spacing=2_000_000, n_bands=world, seed=0)
     cfg = dist.broadcast_config(cfg0, device=coll_dev)  # the only collective of the whole job (RCCL, < 1 KiB)
@@ -144,7 +145,7 @@ def main():
                              grouping_y=int(cfg["grouping_y"]), start_level=cfg["start_level_mdB"] / 1000.0,
                              learn_frames=int(cfg["learn_frames"]), max_batch=nb, device_id=device_index)
     iq = dist.synthetic_batch(cfg, band, nb)
-    d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
+    d_iq = torch.from_numpy(iq.view(np.float32) if iq.dtype == np.complex64 else iq).to(dev)
     # Outputs are double-buffered the way a streaming consumer would hold them: batch k writes set k & 1 while
     # the consumer still owns set (k - 1) & 1.
     cap = nb * 1024
@@ -181,13 +182,14 @@ def main():
         samples_per_step = nb * n * world
         value = samples_per_step * args.steps / elapsed / 1e6
         kern_avg_s = kern_ms / max(launches, 1) / 1e3
-        achieved = ALGO_BYTES_PER_SAMPLE * nb * n / kern_avg_s / 1e9 if launches else None
+        algo_bytes = ALGO_BYTES_PER_SAMPLE if args.fmt == "cf32" else 6.0  # int8 IQ: 2 B in + 4 B out
+        achieved = algo_bytes * nb * n / kern_avg_s / 1e9 if launches else None
         out = {
             "metric": "iq_msamples_per_sec_scanned_8192pt_fft" if n == 8192 else f"iq_msamples_per_sec_scanned_{n}pt_fft",
             "value": round(value, 1), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n}-pt FFT, {fs / 1e6:.3f} MS/s, {nb}-frame batches, CF32 IQ resident in HBM, full chain "
+            "config": {"workload": f"{n}-pt FFT, {fs / 1e6:.3f} MS/s, {nb}-frame batches, {args.fmt.upper()} IQ resident in HBM, full chain "
                                    "(window+FFT+dB -> noise-relative -> 21x21 mean -> threshold -> candidate lists), "
                                    "one band per GPU",
                        "fft_size": n, "frames_per_batch": nb, "bands": world, "candidates_per_batch": ncand,

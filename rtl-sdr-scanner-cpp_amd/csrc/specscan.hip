@@ -293,7 +293,10 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
     const int ablate = c->diag.fft_ablate;
     if (ablate == 1) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 1>, ss::kFft8192W8LdsBytes);
     else if (ablate == 2) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 2>, ss::kFft8192W8LdsBytes);
-    else launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
+    else if constexpr (FMT == ss::FMT_CF32) launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
+    // int8 IQ: the conversion needs a few more registers; at 64 (8 waves/SIMD) the kernel spills and takes 27.7 us per 1024
+    // frames, at 80 (6 waves) 23.0 us. cf32 is the other way round (26.3 vs 26.9 us).
+    else launch8(ss::k_fft8192_psd_w8<FMT, 6>, ss::kFft8192W8LdsBytes);
   }
   if (tabs.dbg && ++c->diag.fft_calls == 20) {
     std::vector<long long> h((size_t)8 * nframes);

@@ -79,7 +79,8 @@ def synthetic_batch(cfg: dict, band: int, nframes: int) -> np.ndarray:
     from . import synth
     b = synth.SyntheticBand(int(cfg["fft_size"]), decim=int(cfg["decim"]), seed=int(cfg["seed"]) + band,
                             on_frame=int(cfg["learn_frames"]) + 30, off_frame=nframes - 50)
-    return b.frames_cf32(nframes)
+    fmt = int(cfg.get("in_format", 0))
+    return b.frames_cf32(nframes) if fmt == 0 else (b.frames_cs8(nframes) if fmt == 1 else b.frames_cu8(nframes))
 
 
 def scan_frame_range(chain, frames, lo: int, hi: int, learn_frames: int, max_batch: int, align: int = 16, halo: int = 20):
