@@ -139,63 +139,93 @@ __global__ __launch_bounds__(512, 6) void k_fft_rows256_psd(const float2* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// N = 4096 (what getFft picks for 0.5 < fs <= 1.024 MS/s), two frames per workgroup of 512 threads, in registers:
-//   n = 16 m + q:  X[k' + 256 kap] = sum_q W_16^(q kap) * W_4096^(q k') * Z_q[k'],   Z_q = FFT256 over m of x[16 m + q]
-// Thread t (frame = t / 256, q = t % 16, j = (t / 16) % 16) loads x[(t % 256) + 256 r] — consecutive threads, consecutive
-// samples — which is exactly element m = j + 16 r of sub-sequence q, runs the two register passes of fft256_passes
-// (32 sub-FFTs per workgroup), then the Z values change owner through LDS ([q][k'] planes, 257-word pitch) so that
-// thread (frame, k' = t % 256) holds Z_0..15[k'], applies W_4096^(q k') from a [q][k'] table and finishes with one more
-// 16-point DFT. Stores run along k'. Three 16-point DFTs and two exchanges: the shape of the 8192-point kernel.
+// N = 256 R, R = 4, 8, 16 (1024, 2048, 4096 points: what getFft picks for fs up to 1.024 MS/s), 32 / R frames per
+// workgroup of 512 threads, in registers:
+//   n = R m + q:  X[k' + 256 kap] = sum_q W_R^(q kap) * W_N^(q k') * Z_q[k'],   Z_q = FFT256 over m of x[R m + q]
+// Thread t loads x[frame][tt + 16 R r] with tt = t % (16 R) — consecutive threads, consecutive samples — which is element
+// m = j + 16 r (j = tt / R) of sub-sequence q = tt % R, runs the two register passes of fft256_passes (32 sub-FFTs per
+// workgroup), then the Z values change owner through LDS ([frame, q][k'] planes, 257-word pitch) so that a thread holds
+// Z_0..R-1[k'] for 16 / R pairs (frame, k'), applies W_N^(q k') from a [q][k'] table and finishes each pair with an
+// R-point DFT. Stores run along k'. For R = 16: three 16-point DFTs and two exchanges, the shape of the 8192-point kernel.
+// Compiled for 4 waves per SIMD: with 80 registers (6 waves) the 4096-point instance spills and is 10 % slower.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kFft4096LdsBytes = 32 * 273 * 4;  // >= 2 frames x 16 x 257 words for the second exchange
+constexpr int kFft256xRLdsBytes = 32 * 273 * 4;  // >= 32 sub-FFTs x 257 words for the second exchange
 
-template <int FMT>
-__global__ __launch_bounds__(512, 4) void k_fft4096_psd(const void* __restrict__ iq, long long item_stride, int nframes,
-                                                        const float* __restrict__ win, const float2* __restrict__ tw256,
-                                                        const float2* __restrict__ tw4096 /* [q][k'] W_4096^(q k') */, float db_off, float scale,
-                                                        float* __restrict__ psd) {
+template <int R>
+__device__ __forceinline__ void dft_small(float2* v) {
+  if constexpr (R == 16) {
+    float2(&w)[16] = *reinterpret_cast<float2(*)[16]>(v);
+    dft16(w);
+  } else if constexpr (R == 8) {
+    dft8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+  } else {
+    dft4(v[0], v[1], v[2], v[3]);
+  }
+}
+template <int R>
+__device__ __forceinline__ constexpr int slot_small(int k) {
+  return R == 16 ? slot16(k) : R == 8 ? slot8(k) : k;
+}
+
+template <int FMT, int LOGR>
+__global__ __launch_bounds__(512, 4) void k_fft256xR_psd(const void* __restrict__ iq, long long item_stride, int nframes,
+                                                         const float* __restrict__ win, const float2* __restrict__ tw256,
+                                                         const float2* __restrict__ twn /* [q][k'] W_N^(q k') */, float db_off, float scale,
+                                                         float* __restrict__ psd) {
+  constexpr int R = 1 << LOGR, N = 256 * R, FPW = 32 / R, U = 16 / R;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s = reinterpret_cast<float*>(smem_raw);
   const int t = threadIdx.x;
-  const int fr = t >> 8, tt = t & 255;
-  const int q = t & 15, j = (t >> 4) & 15;
-  int frame = 2 * blockIdx.x + fr;
-  const bool live = frame < nframes;
-  if (!live) frame = nframes - 1;  // odd frame count: the second half recomputes the last frame and does not store
+  const int fl = t >> (4 + LOGR), tt = t & (16 * R - 1);
+  const int q = tt & (R - 1), j = tt >> LOGR;
+  // frames past the end (ragged last workgroup) recompute the last frame and do not store
+  const int frame = min((int)blockIdx.x * FPW + fl, nframes - 1);
   const size_t in_base = (size_t)frame * (size_t)item_stride;
   float2 a[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int n = tt + 256 * r;
+    const int n = tt + 16 * R * r;
     const float2 x = load_iq<FMT>(iq, in_base + n, scale);
     const float w = win[n];
     a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
   }
   float2 c[16];
-  fft256_passes<kFft256PitchCols>(a, c, s, tw256, (fr << 4) | q, j);  // Z_q[j + 16 k] in c[slot16(k)]
+  const int sub = (fl << LOGR) | q;  // which of the 32 sub-FFTs
+  fft256_passes<kFft256PitchCols>(a, c, s, tw256, sub, j);  // Z_q[j + 16 k] in c[slot16(k)]
   __syncthreads();
-  // second exchange: Z_q[k'] to word (fr * 16 + q) * 257 + k'; thread (fr, k' = tt) reads its 16 q's
-  float* zp = s + ((fr << 4) | q) * 257 + j;
+  // second exchange: Z_q[k'] to word sub * 257 + k'; pair p = t + 512 u = (frame p / 256, k' = p % 256) reads its R q's
+  float* zp = s + sub * 257 + j;
 #pragma unroll
   for (int k = 0; k < 16; ++k) zp[16 * k] = c[slot16(k)].x;
   __syncthreads();
-  const float* zr = s + (fr << 4) * 257 + tt;
 #pragma unroll
-  for (int qq = 0; qq < 16; ++qq) a[qq].x = zr[qq * 257];
+  for (int u = 0; u < U; ++u) {
+    const int p = t + 512 * u;
+    const float* zr = s + ((p >> 8) << LOGR) * 257 + (p & 255);
+#pragma unroll
+    for (int qq = 0; qq < R; ++qq) a[u * R + qq].x = zr[qq * 257];
+  }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k) zp[16 * k] = c[slot16(k)].y;
   __syncthreads();
 #pragma unroll
-  for (int qq = 0; qq < 16; ++qq) {
-    const float2 v = make_float2(a[qq].x, zr[qq * 257]);
-    a[qq] = qq == 0 ? v : cmul(v, tw4096[qq * 256 + tt]);  // W_4096^(q k')
-  }
-  dft16(a);  // X[k' + 256 kap] in a[slot16(kap)]
-  if (live) {
-    float* out = psd + (size_t)frame * 4096;
+  for (int u = 0; u < U; ++u) {
+    const int p = t + 512 * u;
+    const int kp = p & 255;
+    const float* zr = s + ((p >> 8) << LOGR) * 257 + kp;
 #pragma unroll
-    for (int kap = 0; kap < 16; ++kap) out[(tt + 256 * kap) ^ 2048] = psd_db(a[slot16(kap)], db_off);  // fft_v shift=true
+    for (int qq = 0; qq < R; ++qq) {
+      const float2 v = make_float2(a[u * R + qq].x, zr[qq * 257]);
+      a[u * R + qq] = qq == 0 ? v : cmul(v, twn[qq * 256 + kp]);  // W_N^(q k')
+    }
+    dft_small<R>(a + u * R);  // X[k' + 256 kap] in slot kap
+    const int f2 = (int)blockIdx.x * FPW + (p >> 8);
+    if (f2 < nframes) {
+      float* out = psd + (size_t)f2 * N;
+#pragma unroll
+      for (int kap = 0; kap < R; ++kap) out[(kp + 256 * kap) ^ (N / 2)] = psd_db(a[u * R + slot_small<R>(kap)], db_off);  // fft_v shift=true
+    }
   }
 }
 

@@ -109,7 +109,7 @@ struct ss_ctx {
   float* d_avg = nullptr;
   float2* d_work = nullptr;  // four-step intermediate (N > 8192)
   float2* d_tw256 = nullptr; // W_256^(m r), r*16 + m: second pass of the 256-point register FFTs (N >= 65536)
-  float2* d_tw4096 = nullptr;   // N = 4096: [q][k'] W_4096^(q k') for the final radix-16 pass of k_fft4096_psd
+  float2* d_tw_small = nullptr;  // N = 1024, 2048, 4096: [q][k'] W_N^(q k') for the final radix-R pass of k_fft256xR_psd
   float2* d_tw_sub = nullptr;   // N = 2^19, 2^20: [c][b] W_N2^(b c) for k_fft_sub_dft (N2 = N / 256 = 256 A)
   float2* d_tw_cols = nullptr;  // N >= 65536: step-A twiddle factored for k_fft_cols256, [j][n2] W_N^(n2 j) then [k][n2] W_N^(16 n2 k)
   bool use_fft256 = false;
@@ -323,13 +323,25 @@ int launch_fft_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nfram
     case 7: launch_lds<7, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 8: launch_lds<8, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 9: launch_lds<9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
-    case 10: launch_lds<10, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
-    case 11: launch_lds<11, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 10:
+    case 11:
     case 12:
-      if (c->d_tw4096) {
-        hipLaunchKernelGGL((ss::k_fft4096_psd<FMT>), dim3((nframes + 1) / 2), dim3(512), ss::kFft4096LdsBytes, c->stream, d_iq, item_stride,
-                           nframes, (const float*)c->d_win, (const float2*)c->d_tw256, (const float2*)c->d_tw4096, c->db_off, c->cfg.int_scale,
-                           d_psd);
+      if (c->d_tw_small) {
+        const int frames_per_wg = 32 >> (c->logn - 8);
+        const dim3 grid((unsigned)((nframes + frames_per_wg - 1) / frames_per_wg));
+        if (c->logn == 12)
+          hipLaunchKernelGGL((ss::k_fft256xR_psd<FMT, 4>), grid, dim3(512), ss::kFft256xRLdsBytes, c->stream, d_iq, item_stride, nframes,
+                             (const float*)c->d_win, (const float2*)c->d_tw256, (const float2*)c->d_tw_small, c->db_off, c->cfg.int_scale, d_psd);
+        else if (c->logn == 11)
+          hipLaunchKernelGGL((ss::k_fft256xR_psd<FMT, 3>), grid, dim3(512), ss::kFft256xRLdsBytes, c->stream, d_iq, item_stride, nframes,
+                             (const float*)c->d_win, (const float2*)c->d_tw256, (const float2*)c->d_tw_small, c->db_off, c->cfg.int_scale, d_psd);
+        else
+          hipLaunchKernelGGL((ss::k_fft256xR_psd<FMT, 2>), grid, dim3(512), ss::kFft256xRLdsBytes, c->stream, d_iq, item_stride, nframes,
+                             (const float*)c->d_win, (const float2*)c->d_tw256, (const float2*)c->d_tw_small, c->db_off, c->cfg.int_scale, d_psd);
+      } else if (c->logn == 10) {
+        launch_lds<10, FMT>(c, d_iq, item_stride, nframes, d_psd);
+      } else if (c->logn == 11) {
+        launch_lds<11, FMT>(c, d_iq, item_stride, nframes, d_psd);
       } else {
         launch_lds<12, FMT>(c, d_iq, item_stride, nframes, d_psd);
       }
@@ -574,7 +586,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_tw256);
   (void)hipFree(c->d_tw_cols);
   (void)hipFree(c->d_tw_sub);
-  (void)hipFree(c->d_tw4096);
+  (void)hipFree(c->d_tw_small);
   (void)hipFree(c->d_mask);
   (void)hipFree(c->d_counts);
   (void)hipFree(c->d_off);
@@ -755,22 +767,23 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       const double ang = -2.0 * M_PI * (double)k / (double)n;
       tw[(size_t)k] = make_float2((float)cos(ang), (float)sin(ang));
     }
-    if (n == 4096 && !(getenv("SS_FFT_IMPL") && strcmp(getenv("SS_FFT_IMPL"), "generic") == 0)) {
-      std::vector<float2> t256(256), t4k(4096);
+    if ((n == 1024 || n == 2048 || n == 4096) && !(getenv("SS_FFT_IMPL") && strcmp(getenv("SS_FFT_IMPL"), "generic") == 0)) {
+      const int R = n / 256;
+      std::vector<float2> t256(256), tn((size_t)R * 256);
       for (int r = 0; r < 16; ++r)
         for (int m = 0; m < 16; ++m) {
           const double ang = -2.0 * M_PI * (double)(m * r) / 256.0;
           t256[(size_t)(r * 16 + m)] = make_float2((float)cos(ang), (float)sin(ang));
         }
-      for (int q = 0; q < 16; ++q)
+      for (int q = 0; q < R; ++q)
         for (int k = 0; k < 256; ++k) {
-          const double ang = -2.0 * M_PI * (double)(q * k) / 4096.0;
-          t4k[(size_t)(q * 256 + k)] = make_float2((float)cos(ang), (float)sin(ang));
+          const double ang = -2.0 * M_PI * (double)(q * k) / (double)n;
+          tn[(size_t)(q * 256 + k)] = make_float2((float)cos(ang), (float)sin(ang));
         }
       CREATE_HIP(hipMalloc(&c->d_tw256, sizeof(float2) * t256.size()));
       CREATE_HIP(hipMemcpy(c->d_tw256, t256.data(), sizeof(float2) * t256.size(), hipMemcpyHostToDevice));
-      CREATE_HIP(hipMalloc(&c->d_tw4096, sizeof(float2) * t4k.size()));
-      CREATE_HIP(hipMemcpy(c->d_tw4096, t4k.data(), sizeof(float2) * t4k.size(), hipMemcpyHostToDevice));
+      CREATE_HIP(hipMalloc(&c->d_tw_small, sizeof(float2) * tn.size()));
+      CREATE_HIP(hipMemcpy(c->d_tw_small, tn.data(), sizeof(float2) * tn.size(), hipMemcpyHostToDevice));
     }
     if (n >= 16384) {
       const char* impl = getenv("SS_FFT_IMPL");  // "generic" keeps the LDS radix-4 four-step kernels (A/B measurements)
