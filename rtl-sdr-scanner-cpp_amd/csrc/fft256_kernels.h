@@ -151,15 +151,36 @@ __global__ __launch_bounds__(512, 6) void k_fft_rows256_psd(const float2* __rest
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kFft256xRLdsBytes = 32 * 273 * 4;  // >= 32 sub-FFTs x 257 words for the second exchange
 
+// R-point DFT of a[B .. B+R-1] (compile-time base: the array must stay in registers)
+template <int R, int B>
+__device__ __forceinline__ void dft_small(float2 (&a)[16]) {
+  if constexpr (R == 16) dft16(a);
+  else if constexpr (R == 8) dft8(a[B], a[B + 1], a[B + 2], a[B + 3], a[B + 4], a[B + 5], a[B + 6], a[B + 7]);
+  else if constexpr (R == 4) dft4(a[B], a[B + 1], a[B + 2], a[B + 3]);
+  else dft2(a[B], a[B + 1]);
+}
+// all 16 / R groups
 template <int R>
-__device__ __forceinline__ void dft_small(float2* v) {
+__device__ __forceinline__ void dft_small_all(float2 (&a)[16]) {
   if constexpr (R == 16) {
-    float2(&w)[16] = *reinterpret_cast<float2(*)[16]>(v);
-    dft16(w);
+    dft_small<16, 0>(a);
   } else if constexpr (R == 8) {
-    dft8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    dft_small<8, 0>(a);
+    dft_small<8, 8>(a);
+  } else if constexpr (R == 4) {
+    dft_small<4, 0>(a);
+    dft_small<4, 4>(a);
+    dft_small<4, 8>(a);
+    dft_small<4, 12>(a);
   } else {
-    dft4(v[0], v[1], v[2], v[3]);
+    dft_small<2, 0>(a);
+    dft_small<2, 2>(a);
+    dft_small<2, 4>(a);
+    dft_small<2, 6>(a);
+    dft_small<2, 8>(a);
+    dft_small<2, 10>(a);
+    dft_small<2, 12>(a);
+    dft_small<2, 14>(a);
   }
 }
 template <int R>
@@ -219,13 +240,95 @@ __global__ __launch_bounds__(512, 4) void k_fft256xR_psd(const void* __restrict_
       const float2 v = make_float2(a[u * R + qq].x, zr[qq * 257]);
       a[u * R + qq] = qq == 0 ? v : cmul(v, twn[qq * 256 + kp]);  // W_N^(q k')
     }
-    dft_small<R>(a + u * R);  // X[k' + 256 kap] in slot kap
+  }
+  dft_small_all<R>(a);  // X[k' + 256 kap] in slot kap of every group
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int p = t + 512 * u;
+    const int kp = p & 255;
     const int f2 = (int)blockIdx.x * FPW + (p >> 8);
     if (f2 < nframes) {
       float* out = psd + (size_t)f2 * N;
 #pragma unroll
       for (int kap = 0; kap < R; ++kap) out[(kp + 256 * kap) ^ (N / 2)] = psd_db(a[u * R + slot_small<R>(kap)], db_off);  // fft_v shift=true
     }
+  }
+}
+
+// The same decomposition for the ROWS of a four-step with N2 = 256 R, R = 2, 4 (N = 131072, 262144): 32 / R rows k1 per
+// workgroup straight from the work buffer (the step-A twiddle is already in it), X_row[k' + 256 kap] -> bin
+// k1 + 256 (k' + 256 kap). The dB values go through LDS once more ([k2][row], pitch rows + 1) so that stores run along k1.
+constexpr int kFftRowsRLdsBytes = 1024 * 9 * 4;  // R = 4: 1024 k2 x (8 rows + 1); R = 2: 512 x 17 is smaller; both >= 32 x 257
+
+template <int LOGR>
+__global__ __launch_bounds__(512, 4) void k_fft_rows256xR_psd(const float2* __restrict__ work, const float2* __restrict__ tw256,
+                                                              const float2* __restrict__ twn /* [q][k'] W_N2^(q k') */, float db_off,
+                                                              float* __restrict__ psd) {
+  constexpr int R = 1 << LOGR, N2 = 256 * R, FPW = 32 / R, U = 16 / R, LOGN = 16 + LOGR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s = reinterpret_cast<float*>(smem_raw);
+  const int t = threadIdx.x;
+  const int fl = t >> (4 + LOGR), tt = t & (16 * R - 1);
+  const int q = tt & (R - 1), j = tt >> LOGR;
+  constexpr int TILES = 256 / FPW;
+  const int f = blockIdx.x / TILES;
+  const int r0 = (blockIdx.x % TILES) * FPW;
+  const float2* row = work + ((size_t)f << LOGN) + (size_t)(r0 + fl) * N2;
+  float2 a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = row[tt + 16 * R * r];
+  float2 c[16];
+  const int sub = (fl << LOGR) | q;
+  fft256_passes<kFft256PitchCols>(a, c, s, tw256, sub, j);
+  __syncthreads();
+  float* zp = s + sub * 257 + j;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) zp[16 * k] = c[slot16(k)].x;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int p = t + 512 * u;
+    const float* zr = s + ((p >> 8) << LOGR) * 257 + (p & 255);
+#pragma unroll
+    for (int qq = 0; qq < R; ++qq) a[u * R + qq].x = zr[qq * 257];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) zp[16 * k] = c[slot16(k)].y;
+  __syncthreads();
+  float dbv[16];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int p = t + 512 * u;
+    const int kp = p & 255;
+    const float* zr = s + ((p >> 8) << LOGR) * 257 + kp;
+#pragma unroll
+    for (int qq = 0; qq < R; ++qq) {
+      const float2 v = make_float2(a[u * R + qq].x, zr[qq * 257]);
+      a[u * R + qq] = qq == 0 ? v : cmul(v, twn[qq * 256 + kp]);
+    }
+  }
+  dft_small_all<R>(a);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int kap = 0; kap < R; ++kap) dbv[u * R + kap] = psd_db(a[u * R + slot_small<R>(kap)], db_off);
+  }
+  __syncthreads();  // every Z read is done before the plane is reused for the read-out
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int p = t + 512 * u;
+#pragma unroll
+    for (int kap = 0; kap < R; ++kap) s[((p & 255) + 256 * kap) * (FPW + 1) + (p >> 8)] = dbv[u * R + kap];
+  }
+  __syncthreads();
+  float* out = psd + ((size_t)f << LOGN);
+  const int rr = t & (FPW - 1), kb = t / FPW;
+  constexpr int half = 1 << (LOGN - 1);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k2 = kb + (512 / FPW) * i;
+    out[((r0 + rr) + (k2 << 8)) ^ half] = s[k2 * (FPW + 1) + rr];  // fft_v shift=true
   }
 }
 

@@ -109,6 +109,7 @@ struct ss_ctx {
   float* d_avg = nullptr;
   float2* d_work = nullptr;  // four-step intermediate (N > 8192)
   float2* d_tw256 = nullptr; // W_256^(m r), r*16 + m: second pass of the 256-point register FFTs (N >= 65536)
+  float2* d_tw_rowsR = nullptr;  // N = 2^17, 2^18: [q][k'] W_N2^(q k') for k_fft_rows256xR_psd (N2 = 512, 1024)
   float2* d_tw_small = nullptr;  // N = 1024, 2048, 4096: [q][k'] W_N^(q k') for the final radix-R pass of k_fft256xR_psd
   float2* d_tw_sub = nullptr;   // N = 2^19, 2^20: [c][b] W_N2^(b c) for k_fft_sub_dft (N2 = N / 256 = 256 A)
   float2* d_tw_cols = nullptr;  // N >= 65536: step-A twiddle factored for k_fft_cols256, [j][n2] W_N^(n2 j) then [k][n2] W_N^(16 n2 k)
@@ -244,8 +245,16 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
                        (const float2*)c->d_tw256, c->db_off, d_psd, 16, 0);
   } else {
     bool done = false;
+    if constexpr (LOGN2 == 9 || LOGN2 == 10) {
+      if (c->d_tw_rowsR) {  // rows of 512 / 1024 points in registers
+        constexpr int LOGR = LOGN2 - 8;
+        hipLaunchKernelGGL((ss::k_fft_rows256xR_psd<LOGR>), dim3(nframes * (256 / (32 >> LOGR))), dim3(512), ss::kFftRowsRLdsBytes, c->stream,
+                           (const float2*)c->d_work, (const float2*)c->d_tw256, (const float2*)c->d_tw_rowsR, c->db_off, d_psd);
+        done = true;
+      }
+    }
     if constexpr (LOGN2 >= 9) {
-      if (c->d_tw_sub) {
+      if (!done && c->d_tw_sub) {
         // rows of 256 A points (A = 8, 16) as an in-place radix-A step over the stride-256 index, then 256-point rows
         constexpr int A = 1 << (LOGN2 - 8);
         hipLaunchKernelGGL((ss::k_fft_sub_dft<A>), dim3(nframes * 256), dim3(256), 0, c->stream, c->d_work, (const float2*)c->d_tw_sub);
@@ -587,6 +596,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_tw_cols);
   (void)hipFree(c->d_tw_sub);
   (void)hipFree(c->d_tw_small);
+  (void)hipFree(c->d_tw_rowsR);
   (void)hipFree(c->d_mask);
   (void)hipFree(c->d_counts);
   (void)hipFree(c->d_off);
@@ -807,6 +817,17 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
           }
         CREATE_HIP(hipMalloc(&c->d_tw_cols, sizeof(float2) * tc.size()));
         CREATE_HIP(hipMemcpy(c->d_tw_cols, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
+        if ((n2size == 512 || n2size == 1024) && !(getenv("SS_FFT_ROWSR") && getenv("SS_FFT_ROWSR")[0] == '0')) {
+          const int R = n2size / 256;
+          std::vector<float2> tr((size_t)R * 256);
+          for (int q = 0; q < R; ++q)
+            for (int k = 0; k < 256; ++k) {
+              const double ang = -2.0 * M_PI * ((double)q * k) / (double)n2size;
+              tr[(size_t)q * 256 + k] = make_float2((float)cos(ang), (float)sin(ang));
+            }
+          CREATE_HIP(hipMalloc(&c->d_tw_rowsR, sizeof(float2) * tr.size()));
+          CREATE_HIP(hipMemcpy(c->d_tw_rowsR, tr.data(), sizeof(float2) * tr.size(), hipMemcpyHostToDevice));
+        }
         const char* sub_env = getenv("SS_FFT_SUB");  // A/B: "0" never, "1" whenever N2 > 256
         if (n2size > 256 && (sub_env ? sub_env[0] == '1' : n2size >= 2048)) {
           const int A = n2size / 256;
