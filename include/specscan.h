@@ -168,6 +168,13 @@ int ss_read_window(ss_ctx* ctx, int32_t plane, int32_t frame, int32_t lo, int32_
 int ss_spectrogram_size(const ss_ctx* ctx);
 int ss_spectrogram_read(ss_ctx* ctx, int8_t* out, float* mean_out);
 
+/* DataController::pushSpectrogram payload (sources/network/data_controller.cpp:44-57): uint64 time ms, int32 start
+ * (= frequency - sample_rate / 2), int32 stop, int32 step (= sample_rate / size), uint32 size, then the int8 row as it
+ * is. Host-side helper for the row ss_spectrogram_read returned; gives the byte count (out may be NULL to query it),
+ * or < 0 when size < 1 or cap is too small. */
+int ss_spectrogram_payload(uint64_t time_ms, int32_t frequency, int32_t sample_rate, const int8_t* row, int32_t size, uint8_t* out,
+                           int32_t cap);
+
 /* Learned ceiling for the current centre frequency: N floats, -FLT_MAX where nothing was learned.
  * Returns 1 if learning is complete, 0 if still learning, <0 on error. */
 int ss_read_noise(ss_ctx* ctx, float* thr);

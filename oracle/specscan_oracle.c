@@ -829,6 +829,29 @@ int orc_spectrogram_send(orc_spectrogram* g, int8_t* out, float* mean_out) {
   return count;
 }
 
+/* DataController::pushSpectrogram — data_controller.cpp:44-57. `add` appends the raw bytes of each field in turn
+ * (data_controller.cpp:8-20): time (uint64), start, stop, step (Frequency = int32), size (uint32), the int8 row. */
+static void put(uint8_t* buf, size_t* at, const void* field, size_t bytes) {
+  memcpy(buf + *at, field, bytes);
+  *at += bytes;
+}
+int orc_spectrogram_payload(uint64_t time_ms, int32_t frequency, int32_t sample_rate, const int8_t* row, int32_t size, uint8_t* out, int32_t cap) {
+  const int32_t start = frequency - sample_rate / 2; /* :45 */
+  const int32_t stop = frequency + sample_rate / 2;  /* :46 */
+  const int32_t step = sample_rate / size;           /* :47 */
+  const uint32_t n = (uint32_t)size;
+  const size_t need = sizeof(uint64_t) + 3 * sizeof(int32_t) + sizeof(uint32_t) + (size_t)size; /* :48 */
+  size_t at = 0;
+  if ((size_t)cap < need) return -1;
+  put(out, &at, &time_ms, sizeof(time_ms));
+  put(out, &at, &start, sizeof(start));
+  put(out, &at, &stop, sizeof(stop));
+  put(out, &at, &step, sizeof(step));
+  put(out, &at, &n, sizeof(n));
+  put(out, &at, row, (size_t)size);
+  return (int)at;
+}
+
 void orc_stage_seconds(orc_ctx* c, double out[6]) {
   for (int i = 0; i < 6; ++i) {
     out[i] = c->stage[i];

@@ -71,6 +71,8 @@ int orc_spectrogram_size(const orc_spectrogram* g);
 void orc_spectrogram_process(orc_spectrogram* g, const float* psd_row);
 /* returns the number of accumulated frames; out = int8(sum/count), mean_out (nullable) = the float before conversion */
 int orc_spectrogram_send(orc_spectrogram* g, int8_t* out, float* mean_out);
+/* DataController::pushSpectrogram's payload (sources/network/data_controller.cpp:44-57); byte count, or -1 if cap is short */
+int orc_spectrogram_payload(uint64_t time_ms, int32_t frequency, int32_t sample_rate, const int8_t* row, int32_t size, uint8_t* out, int32_t cap);
 
 /* ---- the chain behind the same boundary as ss_* ---- */
 void orc_default_config(ss_config* cfg, int32_t sample_rate, int32_t center_hz);

@@ -1102,6 +1102,25 @@ int ss_spectrogram_read(ss_ctx* c, int8_t* out, float* mean_out) {
   return count;
 }
 
+int ss_spectrogram_payload(uint64_t time_ms, int32_t frequency, int32_t sample_rate, const int8_t* row, int32_t size, uint8_t* out,
+                           int32_t cap) {
+  if (size < 1 || (out && !row)) return SS_ERR_INVALID;  // step = sampleRate / size: the reference never sends an empty row
+  const long long total = (long long)(sizeof(uint64_t) + 3 * sizeof(int32_t) + sizeof(uint32_t)) + size;
+  if (!out) return (int)total;
+  if (total > cap) return SS_ERR_INVALID;
+  const int32_t head[3] = {frequency - sample_rate / 2, frequency + sample_rate / 2, sample_rate / size};  // data_controller.cpp:45-47
+  const uint32_t count = (uint32_t)size;
+  uint8_t* p = out;
+  memcpy(p, &time_ms, sizeof(time_ms));
+  p += sizeof(time_ms);
+  memcpy(p, head, sizeof(head));
+  p += sizeof(head);
+  memcpy(p, &count, sizeof(count));
+  p += sizeof(count);
+  memcpy(p, row, (size_t)size);
+  return (int)total;
+}
+
 int ss_read_noise(ss_ctx* c, float* thr) {
   if (!c || !thr) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);

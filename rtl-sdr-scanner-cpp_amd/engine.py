@@ -43,6 +43,8 @@ def load_library() -> C.CDLL:
         lib.ss_spectrogram_size.restype = C.c_int
         lib.ss_spectrogram_read.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.POINTER(C.c_float)]
         lib.ss_spectrogram_read.restype = C.c_int
+        lib.ss_spectrogram_payload.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        lib.ss_spectrogram_payload.restype = C.c_int
         lib.ss_selftest.argtypes = [C.c_int, C.c_int]
         lib.ss_selftest.restype = C.c_longlong
         lib.ss_feed_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
@@ -64,11 +66,24 @@ def load_library() -> C.CDLL:
 EXPORTS = ("ss_default_config", "ss_device_count", "ss_create", "ss_destroy", "ss_last_error", "ss_process",
            "ss_process_device", "ss_sync", "ss_stream", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
            "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read",
-           "ss_feed_create", "ss_feed_destroy", "ss_feed_acquire", "ss_feed_submit", "ss_feed_collect", "ss_feed_pending")
+           "ss_spectrogram_payload", "ss_feed_create", "ss_feed_destroy", "ss_feed_acquire", "ss_feed_submit", "ss_feed_collect", "ss_feed_pending")
 
 
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def spectrogram_payload(time_ms: int, frequency: int, sample_rate: int, row: np.ndarray) -> bytes:
+    """DataController::pushSpectrogram's MQTT payload (reference sources/network/data_controller.cpp:44-57) for one int8 row."""
+    lib = load_library()
+    a = np.ascontiguousarray(row, dtype=np.int8).reshape(-1)
+    n = lib.ss_spectrogram_payload(time_ms, frequency, sample_rate, None, a.size, None, 0)
+    if n < 0:
+        raise ValueError("spectrogram_payload: empty row")
+    out = np.zeros(n, np.uint8)
+    if lib.ss_spectrogram_payload(time_ms, frequency, sample_rate, a.ctypes.data, a.size, out.ctypes.data, n) != n:
+        raise ValueError("spectrogram_payload")
+    return out.tobytes()
 
 
 class SpectrumEngine(abi.Chain):

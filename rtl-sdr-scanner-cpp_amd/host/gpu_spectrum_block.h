@@ -15,6 +15,11 @@
 // what Transmission::process hands to m_notification.notify (transmission.cpp:67) — goes to a callback, so that the
 // Scanner thread (sources/scanner.cpp:36-64) sees exactly the interface it sees today.
 //
+// With SS_FLAG_SPECTROGRAM in the config the Spectrogram side branch runs on the GPU as well (enableSpectrogram): the
+// block keeps Spectrogram::send's 1000 ms gate per centre frequency (spectrogram.cpp:62-75) and hands the int8 row to a
+// callback with DataController::pushSpectrogram's arguments; ss_spectrogram_payload frames it for the wire. The gate is
+// looked at once per work() call (the reference looks after every frame), so a row closes at a batch boundary.
+//
 // Control calls mirror what SdrDevice does to the blocks it owns: setFrequencyRange (sdr_device.cpp:54-80)
 // -> set_frequency_range() + reset_buffers(); they are serialised against work() inside the library.
 #pragma once
@@ -23,9 +28,11 @@
 
 #include "signal_tracker.h"
 
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <functional>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -49,6 +56,7 @@ class GpuSpectrum : virtual public gr::sync_block {
     m_bins.resize(static_cast<size_t>(m_config.max_batch) * 1024);
     m_avg.resize(m_bins.size());
     m_times.resize(static_cast<size_t>(m_config.max_batch));
+    m_center = (m_config.range_lo + m_config.range_hi) / 2;
   }
 
   ~GpuSpectrum() override { ss_destroy(m_ctx); }
@@ -67,6 +75,15 @@ class GpuSpectrum : virtual public gr::sync_block {
     m_avgPlane.resize(m_rel.size());
   }
   void setClock(Clock clock) { m_clock = std::move(clock); }
+
+  // time (ms), centre frequency, sample rate, int8 row, bins — DataController::pushSpectrogram(time, frequency, sampleRate, data, size)
+  using SpectrogramCallback = std::function<void(int64_t time_ms, int32_t frequency, int32_t sample_rate, const int8_t* row, int size)>;
+  void enableSpectrogram(SpectrogramCallback on_row) {
+    const int size = ss_spectrogram_size(m_ctx);
+    if (size <= 0) throw std::runtime_error("GpuSpectrum: the context was created without SS_FLAG_SPECTROGRAM");
+    m_spectrogramRow.resize(static_cast<size_t>(size));
+    m_onSpectrogram = std::move(on_row);
+  }
 
   int work(int noutput_items, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override {
     const int nframes = noutput_items < m_config.max_batch ? noutput_items : m_config.max_batch;
@@ -101,11 +118,25 @@ class GpuSpectrum : virtual public gr::sync_block {
         if (m_onTransmissions) m_onTransmissions(tx);
       }
     }
+    if (m_onSpectrogram) {
+      // Container's ctor stamps m_lastDataSendTime with the time of the centre frequency's first frame (spectrogram.cpp:9,36)
+      const int32_t center = m_center.load();
+      const auto it = m_spectrogramSent.try_emplace(center, now).first;
+      if (it->second + 1000 < now) {  // SPECTROGRAM_SEND_INTERVAL, config.h:38; spectrogram.cpp:65
+        if (ss_spectrogram_read(m_ctx, m_spectrogramRow.data(), nullptr) > 0) {
+          m_onSpectrogram(now, center, m_config.sample_rate, m_spectrogramRow.data(), static_cast<int>(m_spectrogramRow.size()));
+        }
+        it->second = now;
+      }
+    }
     return nframes;
   }
 
   // SdrDevice::setFrequencyRange's effect on the chain (sdr_device.cpp:66,74,77)
-  void setFrequencyRange(int32_t lo_hz, int32_t hi_hz) { ss_set_frequency_range(m_ctx, lo_hz, hi_hz); }
+  void setFrequencyRange(int32_t lo_hz, int32_t hi_hz) {
+    ss_set_frequency_range(m_ctx, lo_hz, hi_hz);
+    m_center = (lo_hz + hi_hz) / 2;
+  }
   void resetBuffers() {  // Transmission::resetBuffers, transmission.cpp:42-55: signals cleared, averager reset
     ss_reset(m_ctx);
     if (m_tracker) m_tracker->reset();
@@ -124,4 +155,8 @@ class GpuSpectrum : virtual public gr::sync_block {
   TransmissionCallback m_onTransmissions;
   Clock m_clock;
   std::vector<float> m_rel, m_avgPlane;
+  SpectrogramCallback m_onSpectrogram;
+  std::vector<int8_t> m_spectrogramRow;
+  std::map<int32_t, int64_t> m_spectrogramSent;  // Container::m_lastDataSendTime per centre frequency
+  std::atomic<int32_t> m_center{0};  // written by the retuning thread (setFrequencyRange), read by work()
 };

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_oracle_exports_the_same_set(oracle_mod):
     L = oracle_mod.lib()
     for name in pkg.engine.EXPORTS:
-        if name in ("ss_device_count", "ss_process_device", "ss_sync", "ss_stream", "ss_kernel_timing", "ss_kernel_timing_read", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read") or name.startswith("ss_feed_"):
+        if name in ("ss_device_count", "ss_process_device", "ss_sync", "ss_stream", "ss_kernel_timing", "ss_kernel_timing_read", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read") or name.startswith("ss_feed_"):  # (the oracle has its own orc_spectrogram_* object)
             continue  # device-only entry points (streams, pinned staging, PCIe pipelining)
         assert hasattr(L, "orc_" + name[3:]), name
 
@@ -70,3 +70,24 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, fn
+
+
+def test_spectrogram_payload_layout(lib, oracle_mod):
+    """uint64 ms | int32 start | int32 stop | int32 step | uint32 size | int8 row (data_controller.cpp:44-57)."""
+    import ctypes as C
+    import struct
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for fs, size, freq in ((2_048_000, 2048, 145_000_000), (20_000_000, 16384, 433_920_000), (250_000, 250, 27_000_000), (1_000_001, 3, 7)):
+        row = rng.integers(-128, 128, size, dtype=np.int8)
+        got = pkg.engine.spectrogram_payload(1_726_000_000_123, freq, fs, row)
+        want = struct.pack("<Qiiii", 1_726_000_000_123, freq - fs // 2, freq + fs // 2, fs // size, size) + row.tobytes()
+        assert got == want
+        buf = np.zeros(len(got), np.uint8)
+        L = oracle_mod.lib()
+        L.orc_spectrogram_payload.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        assert L.orc_spectrogram_payload(1_726_000_000_123, freq, fs, row.ctypes.data, size, buf.ctypes.data, len(buf)) == len(got)
+        assert buf.tobytes() == got
+    assert lib.ss_spectrogram_payload(0, 0, 1000, None, 0, None, 0) < 0  # the reference never frames an empty row (step = rate / size)
+    short = np.zeros(8, np.uint8)
+    assert lib.ss_spectrogram_payload(0, 0, 1000, np.zeros(4, np.int8).ctypes.data, 4, short.ctypes.data, 8) < 0

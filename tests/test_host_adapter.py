@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
   cfg.learn_frames = 20;
   cfg.learn_ms = 0;
   cfg.max_batch = 16;
+  cfg.flags |= SS_FLAG_SPECTROGRAM;
   std::vector<gr_complex> iq((size_t)n * nframes);
   FILE* fp = fopen(path, "rb");
   if (!fp || fread(iq.data(), sizeof(gr_complex), iq.size(), fp) != iq.size()) return 3;
@@ -71,6 +72,13 @@ int main(int argc, char** argv) {
   tc.timeout_ms = 400;
   std::vector<std::vector<specscan::FrequencyFlush>> tx_per_frame;
   block.enableTracker(tc, [&](const std::vector<specscan::FrequencyFlush>& tx) { tx_per_frame.push_back(tx); });
+  // Spectrogram::send's gate on the same clock; each row framed the way DataController::pushSpectrogram frames it
+  std::vector<std::vector<uint8_t>> spectrogram_payloads;
+  block.enableSpectrogram([&](int64_t t, int32_t frequency, int32_t rate, const int8_t* row, int size) {
+    std::vector<uint8_t> payload((size_t)ss_spectrogram_payload((uint64_t)t, frequency, rate, row, size, nullptr, 0));
+    ss_spectrogram_payload((uint64_t)t, frequency, rate, row, size, payload.data(), (int32_t)payload.size());
+    spectrogram_payloads.push_back(payload);
+  });
   std::vector<float> psd((size_t)n * 16);
   int pos = 0;
   const int sizes[] = {1, 16, 7, 3, 16, 16, 5};
@@ -95,6 +103,12 @@ int main(int argc, char** argv) {
     printf("%s[", i ? "," : "");
     for (size_t k = 0; k < tx_per_frame[i].size(); ++k) printf("%s[%d,%d]", k ? "," : "", tx_per_frame[i][k].shift_hz, (int)tx_per_frame[i][k].flush);
     printf("]");
+  }
+  printf("], \"spectrogram\": [");
+  for (size_t i = 0; i < spectrogram_payloads.size(); ++i) {
+    printf("%s\"", i ? "," : "");
+    for (uint8_t b : spectrogram_payloads[i]) printf("%02x", b);
+    printf("\"");
   }
   printf("]}\n");
   return 0;
@@ -126,9 +140,9 @@ def test_adapter_runs_against_the_library(tmp_path):
     r = subprocess.run([str(exe), str(raw), str(n), str(nframes)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     rep = json.loads(r.stdout.strip().splitlines()[-1])
-    eng = pkg.SpectrumEngine(n * 250, 145_000_000, fft_size=n, decim=1, learn_frames=20, learn_ms=0, max_batch=16)
+    eng = pkg.SpectrumEngine(n * 250, 145_000_000, fft_size=n, decim=1, learn_frames=20, learn_ms=0, max_batch=16, flags=pkg.abi.SS_FLAG_SPECTROGRAM)
     eng2 = pkg.SpectrumEngine(n * 250, 145_000_000, fft_size=n, decim=1, learn_frames=20, learn_ms=0, max_batch=16)
-    want, last, want_tx = [], None, []
+    want, last, want_tx, want_rows, last_sent = [], None, [], [], None
     pos, k = 0, 0
     sizes = [1, 16, 7, 3, 16, 16, 5]
     trk = pkg.tracker.SignalTracker(n, n * 250, group_size=128, min_time_ms=200, timeout_ms=400)
@@ -143,8 +157,18 @@ def test_adapter_runs_against_the_library(tmp_path):
         o = eng.process(iq[pos:pos + s_], t_ms=np.full(s_, 1_700_000_000_000, np.int64), want=("psd",))
         want.extend(np.diff(o["cand_off"]).tolist())
         last = o["psd"]
+        now = 1000 + 40 * pos  # the injected clock, read once per work() call
+        last_sent = now if last_sent is None else last_sent
+        if last_sent + 1000 < now:  # Spectrogram::send, spectrogram.cpp:65
+            row, _mean, cnt = eng.spectrogram_read()
+            assert cnt > 0
+            want_rows.append(pkg.engine.spectrogram_payload(now, 145_000_000, n * 250, row).hex())
+            last_sent = now
         pos += s_
     assert rep["frames"] == nframes and rep["per_frame"] == want and rep["candidates"] == sum(want) > 500
     assert abs(rep["last_psd0"] - float(last[0, 0])) < 1e-4
     # and the list Notification::notify would receive, frame by frame: tuned shifts (Hz) and flush flags
     assert rep["tx"] == want_tx and sum(len(t) for t in want_tx) > 50 and any(f for t in want_tx for _, f in t)
+    # the rows Spectrogram::send would publish on the same clock, framed by DataController::pushSpectrogram: 1 s apart, at batch boundaries
+    assert rep["spectrogram"] == want_rows and len(want_rows) == 3
+    assert len(bytes.fromhex(want_rows[0])) == 8 + 12 + 4 + 256  # getFft(256000, 1000) = 256 bins
