@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--fft", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fmt", default="cf32", choices=["cf32", "cs8", "cu8"], help="IQ sample format in HBM (the headline is cf32)")
+    ap.add_argument("--spectrogram", action="store_true", help="also run the Spectrogram side branch (SS_FLAG_SPECTROGRAM) every batch")
+    ap.add_argument("--no-psd-out", action="store_true", help="detect mode: the caller takes candidates only, no PSD plane is handed out")
     ap.add_argument("--single-buffer", action="store_true", help="one output set instead of two alternating ones")
     ap.add_argument("--time-every", type=int, default=8, help="attach start/stop events to every k-th launch of the FFT kernel")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not attach per-launch events to the FFT kernel (roofline omitted)")
@@ -143,7 +145,8 @@ def main():
     eng = pkg.SpectrumEngine(int(cfg["sample_rate"]), dist.band_center(cfg, band), fft_size=int(cfg["fft_size"]),
                              decim=int(cfg["decim"]), in_format=int(cfg["in_format"]), grouping_x=int(cfg["grouping_x"]),
                              grouping_y=int(cfg["grouping_y"]), start_level=cfg["start_level_mdB"] / 1000.0,
-                             learn_frames=int(cfg["learn_frames"]), max_batch=nb, device_id=device_index)
+                             learn_frames=int(cfg["learn_frames"]), max_batch=nb, device_id=device_index,
+                             flags=pkg.abi.SS_FLAG_SPECTROGRAM if args.spectrogram else 0)
     iq = dist.synthetic_batch(cfg, band, nb)
     d_iq = torch.from_numpy(iq.view(np.float32) if iq.dtype == np.complex64 else iq).to(dev)
     # Outputs are double-buffered the way a streaming consumer would hold them: batch k writes set k & 1 while
@@ -158,7 +161,7 @@ def main():
     def step():
         o = outs[counter[0] % len(outs)]
         counter[0] += 1
-        eng.process_device(d_iq, nb, psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
+        eng.process_device(d_iq, nb, psd=None if args.no_psd_out else o["psd"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
 
     for _ in range(max(args.warmup, 1)):  # first warm-up batch also absorbs the noise-learning frames
         step()
@@ -193,7 +196,7 @@ def main():
                                    "(window+FFT+dB -> noise-relative -> 21x21 mean -> threshold -> candidate lists), "
                                    "one band per GPU",
                        "fft_size": n, "frames_per_batch": nb, "bands": world, "candidates_per_batch": ncand,
-                       "output_sets": len(outs), "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},
+                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "output_sets": len(outs), "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_fft8192_psd (load+window+FFT+dB)",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),

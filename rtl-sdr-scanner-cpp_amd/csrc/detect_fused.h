@@ -74,6 +74,12 @@ struct DetectArgs {
   float* avg_out;
   float* avg_sparse;
   long long* dbg;  // diagnostic (SS_DEBUG_TIMING): per-workgroup wall_clock64 stamps {start, mid, end, class}, or null
+  // Spectrogram side branch (k_detect_fused<..., SPEC = true> only; spectrogram.cpp:45-60)
+  float* spec_partial;             // [frame tile][spec_n]: the tile's frames, bin-decimated and summed in frame order
+  const float* spec_prev_partial;  // the previous launch's partial sums, not yet added to their container (or null)
+  float* spec_prev_sum;            // [spec_n] Container::m_sum they belong to
+  int spec_prev_tiles;
+  int spec_m, spec_n;              // m_decimatorFactor (a power of two <= 256), m_outputSize
 };
 
 // plane[row][byte offset coff]: block-uniform row base (scalar registers) + one 32-bit per-thread offset
@@ -99,7 +105,84 @@ __device__ __forceinline__ void time_means_to_tile(const float (&x)[G - 1 + TF],
   }
 }
 
-template <int G, int GX, int TF, int TB_ = 256>
+// Spectrogram side branch inside the detect kernel (spectrogram.cpp:45-60). Every tile reduces its own frames:
+//   spectrogram_tile_means   all 256 threads: wave w takes the tile's frames 4w..4w+3, lane l the bins 4l..4l+3 of the
+//                            tile (one 16-byte load per frame; the rows were just read by phase 1 and come from L2).
+//                            Per frame the mean of m adjacent raw-PSD bins, summed in ascending bin order as the
+//                            reference does (for m > 4 the lanes to the right hand their four values over one by one),
+//                            then / m. The means go to LDS (the avgY tile is free by then).
+//   spectrogram_tile_sum     thread = output bin: the tile's frames added in frame order -> spec_partial[tile][bin]
+// The partial sums of a batch are added to the container (in frame-tile order, whatever ran when) by the NEXT launch —
+// spectrogram_fold, by the first-dispatched tile of each bin column — or by k_spec_combine when the host needs the
+// container before that (ss_spectrogram_read, retune): kernel boundaries order the writes, no fences or counters.
+template <int TF, int TB>
+__device__ __forceinline__ void spectrogram_tile_means(const DetectArgs& a, float* __restrict__ means, int tid, int f0, int b0) {
+  static_assert(TF == 16 && TB == 256, "four waves x four frames, 64 lanes x four bins");
+  const int m = a.spec_m, n = a.n;
+  const int per_tile = TB / m > 0 ? TB / m : 1;
+  const int lane = tid & 63, w = tid >> 6;
+  const int bin = b0 + 4 * lane;
+  const bool inside = bin < n;
+  float4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int fr = min(max(f0 + 4 * w + i, 0), a.nframes - 1);  // always a legal row; frames outside the batch are skipped by the sum
+    v[i] = *reinterpret_cast<const float4*>(a.psd + (size_t)fr * n + (inside ? bin : 0));
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float* row = means + (4 * w + i) * per_tile;
+    if (m == 1) {
+      if (inside) *reinterpret_cast<float4*>(row + 4 * lane) = v[i];
+    } else if (m == 2) {
+      if (inside) *reinterpret_cast<float2*>(row + 2 * lane) = make_float2((v[i].x + v[i].y) / 2.0f, (v[i].z + v[i].w) / 2.0f);
+    } else {
+      float sum = ((v[i].x + v[i].y) + v[i].z) + v[i].w;
+      const int lanes_per_bin = m >> 2;
+      for (int d = 1; d < lanes_per_bin; ++d) {  // wave-uniform trip count
+        sum += __shfl_down(v[i].x, d);
+        sum += __shfl_down(v[i].y, d);
+        sum += __shfl_down(v[i].z, d);
+        sum += __shfl_down(v[i].w, d);
+      }
+      if (inside && (lane & (lanes_per_bin - 1)) == 0) row[lane / lanes_per_bin] = sum / (float)m;
+    }
+  }
+}
+
+template <int TF, int TB>
+__device__ __forceinline__ void spectrogram_tile_sum(const DetectArgs& a, const float* __restrict__ means, int tid, int ft, int f0, int b0) {
+  const int m = a.spec_m;
+  const int per_tile = TB / m > 0 ? TB / m : 1;
+  const int ob = b0 / m + tid;
+  if (tid >= per_tile || ob >= a.spec_n) return;
+  const int j_lo = max(0, -f0), j_hi = min(TF, a.nframes - f0);  // the tile's frames that belong to this batch
+  float acc = 0.0f;
+#pragma unroll
+  for (int j = 0; j < TF; ++j)
+    if (j >= j_lo && j < j_hi) acc += means[j * per_tile + tid];
+  a.spec_partial[(size_t)ft * a.spec_n + ob] = acc;
+}
+
+template <int TB>
+__device__ __forceinline__ void spectrogram_fold(const DetectArgs& a, int tid, int b0) {
+  const int m = a.spec_m;
+  const int per_tile = TB / m > 0 ? TB / m : 1;
+  const int ob = b0 / m + tid;
+  if (tid >= per_tile || ob >= a.spec_n) return;
+  float acc = a.spec_prev_sum[ob];
+  for (int t0 = 0; t0 < a.spec_prev_tiles; t0 += 16) {
+    float r[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = a.spec_prev_partial[(size_t)min(t0 + i, a.spec_prev_tiles - 1) * a.spec_n + ob];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (t0 + i < a.spec_prev_tiles) acc += r[i];
+  }
+  a.spec_prev_sum[ob] = acc;
+}
+
+template <int G, int GX, int TF, int TB_ = 256, bool SPEC = false>
 __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k_detect_fused(DetectArgs a) {
   using T = DetectTile<G, GX, TF, TB_>;
   constexpr int A = T::A, TB = T::TB, P = T::P, ROWS = T::ROWS, H = T::H, SEGW = T::SEGW, NSEG = T::NSEG, YW = T::YW;
@@ -118,6 +201,9 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
   const int f0 = ft * TF - a.shift;  // batch-relative frame of the tile's first row of outputs; may be negative
   const int b0 = (blockIdx.x % tiles_per_row) * TB;
   if (tid < TF) cnt[tid] = 0;
+  if constexpr (SPEC) {
+    if (a.spec_prev_partial && blockIdx.x < (unsigned)tiles_per_row) spectrogram_fold<TB>(a, tid, b0);
+  }
   // block-uniform classification
   const bool interior = (b0 - A >= 0) && (b0 + TB + A <= n);
   const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes);
@@ -285,6 +371,12 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
   }
   __syncthreads();
   if (tid < TF && cnt[tid] != 0) atomicAdd(&a.counts[f0 + tid], cnt[tid]);
+  if constexpr (SPEC) {
+    // (the __syncthreads above freed the avgY tile)
+    spectrogram_tile_means<TF, TB>(a, tile, tid, f0, b0);
+    __syncthreads();
+    spectrogram_tile_sum<TF, TB>(a, tile, tid, ft, f0, b0);
+  }
   if (a.dbg && tid == 0) {
     a.dbg[4 * blockIdx.x] = t_start;
     a.dbg[4 * blockIdx.x + 1] = t_mid;

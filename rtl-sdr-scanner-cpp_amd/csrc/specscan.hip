@@ -80,6 +80,13 @@ struct ss_ctx {
   std::vector<NoiseState> noise;
   // spectrogram side branch (SS_FLAG_SPECTROGRAM)
   int spec_n = 0, spec_m = 0;  // output bins, input bins per output bin (spectrogram.cpp:14-15)
+  bool spec_in_detect = false;  // accumulated by k_detect_fused instead of the two stand-alone kernels
+  // in-detect form: the partial sums of a launch are folded into their container by the next launch (or by
+  // spectrogram_flush); two buffers alternate
+  float* d_spec_part2[2] = {nullptr, nullptr};
+  int spec_cur = 0;
+  float* spec_pending_sum = nullptr;  // container (SpecState::d_sum) the partial sums in d_spec_part2[spec_cur ^ 1] belong to
+  int spec_pending_tiles = 0;
   std::vector<SpecState> spec;
   float* d_spec_partial = nullptr;
   int frames_pushed = 0;  // Averager::m_frames, saturates at grouping_y
@@ -427,8 +434,8 @@ int run_backend_unfused(ss_ctx* c, const float* d_psd, int nframes, int n_learn,
 }
 
 // Back end for the reference's grouping (21 x 21): two launches, the PSD plane is read once.
-int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, NoiseState* z, float* d_rel_out, float* d_avg_out,
-                      int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
+int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, NoiseState* z, SpecState* spec, float* d_rel_out,
+                      float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
   const int n = c->n;
   constexpr int G = 21, GX = 21, TF = kFusedTF, TB = 256;  // measured against 32-frame and 128-bin tiles: 16 x 256 is fastest
   constexpr int H = kHistRows;
@@ -455,9 +462,25 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   const int shift = (int)(c->abs_frames % TF);
   const int tiles = ((nframes + shift + TF - 1) / TF) * ((n + TB - 1) / TB);
   ss::DetectArgs da{d_psd, z->d_thr,           hist_in,   hist_out,  n,      nframes,   n_learn,  c->frames_pushed,
-                    shift, c->cfg.start_level, c->d_pass, c->d_mask, counts, d_rel_out, avg_full, c->d_avg,         nullptr};
+                    shift, c->cfg.start_level, c->d_pass, c->d_mask, counts, d_rel_out, avg_full, c->d_avg,         nullptr,
+                    nullptr, nullptr,          nullptr,   0,         0,      0};
   if (c->diag.d_detect_stamps && tiles <= 65536) da.dbg = c->diag.d_detect_stamps;
-  hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB>), dim3(tiles), dim3(TB), 0, c->stream, da);
+  if (spec) {
+    da.spec_partial = c->d_spec_part2[c->spec_cur];
+    da.spec_m = c->spec_m;
+    da.spec_n = c->spec_n;
+    if (c->spec_pending_sum) {
+      da.spec_prev_partial = c->d_spec_part2[c->spec_cur ^ 1];
+      da.spec_prev_sum = c->spec_pending_sum;
+      da.spec_prev_tiles = c->spec_pending_tiles;
+    }
+    hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, true>), dim3(tiles), dim3(TB), 0, c->stream, da);
+    c->spec_pending_sum = spec->d_sum;  // (the containers live until the context is destroyed)
+    c->spec_pending_tiles = (nframes + shift + TF - 1) / TF;
+    c->spec_cur ^= 1;
+  } else {
+    hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, false>), dim3(tiles), dim3(TB), 0, c->stream, da);
+  }
   if (da.dbg && ++c->diag.detect_calls == 20) {
     std::vector<long long> h((size_t)4 * tiles);
     (void)hipStreamSynchronize(c->stream);
@@ -483,26 +506,38 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
 
 // Spectrogram::work/process for a batch (spectrogram.cpp:29-60): the container of the current centre frequency
 // accumulates the bin-decimated raw PSD of every frame.
-int spectrogram_accumulate(ss_ctx* c, const float* d_psd, int nframes) {
+// m_containers[frequency] (spectrogram.cpp:33-37): the accumulator of the current centre frequency, created on first use
+SpecState* spectrogram_container(ss_ctx* c) {
   const int32_t center = (c->range_lo + c->range_hi) / 2;
-  SpecState* g = nullptr;
   for (auto& s : c->spec)
-    if (s.center == center) g = &s;
-  if (!g) {
-    SpecState ns;
-    ns.center = center;
-    SS_HIP(c, hipMalloc(&ns.d_sum, sizeof(float) * (size_t)c->spec_n));
-    SS_HIP(c, hipMemsetAsync(ns.d_sum, 0, sizeof(float) * (size_t)c->spec_n, c->stream));
-    c->spec.push_back(ns);
-    g = &c->spec.back();
+    if (s.center == center) return &s;
+  SpecState ns;
+  ns.center = center;
+  if (hipMalloc(&ns.d_sum, sizeof(float) * (size_t)c->spec_n) != hipSuccess) return nullptr;
+  if (hipMemsetAsync(ns.d_sum, 0, sizeof(float) * (size_t)c->spec_n, c->stream) != hipSuccess) {
+    (void)hipFree(ns.d_sum);
+    return nullptr;
   }
+  c->spec.push_back(ns);
+  return &c->spec.back();
+}
+
+// In-detect form: add the partial sums of the last launch to their container now (the next launch would have done it).
+void spectrogram_flush(ss_ctx* c) {
+  if (!c->spec_pending_sum) return;
+  hipLaunchKernelGGL(ss::k_spec_combine, dim3((c->spec_n + 255) / 256), dim3(256), 0, c->stream, (const float*)c->d_spec_part2[c->spec_cur ^ 1],
+                     c->spec_pending_tiles, c->spec_n, c->spec_pending_sum);
+  c->spec_pending_sum = nullptr;
+}
+
+// Stand-alone form (groupings other than 21 x 21, decimation factors above 256): two more kernels over the PSD plane.
+int spectrogram_accumulate(ss_ctx* c, SpecState* g, const float* d_psd, int nframes) {
   constexpr int kChunk = 32;
   const int nchunks = (nframes + kChunk - 1) / kChunk;
   const dim3 grid((c->spec_n + 255) / 256, nchunks);
   hipLaunchKernelGGL(ss::k_spec_partial, grid, dim3(256), 0, c->stream, d_psd, c->n, nframes, c->spec_m, c->spec_n, kChunk, c->d_spec_partial);
   hipLaunchKernelGGL(ss::k_spec_combine, dim3((c->spec_n + 255) / 256), dim3(256), 0, c->stream, (const float*)c->d_spec_partial, nchunks,
                      c->spec_n, g->d_sum);
-  g->count += nframes;
   return SS_OK;
 }
 
@@ -521,11 +556,18 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
   float* d_psd = d_psd_out ? d_psd_out : c->d_psd;
   int st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
   if (st != SS_OK) return st;
+  SpecState* spec = nullptr;
   if (c->spec_n > 0) {
-    st = spectrogram_accumulate(c, d_psd, nframes);
-    if (st != SS_OK) return st;
+    spec = spectrogram_container(c);
+    if (!spec) return fail(c, SS_ERR_NOMEM, "spectrogram container");
+    if (!c->spec_in_detect) {
+      st = spectrogram_accumulate(c, spec, d_psd, nframes);
+      if (st != SS_OK) return st;
+    }
+    spec->count += nframes;
   }
-  st = c->fused ? run_backend_fused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap)
+  st = c->fused ? run_backend_fused(c, d_psd, nframes, n_learn, z, c->spec_in_detect ? spec : nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx,
+                                    d_cand_avg, cand_cap)
                 : run_backend_unfused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap);
   if (st != SS_OK) return st;
   ++c->batch_no;
@@ -597,6 +639,8 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_tw_sub);
   (void)hipFree(c->d_tw_small);
   (void)hipFree(c->d_tw_rowsR);
+  (void)hipFree(c->d_spec_part2[0]);
+  (void)hipFree(c->d_spec_part2[1]);
   (void)hipFree(c->d_mask);
   (void)hipFree(c->d_counts);
   (void)hipFree(c->d_off);
@@ -758,7 +802,15 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     if (out_n > n) out_n = n;
     c->spec_n = out_n;
     c->spec_m = n / out_n;
-    CREATE_HIP(hipMalloc(&c->d_spec_partial, sizeof(float) * (size_t)out_n * (size_t)((cfg->max_batch + 31) / 32)));
+    // inside the detect kernel when that kernel runs and a tile's 256 bins hold whole groups of m: one partial row per
+    // frame tile (a batch that starts inside a tile touches one more)
+    c->spec_in_detect = c->fused && c->spec_m <= 256 && !(getenv("SS_SPEC_IMPL") && strcmp(getenv("SS_SPEC_IMPL"), "standalone") == 0);
+    if (c->spec_in_detect) {
+      const size_t tiles = (size_t)(cfg->max_batch + kFusedTF - 1) / kFusedTF + 1;
+      for (int k = 0; k < 2; ++k) CREATE_HIP(hipMalloc(&c->d_spec_part2[k], sizeof(float) * (size_t)out_n * tiles));
+    } else {
+      CREATE_HIP(hipMalloc(&c->d_spec_partial, sizeof(float) * (size_t)out_n * ((size_t)(cfg->max_batch + 31) / 32)));
+    }
   }
   if (c->logn > 13) CREATE_HIP(hipMalloc(&c->d_work, sizeof(float2) * (size_t)n * (size_t)cfg->max_batch));
 
@@ -1088,6 +1140,7 @@ int ss_spectrogram_read(ss_ctx* c, int8_t* out, float* mean_out) {
   for (auto& s : c->spec)
     if (s.center == center) g = &s;
   if (!g || g->count == 0) return 0;
+  spectrogram_flush(c);
   std::vector<float> sum((size_t)c->spec_n);
   SS_HIP(c, hipMemcpyAsync(sum.data(), g->d_sum, sizeof(float) * sum.size(), hipMemcpyDeviceToHost, c->stream));
   SS_HIP(c, hipMemsetAsync(g->d_sum, 0, sizeof(float) * sum.size(), c->stream));

@@ -193,13 +193,16 @@ def test_entry_points_agree(seed):
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SS_FUZZ_SEEDS4", "6"))))
-def test_random_spectrogram_sessions(oracle_mod, seed):
+@pytest.mark.parametrize("impl", ["detect", "standalone"])
+def test_random_spectrogram_sessions(oracle_mod, seed, impl, monkeypatch):
     """The spectrogram side branch under random sizes (its output size follows min(16384, getFft(fs, 1000))), call sizes,
-    send times and a retune (the accumulator is per centre frequency, spectrogram.cpp:29-60)."""
+    send times and a retune (the accumulator is per centre frequency, spectrogram.cpp:29-60); accumulated inside the
+    detect kernel (decimation factors up to 64) or by the stand-alone kernels."""
     import ctypes as C
+    monkeypatch.setenv("SS_SPEC_IMPL", impl)
     rng = np.random.default_rng(12000 + seed)
     n = int(rng.choice([1024, 4096, 8192, 16384]))
-    fs = n * int(rng.choice([125, 250]))
+    fs = n * int(rng.choice([4, 16, 125, 250, 1000, 2000]))  # decimation factors 128, 32, 8, 4, 1, 1
     center = 100_000_000
     nframes = int(rng.integers(80, 160))
     max_batch = int(rng.choice([8, 32, 64]))

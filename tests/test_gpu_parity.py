@@ -284,11 +284,13 @@ def test_two_contexts_are_independent(oracle_mod):
     check_plane("b", np.concatenate([rb1["avg"], rb2["avg"]]), ob["avg"])
 
 
-def test_spectrogram_side_branch(oracle_mod):
+@pytest.mark.parametrize("impl", ["detect", "standalone"])
+def test_spectrogram_side_branch(oracle_mod, impl, monkeypatch):
     """Spectrogram::process/send (spectrogram.cpp:45-75) on the raw PSD: bin-decimated mean accumulated over frames,
     published as int8 by the C++ float -> int8 conversion. The float means agree to 1e-4 dB; the int8 bytes are
     identical wherever the reference's own mean is not within 1e-3 of an integer (there truncation decides)."""
     import ctypes as C
+    monkeypatch.setenv("SS_SPEC_IMPL", impl)  # inside k_detect_fused (default) or the two stand-alone kernels
     n, fs, center = 8192, 2_048_000, 145_000_000
     band = pkg.synth.SyntheticBand(n, seed=51, on_frame=20, off_frame=90)
     iq = band.frames_cf32(150)
