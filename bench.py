@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--fmt", default="cf32", choices=["cf32", "cs8", "cu8"], help="IQ sample format in HBM (the headline is cf32)")
     ap.add_argument("--spectrogram", action="store_true", help="also run the Spectrogram side branch (SS_FLAG_SPECTROGRAM) every batch")
     ap.add_argument("--no-psd-out", action="store_true", help="detect mode: the caller takes candidates only, no PSD plane is handed out")
+    ap.add_argument("--planes", action="store_true", help="full mode: the rel and avg planes are handed out as well (20 B/sample)")
+    ap.add_argument("--decim", type=int, default=1, help="frame decimation D: items of N*D samples, the first N of each are scanned (reference: 5 at 2.048 MS/s)")
     ap.add_argument("--single-buffer", action="store_true", help="one output set instead of two alternating ones")
     ap.add_argument("--time-every", type=int, default=8, help="attach start/stop events to every k-th launch of the FFT kernel")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not attach per-launch events to the FFT kernel (roofline omitted)")
@@ -136,7 +138,7 @@ def main():
     n, fs, nb = args.fft, 2_048_000 * (args.fft // 8192 if args.fft >= 8192 else 1), args.frames
     cfg0 = None
     if rank == 0:
-        cfg0 = dict(fft_size=n, sample_rate=fs, decim=1, in_format={"cf32": 0, "cs8": 1, "cu8": 2}[args.fmt], grouping_x=21, grouping_y=21,
+        cfg0 = dict(fft_size=n, sample_rate=fs, decim=args.decim, in_format={"cf32": 0, "cs8": 1, "cu8": 2}[args.fmt], grouping_x=21, grouping_y=21,
                     start_level_mdB=8000, learn_frames=100, learn_ms=2000, max_batch=nb, band0_center=140_000_000,
                     band_spacing=2_000_000, n_bands=world, seed=0)
     cfg = dist.broadcast_config(cfg0, device=coll_dev)  # the only collective of the whole job (RCCL, < 1 KiB)
@@ -153,7 +155,9 @@ def main():
     # the consumer still owns set (k - 1) & 1.
     cap = nb * 1024
     outs = [dict(psd=torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
-                 idx=torch.empty(cap, dtype=torch.int32, device=dev), avg=torch.empty(cap, dtype=torch.float32, device=dev))
+                 idx=torch.empty(cap, dtype=torch.int32, device=dev), avg=torch.empty(cap, dtype=torch.float32, device=dev),
+                 rel_plane=torch.empty((nb, n), dtype=torch.float32, device=dev) if args.planes else None,
+                 avg_plane=torch.empty((nb, n), dtype=torch.float32, device=dev) if args.planes else None)
             for _ in range(1 if args.single_buffer else 2)]
     torch.cuda.synchronize()
     counter = [0]
@@ -161,7 +165,7 @@ def main():
     def step():
         o = outs[counter[0] % len(outs)]
         counter[0] += 1
-        eng.process_device(d_iq, nb, psd=None if args.no_psd_out else o["psd"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
+        eng.process_device(d_iq, nb, psd=None if args.no_psd_out else o["psd"], rel=o["rel_plane"], avg=o["avg_plane"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
 
     for _ in range(max(args.warmup, 1)):  # first warm-up batch also absorbs the noise-learning frames
         step()
@@ -196,7 +200,7 @@ def main():
                                    "(window+FFT+dB -> noise-relative -> 21x21 mean -> threshold -> candidate lists), "
                                    "one band per GPU",
                        "fft_size": n, "frames_per_batch": nb, "bands": world, "candidates_per_batch": ncand,
-                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "output_sets": len(outs), "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},
+                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "output_sets": len(outs), "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_fft8192_psd (load+window+FFT+dB)",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
