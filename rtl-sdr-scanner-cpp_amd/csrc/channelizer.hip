@@ -144,6 +144,7 @@ std::vector<float> design_resampler_taps(int interp, int decim) {
 struct Stage {
   int interp = 1, decim = 1, ntaps = 0, nt = 0;  // nt = taps per polyphase arm = block history
   std::vector<float> taps;
+  float* d_arm_dec = nullptr;  // fast first stage: h[D t + b] at [t][b], b padded to 64 per pass, zeros beyond D and ntaps
   float* d_arm = nullptr;  // [interp][nt]: arm[i][j] = taps[i + j * interp], zero padded (rational_resampler_impl::install_taps)
   float2* d_buf = nullptr;  // stages > 0: per slot [hist (nt-1) | new samples], stride buf_stride
   long long buf_stride = 0;
@@ -212,6 +213,7 @@ struct ChanArgs {
   const float2* in_buf;  // !ROTATE: per slot [hist (nt-1) | new]
   long long in_stride;
   const float* arm;
+  const float* arm_dec;  // k_chan_dec: taps by (tap-in-branch t, branch b): [33][64 * passes], zero outside the filter
   const float2* ptab;  // decimating fast path: per slot exp(2*pi*i*k*df), k = 0 .. ptab_stride-1
   long long ptab_stride;
   int interp, decim, nt, tile;
@@ -351,7 +353,11 @@ __global__ void k_chan_ptab(float2* __restrict__ tab, int n, double df) {
   if (k < n) tab[k] = phase_of(0.0, df, k);
 }
 
-template <int LOGG, int PASSES>
+// Two instantiations share the grid of tiles: FULL takes the tiles whose whole span lies in this call's input and that
+// produce a full set of outputs — straight-line staging and LDS reads at fixed offsets, nothing clamped; the other one
+// takes the few that start in the slot's history (tiles 0..2 at most: three tiles cover more than the filter) or end
+// ragged (the last one).
+template <int LOGG, int PASSES, bool FULL>
 __global__ __launch_bounds__(256) void k_chan_dec(ChanArgs a) {
   constexpr int GL = 1 << LOGG, G = 64 / GL, A = kDecA, R = kDecR, W = A - 1 + R;
   extern __shared__ __attribute__((aligned(16))) unsigned char chan_smem[];
@@ -359,33 +365,51 @@ __global__ __launch_bounds__(256) void k_chan_dec(ChanArgs a) {
   const int s = blockIdx.y;
   const int nout = a.nout[s];
   const int tile_out = (int)(blockDim.x >> 6) * G * R;
-  const int m0 = blockIdx.x * tile_out;
+  int tile_index = blockIdx.x;
+  if (!FULL && blockIdx.x == 3) {
+    tile_index = (nout - 1) / tile_out;  // the last tile, unless it is one of the first three
+    if (tile_index < 3) return;
+  }
+  const int m0 = tile_index * tile_out;
   if (m0 >= nout) return;
   const int slot = a.slot[s];
-  const int D = a.decim, ntaps = a.nt, h = a.nt - 1;
+  const int D = a.decim, h = a.nt - 1;
   const int tcount = min(tile_out, nout - m0);
   const int p_first = a.skip0[s] + m0 * D;  // interpolation 1: the arm counter is always 0
   const int p_last = p_first + (tcount - 1) * D;
   const int n_lo = p_first - (A * D - 1);  // oldest sample any lane touches (taps beyond ntaps are zero)
   const int span = p_last - n_lo + 1;
+  if (FULL != (n_lo >= 0 && tcount == tile_out)) return;  // block-uniform: the other instantiation has this tile
   const float2 P0 = phase_of(a.f0[s], a.df[s], n_lo);
   const float2* ptab = a.ptab + (size_t)slot * a.ptab_stride;
-  if (n_lo >= 0) {
-    // every sample of the span is in this call's input: eight independent, unconditional (clamped) loads per thread in
-    // flight at a time — a load, its arithmetic and its store per loop trip would serialise on the memory latency
+  // this lane's taps of the first pass: requested before the staging so that their latency hides behind it
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lg = lane & (GL - 1), g = lane >> LOGG;
+  constexpr bool kTapsFirst = LOGG == 6 && PASSES == 1;
+  constexpr int kTapPitch = 64 * PASSES;
+  float H0[A];
+  if constexpr (kTapsFirst) {
+#pragma unroll
+    for (int t = 0; t < A; ++t) H0[t] = a.arm_dec[t * kTapPitch + lg];
+  }
+  if (FULL || n_lo >= 0) {
+    // every sample of the span is in this call's input: up to 24 independent, unconditional (clamped) loads per thread
+    // in flight (the whole span of a 64-output tile at D = 64) — a load, its arithmetic and its store per loop trip would
+    // serialise on the memory latency. Phase of sample idx = TPB u + tid: (P0 T[tid]) T[TPB u], the second factor
+    // block-uniform (scalar loads), so the table costs one vector load per thread instead of one per sample.
+    constexpr int U = LOGG == 6 ? 24 : 12;  // smaller tiles keep four waves per SIMD: fewer registers
+    const int TPB = (int)blockDim.x;  // 64, 128 or 256: as many waves as the span leaves LDS for
     const float2* src = a.in_raw + n_lo;
-    for (int base = 0; base < span; base += 8 * (int)blockDim.x) {
-      float2 xv[8], tv[8];
+    const float2 q = cmulf(P0, ptab[threadIdx.x]);
+    for (int base = 0; base < span; base += U * TPB) {
+      float2 xv[U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = min(base + u * (int)blockDim.x + (int)threadIdx.x, span - 1);
-        xv[u] = src[idx];
-        tv[u] = ptab[idx];
-      }
+      for (int u = 0; u < U; ++u) xv[u] = src[min(base + u * TPB + (int)threadIdx.x, span - 1)];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int idx = base + u * (int)blockDim.x + (int)threadIdx.x;
-        if (idx < span) lds[idx] = rotate(xv[u], cmulf(P0, tv[u]));
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * TPB + (int)threadIdx.x;
+        const float2 th = ptab[min(base + u * TPB, span - 1)];
+        if (idx < span) lds[idx] = rotate(xv[u], cmulf(q, th));
       }
     }
   } else {
@@ -398,30 +422,23 @@ __global__ __launch_bounds__(256) void k_chan_dec(ChanArgs a) {
     }
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int lg = lane & (GL - 1), g = lane >> LOGG;
   const int blk = wave * G + g;  // this group's block of R outputs inside the tile
   float v[2 * R];
 #pragma unroll
   for (int i = 0; i < 2 * R; ++i) v[i] = 0.0f;
-  if (blk * R < tcount) {
+  if (FULL || blk * R < tcount) {
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
       const int b = lg + 64 * pass;
-      const bool live = b < D;
-      const int bc = min(b, D - 1);
+      const int bc = min(b, D - 1);  // lanes beyond the last branch read a legal sample and multiply it by zero taps
       float H[A];
 #pragma unroll
-      for (int t = 0; t < A; ++t) {
-        const int k = D * t + bc;
-        const float tap = a.arm[min(k, ntaps - 1)];
-        H[t] = (live && k < ntaps) ? tap : 0.0f;
-      }
+      for (int t = 0; t < A; ++t) H[t] = (kTapsFirst && pass == 0) ? H0[t] : a.arm_dec[t * kTapPitch + b];
       // w[k] = x[p(m_blk + k - 32) - b]: LDS index of k = 0 is (p_first - n_lo) + blk*R*D - 32 D - b, then steps of D
       const int i0 = (A * D - 1) + blk * R * D - (A - 1) * D - bc;
       float2 w[W];
 #pragma unroll
-      for (int k = 0; k < W; ++k) w[k] = lds[min(i0 + k * D, span - 1)];
+      for (int k = 0; k < W; ++k) w[k] = lds[FULL ? i0 + k * D : min(i0 + k * D, span - 1)];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
 #pragma unroll
@@ -461,7 +478,7 @@ __global__ __launch_bounds__(256) void k_chan_dec(ChanArgs a) {
       const int idx = base + i;  // 2 r + component
       const int r = idx >> 1, comp = idx & 1;
       const int m = m0 + blk * R + r;
-      if (blk * R + r < tcount) {
+      if (FULL || blk * R + r < tcount) {
         const float y = v[i];
         if (a.next_buf) reinterpret_cast<float*>(a.next_buf + (size_t)slot * a.next_stride + a.next_hist + m)[comp] = y;
         if (m < a.cap) {
@@ -515,6 +532,7 @@ void free_sc(sc_ctx* c) {
   if (!c) return;
   for (auto& st : c->stages) {
     (void)hipFree(st.d_arm);
+    (void)hipFree(st.d_arm_dec);
     (void)hipFree(st.d_buf);
   }
   (void)hipFree(c->d_hist0);
@@ -546,6 +564,7 @@ int run_stages(sc_ctx* c, const float2* d_iq, int nsamples, int8_t* d_out_i8, fl
     a.in_buf = st.d_buf;
     a.in_stride = st.buf_stride;
     a.arm = st.d_arm;
+    a.arm_dec = st.d_arm_dec;
     a.ptab = c->d_ptab;
     a.ptab_stride = c->ptab_stride;
     a.interp = st.interp;
@@ -573,14 +592,21 @@ int run_stages(sc_ctx* c, const float2* d_iq, int nsamples, int8_t* d_out_i8, fl
     }
     const size_t lds_bytes = sizeof(float2) * (size_t)st.lds_floats2;
     if (max_out > 0 && k == 0 && st.fast) {
-      const dim3 grid((unsigned)((max_out + st.tile - 1) / st.tile), (unsigned)a.nslots), block((unsigned)(64 * st.waves));
+      // every tile is offered to both instantiations; each keeps the ones of its kind (edge tiles: 0, 1, 2 and the last)
+      const dim3 grid((unsigned)((max_out + st.tile - 1) / st.tile), (unsigned)a.nslots), edge(4, (unsigned)a.nslots), block((unsigned)(64 * st.waves));
+#define SC_LAUNCH_DEC(LOGG_, PASSES_)                                                                        \
+  do {                                                                                                       \
+    hipLaunchKernelGGL((k_chan_dec<LOGG_, PASSES_, false>), edge, block, lds_bytes, c->stream, a);           \
+    if (grid.x > 1) hipLaunchKernelGGL((k_chan_dec<LOGG_, PASSES_, true>), grid, block, lds_bytes, c->stream, a); \
+  } while (0)
       switch (st.logg * 2 + (st.passes - 1)) {
-        case 6: hipLaunchKernelGGL((k_chan_dec<3, 1>), grid, block, lds_bytes, c->stream, a); break;
-        case 8: hipLaunchKernelGGL((k_chan_dec<4, 1>), grid, block, lds_bytes, c->stream, a); break;
-        case 10: hipLaunchKernelGGL((k_chan_dec<5, 1>), grid, block, lds_bytes, c->stream, a); break;
-        case 12: hipLaunchKernelGGL((k_chan_dec<6, 1>), grid, block, lds_bytes, c->stream, a); break;
-        default: hipLaunchKernelGGL((k_chan_dec<6, 2>), grid, block, lds_bytes, c->stream, a); break;
+        case 6: SC_LAUNCH_DEC(3, 1); break;
+        case 8: SC_LAUNCH_DEC(4, 1); break;
+        case 10: SC_LAUNCH_DEC(5, 1); break;
+        case 12: SC_LAUNCH_DEC(6, 1); break;
+        default: SC_LAUNCH_DEC(6, 2); break;
       }
+#undef SC_LAUNCH_DEC
     } else if (max_out > 0) {
       const dim3 grid((unsigned)((max_out + st.tile - 1) / st.tile), (unsigned)a.nslots);
       if (k == 0) hipLaunchKernelGGL(k_chan_stage<true>, grid, dim3(256), lds_bytes, c->stream, a);
@@ -707,6 +733,15 @@ int sc_create(const sc_config* cfg, sc_ctx** out) {
     for (int k = 0; k < st.ntaps; ++k) arm[(size_t)(k % st.interp) * st.nt + k / st.interp] = st.taps[(size_t)k];
     SC_CREATE_HIP(hipMalloc(&st.d_arm, sizeof(float) * arm.size()));
     SC_CREATE_HIP(hipMemcpy(st.d_arm, arm.data(), sizeof(float) * arm.size(), hipMemcpyHostToDevice));
+    if (st.fast) {
+      const int pitch = 64 * st.passes;
+      std::vector<float> dec((size_t)kDecA * (size_t)pitch, 0.0f);
+      for (int t = 0; t < kDecA; ++t)
+        for (int b = 0; b < st.decim; ++b)
+          if (st.decim * t + b < st.ntaps) dec[(size_t)t * pitch + b] = st.taps[(size_t)(st.decim * t + b)];
+      SC_CREATE_HIP(hipMalloc(&st.d_arm_dec, sizeof(float) * dec.size()));
+      SC_CREATE_HIP(hipMemcpy(st.d_arm_dec, dec.data(), sizeof(float) * dec.size(), hipMemcpyHostToDevice));
+    }
     if (!c->stages.empty()) {
       st.buf_stride = (long long)(st.nt - 1) + st.max_in;
       SC_CREATE_HIP(hipMalloc(&st.d_buf, sizeof(float2) * (size_t)st.buf_stride * (size_t)cfg->channels));
