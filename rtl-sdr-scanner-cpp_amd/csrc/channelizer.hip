@@ -353,20 +353,18 @@ __global__ void k_chan_ptab(float2* __restrict__ tab, int n, double df) {
   if (k < n) tab[k] = phase_of(0.0, df, k);
 }
 
-// Two instantiations share the grid of tiles: FULL takes the tiles whose whole span lies in this call's input and that
+// Two instantiations share the tiles: FULL takes the tiles whose whole span lies in this call's input and that
 // produce a full set of outputs — straight-line staging and LDS reads at fixed offsets, nothing clamped; the other one
 // takes the few that start in the slot's history (tiles 0..2 at most: three tiles cover more than the filter) or end
 // ragged (the last one).
 template <int LOGG, int PASSES, bool FULL>
-__global__ __launch_bounds__(256) void k_chan_dec(ChanArgs a) {
+__device__ __forceinline__ void chan_dec_tile(const ChanArgs& a, float2* __restrict__ lds, int block_x) {
   constexpr int GL = 1 << LOGG, G = 64 / GL, A = kDecA, R = kDecR, W = A - 1 + R;
-  extern __shared__ __attribute__((aligned(16))) unsigned char chan_smem[];
-  float2* lds = reinterpret_cast<float2*>(chan_smem);
   const int s = blockIdx.y;
   const int nout = a.nout[s];
   const int tile_out = (int)(blockDim.x >> 6) * G * R;
-  int tile_index = blockIdx.x;
-  if (!FULL && blockIdx.x == 3) {
+  int tile_index = block_x;
+  if (!FULL && block_x == 3) {
     tile_index = (nout - 1) / tile_out;  // the last tile, unless it is one of the first three
     if (tile_index < 3) return;
   }
@@ -392,33 +390,43 @@ __global__ __launch_bounds__(256) void k_chan_dec(ChanArgs a) {
 #pragma unroll
     for (int t = 0; t < A; ++t) H0[t] = a.arm_dec[t * kTapPitch + lg];
   }
-  if (FULL || n_lo >= 0) {
-    // every sample of the span is in this call's input: up to 24 independent, unconditional (clamped) loads per thread
-    // in flight (the whole span of a 64-output tile at D = 64) — a load, its arithmetic and its store per loop trip would
-    // serialise on the memory latency. Phase of sample idx = TPB u + tid: (P0 T[tid]) T[TPB u], the second factor
-    // block-uniform (scalar loads), so the table costs one vector load per thread instead of one per sample.
+  {
+    // Up to 24 independent, unconditional loads per thread in flight (the whole span of a 64-output tile at D = 64), all
+    // on legal addresses — a load, its arithmetic and its store per loop trip would serialise on the memory latency.
+    // Phase of sample idx = TPB u + tid: (P0 T[tid]) T[TPB u], the second factor block-uniform (scalar loads), so the
+    // table costs one vector load per thread instead of one per sample. Tiles that begin before this call's input
+    // (edge instantiation only) take those samples, already rotated, from the slot's history; before that, zeros.
     constexpr int U = LOGG == 6 ? 24 : 12;  // smaller tiles keep four waves per SIMD: fewer registers
     const int TPB = (int)blockDim.x;  // 64, 128 or 256: as many waves as the span leaves LDS for
     const float2* src = a.in_raw + n_lo;
+    const float2* hist = a.hist0 + (size_t)slot * a.hist0_stride + h + n_lo;  // hist[idx] = stream sample n_lo + idx < 0
     const float2 q = cmulf(P0, ptab[threadIdx.x]);
-    for (int base = 0; base < span; base += U * TPB) {
+    if (FULL && span == U * TPB) {
+      // the span of a full tile at D = 64 is exactly 24 samples per thread: no clamps, no predicates
       float2 xv[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) xv[u] = src[min(base + u * TPB + (int)threadIdx.x, span - 1)];
+      for (int u = 0; u < U; ++u) xv[u] = src[u * TPB + (int)threadIdx.x];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = base + u * TPB + (int)threadIdx.x;
-        const float2 th = ptab[min(base + u * TPB, span - 1)];
-        if (idx < span) lds[idx] = rotate(xv[u], cmulf(q, th));
+      for (int u = 0; u < U; ++u) lds[u * TPB + (int)threadIdx.x] = rotate(xv[u], cmulf(q, ptab[u * TPB]));
+    } else {
+      for (int base = 0; base < span; base += U * TPB) {
+        float2 xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = min(base + u * TPB + (int)threadIdx.x, span - 1);
+          const float2* p = src + idx;
+          if (!FULL && n_lo + idx < 0) p = hist + max(idx, -(h + n_lo));
+          xv[u] = *p;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * TPB + (int)threadIdx.x;
+          const float2 th = ptab[min(base + u * TPB, span - 1)];
+          float2 v = rotate(xv[u], cmulf(q, th));
+          if (!FULL && n_lo + idx < 0) v = n_lo + idx >= -h ? xv[u] : make_float2(0.0f, 0.0f);
+          if (idx < span) lds[idx] = v;
+        }
       }
-    }
-  } else {
-    for (int idx = threadIdx.x; idx < span; idx += blockDim.x) {
-      const int n = n_lo + idx;
-      float2 v = make_float2(0.0f, 0.0f);
-      if (n >= 0) v = rotate(a.in_raw[n], cmulf(P0, ptab[idx]));
-      else if (n >= -h) v = a.hist0[(size_t)slot * a.hist0_stride + (h + n)];
-      lds[idx] = v;
     }
   }
   __syncthreads();
@@ -488,6 +496,25 @@ __global__ __launch_bounds__(256) void k_chan_dec(ChanArgs a) {
       }
     }
   }
+}
+
+// One launch: blocks [0, gridDim.x - 4) offer every tile to the full-tile code, the last four blocks offer tiles 0, 1, 2 and
+// the last one to the edge code (block-uniform branch; each side returns at once when the tile is of the other kind).
+template <int LOGG, int PASSES>
+__global__ __launch_bounds__(256) void k_chan_dec(ChanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chan_smem[];
+  float2* lds = reinterpret_cast<float2*>(chan_smem);
+  const int ntiles = (int)gridDim.x - 4;
+  if ((int)blockIdx.x < ntiles) chan_dec_tile<LOGG, PASSES, true>(a, lds, (int)blockIdx.x);
+  else chan_dec_tile<LOGG, PASSES, false>(a, lds, (int)blockIdx.x - ntiles);
+}
+
+// The same as two launches (edge tiles first: grid.x = 4): where the merged kernel's register count — the larger of the
+// two sides' — would cost a wave per SIMD (measured: D <= 32 and the two-pass D > 64 form are faster split, D = 33..64 merged).
+template <int LOGG, int PASSES, bool FULL>
+__global__ __launch_bounds__(256) void k_chan_dec_split(ChanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chan_smem[];
+  chan_dec_tile<LOGG, PASSES, FULL>(a, reinterpret_cast<float2*>(chan_smem), (int)blockIdx.x);
 }
 
 // After a call: the newest h samples of [history | new samples] become the history. One workgroup per slot, staged
@@ -592,21 +619,23 @@ int run_stages(sc_ctx* c, const float2* d_iq, int nsamples, int8_t* d_out_i8, fl
     }
     const size_t lds_bytes = sizeof(float2) * (size_t)st.lds_floats2;
     if (max_out > 0 && k == 0 && st.fast) {
-      // every tile is offered to both instantiations; each keeps the ones of its kind (edge tiles: 0, 1, 2 and the last)
-      const dim3 grid((unsigned)((max_out + st.tile - 1) / st.tile), (unsigned)a.nslots), edge(4, (unsigned)a.nslots), block((unsigned)(64 * st.waves));
-#define SC_LAUNCH_DEC(LOGG_, PASSES_)                                                                        \
-  do {                                                                                                       \
-    hipLaunchKernelGGL((k_chan_dec<LOGG_, PASSES_, false>), edge, block, lds_bytes, c->stream, a);           \
-    if (grid.x > 1) hipLaunchKernelGGL((k_chan_dec<LOGG_, PASSES_, true>), grid, block, lds_bytes, c->stream, a); \
+      // every tile is offered to the full-tile code, tiles 0, 1, 2 and the last one also to the edge code (four more blocks,
+      // or a launch of their own)
+      const unsigned tiles = (unsigned)((max_out + st.tile - 1) / st.tile);
+      const dim3 merged(tiles + 4u, (unsigned)a.nslots), grid(tiles, (unsigned)a.nslots), edge(4, (unsigned)a.nslots), block((unsigned)(64 * st.waves));
+#define SC_LAUNCH_SPLIT(LOGG_, PASSES_)                                                                                          \
+  do {                                                                                                                           \
+    hipLaunchKernelGGL((k_chan_dec_split<LOGG_, PASSES_, false>), edge, block, lds_bytes, c->stream, a);                         \
+    if (tiles > 1) hipLaunchKernelGGL((k_chan_dec_split<LOGG_, PASSES_, true>), grid, block, lds_bytes, c->stream, a);           \
   } while (0)
       switch (st.logg * 2 + (st.passes - 1)) {
-        case 6: SC_LAUNCH_DEC(3, 1); break;
-        case 8: SC_LAUNCH_DEC(4, 1); break;
-        case 10: SC_LAUNCH_DEC(5, 1); break;
-        case 12: SC_LAUNCH_DEC(6, 1); break;
-        default: SC_LAUNCH_DEC(6, 2); break;
+        case 6: SC_LAUNCH_SPLIT(3, 1); break;
+        case 8: SC_LAUNCH_SPLIT(4, 1); break;
+        case 10: SC_LAUNCH_SPLIT(5, 1); break;
+        case 12: hipLaunchKernelGGL((k_chan_dec<6, 1>), merged, block, lds_bytes, c->stream, a); break;
+        default: SC_LAUNCH_SPLIT(6, 2); break;
       }
-#undef SC_LAUNCH_DEC
+#undef SC_LAUNCH_SPLIT
     } else if (max_out > 0) {
       const dim3 grid((unsigned)((max_out + st.tile - 1) / st.tile), (unsigned)a.nslots);
       if (k == 0) hipLaunchKernelGGL(k_chan_stage<true>, grid, dim3(256), lds_bytes, c->stream, a);
