@@ -284,6 +284,63 @@ def test_two_contexts_are_independent(oracle_mod):
     check_plane("b", np.concatenate([rb1["avg"], rb2["avg"]]), ob["avg"])
 
 
+def test_contexts_on_their_own_threads_with_control_calls_from_a_third():
+    """The reference runs one chain per device, each on GNU Radio's scheduler threads, and reads / retunes them from the
+    Scanner thread (control entry points take the block's mutex). Four contexts driven from four threads while
+    a fifth thread keeps reading their noise ceilings: every context must produce exactly what it produces alone."""
+    import threading
+    n, fs, nframes, chunk = 2048, 512_000, 160, 16
+    seeds = [31, 32, 33, 34]
+    bands = [pkg.synth.SyntheticBand(n, seed=s_, on_frame=30, off_frame=120) for s_ in seeds]
+    data = [b.frames_cf32(nframes) for b in bands]
+
+    def scan(eng, x, retune_at, out):
+        for pos in range(0, nframes, chunk):
+            if pos == retune_at:  # what SdrDevice::setFrequencyRange does to its chain (sdr_device.cpp:66-77)
+                eng.set_frequency_range(150_000_000 - fs // 2, 150_000_000 + fs // 2)
+                eng.reset()
+            r = eng.process(x[pos:pos + chunk], want=("avg",))
+            out.append((r["avg"].copy(), r["cand_off"].copy(), r["cand_idx"].copy()))
+
+    def make(k):
+        return pkg.SpectrumEngine(fs, 140_000_000 + 2_000_000 * k, fft_size=n, decim=1, learn_frames=10, max_batch=chunk)
+
+    alone = []
+    for k in range(4):
+        out = []
+        scan(make(k), data[k], 96 if k % 2 else -1, out)
+        alone.append(out)
+    engines = [make(k) for k in range(4)]
+    together = [[] for _ in range(4)]
+    stop = threading.Event()
+    reads = [0]
+
+    def poke():
+        while not stop.is_set():
+            for e in engines:
+                thr, _learned = e.read_noise()
+                assert thr.shape == (n,)
+                reads[0] += 1
+
+    workers = [threading.Thread(target=scan, args=(engines[k], data[k], 96 if k % 2 else -1, together[k])) for k in range(4)]
+    poker = threading.Thread(target=poke)
+    poker.start()
+    for w in workers:
+        w.start()
+    for w in workers:
+        w.join()
+    stop.set()
+    poker.join()
+    assert reads[0] > 0
+    for k in range(4):
+        assert len(together[k]) == len(alone[k]) == nframes // chunk
+        for (a1, o1, i1), (a2, o2, i2) in zip(alone[k], together[k]):
+            np.testing.assert_array_equal(a1, a2)
+            np.testing.assert_array_equal(o1, o2)
+            np.testing.assert_array_equal(i1, i2)
+    assert sum(int(o[-1]) for _, o, _ in alone[0]) > 100
+
+
 @pytest.mark.parametrize("impl", ["detect", "standalone"])
 def test_spectrogram_side_branch(oracle_mod, impl, monkeypatch):
     """Spectrogram::process/send (spectrogram.cpp:45-75) on the raw PSD: bin-decimated mean accumulated over frames,
