@@ -258,12 +258,16 @@ __global__ __launch_bounds__(512, 4) void k_fft256xR_psd(const void* __restrict_
 // The same decomposition for the ROWS of a four-step with N2 = 256 R, R = 2, 4 (N = 131072, 262144): 32 / R rows k1 per
 // workgroup straight from the work buffer (the step-A twiddle is already in it), X_row[k' + 256 kap] -> bin
 // k1 + 256 (k' + 256 kap). The dB values go through LDS once more ([k2][row], pitch rows + 1) so that stores run along k1.
-constexpr int kFftRowsRLdsBytes = 1024 * 9 * 4;  // R = 4: 1024 k2 x (8 rows + 1); R = 2: 512 x 17 is smaller; both >= 32 x 257
+// LDS of k_fft_rows256xR_psd: the Z planes (32 sub-sequences x 257) or the read-out tile (N2 k2 x (32 / R rows + 1)), whichever is larger
+constexpr int fft_rowsR_lds_bytes(int logr) {
+  const int n2 = 256 << logr, fpw = 32 >> logr;
+  return 4 * (n2 * (fpw + 1) > 32 * 257 ? n2 * (fpw + 1) : 32 * 257);
+}
 
 template <int LOGR>
 __global__ __launch_bounds__(512, 4) void k_fft_rows256xR_psd(const float2* __restrict__ work, const float2* __restrict__ tw256,
                                                               const float2* __restrict__ twn /* [q][k'] W_N2^(q k') */, float db_off,
-                                                              float* __restrict__ psd) {
+                                                              float* __restrict__ psd, int xcd_map) {
   constexpr int R = 1 << LOGR, N2 = 256 * R, FPW = 32 / R, U = 16 / R, LOGN = 16 + LOGR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s = reinterpret_cast<float*>(smem_raw);
@@ -271,8 +275,20 @@ __global__ __launch_bounds__(512, 4) void k_fft_rows256xR_psd(const float2* __re
   const int fl = t >> (4 + LOGR), tt = t & (16 * R - 1);
   const int q = tt & (R - 1), j = tt >> LOGR;
   constexpr int TILES = 256 / FPW;
-  const int f = blockIdx.x / TILES;
-  const int r0 = (blockIdx.x % TILES) * FPW;
+  // A tile's dB values leave as runs of FPW floats along k1 (one run per k2): 32 / FPW neighbouring tiles share every
+  // 128-byte line of the PSD plane. Consecutive blocks go to consecutive XCDs (block b -> XCD b mod 8, each with its own
+  // L2), so with the plain order the pieces of a line are written through eight different L2s; xcd_map hands XCD x
+  // the rows [32 x, 32 x + 32) of every frame, its tiles in consecutive blocks of that XCD, and the pieces meet in one L2.
+  int f, r0;
+  if (xcd_map) {
+    constexpr int GT = 32 / FPW;  // tiles per 32-row group
+    const int x = blockIdx.x & 7, v = blockIdx.x >> 3;
+    f = v / GT;
+    r0 = (x * GT + v % GT) * FPW;
+  } else {
+    f = blockIdx.x / TILES;
+    r0 = (blockIdx.x % TILES) * FPW;
+  }
   const float2* row = work + ((size_t)f << LOGN) + (size_t)(r0 + fl) * N2;
   float2 a[16];
 #pragma unroll

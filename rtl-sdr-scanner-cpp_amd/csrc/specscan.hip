@@ -116,7 +116,8 @@ struct ss_ctx {
   float* d_avg = nullptr;
   float2* d_work = nullptr;  // four-step intermediate (N > 8192)
   float2* d_tw256 = nullptr; // W_256^(m r), r*16 + m: second pass of the 256-point register FFTs (N >= 65536)
-  float2* d_tw_rowsR = nullptr;  // N = 2^17, 2^18: [q][k'] W_N2^(q k') for k_fft_rows256xR_psd (N2 = 512, 1024)
+  bool fft_xcd_map = true;  // k_fft_rows256xR_psd: XCD-aware tile order
+  float2* d_tw_rowsR = nullptr;  // N = 2^17 .. 2^19: [q][k'] W_N2^(q k') for k_fft_rows256xR_psd (N2 = 512 .. 2048)
   float2* d_tw_small = nullptr;  // N = 1024, 2048, 4096: [q][k'] W_N^(q k') for the final radix-R pass of k_fft256xR_psd
   float2* d_tw_sub = nullptr;   // N = 2^19, 2^20: [c][b] W_N2^(b c) for k_fft_sub_dft (N2 = N / 256 = 256 A)
   float2* d_tw_cols = nullptr;  // N >= 65536: step-A twiddle factored for k_fft_cols256, [j][n2] W_N^(n2 j) then [k][n2] W_N^(16 n2 k)
@@ -252,11 +253,12 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
                        (const float2*)c->d_tw256, c->db_off, d_psd, 16, 0);
   } else {
     bool done = false;
-    if constexpr (LOGN2 == 9 || LOGN2 == 10) {
-      if (c->d_tw_rowsR) {  // rows of 512 / 1024 points in registers
+    if constexpr (LOGN2 >= 9 && LOGN2 <= 12) {
+      if (c->d_tw_rowsR) {  // rows of 256 R points: R sub-sequences through the register passes, an R-point DFT across them
         constexpr int LOGR = LOGN2 - 8;
-        hipLaunchKernelGGL((ss::k_fft_rows256xR_psd<LOGR>), dim3(nframes * (256 / (32 >> LOGR))), dim3(512), ss::kFftRowsRLdsBytes, c->stream,
-                           (const float2*)c->d_work, (const float2*)c->d_tw256, (const float2*)c->d_tw_rowsR, c->db_off, d_psd);
+        hipLaunchKernelGGL((ss::k_fft_rows256xR_psd<LOGR>), dim3(nframes * (256 / (32 >> LOGR))), dim3(512), ss::fft_rowsR_lds_bytes(LOGR),
+                           c->stream, (const float2*)c->d_work, (const float2*)c->d_tw256, (const float2*)c->d_tw_rowsR, c->db_off, d_psd,
+                           c->fft_xcd_map ? 1 : 0);
         done = true;
       }
     }
@@ -869,7 +871,9 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
           }
         CREATE_HIP(hipMalloc(&c->d_tw_cols, sizeof(float2) * tc.size()));
         CREATE_HIP(hipMemcpy(c->d_tw_cols, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
-        if ((n2size == 512 || n2size == 1024) && !(getenv("SS_FFT_ROWSR") && getenv("SS_FFT_ROWSR")[0] == '0')) {
+        const char* rows_env = getenv("SS_FFT_ROWSR");  // A/B: "0" never, "1" for every N2 = 512 .. 4096
+        c->fft_xcd_map = !(getenv("SS_FFT_XCDMAP") && getenv("SS_FFT_XCDMAP")[0] == '0');
+        if (n2size >= 512 && n2size <= 4096 && (rows_env ? rows_env[0] == '1' : n2size <= 2048)) {  // 4096-point rows: a tie with the two-kernel form
           const int R = n2size / 256;
           std::vector<float2> tr((size_t)R * 256);
           for (int q = 0; q < R; ++q)
@@ -881,7 +885,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
           CREATE_HIP(hipMemcpy(c->d_tw_rowsR, tr.data(), sizeof(float2) * tr.size(), hipMemcpyHostToDevice));
         }
         const char* sub_env = getenv("SS_FFT_SUB");  // A/B: "0" never, "1" whenever N2 > 256
-        if (n2size > 256 && (sub_env ? sub_env[0] == '1' : n2size >= 2048)) {
+        if (n2size > 256 && !c->d_tw_rowsR && (sub_env ? sub_env[0] == '1' : n2size >= 2048)) {
           const int A = n2size / 256;
           std::vector<float2> ts((size_t)A * 256);
           for (int cc = 0; cc < A; ++cc)

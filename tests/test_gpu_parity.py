@@ -120,9 +120,13 @@ def test_gpu_fft_is_as_accurate_as_the_cpu_fp32_ffts(oracle_mod):
     assert np.abs(got - exact_db)[~weak].max() < 2e-5 and np.abs(ref - exact_db)[~weak].max() < 2e-5
 
 
-@pytest.mark.parametrize("logn", [20, 19, 18])
-def test_one_million_point_frames(oracle_mod, logn):
-    """BASELINE config 5 frame size (2^20; 2^19 takes the same three-pass path with radix 8, 2^18 the two-pass path with generic 1024-point rows), detect chain on a few frames."""
+@pytest.mark.parametrize("logn,rows", [(20, ""), (20, "1"), (19, ""), (19, "0"), (18, ""), (18, "0"), (17, "0")])
+def test_one_million_point_frames(oracle_mod, logn, rows, monkeypatch):
+    """BASELINE config 5 frame size (2^20) and the sizes below it, detect chain on a few frames. Rows of the four-step
+    transform: one register-pass kernel per row of 512 .. 2048 points (default up to 2^19; forced for 2^20 with
+    SS_FFT_ROWSR=1), or radix-A step + 256-point rows (default at 2^20, forced with "0"; generic LDS rows below 2^19)."""
+    if rows:
+        monkeypatch.setenv("SS_FFT_ROWSR", rows)
     n, fs, center = 1 << logn, 61_440_000, 400_000_000
     band = pkg.synth.SyntheticBand(n, seed=9, on_frame=2, off_frame=100, comb_width=48)
     iq = band.frames_cf32(6)
