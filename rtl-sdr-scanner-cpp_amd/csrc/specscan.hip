@@ -67,12 +67,41 @@ struct ss_ctx {
   // development diagnostics, read from the environment once at ss_create and owned by the context:
   //   SS_DEBUG_TIMING_FFT=<file> / SS_DEBUG_TIMING=<file>: per-workgroup clock stamps of the 20th FFT / detect launch
   //   SS_FFT_ABLATE=1|2: memory-only / transform-only variant of the 8192-point kernel (profiles/README.md)
+  // Measurement hooks, read from the environment once, in ss_create (Diag::read); none of them changes results beyond
+  // the parity contract, all of them exist to time one implementation against another (DESIGN.md "Measurement hooks").
   struct Diag {
-    std::string fft_stamp_path, detect_stamp_path;
-    long long* d_fft_stamps = nullptr;     // 8 stamps x up to 8192 workgroups
-    long long* d_detect_stamps = nullptr;  // 4 stamps x up to 65536 workgroups
+    std::string fft_stamp_path, detect_stamp_path;  // SS_DEBUG_TIMING_FFT / SS_DEBUG_TIMING: files for per-workgroup clock stamps
+    long long* d_fft_stamps = nullptr;              // 8 stamps x up to 8192 workgroups
+    long long* d_detect_stamps = nullptr;           // 4 stamps x up to 65536 workgroups
     int fft_calls = 0, detect_calls = 0;
-    int fft_ablate = 0;
+    int fft_ablate = 0;            // SS_FFT_ABLATE: 1 = memory traffic only, 2 = transform only (8192-point kernel; results are garbage)
+    bool backend_unfused = false;  // SS_BACKEND=unfused: per-stage back-end kernels also for the 21 x 21 grouping
+    bool fft_generic = false;      // SS_FFT_IMPL=generic: radix-4 LDS kernels instead of the register-pass ones
+    bool fft_wide = false;         // SS_FFT_IMPL=wide: the four-wave 8192-point kernel instead of the eight-wave one
+    int fft_rows_r = -1;           // SS_FFT_ROWSR: 0 never / 1 always use k_fft_rows256xR_psd for N2 = 512..4096 (-1: up to 2048)
+    int fft_sub = -1;              // SS_FFT_SUB: 0 never / 1 always split N2 > 256 rows into radix-A step + 256-point rows (-1: from 2048)
+    bool fft_xcd_map = true;       // SS_FFT_XCDMAP=0: plain tile order in k_fft_rows256xR_psd
+    bool spec_standalone = false;  // SS_SPEC_IMPL=standalone: spectrogram by its own two kernels instead of inside k_detect_fused
+    void read() {
+      const auto is = [](const char* name, const char* value) {
+        const char* v = getenv(name);
+        return v && strcmp(v, value) == 0;
+      };
+      const auto tri = [](const char* name) {
+        const char* v = getenv(name);
+        return !v ? -1 : (v[0] == '1' ? 1 : 0);
+      };
+      if (const char* pth = getenv("SS_DEBUG_TIMING_FFT")) fft_stamp_path = pth;
+      if (const char* pth = getenv("SS_DEBUG_TIMING")) detect_stamp_path = pth;
+      if (const char* ab = getenv("SS_FFT_ABLATE")) fft_ablate = atoi(ab);
+      backend_unfused = is("SS_BACKEND", "unfused");
+      fft_generic = is("SS_FFT_IMPL", "generic");
+      fft_wide = is("SS_FFT_IMPL", "wide");
+      fft_rows_r = tri("SS_FFT_ROWSR");
+      fft_sub = tri("SS_FFT_SUB");
+      fft_xcd_map = tri("SS_FFT_XCDMAP") != 0;
+      spec_standalone = is("SS_SPEC_IMPL", "standalone");
+    }
   } diag;
   uint8_t* d_pass = nullptr;
   bool pass_dirty = true;
@@ -116,7 +145,6 @@ struct ss_ctx {
   float* d_avg = nullptr;
   float2* d_work = nullptr;  // four-step intermediate (N > 8192)
   float2* d_tw256 = nullptr; // W_256^(m r), r*16 + m: second pass of the 256-point register FFTs (N >= 65536)
-  bool fft_xcd_map = true;  // k_fft_rows256xR_psd: XCD-aware tile order
   float2* d_tw_rowsR = nullptr;  // N = 2^17 .. 2^19: [q][k'] W_N2^(q k') for k_fft_rows256xR_psd (N2 = 512 .. 2048)
   float2* d_tw_small = nullptr;  // N = 1024, 2048, 4096: [q][k'] W_N^(q k') for the final radix-R pass of k_fft256xR_psd
   float2* d_tw_sub = nullptr;   // N = 2^19, 2^20: [c][b] W_N2^(b c) for k_fft_sub_dft (N2 = N / 256 = 256 A)
@@ -258,7 +286,7 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
         constexpr int LOGR = LOGN2 - 8;
         hipLaunchKernelGGL((ss::k_fft_rows256xR_psd<LOGR>), dim3(nframes * (256 / (32 >> LOGR))), dim3(512), ss::fft_rowsR_lds_bytes(LOGR),
                            c->stream, (const float2*)c->d_work, (const float2*)c->d_tw256, (const float2*)c->d_tw_rowsR, c->db_off, d_psd,
-                           c->fft_xcd_map ? 1 : 0);
+                           c->diag.fft_xcd_map ? 1 : 0);
         done = true;
       }
     }
@@ -757,19 +785,10 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   CREATE_HIP(hipMalloc(&c->d_win, sizeof(float) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_tw, sizeof(float2) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_pass, (size_t)n));
-  if (const char* pth = getenv("SS_DEBUG_TIMING_FFT")) {
-    c->diag.fft_stamp_path = pth;
-    CREATE_HIP(hipMalloc(&c->diag.d_fft_stamps, sizeof(long long) * 8 * 8192));
-  }
-  if (const char* pth = getenv("SS_DEBUG_TIMING")) {
-    c->diag.detect_stamp_path = pth;
-    CREATE_HIP(hipMalloc(&c->diag.d_detect_stamps, sizeof(long long) * 4 * 65536));
-  }
-  if (const char* ab = getenv("SS_FFT_ABLATE")) c->diag.fft_ablate = atoi(ab);
-  {
-    const char* be = getenv("SS_BACKEND");  // "unfused" forces the per-stage kernels (A/B measurements)
-    c->fused = G == 21 && cfg->grouping_x == 21 && cfg->max_batch <= 65536 && !(be && strcmp(be, "unfused") == 0);
-  }
+  c->diag.read();
+  if (!c->diag.fft_stamp_path.empty()) CREATE_HIP(hipMalloc(&c->diag.d_fft_stamps, sizeof(long long) * 8 * 8192));
+  if (!c->diag.detect_stamp_path.empty()) CREATE_HIP(hipMalloc(&c->diag.d_detect_stamps, sizeof(long long) * 4 * 65536));
+  c->fused = G == 21 && cfg->grouping_x == 21 && cfg->max_batch <= 65536 && !c->diag.backend_unfused;
   if (c->fused) {
     {
       // ring capacity: at least three windows (a long batch needs a free one next to the one it reads), more when rows
@@ -806,7 +825,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     c->spec_m = n / out_n;
     // inside the detect kernel when that kernel runs and a tile's 256 bins hold whole groups of m: one partial row per
     // frame tile (a batch that starts inside a tile touches one more)
-    c->spec_in_detect = c->fused && c->spec_m <= 256 && !(getenv("SS_SPEC_IMPL") && strcmp(getenv("SS_SPEC_IMPL"), "standalone") == 0);
+    c->spec_in_detect = c->fused && c->spec_m <= 256 && !c->diag.spec_standalone;
     if (c->spec_in_detect) {
       const size_t tiles = (size_t)(cfg->max_batch + kFusedTF - 1) / kFusedTF + 1;
       for (int k = 0; k < 2; ++k) CREATE_HIP(hipMalloc(&c->d_spec_part2[k], sizeof(float) * (size_t)out_n * tiles));
@@ -831,7 +850,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       const double ang = -2.0 * M_PI * (double)k / (double)n;
       tw[(size_t)k] = make_float2((float)cos(ang), (float)sin(ang));
     }
-    if ((n == 1024 || n == 2048 || n == 4096) && !(getenv("SS_FFT_IMPL") && strcmp(getenv("SS_FFT_IMPL"), "generic") == 0)) {
+    if ((n == 1024 || n == 2048 || n == 4096) && !c->diag.fft_generic) {
       const int R = n / 256;
       std::vector<float2> t256(256), tn((size_t)R * 256);
       for (int r = 0; r < 16; ++r)
@@ -850,8 +869,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       CREATE_HIP(hipMemcpy(c->d_tw_small, tn.data(), sizeof(float2) * tn.size(), hipMemcpyHostToDevice));
     }
     if (n >= 16384) {
-      const char* impl = getenv("SS_FFT_IMPL");  // "generic" keeps the LDS radix-4 four-step kernels (A/B measurements)
-      c->use_fft256 = !(impl && strcmp(impl, "generic") == 0);
+      c->use_fft256 = !c->diag.fft_generic;
       std::vector<float2> t256(256);
       for (int r = 0; r < 16; ++r)
         for (int m = 0; m < 16; ++m) {
@@ -871,9 +889,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
           }
         CREATE_HIP(hipMalloc(&c->d_tw_cols, sizeof(float2) * tc.size()));
         CREATE_HIP(hipMemcpy(c->d_tw_cols, tc.data(), sizeof(float2) * tc.size(), hipMemcpyHostToDevice));
-        const char* rows_env = getenv("SS_FFT_ROWSR");  // A/B: "0" never, "1" for every N2 = 512 .. 4096
-        c->fft_xcd_map = !(getenv("SS_FFT_XCDMAP") && getenv("SS_FFT_XCDMAP")[0] == '0');
-        if (n2size >= 512 && n2size <= 4096 && (rows_env ? rows_env[0] == '1' : n2size <= 2048)) {  // 4096-point rows: a tie with the two-kernel form
+        if (n2size >= 512 && n2size <= 4096 && (c->diag.fft_rows_r >= 0 ? c->diag.fft_rows_r == 1 : n2size <= 2048)) {  // 4096-point rows: a tie with the two-kernel form
           const int R = n2size / 256;
           std::vector<float2> tr((size_t)R * 256);
           for (int q = 0; q < R; ++q)
@@ -884,8 +900,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
           CREATE_HIP(hipMalloc(&c->d_tw_rowsR, sizeof(float2) * tr.size()));
           CREATE_HIP(hipMemcpy(c->d_tw_rowsR, tr.data(), sizeof(float2) * tr.size(), hipMemcpyHostToDevice));
         }
-        const char* sub_env = getenv("SS_FFT_SUB");  // A/B: "0" never, "1" whenever N2 > 256
-        if (n2size > 256 && !c->d_tw_rowsR && (sub_env ? sub_env[0] == '1' : n2size >= 2048)) {
+        if (n2size > 256 && !c->d_tw_rowsR && (c->diag.fft_sub >= 0 ? c->diag.fft_sub == 1 : n2size >= 2048)) {
           const int A = n2size / 256;
           std::vector<float2> ts((size_t)A * 256);
           for (int cc = 0; cc < A; ++cc)
@@ -899,9 +914,8 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       }
     }
     if (n == 8192) {
-      const char* impl = getenv("SS_FFT_IMPL");  // "generic" selects the radix-4 LDS kernel (A/B measurements)
-      c->use_fft8192 = !(impl && strcmp(impl, "generic") == 0);
-      if (impl && strcmp(impl, "wide") == 0) c->fft8192_variant = 2;
+      c->use_fft8192 = !c->diag.fft_generic;
+      if (c->diag.fft_wide) c->fft8192_variant = 2;
       std::vector<float2> t8((size_t)(256 + 1024 + 2048));
       auto W = [](double num, double den) {
         const double ang = -2.0 * M_PI * num / den;
