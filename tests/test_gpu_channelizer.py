@@ -149,6 +149,33 @@ def test_result_does_not_depend_on_the_call_sizes():
     assert (c8 != w8).mean() < 1e-3
 
 
+@pytest.mark.parametrize("fs,bw", [(2_048_000, 32_000), (2_000_000, 20_000), (2_048_000, 16_000), (250_000, 25_000)])
+def test_branch_kernel_equals_the_generic_stage_kernel(fs, bw, monkeypatch):
+    """The polyphase-by-branch first stage (full-tile and edge code) against the one-output-per-lane kernel (SC_GENERIC=1)
+    on the same stream cut into the same ragged calls: two summation orders of the same fp32 products."""
+    n = 140_000
+    x = _stream(n, fs, [fs / 7.0, -fs / 5.0], seed=9)
+    outs = []
+    for generic in ("0", "1"):
+        monkeypatch.setenv("SC_GENERIC", generic)
+        ch = Channelizer(fs, bw, channels=2, max_samples=1 << 16)
+        ch.start(0, int(fs / 7))
+        ch.start(1, int(-fs / 5))
+        parts, pos = [[], []], 0
+        for s_ in (3, 40_000, 65_536, 1, 20_000, 14_460):
+            r = ch.process(x[pos:pos + s_])
+            for k in (0, 1):
+                parts[k].append(r[k][1])
+            pos += s_
+        assert pos == n
+        outs.append([np.concatenate(p) for p in parts])
+        ch.close()
+    for k in (0, 1):
+        a, b = outs[0][k], outs[1][k]
+        assert len(a) == len(b) > 500
+        assert np.abs(a - b).max() < 3e-6 * np.abs(b).max()
+
+
 def test_start_stop_keeps_state_like_the_reference():
     """An idle slot sees no samples (Blocker drops them): its rotator phase and filter histories stay as they were and
     the next recording starts from them (recorder.cpp:58-87 never resets the blocks)."""

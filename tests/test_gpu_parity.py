@@ -92,6 +92,31 @@ def test_engine_matches_oracle(oracle_mod, n, fs, decim, fmt, nframes, chunk, le
     check_plane("noise ceiling", thr_g[None], thr_o[None])
 
 
+ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurement hook of DESIGN.md 6f meets the same contract
+    ({"SS_BACKEND": "unfused"}, 8192, 2_048_000, "cf32"),
+    ({"SS_FFT_IMPL": "generic"}, 8192, 2_048_000, "cf32"),
+    ({"SS_FFT_IMPL": "wide"}, 8192, 2_048_000, "cs8"),
+    ({"SS_FFT_IMPL": "generic"}, 2048, 512_000, "cf32"),
+    ({"SS_FFT_IMPL": "generic"}, 65536, 20_000_000, "cs8"),
+    ({"SS_FFT_ROWSR": "0", "SS_FFT_SUB": "1"}, 131072, 20_000_000, "cf32"),
+    ({"SS_FFT_XCDMAP": "0"}, 262144, 20_000_000, "cf32"),
+]
+
+
+@pytest.mark.parametrize("env,n,fs,fmt", ALTERNATIVES, ids=lambda v: "-".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
+def test_alternative_implementations_meet_the_contract(oracle_mod, monkeypatch, env, n, fs, fmt):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    nframes, learn = 48, 6
+    band = pkg.synth.SyntheticBand(n, seed=14, on_frame=learn + 5, off_frame=nframes - 3)
+    iq, in_format = (band.frames_cf32(nframes), pkg.abi.SS_FMT_CF32) if fmt == "cf32" else (band.frames_cs8(nframes), pkg.abi.SS_FMT_CS8)
+    kw = dict(fft_size=n, decim=1, in_format=in_format, learn_frames=learn, max_batch=20)
+    got = _run(pkg.SpectrumEngine(fs, 145_000_000, **kw), iq, 20)
+    ref = _run(oracle_mod.oracle_chain(fs, 145_000_000, **kw), iq, 20)
+    errs, ncand, ndc = check_all(got, ref)
+    assert ncand > 50 and ndc <= max(2, ncand // 200), (ncand, ndc)
+
+
 def test_gpu_fft_is_as_accurate_as_the_cpu_fp32_ffts(oracle_mod):
     """Against an fp64 evaluation of the same definition (window, FFT, |X|^2/fs), the engine's PSD is as close
     as the oracle's fp32 FFT is (and as MKL's FFTW interface is, tests/test_oracle_fft.py): the parity
