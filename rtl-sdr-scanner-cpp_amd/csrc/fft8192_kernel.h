@@ -281,7 +281,8 @@ __device__ __forceinline__ float2 mulw32_if(float2 x, bool on) {
   return on ? y : x;
 }
 
-// ABLATE (diagnostic, SS_FFT_ABLATE): 1 = memory traffic only (same loads and store count, no transform), 2 = transform
+// ABLATE (diagnostic, SS_FFT_ABLATE): 1 = memory traffic only (same loads and store count, no transform), 3 / 4 = the same
+// bytes with 16-byte stores / 16-byte loads and stores (19.5 / 20.0 / 16.7 us per 1024 frames), 2 = transform
 // only (no global loads, stores never execute). Measured at 1024 / 4096 frames per launch: full 26.1 / 90.7 us,
 // memory only 19.2 / 72.3 us, transform only 16.7 / 48.6 us — see DESIGN.md.
 template <int FMT, int WAVES_PER_SIMD, bool DBG = false, int ABLATE = 0>
@@ -296,6 +297,30 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
   long long ts[DBG ? 8 : 1] = {};  // DBG: per-workgroup wall_clock64 stamps of the phases (SS_DEBUG_TIMING_FFT)
   if constexpr (DBG) if (t == 0) ts[0] = wall_clock64();
 
+  if constexpr (ABLATE == 3 || ABLATE == 4) {
+    // what the same bytes cost with wider accesses: 3 = the kernel's own 8-byte loads + 16-byte stores, 4 = 16-byte loads too
+    float acc[16];
+    if constexpr (ABLATE == 3) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float2 x = load_iq<FMT>(iq, in_base + t + 512 * r, scale);
+        acc[r] = x.x + x.y * win[t + 512 * r];
+      }
+    } else {
+      const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(iq) + in_base);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float4 x = src[t + 512 * r];
+        const float2 w = reinterpret_cast<const float2*>(win)[t + 512 * r];
+        acc[2 * r] = x.x + x.y * w.x;
+        acc[2 * r + 1] = x.z + x.w * w.y;
+      }
+    }
+    float4* dst = reinterpret_cast<float4*>(psd + frame * 8192);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[t + 512 * r] = make_float4(acc[4 * r], acc[4 * r + 1], acc[4 * r + 2], acc[4 * r + 3]);
+    return;
+  }
   // ---------------- pass 1: radix 16, Ns = 1, butterfly j = t ----------------
   float2 a[16];
 #pragma unroll

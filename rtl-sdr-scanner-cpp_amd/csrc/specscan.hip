@@ -74,7 +74,7 @@ struct ss_ctx {
     long long* d_fft_stamps = nullptr;              // 8 stamps x up to 8192 workgroups
     long long* d_detect_stamps = nullptr;           // 4 stamps x up to 65536 workgroups
     int fft_calls = 0, detect_calls = 0;
-    int fft_ablate = 0;            // SS_FFT_ABLATE: 1 = memory traffic only, 2 = transform only (8192-point kernel; results are garbage)
+    int fft_ablate = 0;            // SS_FFT_ABLATE: 1 = memory traffic only, 2 = transform only, 3 / 4 = traffic with wider accesses (8192-point kernel; results are garbage)
     bool backend_unfused = false;  // SS_BACKEND=unfused: per-stage back-end kernels also for the 21 x 21 grouping
     bool fft_generic = false;      // SS_FFT_IMPL=generic: radix-4 LDS kernels instead of the register-pass ones
     bool fft_wide = false;         // SS_FFT_IMPL=wide: the four-wave 8192-point kernel instead of the eight-wave one
@@ -339,6 +339,8 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
     const int ablate = c->diag.fft_ablate;
     if (ablate == 1) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 1>, ss::kFft8192W8LdsBytes);
     else if (ablate == 2) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 2>, ss::kFft8192W8LdsBytes);
+    else if (ablate == 3) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 3>, ss::kFft8192W8LdsBytes);
+    else if (ablate == 4 && FMT == ss::FMT_CF32) launch8(ss::k_fft8192_psd_w8<ss::FMT_CF32, 8, false, 4>, ss::kFft8192W8LdsBytes);
     else if constexpr (FMT == ss::FMT_CF32) launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
     // int8 IQ: the conversion needs a few more registers; at 64 (8 waves/SIMD) the kernel spills and takes 27.7 us per 1024
     // frames, at 80 (6 waves) 23.0 us. cf32 is the other way round (26.3 vs 26.9 us).
