@@ -132,6 +132,23 @@ __device__ __forceinline__ void dft32(float2 (&v)[32]) {
 //   tw2[r*16 + m]   = W_256^(m r)        r = 0..15, m = 0..15
 //   tw3a[r1*256 + t] = W_8192^(t r1)     r1 = 0..3
 //   tw3b[r2*256 + t] = W_2048^(t r2)     r2 = 0..7
+// Raw buffer resources (base in scalar registers, one 32-bit per-thread byte offset, a scalar or immediate offset per
+// access): the 16 + 16 loads and 16 stores of a thread then need no address arithmetic in the vector pipe at all — with
+// flat global addressing the compiler builds a 64-bit address per access whose offset exceeds the 12-bit immediate.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);  // raw, 32-bit data format (gfx9)
+}
+__device__ __forceinline__ float2 buffer_load_f2(__amdgpu_buffer_rsrc_t r, int voffset_bytes, int soffset_bytes) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voffset_bytes, soffset_bytes, 0);
+  return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+}
+__device__ __forceinline__ float buffer_load_f1(__amdgpu_buffer_rsrc_t r, int voffset_bytes, int soffset_bytes) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voffset_bytes, soffset_bytes, 0));
+}
+__device__ __forceinline__ void buffer_store_f1(__amdgpu_buffer_rsrc_t r, int voffset_bytes, int soffset_bytes, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voffset_bytes, soffset_bytes, 0);
+}
+
 struct Fft8192Tables {
   const float2* tw2;
   const float2* tw3a;
@@ -323,13 +340,25 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
   }
   // ---------------- pass 1: radix 16, Ns = 1, butterfly j = t ----------------
   float2 a[16];
+  constexpr bool kBuf = FMT == FMT_CF32 && ABLATE == 0;  // buffer addressing (the int8 formats and the ablations keep flat loads)
+  if constexpr (kBuf) {
+    const __amdgpu_buffer_rsrc_t rin = buffer_of(reinterpret_cast<const float2*>(iq) + in_base, 8192 * 8);
+    const __amdgpu_buffer_rsrc_t rwin = buffer_of(win, 8192 * 4);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e = t + 512 * r;
-    const float2 x = load_iq<FMT>(iq, in_base + e, scale);
-    const float w = win[e];
-    a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
-    if constexpr (ABLATE == 2) a[r] = make_float2(__int_as_float(0x3f800000 + e), db_off * (float)r);  // no global loads
+    for (int r = 0; r < 16; ++r) {
+      const float2 x = buffer_load_f2(rin, t * 8, 4096 * r);
+      const float w = buffer_load_f1(rwin, t * 4, 2048 * r);
+      a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int e = t + 512 * r;
+      const float2 x = load_iq<FMT>(iq, in_base + e, scale);
+      const float w = win[e];
+      a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
+      if constexpr (ABLATE == 2) a[r] = make_float2(__int_as_float(0x3f800000 + e), db_off * (float)r);  // no global loads
+    }
   }
   if constexpr (DBG) if (t == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -439,6 +468,12 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
         out[bin0 ^ 4096] = psd_db(cadd(e, o), db_off);
         out[bin1 ^ 4096] = psd_db(csub(e, o), db_off);
       }
+    } else if constexpr (kBuf) {
+      // bin0 < 4096: the half rotation (fft_v shift = true) sends X[kk] to bin0 + 4096 and X[kk + 16] to bin0
+      const __amdgpu_buffer_rsrc_t rout = buffer_of(out, 8192 * 4);
+      const int voff = (j + 2048 * h) * 4;
+      buffer_store_f1(rout, voff, 1024 * k + 16384, psd_db(cadd(e, o), db_off));
+      buffer_store_f1(rout, voff, 1024 * k, psd_db(csub(e, o), db_off));
     } else {
       out[bin0 ^ 4096] = psd_db(cadd(e, o), db_off);
       out[bin1 ^ 4096] = psd_db(csub(e, o), db_off);
