@@ -340,13 +340,21 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
   }
   // ---------------- pass 1: radix 16, Ns = 1, butterfly j = t ----------------
   float2 a[16];
-  constexpr bool kBuf = FMT == FMT_CF32 && ABLATE == 0;  // buffer addressing (the int8 formats and the ablations keep flat loads)
+  constexpr bool kBuf = ABLATE == 0;  // buffer addressing (the ablations keep flat loads)
   if constexpr (kBuf) {
-    const __amdgpu_buffer_rsrc_t rin = buffer_of(reinterpret_cast<const float2*>(iq) + in_base, 8192 * 8);
+    constexpr int kSample = FMT == FMT_CF32 ? 8 : 2;  // bytes per IQ sample
+    const __amdgpu_buffer_rsrc_t rin = buffer_of(reinterpret_cast<const char*>(iq) + in_base * kSample, 8192 * kSample);
     const __amdgpu_buffer_rsrc_t rwin = buffer_of(win, 8192 * 4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float2 x = buffer_load_f2(rin, t * 8, 4096 * r);
+      float2 x;
+      if constexpr (FMT == FMT_CF32) {
+        x = buffer_load_f2(rin, t * 8, 4096 * r);
+      } else {
+        const unsigned short raw = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rin, t * 2, 1024 * r, 0);
+        if constexpr (FMT == FMT_CS8) x = make_float2((float)(signed char)(raw & 0xff) * scale, (float)(signed char)(raw >> 8) * scale);
+        else x = make_float2(((float)(raw & 0xff) - 127.5f) * scale, ((float)(raw >> 8) - 127.5f) * scale);
+      }
       const float w = buffer_load_f1(rwin, t * 4, 2048 * r);
       a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
     }

@@ -342,9 +342,9 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
     else if (ablate == 3) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 3>, ss::kFft8192W8LdsBytes);
     else if (ablate == 4 && FMT == ss::FMT_CF32) launch8(ss::k_fft8192_psd_w8<ss::FMT_CF32, 8, false, 4>, ss::kFft8192W8LdsBytes);
     else if constexpr (FMT == ss::FMT_CF32) launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
-    // int8 IQ: the conversion needs a few more registers; at 64 (8 waves/SIMD) the kernel spills and takes 27.7 us per 1024
-    // frames, at 80 (6 waves) 23.0 us. cf32 is the other way round (26.3 vs 26.9 us).
-    else launch8(ss::k_fft8192_psd_w8<FMT, 6>, ss::kFft8192W8LdsBytes);
+    // (int8 IQ ran best at 6 waves per SIMD, 80 registers, while the compiler packed fp32 pairs: 23.0 vs 27.7 us; built
+    // without the SLP vectorizer the 64-register form does not spill and wins, 21.4 vs 22.4 us)
+    else launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
   }
   if (tabs.dbg && ++c->diag.fft_calls == 20) {
     std::vector<long long> h((size_t)8 * nframes);
