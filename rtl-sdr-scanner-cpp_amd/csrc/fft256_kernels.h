@@ -60,7 +60,7 @@ __device__ __forceinline__ void fft256_passes(float2 (&a)[16], float2 (&c)[16], 
 }
 
 template <int FMT>
-__global__ __launch_bounds__(512, 5) void k_fft_cols256(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
+__global__ __launch_bounds__(512, 8) void k_fft_cols256(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
                                                         const float2* __restrict__ tw256, const float2* __restrict__ twc, float scale,
                                                         float2* __restrict__ work, int logn2) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512, 5) void k_fft_cols256(const void* __restrict__
 // Rows of 256 points spaced row_stride apart: N2 = 256 (row_stride 256, nsub 1) directly after the columns pass, or
 // N2 = 256 A after k_fft_sub_dft (row_stride N2, nsub = A sub-rows c per row). Output bin of X_row[d] is
 // k1 + 256 c + 256 nsub d; a workgroup takes 32 consecutive k1 of one c so that stores run along k1.
-__global__ __launch_bounds__(512, 6) void k_fft_rows256_psd(const float2* __restrict__ work, const float2* __restrict__ tw256, float db_off,
+__global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __restrict__ work, const float2* __restrict__ tw256, float db_off,
                                                             float* __restrict__ psd, int logn, int lognsub) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s = reinterpret_cast<float*>(smem_raw);
@@ -189,7 +189,7 @@ __device__ __forceinline__ constexpr int slot_small(int k) {
 }
 
 template <int FMT, int LOGR>
-__global__ __launch_bounds__(512, 4) void k_fft256xR_psd(const void* __restrict__ iq, long long item_stride, int nframes,
+__global__ __launch_bounds__(512, LOGR == 4 ? 4 : 6) void k_fft256xR_psd(const void* __restrict__ iq, long long item_stride, int nframes,
                                                          const float* __restrict__ win, const float2* __restrict__ tw256,
                                                          const float2* __restrict__ twn /* [q][k'] W_N^(q k') */, float db_off, float scale,
                                                          float* __restrict__ psd) {
