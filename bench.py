@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--no-psd-out", action="store_true", help="detect mode: the caller takes candidates only, no PSD plane is handed out")
     ap.add_argument("--planes", action="store_true", help="full mode: the rel and avg planes are handed out as well (20 B/sample)")
     ap.add_argument("--decim", type=int, default=1, help="frame decimation D: items of N*D samples, the first N of each are scanned (reference: 5 at 2.048 MS/s)")
+    ap.add_argument("--lanes", type=int, default=1, help="ss_pipe with this many lanes (batches of the one band in flight side by side); 1 = one context")
     ap.add_argument("--single-buffer", action="store_true", help="one output set instead of two alternating ones")
     ap.add_argument("--time-every", type=int, default=8, help="attach start/stop events to every k-th launch of the FFT kernel")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not attach per-launch events to the FFT kernel (roofline omitted)")
@@ -144,11 +145,16 @@ def main():
     cfg = dist.broadcast_config(cfg0, device=coll_dev)  # the only collective of the whole job (RCCL, < 1 KiB)
     band = dist.bands_for_rank(int(cfg["n_bands"]), rank, world)[0]
 
-    eng = pkg.SpectrumEngine(int(cfg["sample_rate"]), dist.band_center(cfg, band), fft_size=int(cfg["fft_size"]),
-                             decim=int(cfg["decim"]), in_format=int(cfg["in_format"]), grouping_x=int(cfg["grouping_x"]),
-                             grouping_y=int(cfg["grouping_y"]), start_level=cfg["start_level_mdB"] / 1000.0,
-                             learn_frames=int(cfg["learn_frames"]), max_batch=nb, device_id=device_index,
-                             flags=pkg.abi.SS_FLAG_SPECTROGRAM if args.spectrogram else 0)
+    eng_kw = dict(fft_size=int(cfg["fft_size"]), decim=int(cfg["decim"]), in_format=int(cfg["in_format"]), grouping_x=int(cfg["grouping_x"]),
+                  grouping_y=int(cfg["grouping_y"]), start_level=cfg["start_level_mdB"] / 1000.0, learn_frames=int(cfg["learn_frames"]),
+                  max_batch=nb, device_id=device_index, flags=pkg.abi.SS_FLAG_SPECTROGRAM if args.spectrogram else 0)
+    if args.lanes > 1:
+        if args.planes or args.spectrogram:
+            raise SystemExit("--lanes: candidates and the PSD plane only")
+        eng = pkg.engine.Pipe(int(cfg["sample_rate"]), dist.band_center(cfg, band), lanes=args.lanes, **eng_kw)
+        args.no_kernel_timing = True  # per-launch events belong to one context; the lanes overlap each other's kernels
+    else:
+        eng = pkg.SpectrumEngine(int(cfg["sample_rate"]), dist.band_center(cfg, band), **eng_kw)
     iq = dist.synthetic_batch(cfg, band, nb)
     d_iq = torch.from_numpy(iq.view(np.float32) if iq.dtype == np.complex64 else iq).to(dev)
     # Outputs are double-buffered the way a streaming consumer would hold them: batch k writes set k & 1 while
@@ -158,19 +164,23 @@ def main():
                  idx=torch.empty(cap, dtype=torch.int32, device=dev), avg=torch.empty(cap, dtype=torch.float32, device=dev),
                  rel_plane=torch.empty((nb, n), dtype=torch.float32, device=dev) if args.planes else None,
                  avg_plane=torch.empty((nb, n), dtype=torch.float32, device=dev) if args.planes else None)
-            for _ in range(1 if args.single_buffer else 2)]
+            for _ in range(1 if args.single_buffer else max(2, args.lanes + 1))]  # a lane's outputs stay its own until its batch is done
     torch.cuda.synchronize()
     counter = [0]
 
     def step():
         o = outs[counter[0] % len(outs)]
         counter[0] += 1
-        eng.process_device(d_iq, nb, psd=None if args.no_psd_out else o["psd"], rel=o["rel_plane"], avg=o["avg_plane"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
+        if args.lanes > 1:
+            eng.process_device(d_iq, nb, psd=None if args.no_psd_out else o["psd"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
+        else:
+            eng.process_device(d_iq, nb, psd=None if args.no_psd_out else o["psd"], rel=o["rel_plane"], avg=o["avg_plane"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
 
     for _ in range(max(args.warmup, 1)):  # first warm-up batch also absorbs the noise-learning frames
         step()
     eng.sync()
-    eng.kernel_timing(0 if args.no_kernel_timing else args.time_every)
+    if args.lanes == 1:
+        eng.kernel_timing(0 if args.no_kernel_timing else args.time_every)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -180,8 +190,10 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     t1 = time.perf_counter()
-    kern_ms, launches = eng.kernel_timing_read()
-    eng.kernel_timing(0)
+    kern_ms, launches = (0.0, 0)
+    if args.lanes == 1:
+        kern_ms, launches = eng.kernel_timing_read()
+        eng.kernel_timing(0)
     elapsed = dist.max_over_ranks(t1 - t0, device=coll_dev)
     ncand = int(outs[(counter[0] - 1) % len(outs)]["off"][-1].item())
 
@@ -200,7 +212,7 @@ def main():
                                    "(window+FFT+dB -> noise-relative -> 21x21 mean -> threshold -> candidate lists), "
                                    "one band per GPU",
                        "fft_size": n, "frames_per_batch": nb, "bands": world, "candidates_per_batch": ncand,
-                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "output_sets": len(outs), "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},
+                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "lanes": args.lanes, "output_sets": len(outs), "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_fft8192_psd (load+window+FFT+dB)",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),

@@ -212,6 +212,37 @@ int ss_feed_submit(ss_feed* feed, int32_t nframes, const int64_t* t_ms, int64_t 
 int ss_feed_collect(ss_feed* feed, ss_feed_result* out);
 int ss_feed_pending(const ss_feed* feed);
 
+/* ---- lanes: one band, several batches in flight on the device (SURVEY.md 8e-2 applied inside one GPU) ---------
+ * The kernels of one batch run one after the other, each in lock step across the chip; a second batch could use what
+ * they leave idle, but batch k+1 of the SAME context depends on batch k (the 21-frame averager, averager.cpp:14-25).
+ * A pipe therefore owns `lanes` contexts with identical configuration and hands consecutive calls to them in turn. A
+ * lane that did not see the previous call first restarts its averager (Averager::reset) and re-scans a halo of the
+ * 32..47 frames before the call (the GROUPING_Y - 1 = 20 frames of history, sources/config.h:29, of the first frame of the
+ * call's first 16-frame tile, from a tile boundary — the engine's sliding sums restart per tile), whose input the pipe keeps
+ * from call to call; the halo's outputs are dropped. This is frame-range sharding with recomputed halos: every frame past the averager's warm-up gets the same
+ * candidates and planes, bit for bit, as from ss_process_device on one context (tests/test_gpu_pipe.py). While a centre
+ * frequency is still learning its noise ceiling (noise_learner.cpp:36-52), and for calls shorter than 64 frames, every lane
+ * processes the call, so that all lanes hold the same ceiling and stay contiguous.
+ *
+ * Device pointers in, device pointers out, asynchronous like ss_process_device: the outputs of a call are complete
+ * after ss_pipe_sync (or once `lanes` further calls have been made and synchronised on). d_iq must stay intact until the
+ * call's work is done. Learning counts frames (learn_frames), as ss_process_device does. SS_FLAG_SPECTROGRAM and
+ * SS_FLAG_KEEP_PLANES are per-context features and are refused here.
+ *
+ * State of this round: results are exact; the speed-up is not there yet. A call costs the host about twelve HIP calls (tail
+ * copy, two event records, two waits, the averager restart, two three-kernel batches) = 40..50 us, more than the 35 us the
+ * device needs with two or three lanes, so a pipe scans at the pace of one context (scripts/alt_pipe_probe.py
+ * shows the device side: 223 / 244 GS/s with two / three contexts against 187). */
+typedef struct ss_pipe ss_pipe;
+int ss_pipe_create(const ss_config* cfg, int32_t lanes, ss_pipe** out); /* lanes 1..4; cfg->max_batch >= 64 */
+void ss_pipe_destroy(ss_pipe* pipe);
+const char* ss_pipe_last_error(const ss_pipe* pipe);
+int ss_pipe_process_device(ss_pipe* pipe, const void* d_iq, int32_t nframes, float* d_psd_db, int32_t* d_cand_off, int32_t* d_cand_idx,
+                           float* d_cand_avg, int32_t cand_cap);
+int ss_pipe_sync(ss_pipe* pipe);
+int ss_pipe_set_frequency_range(ss_pipe* pipe, int32_t lo_hz, int32_t hi_hz); /* SdrDevice::setFrequencyRange, every lane */
+int ss_pipe_reset(ss_pipe* pipe);                                             /* Transmission::resetBuffers, every lane */
+
 #ifdef __cplusplus
 }
 #endif

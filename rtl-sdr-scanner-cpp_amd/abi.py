@@ -77,6 +77,26 @@ def bind(lib: C.CDLL, prefix: str) -> None:
     f("read_noise").restype = C.c_int
 
 
+def apply_overrides(cfg, overrides: dict) -> list:
+    """Set ss_config fields from keyword overrides; returns the arrays the config points into (keep them alive)."""
+    keep = []
+    for k, v in overrides.items():
+        if k == "window" and v is not None:
+            w = np.ascontiguousarray(v, dtype=np.float32)
+            keep.append(w)
+            cfg.window = _fp(w)
+        elif k == "ignored":
+            ig = np.ascontiguousarray(v, dtype=np.int32).reshape(-1)
+            keep.append(ig)
+            cfg.ignored = _ip(ig)
+            cfg.n_ignored = ig.size // 2
+        else:
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown ss_config field {k}")
+            setattr(cfg, k, v)
+    return keep
+
+
 class Chain:
     """One scan chain behind the C ABI (host-buffer entry points), numpy in / numpy out.
 
@@ -90,21 +110,7 @@ class Chain:
         bind(lib, prefix)
         cfg = SsConfig()
         self._f("default_config")(C.byref(cfg), int(sample_rate), int(center_hz))
-        self._keep = []
-        for k, v in overrides.items():
-            if k == "window" and v is not None:
-                w = np.ascontiguousarray(v, dtype=np.float32)
-                self._keep.append(w)
-                cfg.window = _fp(w)
-            elif k == "ignored":
-                ig = np.ascontiguousarray(v, dtype=np.int32).reshape(-1)
-                self._keep.append(ig)
-                cfg.ignored = _ip(ig)
-                cfg.n_ignored = ig.size // 2
-            else:
-                if not hasattr(cfg, k):
-                    raise TypeError(f"unknown ss_config field {k}")
-                setattr(cfg, k, v)
+        self._keep = apply_overrides(cfg, overrides)
         self.cfg = cfg
         h = C.c_void_p()
         st = self._f("create")(C.byref(cfg), C.byref(h))

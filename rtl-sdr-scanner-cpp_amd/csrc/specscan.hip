@@ -1407,4 +1407,238 @@ int ss_feed_collect(ss_feed* f, ss_feed_result* out) {
   return SS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// ss_pipe: several lanes (contexts) taking the calls of one band in turn — include/specscan.h
+// ---------------------------------------------------------------------------------------------------------------
+struct ss_pipe {
+  // A frame's time mean slides from the first frame of its 16-frame tile (k_detect_fused), whose own 21-term sum reaches
+  // 20 frames further back: a lane that starts at frame s must therefore re-scan from the tile boundary at or below
+  // floor(s / 16) * 16 - 20, i.e. from floor(s / 16) * 16 - 32: 32..47 frames.
+  static constexpr int kHaloMax = 47;
+  static constexpr int kSmallCall = 64;  // calls shorter than this go to every lane (a halo must fit inside the previous call)
+  ss_config cfg{};
+  std::vector<ss_ctx*> lanes;
+  std::vector<long long> next_abs;  // per lane: absolute index of the frame it expects next (contiguous) or -1
+  int turn = 0;
+  long long abs = 0;        // frames since the last reset of the pipe
+  long long prev_start = 0;  // absolute start and length of the previous call
+  int prev_n = 0;
+  // the last kHaloMax input frames of each call, items of N samples (the decimated part of the N*D items), a ring of slots
+  std::vector<void*> d_tail;
+  std::vector<hipEvent_t> ev_tail;    // slot filled (recorded on the producing lane's stream)
+  std::vector<hipEvent_t> ev_halo;    // slot consumed (recorded on the consuming lane's stream)
+  std::vector<char> halo_used;        // ev_halo[slot] has been recorded since the slot was filled
+  long long calls = 0;
+  // noise learning per centre frequency, mirrored by frame count (plan_learning)
+  std::vector<std::pair<int32_t, long long>> seen;  // centre -> frames seen
+  int32_t range_lo = 0, range_hi = 0;
+  std::mutex mtx;
+  char err[512] = {0};
+};
+
+namespace {
+int pipe_fail(ss_pipe* p, int status, const char* fmt, ...) {
+  char* dst = p ? p->err : g_create_err;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(dst, 512, fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+long long* pipe_seen(ss_pipe* p) {
+  const int32_t center = (p->range_lo + p->range_hi) / 2;
+  for (auto& kv : p->seen)
+    if (kv.first == center) return &kv.second;
+  p->seen.emplace_back(center, 0);
+  return &p->seen.back().second;
+}
+
+int lane_status(ss_pipe* p, ss_ctx* lane, int st) {
+  if (st != SS_OK) snprintf(p->err, sizeof(p->err), "%s", lane->err);
+  return st;
+}
+}  // namespace
+
+const char* ss_pipe_last_error(const ss_pipe* pipe) { return pipe ? pipe->err : g_create_err; }
+
+void ss_pipe_destroy(ss_pipe* p) {
+  if (!p) return;
+  for (ss_ctx* c : p->lanes) {
+    if (c) (void)hipStreamSynchronize(c->stream);
+  }
+  for (void* t : p->d_tail) (void)hipFree(t);
+  for (hipEvent_t e : p->ev_tail) (void)hipEventDestroy(e);
+  for (hipEvent_t e : p->ev_halo) (void)hipEventDestroy(e);
+  for (ss_ctx* c : p->lanes) ss_destroy(c);
+  delete p;
+}
+
+int ss_pipe_create(const ss_config* cfg, int32_t lanes, ss_pipe** out) {
+  if (!cfg || !out) return pipe_fail(nullptr, SS_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (lanes < 1 || lanes > 4) return pipe_fail(nullptr, SS_ERR_INVALID, "lanes %d not in 1..4", lanes);
+  if (cfg->max_batch < ss_pipe::kSmallCall) return pipe_fail(nullptr, SS_ERR_INVALID, "max_batch %d < %d", cfg->max_batch, ss_pipe::kSmallCall);
+  if (cfg->flags & (SS_FLAG_SPECTROGRAM | SS_FLAG_KEEP_PLANES)) return pipe_fail(nullptr, SS_ERR_INVALID, "per-context flags are not available on a pipe");
+  if (cfg->grouping_y - 1 > 20) return pipe_fail(nullptr, SS_ERR_INVALID, "grouping_y %d: the halo covers 20 frames of history", cfg->grouping_y);
+  ss_pipe* p = new (std::nothrow) ss_pipe();
+  if (!p) return pipe_fail(nullptr, SS_ERR_NOMEM, "out of host memory");
+  p->cfg = *cfg;
+  p->range_lo = cfg->range_lo;
+  p->range_hi = cfg->range_hi;
+  for (int l = 0; l < lanes; ++l) {
+    ss_ctx* c = nullptr;
+    const int st = ss_create(cfg, &c);
+    if (st != SS_OK) {
+      ss_pipe_destroy(p);
+      return st;  // ss_last_error(NULL) holds the message
+    }
+    p->lanes.push_back(c);
+    p->next_abs.push_back(0);
+  }
+  const int slots = lanes + 2;
+  const size_t tail_bytes = (size_t)ss_pipe::kHaloMax * (size_t)cfg->fft_size * in_bytes_per_sample(cfg->in_format);
+  for (int k = 0; k < slots; ++k) {
+    void* t = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipMalloc(&t, tail_bytes) != hipSuccess || hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
+      if (t) (void)hipFree(t);
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      ss_pipe_destroy(p);
+      return pipe_fail(nullptr, SS_ERR_HIP, "ss_pipe_create: tail slot allocation failed");
+    }
+    p->d_tail.push_back(t);
+    p->ev_tail.push_back(e0);
+    p->ev_halo.push_back(e1);
+    p->halo_used.push_back(0);
+  }
+  *out = p;
+  return SS_OK;
+}
+
+int ss_pipe_sync(ss_pipe* p) {
+  if (!p) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(p->mtx);
+  for (ss_ctx* c : p->lanes) {
+    const int st = ss_sync(c);
+    if (st != SS_OK) return lane_status(p, c, st);
+  }
+  return SS_OK;
+}
+
+int ss_pipe_set_frequency_range(ss_pipe* p, int32_t lo_hz, int32_t hi_hz) {
+  if (!p) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(p->mtx);
+  p->range_lo = lo_hz;
+  p->range_hi = hi_hz;
+  for (ss_ctx* c : p->lanes) {
+    const int st = ss_set_frequency_range(c, lo_hz, hi_hz);
+    if (st != SS_OK) return lane_status(p, c, st);
+  }
+  return SS_OK;
+}
+
+int ss_pipe_reset(ss_pipe* p) {
+  if (!p) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(p->mtx);
+  for (size_t l = 0; l < p->lanes.size(); ++l) {
+    const int st = ss_reset(p->lanes[l]);
+    if (st != SS_OK) return lane_status(p, p->lanes[l], st);
+    p->next_abs[l] = 0;
+  }
+  p->abs = 0;
+  p->prev_start = 0;
+  p->prev_n = 0;
+  return SS_OK;
+}
+
+int ss_pipe_process_device(ss_pipe* p, const void* d_iq, int32_t nframes, float* d_psd_db, int32_t* d_cand_off, int32_t* d_cand_idx,
+                           float* d_cand_avg, int32_t cand_cap) {
+  if (!p) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(p->mtx);
+  if (nframes < 0 || (nframes > 0 && !d_iq) || cand_cap < 0) return pipe_fail(p, SS_ERR_INVALID, "bad d_iq/nframes/cand_cap");
+  if (nframes > p->cfg.max_batch) return pipe_fail(p, SS_ERR_BATCH, "nframes %d > max_batch %d", nframes, p->cfg.max_batch);
+  const int nlanes = (int)p->lanes.size();
+  if (nframes == 0) return lane_status(p, p->lanes[0], ss_process_device(p->lanes[0], d_iq, 0, d_psd_db, nullptr, nullptr, d_cand_off, d_cand_idx, d_cand_avg, cand_cap));
+  const long long start = p->abs;
+  long long* seen = pipe_seen(p);
+  const bool learning = *seen < p->cfg.learn_frames;  // this call still holds learning frames: every lane must take it
+  // halo of a lane that missed the previous call: back to the tile boundary 32 frames below this call's first tile
+  const int halo = 32 + (int)(start % 16);
+  const bool halo_ok = p->prev_n >= ss_pipe::kHaloMax && p->prev_start + p->prev_n == start && start - halo >= 0;
+  const bool everyone = nlanes == 1 || learning || nframes < ss_pipe::kSmallCall;
+  const size_t sample = in_bytes_per_sample(p->cfg.in_format);
+  const size_t n = (size_t)p->cfg.fft_size;
+  const size_t item = n * (size_t)p->cfg.decim * sample;  // bytes per input item
+  const int slots = (int)p->d_tail.size();
+  const int prev_slot = (int)((p->calls + slots - 1) % slots), cur_slot = (int)(p->calls % slots);
+
+  auto run_lane = [&](int l, bool with_outputs) -> int {
+    ss_ctx* c = p->lanes[(size_t)l];
+    if (p->next_abs[(size_t)l] != start) {
+      // the lane missed frames: restart its averager and re-scan the halo from the previous call's tail
+      if (!halo_ok) return pipe_fail(p, SS_ERR_INVALID, "lane %d is not contiguous and no halo is available (internal)", l);
+      int st = ss_reset(c);
+      if (st != SS_OK) return lane_status(p, c, st);
+      SS_HIP(c, hipStreamWaitEvent(c->stream, p->ev_tail[(size_t)prev_slot], 0));
+      const char* tail = static_cast<const char*>(p->d_tail[(size_t)prev_slot]) + (size_t)(ss_pipe::kHaloMax - halo) * n * sample;
+      {
+        std::lock_guard<std::mutex> lane_lock(c->mtx);
+        NoiseState* z = nullptr;
+        st = get_noise(c, &z);
+        if (st == SS_OK) {
+          st = run_batch(c, tail, (long long)n, halo, plan_learning(c, z, halo, nullptr), z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+        }
+      }
+      if (st != SS_OK) return lane_status(p, c, st);
+      SS_HIP(c, hipEventRecord(p->ev_halo[(size_t)prev_slot], c->stream));
+      p->halo_used[(size_t)prev_slot] = 1;
+    }
+    const int st = with_outputs ? ss_process_device(c, d_iq, nframes, d_psd_db, nullptr, nullptr, d_cand_off, d_cand_idx, d_cand_avg, cand_cap)
+                                : ss_process_device(c, d_iq, nframes, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+    if (st != SS_OK) return lane_status(p, c, st);
+    p->next_abs[(size_t)l] = start + nframes;
+    return SS_OK;
+  };
+
+  const int owner = everyone ? 0 : p->turn;
+  // keep this call's tail for whoever takes the next one: copied on the owner's stream before its own work, so that it is
+  // ready long before another lane asks for it; the slot's previous reader (ring of lanes + 2 slots) must be done with it
+  if (nframes >= ss_pipe::kHaloMax && nlanes > 1) {
+    ss_ctx* c = p->lanes[(size_t)owner];
+    SS_HIP(c, hipSetDevice(c->cfg.device_id));
+    if (p->halo_used[(size_t)cur_slot]) {
+      SS_HIP(c, hipStreamWaitEvent(c->stream, p->ev_halo[(size_t)cur_slot], 0));
+      p->halo_used[(size_t)cur_slot] = 0;
+    }
+    const char* src = static_cast<const char*>(d_iq) + (size_t)(nframes - ss_pipe::kHaloMax) * item;
+    if ((n * sample) % 16 == 0 && item % 16 == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+      // (a kernel launch costs the host a third of what hipMemcpy2DAsync does)
+      hipLaunchKernelGGL(ss::k_copy_pitched, dim3(256), dim3(256), 0, c->stream, reinterpret_cast<const uint4*>(src), item / 16,
+                         static_cast<uint4*>(p->d_tail[(size_t)cur_slot]), (int)(n * sample / 16), ss_pipe::kHaloMax);
+    } else {
+      SS_HIP(c, hipMemcpy2DAsync(p->d_tail[(size_t)cur_slot], n * sample, src, item, n * sample, (size_t)ss_pipe::kHaloMax, hipMemcpyDeviceToDevice, c->stream));
+    }
+    SS_HIP(c, hipEventRecord(p->ev_tail[(size_t)cur_slot], c->stream));
+  }
+  if (everyone) {
+    for (int l = 0; l < nlanes; ++l) {
+      const int st = run_lane(l, l == 0);
+      if (st != SS_OK) return st;
+    }
+  } else {
+    const int st = run_lane(owner, true);
+    if (st != SS_OK) return st;
+    p->turn = (p->turn + 1) % nlanes;
+  }
+  *seen += nframes;
+  p->prev_start = start;
+  p->prev_n = nframes;
+  p->abs = start + nframes;
+  ++p->calls;
+  return SS_OK;
+}
+
 }  // extern "C"

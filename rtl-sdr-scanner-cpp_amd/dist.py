@@ -86,10 +86,11 @@ def synthetic_batch(cfg: dict, band: int, nframes: int) -> np.ndarray:
 def scan_frame_range(chain, frames, lo: int, hi: int, learn_frames: int, max_batch: int, align: int = 16, halo: int = 20):
     """One rank's share of a recorded band, frames [lo, hi) of ``frames`` ([nframes, N*D] items), with no exchange between
     ranks (BASELINE config 5): every rank first runs the learning prefix [0, learn_frames) itself so that
-    all ranks hold the same noise ceiling, resets the averager, and re-reads a halo before its range — the 20 frames the
-    21-frame mean needs (GROUPING_Y - 1), extended back to a multiple of ``align`` frames so that the engine's frame tiles
-    (which restart their sliding sums every 16 frames since the last reset) fall where they fall in a single-rank run. The
-    outputs of halo frames are dropped. Returns per-frame candidate lists for [lo, hi), bit-identical to a single-rank scan
+    all ranks hold the same noise ceiling, resets the averager, and re-reads a halo before its range — the engine restarts
+    its sliding sums every ``align`` = 16 frames since the last reset, so a frame's mean depends on the 20 frames
+    (GROUPING_Y - 1) before the FIRST frame of its tile: the halo starts at the tile boundary at or below
+    floor(lo / 16) * 16 - 20, which also puts the rank's tiles where they fall in a single-rank run. The outputs of halo
+    frames are dropped. Returns per-frame candidate lists for [lo, hi), bit-identical to a single-rank scan
     for every frame past the averager's warm-up (lo >= learn_frames + halo)."""
     if lo >= hi:
         return []
@@ -98,7 +99,8 @@ def scan_frame_range(chain, frames, lo: int, hi: int, learn_frames: int, max_bat
         n = min(max_batch, learn_frames - pos)
         chain.process(frames[pos:pos + n], want=())
         pos += n
-    start = max(learn_frames, ((lo - halo) // align) * align)
+    # a frame's time mean slides from the first frame of its tile, whose own sum reaches `halo` frames further back
+    start = max(learn_frames, (((lo // align) * align - halo) // align) * align)
     if start > learn_frames:
         chain.reset()  # Averager::reset: ring and frame counter to zero; the engine's tile origin moves to `start`
     # frames of the range that lie inside the learning prefix never have candidates (noise_learner.cpp:45-51)

@@ -66,7 +66,8 @@ def load_library() -> C.CDLL:
 EXPORTS = ("ss_default_config", "ss_device_count", "ss_create", "ss_destroy", "ss_last_error", "ss_process",
            "ss_process_device", "ss_sync", "ss_stream", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
            "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read",
-           "ss_spectrogram_payload", "ss_feed_create", "ss_feed_destroy", "ss_feed_acquire", "ss_feed_submit", "ss_feed_collect", "ss_feed_pending")
+           "ss_spectrogram_payload", "ss_pipe_create", "ss_pipe_destroy", "ss_pipe_last_error", "ss_pipe_process_device", "ss_pipe_sync",
+           "ss_pipe_set_frequency_range", "ss_pipe_reset", "ss_feed_create", "ss_feed_destroy", "ss_feed_acquire", "ss_feed_submit", "ss_feed_collect", "ss_feed_pending")
 
 
 def _ptr(t):
@@ -192,3 +193,60 @@ class Feed:
         if r.psd_db:
             out["psd"] = np.ctypeslib.as_array(r.psd_db, shape=(nf, self._e.n))
         return out
+
+
+class Pipe:
+    """One band, several lanes (contexts) taking its calls in turn — ss_pipe_* of include/specscan.h. Device tensors in and
+    out, asynchronous; results equal SpectrumEngine.process_device on one context (past the averager's warm-up)."""
+
+    def __init__(self, sample_rate: int, center_hz: int, lanes: int = 2, **overrides):
+        self._lib = load_library()
+        L = self._lib
+        L.ss_pipe_create.argtypes = [C.POINTER(abi.SsConfig), C.c_int32, C.POINTER(C.c_void_p)]
+        L.ss_pipe_destroy.argtypes = [C.c_void_p]
+        L.ss_pipe_destroy.restype = None
+        L.ss_pipe_last_error.argtypes = [C.c_void_p]
+        L.ss_pipe_last_error.restype = C.c_char_p
+        L.ss_pipe_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.ss_pipe_sync.argtypes = [C.c_void_p]
+        L.ss_pipe_set_frequency_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.ss_pipe_reset.argtypes = [C.c_void_p]
+        abi.bind(L, "ss_")
+        cfg = abi.SsConfig()
+        L.ss_default_config(C.byref(cfg), int(sample_rate), int(center_hz))
+        keep = abi.apply_overrides(cfg, overrides)
+        self._keep = keep
+        self.n = cfg.fft_size
+        h = C.c_void_p()
+        st = L.ss_pipe_create(C.byref(cfg), int(lanes), C.byref(h))
+        if st != 0:
+            raise abi.SpecscanError(st, (L.ss_pipe_last_error(None) or b"").decode())
+        self._h = h
+
+    def _check(self, st):
+        if st != 0 and st != abi.SS_ERR_CAND_OVERFLOW:
+            raise abi.SpecscanError(st, (self._lib.ss_pipe_last_error(self._h) or b"").decode())
+
+    def process_device(self, iq, nframes: int, psd=None, cand_off=None, cand_idx=None, cand_avg=None):
+        cap = 0 if cand_idx is None else int(cand_idx.numel())
+        self._check(self._lib.ss_pipe_process_device(self._h, _ptr(iq), int(nframes), _ptr(psd), _ptr(cand_off), _ptr(cand_idx), _ptr(cand_avg), cap))
+
+    def sync(self):
+        self._check(self._lib.ss_pipe_sync(self._h))
+
+    def set_frequency_range(self, lo: int, hi: int):
+        self._check(self._lib.ss_pipe_set_frequency_range(self._h, int(lo), int(hi)))
+
+    def reset(self):
+        self._check(self._lib.ss_pipe_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ss_pipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
