@@ -225,14 +225,14 @@ int ss_feed_pending(const ss_feed* feed);
  * processes the call, so that all lanes hold the same ceiling and stay contiguous.
  *
  * Device pointers in, device pointers out, asynchronous like ss_process_device: the outputs of a call are complete
- * after ss_pipe_sync (or once `lanes` further calls have been made and synchronised on). d_iq must stay intact until the
- * call's work is done. Learning counts frames (learn_frames), as ss_process_device does. SS_FLAG_SPECTROGRAM and
+ * after ss_pipe_sync. d_iq must stay intact until ss_pipe_sync. Learning counts frames (learn_frames), as ss_process_device does. SS_FLAG_SPECTROGRAM and
  * SS_FLAG_KEEP_PLANES are per-context features and are refused here.
  *
- * State of this round: results are exact; the speed-up is not there yet. A call costs the host about twelve HIP calls (tail
- * copy, two event records, two waits, the averager restart, two three-kernel batches) = 40..50 us, more than the 35 us the
- * device needs with two or three lanes, so a pipe scans at the pace of one context (scripts/alt_pipe_probe.py
- * shows the device side: 223 / 244 GS/s with two / three contexts against 187). */
+ * What a turn costs the host decides whether lanes pay (a HIP call is 3-4 us here, a batch ~35 us on the device), so a turn
+ * is six launches and no events: the tail of call k is copied on the stream of the lane that takes call k + 1 — which is
+ * why d_iq has to stay intact until ss_pipe_sync, not just until the call's own work is done —, the restart is bookkeeping
+ * only, and the halo runs FFT + detect for the ring alone. 8192 points, 1024-frame calls (bench.py --lanes): 197 / 223 GS/s
+ * with two / three lanes against 187 for one context; four lanes: 180. */
 typedef struct ss_pipe ss_pipe;
 int ss_pipe_create(const ss_config* cfg, int32_t lanes, ss_pipe** out); /* lanes 1..4; cfg->max_batch >= 64 */
 void ss_pipe_destroy(ss_pipe* pipe);

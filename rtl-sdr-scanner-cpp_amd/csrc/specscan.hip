@@ -135,6 +135,7 @@ struct ss_ctx {
   int cnt_frames[2] = {0, 0};             // how many entries of each half may be non-zero
   float* d_relplane = nullptr;            // full rel plane, only when a caller asks for it (lazy)
   int last_n_learn = 0;
+  bool history_only = false;  // ss_pipe halo: run the chain for the averager ring only (no candidates, no emit)
   const float* last_hist = nullptr;       // ring rows as they were before the last batch
   float* last_thr = nullptr;
   // back end, unfused path (any other grouping): one buffer holds the ring rows + the batch rows
@@ -497,6 +498,8 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
                     shift, c->cfg.start_level, c->d_pass, c->d_mask, counts, d_rel_out, avg_full, c->d_avg,         nullptr,
                     nullptr, nullptr,          nullptr,   0,         0,      0};
   if (c->diag.d_detect_stamps && tiles <= 65536) da.dbg = c->diag.d_detect_stamps;
+  const bool history_only = c->history_only;
+  if (history_only) da.start_level = NAN;  // startLevel <= avg is false for every avg: no hits, the counters stay clean
   if (spec) {
     da.spec_partial = c->d_spec_part2[c->spec_cur];
     da.spec_m = c->spec_m;
@@ -522,15 +525,17 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
       fclose(fp);
     }
   }
-  hipLaunchKernelGGL(ss::k_cand_emit, dim3(nframes), dim3(64), 0, c->stream, (const uint32_t*)c->d_mask, n / 32, n, nframes,
-                     (const int*)counts, counts_next, c->cnt_frames[c->cnt_cur ^ 1], (const float*)(avg_full ? avg_full : c->d_avg), cand_cap,
-                     c->d_off, d_cand_off,
-                     (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr, d_cand_avg);
+  if (!history_only) {
+    hipLaunchKernelGGL(ss::k_cand_emit, dim3(nframes), dim3(64), 0, c->stream, (const uint32_t*)c->d_mask, n / 32, n, nframes,
+                       (const int*)counts, counts_next, c->cnt_frames[c->cnt_cur ^ 1], (const float*)(avg_full ? avg_full : c->d_avg), cand_cap,
+                       c->d_off, d_cand_off,
+                       (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr, d_cand_avg);
+    c->cnt_frames[c->cnt_cur] = nframes;   // this half now holds nframes counts (read by the emit above, cleared by the next one)
+    c->cnt_frames[c->cnt_cur ^ 1] = 0;     // just cleared
+    c->cnt_cur ^= 1;
+  }
   c->last_hist = hist_in;
   c->hist_start = next_start;
-  c->cnt_frames[c->cnt_cur] = nframes;   // this half now holds nframes counts (read by the emit above, cleared by the next one)
-  c->cnt_frames[c->cnt_cur ^ 1] = 0;     // just cleared
-  c->cnt_cur ^= 1;
   c->last_n_learn = n_learn;
   c->last_thr = z->d_thr;
   return SS_OK;
@@ -1409,28 +1414,34 @@ int ss_feed_collect(ss_feed* f, ss_feed_result* out) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // ss_pipe: several lanes (contexts) taking the calls of one band in turn — include/specscan.h
+//
+// What a lane's turn costs the host decides whether lanes pay: every HIP call is 3-4 us here (also from several threads:
+// the runtime serialises them), a batch takes ~35 us on the device with two or three lanes. A turn is therefore kept to six
+// calls and no events: the tail of call k is copied onto the stream of the lane that takes call k + 1 (its own slot,
+// written and read in stream order), the averager restart is bookkeeping only (whatever the ring holds reaches halo frames
+// only, see kHaloMax), and the halo runs the chain for the ring alone (FFT + detect, no candidates, no emit).
 // ---------------------------------------------------------------------------------------------------------------
 struct ss_pipe {
   // A frame's time mean slides from the first frame of its 16-frame tile (k_detect_fused), whose own 21-term sum reaches
   // 20 frames further back: a lane that starts at frame s must therefore re-scan from the tile boundary at or below
-  // floor(s / 16) * 16 - 20, i.e. from floor(s / 16) * 16 - 32: 32..47 frames.
+  // floor(s / 16) * 16 - 20, i.e. from floor(s / 16) * 16 - 32: 32..47 frames. Frames of the halo itself may see what the
+  // ring held before (the first tiles reach back into it); they are dropped.
   static constexpr int kHaloMax = 47;
   static constexpr int kSmallCall = 64;  // calls shorter than this go to every lane (a halo must fit inside the previous call)
+  struct Lane {
+    ss_ctx* c = nullptr;
+    long long next_abs = 0;   // absolute index of the frame the lane expects next
+    void* d_tail = nullptr;   // the last kHaloMax input frames of some call, items of N samples (the decimated part of the items)
+    long long tail_call = -1;  // which call's
+  };
   ss_config cfg{};
-  std::vector<ss_ctx*> lanes;
-  std::vector<long long> next_abs;  // per lane: absolute index of the frame it expects next (contiguous) or -1
+  std::vector<Lane> lanes;
   int turn = 0;
-  long long abs = 0;        // frames since the last reset of the pipe
+  long long abs = 0;         // frames since the last reset of the pipe
   long long prev_start = 0;  // absolute start and length of the previous call
   int prev_n = 0;
-  // the last kHaloMax input frames of each call, items of N samples (the decimated part of the N*D items), a ring of slots
-  std::vector<void*> d_tail;
-  std::vector<hipEvent_t> ev_tail;    // slot filled (recorded on the producing lane's stream)
-  std::vector<hipEvent_t> ev_halo;    // slot consumed (recorded on the consuming lane's stream)
-  std::vector<char> halo_used;        // ev_halo[slot] has been recorded since the slot was filled
   long long calls = 0;
-  // noise learning per centre frequency, mirrored by frame count (plan_learning)
-  std::vector<std::pair<int32_t, long long>> seen;  // centre -> frames seen
+  std::vector<std::pair<int32_t, long long>> seen;  // noise learning per centre frequency, by frame count (plan_learning)
   int32_t range_lo = 0, range_hi = 0;
   std::mutex mtx;
   char err[512] = {0};
@@ -1458,19 +1469,68 @@ int lane_status(ss_pipe* p, ss_ctx* lane, int st) {
   if (st != SS_OK) snprintf(p->err, sizeof(p->err), "%s", lane->err);
   return st;
 }
+
+// Averager::reset + the halo: afterwards the lane's ring holds the frames before `start` and its tile origin is the halo's first frame
+int lane_rescan(ss_pipe* p, ss_pipe::Lane& L, int halo) {
+  ss_ctx* c = L.c;
+  const size_t row = (size_t)p->cfg.fft_size * in_bytes_per_sample(p->cfg.in_format);
+  const char* tail = static_cast<const char*>(L.d_tail) + (size_t)(ss_pipe::kHaloMax - halo) * row;
+  if (!c->fused) {  // per-stage back end: the plain restart and a plain batch whose outputs nobody takes
+    int st = ss_reset(c);
+    if (st != SS_OK) return lane_status(p, c, st);
+    std::lock_guard<std::mutex> lane_lock(c->mtx);
+    NoiseState* z = nullptr;
+    st = get_noise(c, &z);
+    if (st == SS_OK) st = run_batch(c, tail, (long long)p->cfg.fft_size, halo, plan_learning(c, z, halo, nullptr), z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+    return lane_status(p, c, st);
+  }
+  std::lock_guard<std::mutex> lane_lock(c->mtx);
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  c->frames_pushed = 0;  // ss_reset's bookkeeping without clearing the ring
+  c->abs_frames = 0;
+  c->rot_frames = 0;
+  c->last_n = 0;
+  NoiseState* z = nullptr;
+  int st = get_noise(c, &z);
+  if (st == SS_OK) {
+    c->history_only = true;
+    st = run_batch(c, tail, (long long)p->cfg.fft_size, halo, plan_learning(c, z, halo, nullptr), z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+    c->history_only = false;
+  }
+  return lane_status(p, c, st);
+}
+
+// the last kHaloMax frames of a call's input -> the lane's slot, on the lane's stream
+int lane_keep_tail(ss_pipe* p, ss_pipe::Lane& L, const void* d_iq, int nframes, long long call) {
+  ss_ctx* c = L.c;
+  const size_t sample = in_bytes_per_sample(p->cfg.in_format);
+  const size_t n = (size_t)p->cfg.fft_size;
+  const size_t item = n * (size_t)p->cfg.decim * sample;
+  const char* src = static_cast<const char*>(d_iq) + (size_t)(nframes - ss_pipe::kHaloMax) * item;
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  if ((n * sample) % 16 == 0 && item % 16 == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+    // (a kernel launch costs the host a third of what hipMemcpy2DAsync does)
+    hipLaunchKernelGGL(ss::k_copy_pitched, dim3(256), dim3(256), 0, c->stream, reinterpret_cast<const uint4*>(src), item / 16,
+                       static_cast<uint4*>(L.d_tail), (int)(n * sample / 16), ss_pipe::kHaloMax);
+  } else {
+    SS_HIP(c, hipMemcpy2DAsync(L.d_tail, n * sample, src, item, n * sample, (size_t)ss_pipe::kHaloMax, hipMemcpyDeviceToDevice, c->stream));
+  }
+  L.tail_call = call;
+  return SS_OK;
+}
 }  // namespace
 
 const char* ss_pipe_last_error(const ss_pipe* pipe) { return pipe ? pipe->err : g_create_err; }
 
 void ss_pipe_destroy(ss_pipe* p) {
   if (!p) return;
-  for (ss_ctx* c : p->lanes) {
-    if (c) (void)hipStreamSynchronize(c->stream);
+  for (auto& L : p->lanes) {
+    if (L.c) (void)hipStreamSynchronize(L.c->stream);
   }
-  for (void* t : p->d_tail) (void)hipFree(t);
-  for (hipEvent_t e : p->ev_tail) (void)hipEventDestroy(e);
-  for (hipEvent_t e : p->ev_halo) (void)hipEventDestroy(e);
-  for (ss_ctx* c : p->lanes) ss_destroy(c);
+  for (auto& L : p->lanes) {
+    (void)hipFree(L.d_tail);
+    ss_destroy(L.c);
+  }
   delete p;
 }
 
@@ -1486,33 +1546,19 @@ int ss_pipe_create(const ss_config* cfg, int32_t lanes, ss_pipe** out) {
   p->cfg = *cfg;
   p->range_lo = cfg->range_lo;
   p->range_hi = cfg->range_hi;
+  const size_t tail_bytes = (size_t)ss_pipe::kHaloMax * (size_t)cfg->fft_size * in_bytes_per_sample(cfg->in_format);
   for (int l = 0; l < lanes; ++l) {
-    ss_ctx* c = nullptr;
-    const int st = ss_create(cfg, &c);
+    ss_pipe::Lane L;
+    const int st = ss_create(cfg, &L.c);
     if (st != SS_OK) {
       ss_pipe_destroy(p);
       return st;  // ss_last_error(NULL) holds the message
     }
-    p->lanes.push_back(c);
-    p->next_abs.push_back(0);
-  }
-  const int slots = lanes + 2;
-  const size_t tail_bytes = (size_t)ss_pipe::kHaloMax * (size_t)cfg->fft_size * in_bytes_per_sample(cfg->in_format);
-  for (int k = 0; k < slots; ++k) {
-    void* t = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipMalloc(&t, tail_bytes) != hipSuccess || hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
-      if (t) (void)hipFree(t);
-      if (e0) (void)hipEventDestroy(e0);
-      if (e1) (void)hipEventDestroy(e1);
+    p->lanes.push_back(L);
+    if (hipMalloc(&p->lanes.back().d_tail, tail_bytes) != hipSuccess) {
       ss_pipe_destroy(p);
       return pipe_fail(nullptr, SS_ERR_HIP, "ss_pipe_create: tail slot allocation failed");
     }
-    p->d_tail.push_back(t);
-    p->ev_tail.push_back(e0);
-    p->ev_halo.push_back(e1);
-    p->halo_used.push_back(0);
   }
   *out = p;
   return SS_OK;
@@ -1521,9 +1567,9 @@ int ss_pipe_create(const ss_config* cfg, int32_t lanes, ss_pipe** out) {
 int ss_pipe_sync(ss_pipe* p) {
   if (!p) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(p->mtx);
-  for (ss_ctx* c : p->lanes) {
-    const int st = ss_sync(c);
-    if (st != SS_OK) return lane_status(p, c, st);
+  for (auto& L : p->lanes) {
+    const int st = ss_sync(L.c);
+    if (st != SS_OK) return lane_status(p, L.c, st);
   }
   return SS_OK;
 }
@@ -1533,9 +1579,9 @@ int ss_pipe_set_frequency_range(ss_pipe* p, int32_t lo_hz, int32_t hi_hz) {
   std::lock_guard<std::mutex> lock(p->mtx);
   p->range_lo = lo_hz;
   p->range_hi = hi_hz;
-  for (ss_ctx* c : p->lanes) {
-    const int st = ss_set_frequency_range(c, lo_hz, hi_hz);
-    if (st != SS_OK) return lane_status(p, c, st);
+  for (auto& L : p->lanes) {
+    const int st = ss_set_frequency_range(L.c, lo_hz, hi_hz);
+    if (st != SS_OK) return lane_status(p, L.c, st);
   }
   return SS_OK;
 }
@@ -1543,10 +1589,11 @@ int ss_pipe_set_frequency_range(ss_pipe* p, int32_t lo_hz, int32_t hi_hz) {
 int ss_pipe_reset(ss_pipe* p) {
   if (!p) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(p->mtx);
-  for (size_t l = 0; l < p->lanes.size(); ++l) {
-    const int st = ss_reset(p->lanes[l]);
-    if (st != SS_OK) return lane_status(p, p->lanes[l], st);
-    p->next_abs[l] = 0;
+  for (auto& L : p->lanes) {
+    const int st = ss_reset(L.c);
+    if (st != SS_OK) return lane_status(p, L.c, st);
+    L.next_abs = 0;
+    L.tail_call = -1;
   }
   p->abs = 0;
   p->prev_start = 0;
@@ -1561,7 +1608,7 @@ int ss_pipe_process_device(ss_pipe* p, const void* d_iq, int32_t nframes, float*
   if (nframes < 0 || (nframes > 0 && !d_iq) || cand_cap < 0) return pipe_fail(p, SS_ERR_INVALID, "bad d_iq/nframes/cand_cap");
   if (nframes > p->cfg.max_batch) return pipe_fail(p, SS_ERR_BATCH, "nframes %d > max_batch %d", nframes, p->cfg.max_batch);
   const int nlanes = (int)p->lanes.size();
-  if (nframes == 0) return lane_status(p, p->lanes[0], ss_process_device(p->lanes[0], d_iq, 0, d_psd_db, nullptr, nullptr, d_cand_off, d_cand_idx, d_cand_avg, cand_cap));
+  if (nframes == 0) return lane_status(p, p->lanes[0].c, ss_process_device(p->lanes[0].c, d_iq, 0, d_psd_db, nullptr, nullptr, d_cand_off, d_cand_idx, d_cand_avg, cand_cap));
   const long long start = p->abs;
   long long* seen = pipe_seen(p);
   const bool learning = *seen < p->cfg.learn_frames;  // this call still holds learning frames: every lane must take it
@@ -1569,69 +1616,44 @@ int ss_pipe_process_device(ss_pipe* p, const void* d_iq, int32_t nframes, float*
   const int halo = 32 + (int)(start % 16);
   const bool halo_ok = p->prev_n >= ss_pipe::kHaloMax && p->prev_start + p->prev_n == start && start - halo >= 0;
   const bool everyone = nlanes == 1 || learning || nframes < ss_pipe::kSmallCall;
-  const size_t sample = in_bytes_per_sample(p->cfg.in_format);
-  const size_t n = (size_t)p->cfg.fft_size;
-  const size_t item = n * (size_t)p->cfg.decim * sample;  // bytes per input item
-  const int slots = (int)p->d_tail.size();
-  const int prev_slot = (int)((p->calls + slots - 1) % slots), cur_slot = (int)(p->calls % slots);
-
-  auto run_lane = [&](int l, bool with_outputs) -> int {
-    ss_ctx* c = p->lanes[(size_t)l];
-    if (p->next_abs[(size_t)l] != start) {
-      // the lane missed frames: restart its averager and re-scan the halo from the previous call's tail
-      if (!halo_ok) return pipe_fail(p, SS_ERR_INVALID, "lane %d is not contiguous and no halo is available (internal)", l);
-      int st = ss_reset(c);
-      if (st != SS_OK) return lane_status(p, c, st);
-      SS_HIP(c, hipStreamWaitEvent(c->stream, p->ev_tail[(size_t)prev_slot], 0));
-      const char* tail = static_cast<const char*>(p->d_tail[(size_t)prev_slot]) + (size_t)(ss_pipe::kHaloMax - halo) * n * sample;
-      {
-        std::lock_guard<std::mutex> lane_lock(c->mtx);
-        NoiseState* z = nullptr;
-        st = get_noise(c, &z);
-        if (st == SS_OK) {
-          st = run_batch(c, tail, (long long)n, halo, plan_learning(c, z, halo, nullptr), z, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
-        }
-      }
-      if (st != SS_OK) return lane_status(p, c, st);
-      SS_HIP(c, hipEventRecord(p->ev_halo[(size_t)prev_slot], c->stream));
-      p->halo_used[(size_t)prev_slot] = 1;
-    }
-    const int st = with_outputs ? ss_process_device(c, d_iq, nframes, d_psd_db, nullptr, nullptr, d_cand_off, d_cand_idx, d_cand_avg, cand_cap)
-                                : ss_process_device(c, d_iq, nframes, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
-    if (st != SS_OK) return lane_status(p, c, st);
-    p->next_abs[(size_t)l] = start + nframes;
-    return SS_OK;
-  };
-
   const int owner = everyone ? 0 : p->turn;
-  // keep this call's tail for whoever takes the next one: copied on the owner's stream before its own work, so that it is
-  // ready long before another lane asks for it; the slot's previous reader (ring of lanes + 2 slots) must be done with it
-  if (nframes >= ss_pipe::kHaloMax && nlanes > 1) {
-    ss_ctx* c = p->lanes[(size_t)owner];
-    SS_HIP(c, hipSetDevice(c->cfg.device_id));
-    if (p->halo_used[(size_t)cur_slot]) {
-      SS_HIP(c, hipStreamWaitEvent(c->stream, p->ev_halo[(size_t)cur_slot], 0));
-      p->halo_used[(size_t)cur_slot] = 0;
-    }
-    const char* src = static_cast<const char*>(d_iq) + (size_t)(nframes - ss_pipe::kHaloMax) * item;
-    if ((n * sample) % 16 == 0 && item % 16 == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
-      // (a kernel launch costs the host a third of what hipMemcpy2DAsync does)
-      hipLaunchKernelGGL(ss::k_copy_pitched, dim3(256), dim3(256), 0, c->stream, reinterpret_cast<const uint4*>(src), item / 16,
-                         static_cast<uint4*>(p->d_tail[(size_t)cur_slot]), (int)(n * sample / 16), ss_pipe::kHaloMax);
-    } else {
-      SS_HIP(c, hipMemcpy2DAsync(p->d_tail[(size_t)cur_slot], n * sample, src, item, n * sample, (size_t)ss_pipe::kHaloMax, hipMemcpyDeviceToDevice, c->stream));
-    }
-    SS_HIP(c, hipEventRecord(p->ev_tail[(size_t)cur_slot], c->stream));
-  }
-  if (everyone) {
-    for (int l = 0; l < nlanes; ++l) {
-      const int st = run_lane(l, l == 0);
+
+  for (int l = 0; l < nlanes; ++l) {
+    if (!everyone && l != owner) continue;
+    ss_pipe::Lane& L = p->lanes[(size_t)l];
+    if (L.next_abs != start) {
+      if (!halo_ok) return pipe_fail(p, SS_ERR_INVALID, "lane %d is not contiguous and no halo is available (internal)", l);
+      if (L.tail_call != p->calls - 1) {
+        // only the lane next in turn was given the previous call's tail; a short or learning call after calls taken in turn
+        // needs it on the others too (three lanes or more): let the device finish and copy it across. Rare.
+        const ss_pipe::Lane* from = nullptr;
+        for (const auto& o : p->lanes)
+          if (o.tail_call == p->calls - 1) from = &o;
+        if (!from) return pipe_fail(p, SS_ERR_INVALID, "the previous call's tail was not kept (internal)");
+        for (auto& o : p->lanes) {
+          const int st = ss_sync(o.c);
+          if (st != SS_OK) return lane_status(p, o.c, st);
+        }
+        const size_t tail_bytes = (size_t)ss_pipe::kHaloMax * (size_t)p->cfg.fft_size * in_bytes_per_sample(p->cfg.in_format);
+        SS_HIP(L.c, hipMemcpyAsync(L.d_tail, from->d_tail, tail_bytes, hipMemcpyDeviceToDevice, L.c->stream));
+        L.tail_call = p->calls - 1;
+      }
+      const int st = lane_rescan(p, L, halo);
       if (st != SS_OK) return st;
     }
-  } else {
-    const int st = run_lane(owner, true);
-    if (st != SS_OK) return st;
+    const int st = l == owner ? ss_process_device(L.c, d_iq, nframes, d_psd_db, nullptr, nullptr, d_cand_off, d_cand_idx, d_cand_avg, cand_cap)
+                              : ss_process_device(L.c, d_iq, nframes, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+    if (st != SS_OK && st != SS_ERR_CAND_OVERFLOW) return lane_status(p, L.c, st);
+    L.next_abs = start + nframes;
+  }
+  if (!everyone) {
+    // the lane next in turn will have missed this call: give it the tail now, on its own stream (d_iq stays valid until
+    // ss_pipe_sync, by contract)
     p->turn = (p->turn + 1) % nlanes;
+    if (nframes >= ss_pipe::kHaloMax) {
+      const int st = lane_keep_tail(p, p->lanes[(size_t)p->turn], d_iq, nframes, p->calls);
+      if (st != SS_OK) return st;
+    }
   }
   *seen += nframes;
   p->prev_start = start;
