@@ -47,7 +47,7 @@ __device__ __forceinline__ float2 mulw32(float2 x) {
     // rotate (c0 - i s0) by (-i)^q
     constexpr float c = q == 0 ? c0 : q == 1 ? -s0 : q == 2 ? -c0 : s0;
     constexpr float s = q == 0 ? -s0 : q == 1 ? -c0 : q == 2 ? s0 : c0;  // imaginary part of W
-    return make_float2(x.x * c - x.y * s, x.x * s + x.y * c);
+    return make_float2(fmaf(x.x, c, -(x.y * s)), fmaf(x.x, s, x.y * c));  // explicit, like cmul
   }
 }
 

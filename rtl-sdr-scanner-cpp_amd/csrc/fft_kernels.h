@@ -18,8 +18,11 @@ constexpr int kFftThreads = 256;
 
 enum { FMT_CF32 = 0, FMT_CS8 = 1, FMT_CU8 = 2 };
 
+// The fused form is spelled out: left to -ffp-contract the compiler picks which of the two products goes into the FMA per
+// call site, and two copies of the same butterfly (the unrolled halves of k_fft256xR_psd<3>) then round differently — a
+// frame's PSD must not depend on its position in the batch.
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+  return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }

@@ -117,6 +117,24 @@ def test_alternative_implementations_meet_the_contract(oracle_mod, monkeypatch, 
     assert ncand > 50 and ndc <= max(2, ncand // 200), (ncand, ndc)
 
 
+@pytest.mark.parametrize("n,fmt", [(512, "cs8"), (1024, "cf32"), (2048, "cs8"), (2048, "cf32"), (4096, "cu8"), (8192, "cf32"), (16384, "cs8"),
+                                   (65536, "cf32"), (131072, "cs8")])
+def test_psd_of_a_frame_does_not_depend_on_its_position_in_the_batch(n, fmt):
+    """Kernels that take several frames per workgroup must round every frame the same way (the two unrolled halves of the
+    2048-point kernel once did not: the compiler chose the FMA operand per call site): frame-range sharding, ss_pipe and
+    'any cut of the stream gives the same bits' all rest on it."""
+    band = pkg.synth.SyntheticBand(n, seed=8, on_frame=5, off_frame=400)
+    nf = 24 if n <= 16384 else 10
+    iq, in_format = {"cf32": (band.frames_cf32, pkg.abi.SS_FMT_CF32), "cs8": (band.frames_cs8, pkg.abi.SS_FMT_CS8),
+                     "cu8": (band.frames_cu8, pkg.abi.SS_FMT_CU8)}[fmt]
+    iq = iq(nf)
+    kw = dict(fft_size=n, decim=1, in_format=in_format, learn_frames=2, max_batch=nf)
+    ref = pkg.SpectrumEngine(250 * n, 145_000_000, **kw).process(iq, want=("psd",))["psd"]
+    for off in (1, 2, 3, 5):
+        got = pkg.SpectrumEngine(250 * n, 145_000_000, **kw).process(iq[off:], want=("psd",))["psd"]
+        np.testing.assert_array_equal(got, ref[off:], err_msg=f"batch starting at frame {off}")
+
+
 def test_gpu_fft_is_as_accurate_as_the_cpu_fp32_ffts(oracle_mod):
     """Against an fp64 evaluation of the same definition (window, FFT, |X|^2/fs), the engine's PSD is as close
     as the oracle's fp32 FFT is (and as MKL's FFTW interface is, tests/test_oracle_fft.py): the parity

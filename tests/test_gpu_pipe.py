@@ -94,3 +94,47 @@ def test_pipe_argument_errors():
         pkg.engine.Pipe(512_000, 100_000_000, lanes=2, fft_size=2048, max_batch=32)
     with pytest.raises(pkg.abi.SpecscanError):
         pkg.engine.Pipe(512_000, 100_000_000, lanes=2, fft_size=2048, max_batch=128, flags=pkg.abi.SS_FLAG_SPECTROGRAM)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SS_PIPE_SEEDS", "6"))))
+def test_random_call_sequences(seed):
+    """Random lane counts, frame sizes, formats, call sizes (1 .. 300 frames: long calls taken in turn, short ones by every lane,
+    every alignment of the halo), with a retune + reset somewhere: a pipe and one context must agree bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(9000 + seed)
+    lanes = int(rng.integers(2, 5))
+    n = int(rng.choice([1024, 2048, 8192, 16384]))
+    decim = int(rng.choice([1, 1, 2]))
+    fmt = str(rng.choice(["cf32", "cs8"]))
+    learn = int(rng.integers(5, 60))
+    fs, center = 250 * n, 145_000_000
+    calls = []
+    while sum(calls) < 1200:
+        calls.append(int(rng.integers(64, 301)) if rng.random() < 0.7 else int(rng.integers(1, 64)))
+    total = sum(calls)
+    band = pkg.synth.SyntheticBand(n, decim=decim, seed=seed, on_frame=learn + 10, off_frame=total - 30)
+    if fmt == "cf32":
+        in_format = pkg.abi.SS_FMT_CF32
+        d_iq = torch.from_numpy(band.frames_cf32(total).view(np.float32).reshape(total, -1)).to(dev)
+    else:
+        in_format = pkg.abi.SS_FMT_CS8
+        d_iq = torch.from_numpy(band.frames_cs8(total).reshape(total, -1)).to(dev)
+    kw = dict(fft_size=n, decim=decim, in_format=in_format, learn_frames=learn, max_batch=300)
+    one, pipe = pkg.SpectrumEngine(fs, center, **kw), pkg.engine.Pipe(fs, center, lanes=lanes, **kw)
+    cut = int(rng.integers(2, len(calls) - 2))
+    a = _scan(one, d_iq, calls[:cut], n, None, dev, torch)
+    b = _scan(pipe, d_iq, calls[:cut], n, None, dev, torch)
+    if rng.random() < 0.7:  # SdrDevice::setFrequencyRange: retune + Transmission::resetBuffers
+        for obj in (one, pipe):
+            obj.set_frequency_range(center + fs - fs // 2, center + fs + fs // 2)
+            obj.reset()
+    off = sum(calls[:cut])
+    a += _scan(one, d_iq[off:], calls[cut:], n, None, dev, torch)
+    b += _scan(pipe, d_iq[off:], calls[cut:], n, None, dev, torch)
+    for k, ((p1, o1, i1, a1), (p2, o2, i2, a2)) in enumerate(zip(a, b)):
+        np.testing.assert_array_equal(p1, p2, err_msg=f"seed {seed}: psd of call {k}")
+        np.testing.assert_array_equal(o1, o2, err_msg=f"seed {seed}: offsets of call {k}")
+        np.testing.assert_array_equal(i1, i2, err_msg=f"seed {seed}: bins of call {k}")
+        np.testing.assert_array_equal(a1, a2, err_msg=f"seed {seed}: powers of call {k}")
+    pipe.close()
