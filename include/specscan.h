@@ -232,7 +232,8 @@ int ss_feed_pending(const ss_feed* feed);
  * is six launches and no events: the tail of call k is copied on the stream of the lane that takes call k + 1 — which is
  * why d_iq has to stay intact until ss_pipe_sync, not just until the call's own work is done —, the restart is bookkeeping
  * only, and the halo runs FFT + detect for the ring alone. 8192 points, 1024-frame calls (bench.py --lanes): 197 / 223 GS/s
- * with two / three lanes against 187 for one context; four lanes: 180. */
+ * with two / three lanes against 187 for one context; four lanes: 180. The halo is 32..47 frames whatever the call's size:
+ * lanes are for calls of many hundreds of frames (65536 points, 128-frame calls: 97 GS/s against 128 for one context). */
 typedef struct ss_pipe ss_pipe;
 int ss_pipe_create(const ss_config* cfg, int32_t lanes, ss_pipe** out); /* lanes 1..4; cfg->max_batch >= 64 */
 void ss_pipe_destroy(ss_pipe* pipe);
