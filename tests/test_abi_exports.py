@@ -60,6 +60,9 @@ def test_no_gpu_means_loud_failure(lib):
     h = C.c_void_p()
     assert lib.ss_create(C.byref(cfg), C.byref(h)) == pkg.abi.SS_ERR_NO_DEVICE
     assert b"HIP device" in lib.ss_last_error(None)
+    with pytest.raises(pkg.abi.SpecscanError) as e:  # a pipe is contexts: the same refusal
+        pkg.engine.Pipe(2_048_000, 145_000_000, lanes=2)
+    assert e.value.args and "HIP device" in str(e.value)
 
 
 def test_product_never_imports_the_oracle():
