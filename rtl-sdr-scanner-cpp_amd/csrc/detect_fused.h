@@ -80,6 +80,10 @@ struct DetectArgs {
   float* spec_prev_sum;            // [spec_n] Container::m_sum they belong to
   int spec_prev_tiles;
   int spec_m, spec_n;              // m_decimatorFactor (a power of two <= 256), m_outputSize
+  // k_detect_fused<..., TWO = true> (ss_pipe): PSD rows of batch frames >= split live in psd_b (row 0 = frame split); frames
+  // below split are a re-scanned halo and report no candidates
+  const float* psd_b;
+  int split;
 };
 
 // plane[row][byte offset coff]: block-uniform row base (scalar registers) + one 32-bit per-thread offset
@@ -182,7 +186,7 @@ __device__ __forceinline__ void spectrogram_fold(const DetectArgs& a, int tid, i
   a.spec_prev_sum[ob] = acc;
 }
 
-template <int G, int GX, int TF, int TB_ = 256, bool SPEC = false>
+template <int G, int GX, int TF, int TB_ = 256, bool SPEC = false, bool TWO = false>
 __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k_detect_fused(DetectArgs a) {
   using T = DetectTile<G, GX, TF, TB_>;
   constexpr int A = T::A, TB = T::TB, P = T::P, ROWS = T::ROWS, H = T::H, SEGW = T::SEGW, NSEG = T::NSEG, YW = T::YW;
@@ -206,7 +210,8 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
   }
   // block-uniform classification
   const bool interior = (b0 - A >= 0) && (b0 + TB + A <= n);
-  const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes);
+  bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes);
+  if constexpr (TWO) steady = steady && (f0 - (G - 1) >= a.split || f0 + TF <= a.split);  // all rows of the tile in one plane
   const int first_hist = nframes - H;  // batch frames >= first_hist become the ring rows [frame - first_hist]
   const bool writes_hist = f0 + TF > first_hist;
 
@@ -224,6 +229,9 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
         const float t = a.thr[colc];
         // block-uniform row base (scalar registers) + one 32-bit per-thread byte offset
         const char* p = reinterpret_cast<const char*>(a.psd + (size_t)(f0 - (G - 1)) * n);
+        if constexpr (TWO) {
+          if (f0 - (G - 1) >= a.split) p = reinterpret_cast<const char*>(a.psd_b + (size_t)(f0 - (G - 1) - a.split) * n);
+        }
         const uint32_t coff = (uint32_t)colc * 4u;
         float x[ROWS];
 #pragma unroll
@@ -272,6 +280,9 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
         for (int r = 0; r < ROWS; ++r) {
           const int fr = f0 - (G - 1) + r;
           const float* src = fr < 0 ? a.hist_in + (size_t)max(H + fr, 0) * n : a.psd + (size_t)min(fr, nframes - 1) * n;
+          if constexpr (TWO) {
+            if (fr >= a.split) src = a.psd_b + (size_t)(min(fr, nframes - 1) - a.split) * n;
+          }
           x[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + coff);
         }
 #pragma unroll
@@ -361,6 +372,9 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
           if (bits & (1u << o)) dst[o] = outv[o];
       }
     }
+    if constexpr (TWO) {
+      if (f < a.split) bits = 0;  // halo frames: for the ring only
+    }
     // lanes q and q + TF hold the same frame, segments seg and seg + 1: together one 32-bit mask word
     const uint32_t hi_bits = __shfl_down(bits, TF);
     if ((seg & 1) == 0 && live) {
@@ -403,7 +417,8 @@ __global__ void k_hist_shift(const float* __restrict__ hist_in, float* __restric
 __global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ maskbits, int words_per_row, int n, int nframes,
                                                   const int* __restrict__ counts, int* __restrict__ counts_next, int clear_n,
                                                   const float* __restrict__ avg, int cap, int* __restrict__ off_int,
-                                                  int* __restrict__ off_out, int* __restrict__ cand_idx, float* __restrict__ cand_avg) {
+                                                  int* __restrict__ off_out, int* __restrict__ cand_idx, float* __restrict__ cand_avg,
+                                                  int out_shift /* frames below it (ss_pipe halo) have no entry in off_out */) {
   constexpr int LIST = 2048;
   __shared__ int list[LIST];
   const int f = blockIdx.x;
@@ -432,10 +447,10 @@ __global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ m
   const int mine = counts[f];
   if (lane == 0) {
     off_int[f] = begin;
-    if (off_out) off_out[f] = begin;
+    if (off_out && f >= out_shift) off_out[f - out_shift] = begin;
     if (f == nframes - 1) {
       off_int[nframes] = begin + mine;
-      if (off_out) off_out[nframes] = begin + mine;
+      if (off_out) off_out[nframes - out_shift] = begin + mine;
     }
     // the other half of the double-buffered counters held the PREVIOUS batch (clear_n frames, possibly more than this one)
     for (int g = f; g < clear_n; g += nframes) counts_next[g] = 0;

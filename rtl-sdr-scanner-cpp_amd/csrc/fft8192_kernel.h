@@ -302,14 +302,33 @@ __device__ __forceinline__ float2 mulw32_if(float2 x, bool on) {
 // bytes with 16-byte stores / 16-byte loads and stores (19.5 / 20.0 / 16.7 us per 1024 frames), 2 = transform
 // only (no global loads, stores never execute). Measured at 1024 / 4096 frames per launch: full 26.1 / 90.7 us,
 // memory only 19.2 / 72.3 us, transform only 16.7 / 48.6 us — see DESIGN.md.
-template <int FMT, int WAVES_PER_SIMD, bool DBG = false, int ABLATE = 0>
-__global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const void* __restrict__ iq, long long item_stride,
+// TWO (ss_pipe): frames [0, split) come from `iq` / go to `psd` as usual, frames >= split from a second source to a second
+// plane (a lane re-scans the halo it kept and scans the caller's batch in one launch).
+struct Fft8192Second {
+  const void* iq;
+  long long item_stride;
+  float* psd;
+  int split;
+};
+
+template <int FMT, int WAVES_PER_SIMD, bool DBG = false, int ABLATE = 0, bool TWO = false>
+__global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const void* __restrict__ iq_a, long long item_stride,
                                                                           const float* __restrict__ win, Fft8192Tables tabs, float db_off,
-                                                                          float scale, float* __restrict__ psd) {
+                                                                          float scale, float* __restrict__ psd_a, Fft8192Second second) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s = reinterpret_cast<float*>(smem_raw);
   const int t = threadIdx.x;
-  const size_t frame = blockIdx.x;
+  size_t frame = blockIdx.x;
+  const void* iq = iq_a;
+  float* psd = psd_a;
+  if constexpr (TWO) {
+    if ((int)blockIdx.x >= second.split) {  // block-uniform
+      frame = blockIdx.x - (size_t)second.split;
+      iq = second.iq;
+      item_stride = second.item_stride;
+      psd = second.psd;
+    }
+  }
   const size_t in_base = frame * (size_t)item_stride;
   long long ts[DBG ? 8 : 1] = {};  // DBG: per-workgroup wall_clock64 stamps of the phases (SS_DEBUG_TIMING_FFT)
   if constexpr (DBG) if (t == 0) ts[0] = wall_clock64();

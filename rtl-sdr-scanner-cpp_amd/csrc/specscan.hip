@@ -136,6 +136,14 @@ struct ss_ctx {
   float* d_relplane = nullptr;            // full rel plane, only when a caller asks for it (lazy)
   int last_n_learn = 0;
   bool history_only = false;  // ss_pipe halo: run the chain for the averager ring only (no candidates, no emit)
+  // ss_pipe, 8192 points: one launch over [halo | batch] — frames >= split are read from / written to a second place and
+  // only they report candidates (transient: set around one run_batch call)
+  struct Two {
+    const void* iq_b = nullptr;
+    long long stride_b = 0;
+    float* psd_b = nullptr;
+    int split = 0;
+  } two;
   const float* last_hist = nullptr;       // ring rows as they were before the last batch
   float* last_thr = nullptr;
   // back end, unfused path (any other grouping): one buffer holds the ring rows + the batch rows
@@ -325,13 +333,14 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
                          c->cfg.int_scale, d_psd);
     }
   };
+  const ss::Fft8192Second second{c->two.iq_b, c->two.stride_b, c->two.psd_b, c->two.split};
   auto launch8 = [&](auto kernel, int lds_bytes) {
     if (timed) {
       hipExtLaunchKernelGGL(kernel, dim3(nframes), dim3(512), lds_bytes, c->stream, e0, e1, 0, d_iq, item_stride, (const float*)c->d_win, tabs,
-                            c->db_off, c->cfg.int_scale, d_psd);
+                            c->db_off, c->cfg.int_scale, d_psd, second);
     } else {
       hipLaunchKernelGGL(kernel, dim3(nframes), dim3(512), lds_bytes, c->stream, d_iq, item_stride, (const float*)c->d_win, tabs, c->db_off,
-                         c->cfg.int_scale, d_psd);
+                         c->cfg.int_scale, d_psd, second);
     }
   };
   if (c->fft8192_variant == 2) launch(ss::k_fft8192_psd<FMT>, ss::kFft8192LdsBytes);
@@ -342,9 +351,9 @@ void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nfra
     else if (ablate == 2) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 2>, ss::kFft8192W8LdsBytes);
     else if (ablate == 3) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 3>, ss::kFft8192W8LdsBytes);
     else if (ablate == 4 && FMT == ss::FMT_CF32) launch8(ss::k_fft8192_psd_w8<ss::FMT_CF32, 8, false, 4>, ss::kFft8192W8LdsBytes);
-    else if constexpr (FMT == ss::FMT_CF32) launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
     // (int8 IQ ran best at 6 waves per SIMD, 80 registers, while the compiler packed fp32 pairs: 23.0 vs 27.7 us; built
     // without the SLP vectorizer the 64-register form does not spill and wins, 21.4 vs 22.4 us)
+    else if (c->two.split > 0) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 0, true>, ss::kFft8192W8LdsBytes);
     else launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
   }
   if (tabs.dbg && ++c->diag.fft_calls == 20) {
@@ -496,7 +505,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   const int tiles = ((nframes + shift + TF - 1) / TF) * ((n + TB - 1) / TB);
   ss::DetectArgs da{d_psd, z->d_thr,           hist_in,   hist_out,  n,      nframes,   n_learn,  c->frames_pushed,
                     shift, c->cfg.start_level, c->d_pass, c->d_mask, counts, d_rel_out, avg_full, c->d_avg,         nullptr,
-                    nullptr, nullptr,          nullptr,   0,         0,      0};
+                    nullptr, nullptr,          nullptr,   0,         0,      0,         c->two.psd_b, c->two.split};
   if (c->diag.d_detect_stamps && tiles <= 65536) da.dbg = c->diag.d_detect_stamps;
   const bool history_only = c->history_only;
   if (history_only) da.start_level = NAN;  // startLevel <= avg is false for every avg: no hits, the counters stay clean
@@ -513,6 +522,8 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
     c->spec_pending_sum = spec->d_sum;  // (the containers live until the context is destroyed)
     c->spec_pending_tiles = (nframes + shift + TF - 1) / TF;
     c->spec_cur ^= 1;
+  } else if (c->two.split > 0) {
+    hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, false, true>), dim3(tiles), dim3(TB), 0, c->stream, da);
   } else {
     hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, false>), dim3(tiles), dim3(TB), 0, c->stream, da);
   }
@@ -529,7 +540,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
     hipLaunchKernelGGL(ss::k_cand_emit, dim3(nframes), dim3(64), 0, c->stream, (const uint32_t*)c->d_mask, n / 32, n, nframes,
                        (const int*)counts, counts_next, c->cnt_frames[c->cnt_cur ^ 1], (const float*)(avg_full ? avg_full : c->d_avg), cand_cap,
                        c->d_off, d_cand_off,
-                       (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr, d_cand_avg);
+                       (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr, d_cand_avg, c->two.split);
     c->cnt_frames[c->cnt_cur] = nframes;   // this half now holds nframes counts (read by the emit above, cleared by the next one)
     c->cnt_frames[c->cnt_cur ^ 1] = 0;     // just cleared
     c->cnt_cur ^= 1;
@@ -1500,6 +1511,34 @@ int lane_rescan(ss_pipe* p, ss_pipe::Lane& L, int halo) {
   return lane_status(p, c, st);
 }
 
+// 8192 points, 21 x 21: the restart, the halo and the call as ONE batch of halo + nframes frames — the FFT kernel reads the
+// frames below `halo` from the lane's tail slot and the rest from the caller, the detect kernel reads PSD rows from the two
+// planes accordingly and lets only the caller's frames report candidates, the emit kernel numbers frames from `halo` on.
+// Three launches instead of five, and no small kernels in front of the big ones.
+int lane_rescan_and_process(ss_pipe* p, ss_pipe::Lane& L, int halo, const void* d_iq, int nframes, float* d_psd_db, int32_t* d_cand_off,
+                            int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
+  ss_ctx* c = L.c;
+  const size_t row = (size_t)p->cfg.fft_size * in_bytes_per_sample(p->cfg.in_format);
+  const char* tail = static_cast<const char*>(L.d_tail) + (size_t)(ss_pipe::kHaloMax - halo) * row;
+  std::lock_guard<std::mutex> lane_lock(c->mtx);
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  c->frames_pushed = 0;  // ss_reset's bookkeeping without clearing the ring
+  c->abs_frames = 0;
+  c->rot_frames = 0;
+  c->last_n = 0;
+  NoiseState* z = nullptr;
+  int st = get_noise(c, &z);
+  if (st != SS_OK) return lane_status(p, c, st);
+  const int n_learn = plan_learning(c, z, halo + nframes, nullptr);  // 0: lanes take turns only once the ceiling is learned
+  c->two.iq_b = d_iq;
+  c->two.stride_b = (long long)c->n * c->cfg.decim;
+  c->two.psd_b = d_psd_db ? d_psd_db : c->d_psd + (size_t)halo * (size_t)c->n;
+  c->two.split = halo;
+  st = run_batch(c, tail, (long long)c->n, halo + nframes, n_learn, z, nullptr, nullptr, nullptr, d_cand_off, d_cand_idx, d_cand_avg, cand_cap);
+  c->two = ss_ctx::Two{};
+  return lane_status(p, c, st);
+}
+
 // the last kHaloMax frames of a call's input -> the lane's slot, on the lane's stream
 int lane_keep_tail(ss_pipe* p, ss_pipe::Lane& L, const void* d_iq, int nframes, long long call) {
   ss_ctx* c = L.c;
@@ -1547,9 +1586,11 @@ int ss_pipe_create(const ss_config* cfg, int32_t lanes, ss_pipe** out) {
   p->range_lo = cfg->range_lo;
   p->range_hi = cfg->range_hi;
   const size_t tail_bytes = (size_t)ss_pipe::kHaloMax * (size_t)cfg->fft_size * in_bytes_per_sample(cfg->in_format);
+  ss_config lane_cfg = *cfg;
+  lane_cfg.max_batch = cfg->max_batch + ss_pipe::kHaloMax;  // a lane may take its halo and the call as one batch
   for (int l = 0; l < lanes; ++l) {
     ss_pipe::Lane L;
-    const int st = ss_create(cfg, &L.c);
+    const int st = ss_create(&lane_cfg, &L.c);
     if (st != SS_OK) {
       ss_pipe_destroy(p);
       return st;  // ss_last_error(NULL) holds the message
@@ -1637,6 +1678,14 @@ int ss_pipe_process_device(ss_pipe* p, const void* d_iq, int32_t nframes, float*
         const size_t tail_bytes = (size_t)ss_pipe::kHaloMax * (size_t)p->cfg.fft_size * in_bytes_per_sample(p->cfg.in_format);
         SS_HIP(L.c, hipMemcpyAsync(L.d_tail, from->d_tail, tail_bytes, hipMemcpyDeviceToDevice, L.c->stream));
         L.tail_call = p->calls - 1;
+      }
+      if (L.c->fused && L.c->use_fft8192 && L.c->fft8192_variant != 2 && !L.c->diag.fft_ablate && L.c->diag.fft_stamp_path.empty()) {
+        const bool out = l == owner;
+        const int st = lane_rescan_and_process(p, L, halo, d_iq, nframes, out ? d_psd_db : nullptr, out ? d_cand_off : nullptr,
+                                               out ? d_cand_idx : nullptr, out ? d_cand_avg : nullptr, out ? cand_cap : 0);
+        if (st != SS_OK && st != SS_ERR_CAND_OVERFLOW) return st;
+        L.next_abs = start + nframes;
+        continue;
       }
       const int st = lane_rescan(p, L, halo);
       if (st != SS_OK) return st;
