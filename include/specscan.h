@@ -229,11 +229,14 @@ int ss_feed_pending(const ss_feed* feed);
  * SS_FLAG_KEEP_PLANES are per-context features and are refused here.
  *
  * What a turn costs the host decides whether lanes pay (a HIP call is 3-4 us here, a batch ~35 us on the device), so a turn
- * is six launches and no events: the tail of call k is copied on the stream of the lane that takes call k + 1 — which is
- * why d_iq has to stay intact until ss_pipe_sync, not just until the call's own work is done —, the restart is bookkeeping
- * only, and the halo runs FFT + detect for the ring alone. 8192 points, 1024-frame calls (bench.py --lanes): 197 / 223 GS/s
- * with two / three lanes against 187 for one context; four lanes: 180. The halo is 32..47 frames whatever the call's size:
- * lanes are for calls of many hundreds of frames (65536 points, 128-frame calls: 97 GS/s against 128 for one context). */
+ * is a handful of launches and no events: the tail of call k is copied on the stream of the lane that takes call k + 1 —
+ * which is why d_iq has to stay intact until ss_pipe_sync, not just until the call's own work is done —, the restart is
+ * bookkeeping only, and for 8192-point frames the halo and the call go through the chain as ONE batch (the FFT and detect
+ * kernels read the halo's rows from the lane's own copies and the rest from the caller; only the caller's frames report
+ * candidates): four launches per turn. Other sizes run the halo as a batch of its own for the ring alone (six launches).
+ * 8192 points, 1024-frame calls (bench.py --lanes): 218 / 248 / 212 GS/s with two / three / four lanes against 188 for one
+ * context (int8 IQ, three lanes: 271). The halo is 32..47 frames whatever the call's size: lanes are for calls of many
+ * hundreds of frames (65536 points, 128-frame calls: 97 GS/s against 128 for one context). */
 typedef struct ss_pipe ss_pipe;
 int ss_pipe_create(const ss_config* cfg, int32_t lanes, ss_pipe** out); /* lanes 1..4; cfg->max_batch >= 64 */
 void ss_pipe_destroy(ss_pipe* pipe);
