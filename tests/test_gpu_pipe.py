@@ -138,3 +138,32 @@ def test_random_call_sequences(seed):
         np.testing.assert_array_equal(i1, i2, err_msg=f"seed {seed}: bins of call {k}")
         np.testing.assert_array_equal(a1, a2, err_msg=f"seed {seed}: powers of call {k}")
     pipe.close()
+
+
+def test_pipe_without_a_psd_plane():
+    """Detect mode: the caller takes candidates only; the lanes keep the PSD rows in their own planes."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, fs, learn, calls = 8192, 2_048_000, 30, [64, 128, 128, 100, 128]
+    total = sum(calls)
+    band = pkg.synth.SyntheticBand(n, seed=3, on_frame=learn + 10, off_frame=total - 10)
+    d_iq = torch.from_numpy(band.frames_cf32(total).view(np.float32).reshape(total, -1)).to(dev)
+    kw = dict(fft_size=n, decim=1, learn_frames=learn, max_batch=128)
+    one, pipe = pkg.SpectrumEngine(fs, 145_000_000, **kw), pkg.engine.Pipe(fs, 145_000_000, lanes=3, **kw)
+    res = []
+    for obj in (one, pipe):
+        pos, bufs = 0, []
+        for nf in calls:
+            off = torch.zeros(nf + 1, dtype=torch.int32, device=dev)
+            idx = torch.empty(nf * 512, dtype=torch.int32, device=dev)
+            avg = torch.empty(nf * 512, dtype=torch.float32, device=dev)
+            obj.process_device(d_iq[pos:pos + nf], nf, psd=None, cand_off=off, cand_idx=idx, cand_avg=avg)
+            bufs.append((off, idx, avg))
+            pos += nf
+        obj.sync()
+        res.append([(o.cpu().numpy(), i.cpu().numpy()[:int(o[-1])], a.cpu().numpy()[:int(o[-1])]) for o, i, a in bufs])
+    for (o1, i1, a1), (o2, i2, a2) in zip(*res):
+        np.testing.assert_array_equal(o1, o2)
+        np.testing.assert_array_equal(i1, i2)
+        np.testing.assert_array_equal(a1, a2)
+    assert sum(int(o[-1]) for o, _, _ in res[0]) > 200
