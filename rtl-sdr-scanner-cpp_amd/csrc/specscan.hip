@@ -1587,7 +1587,9 @@ int ss_pipe_create(const ss_config* cfg, int32_t lanes, ss_pipe** out) {
   p->range_hi = cfg->range_hi;
   const size_t tail_bytes = (size_t)ss_pipe::kHaloMax * (size_t)cfg->fft_size * in_bytes_per_sample(cfg->in_format);
   ss_config lane_cfg = *cfg;
-  lane_cfg.max_batch = cfg->max_batch + ss_pipe::kHaloMax;  // a lane may take its halo and the call as one batch
+  // a lane may take its halo and the call as one batch; the fused back end stops at 65536 frames per batch, so a pipe whose
+  // calls may come that close keeps the lanes at the limit and runs such calls' halos as batches of their own
+  lane_cfg.max_batch = (cfg->max_batch <= 65536 && cfg->max_batch + ss_pipe::kHaloMax > 65536) ? 65536 : cfg->max_batch + ss_pipe::kHaloMax;
   for (int l = 0; l < lanes; ++l) {
     ss_pipe::Lane L;
     const int st = ss_create(&lane_cfg, &L.c);
@@ -1679,7 +1681,8 @@ int ss_pipe_process_device(ss_pipe* p, const void* d_iq, int32_t nframes, float*
         SS_HIP(L.c, hipMemcpyAsync(L.d_tail, from->d_tail, tail_bytes, hipMemcpyDeviceToDevice, L.c->stream));
         L.tail_call = p->calls - 1;
       }
-      if (L.c->fused && L.c->use_fft8192 && L.c->fft8192_variant != 2 && !L.c->diag.fft_ablate && L.c->diag.fft_stamp_path.empty()) {
+      if (L.c->fused && L.c->use_fft8192 && L.c->fft8192_variant != 2 && !L.c->diag.fft_ablate && L.c->diag.fft_stamp_path.empty() &&
+          halo + nframes <= L.c->cfg.max_batch) {
         const bool out = l == owner;
         const int st = lane_rescan_and_process(p, L, halo, d_iq, nframes, out ? d_psd_db : nullptr, out ? d_cand_off : nullptr,
                                                out ? d_cand_idx : nullptr, out ? d_cand_avg : nullptr, out ? cand_cap : 0);
