@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libspecscan.so")
 SOURCES = ["specscan.hip", "channelizer.hip"]
-HEADERS = ["fft_kernels.h", "fft8192_kernel.h", "fft256_kernels.h", "detect_kernels.h", "detect_fused.h", os.path.join("..", "..", "include", "specscan.h"),
+HEADERS = ["fft_kernels.h", "fft8192_kernel.h", "fft256_kernels.h", "detect_kernels.h", "detect_fused.h", "specscan_pipe_impl.h", os.path.join("..", "..", "include", "specscan.h"),
            os.path.join("..", "..", "include", "specscan_channelizer.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
