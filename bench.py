@@ -1,17 +1,24 @@
 #!/usr/bin/env python
 """bench.py — IQ MSamples/s scanned by the spectral-scan hot path on MI355X.
 
-One step = one pass of the whole chain (load + Hamming window + 8192-pt FFT + dB power, noise-relative,
-21-frame x 21-bin averaging, threshold, candidate compaction) over one batch of 1024 synthetic frames
-that is already resident in HBM: BASELINE.json configs[1] ("8192-pt FFT, 2.048 MS/s, 1024-frame batches
-on 1x MI355X"). With --gpus N every rank scans its own band (weak scaling, no data-path collective; the
-scan configuration is broadcast once from rank 0).
+One step = one pass of the whole chain (load + Hamming window + FFT + dB power, noise-relative, 21-frame x 21-bin
+averaging, threshold, candidate compaction) over one batch of synthetic frames already resident in HBM. The default is
+BASELINE.json configs[1]: "8192-pt FFT, 2.048 MS/s, 1024-frame batches on 1x MI355X"; `--config 1|3|4|5` select the
+other BASELINE configs. Every step reads a DIFFERENT input batch and writes a DIFFERENT output set; the sets in rotation
+are sized to exceed the 256 MiB Infinity Cache several times over, so the memory traffic of a step is HBM traffic.
 
-Prints ONE JSON line on rank 0. `roofline` is for the dominant kernel (fused FFT+PSD): algorithmic bytes
-(8 B/sample CF32 in + 4 B/sample dB out = 12 B/sample) x samples per launch / the kernel's
-mean device time, taken from start/stop events attached to each launch on the engine's own stream
-during the timed region. `cpu_baseline` times the reference's own compiled sources (oracle/_ref) —
-or the C oracle where _ref is absent — on the host cores, on a bounded sample of the same workload.
+`python bench.py --gpus N` starts its own N ranks (torch.distributed.run, one process per GPU, RCCL) when it is not already
+running under a launcher. Bands shard across ranks (`--shard bands`, config 4) or one band's frame stream is cut into
+contiguous ranges (`--shard frames`, config 5); there is no data-path collective either way, the scan configuration is
+broadcast once from rank 0.
+
+Prints ONE JSON line on rank 0:
+  value / ms_per_step   whole-job throughput, barrier + device sync on both sides of exactly --steps steps, max over ranks
+  roofline              the dominant kernel (fused load+window+FFT+dB): algorithmic bytes per launch / its mean device time
+                        from start/stop events attached to launches on the engine's own stream inside the timed region
+  roofline_chain        the same algorithmic bytes / the whole step's time (every kernel of the chain, launch gaps included)
+  cpu_baseline          the reference's own compiled sources (oracle/_ref; the C restatement where that is absent) on the
+                        host cores over a bounded sample of the same workload, one thread and all threads
 """
 from __future__ import annotations
 
@@ -19,6 +26,8 @@ import argparse
 import json
 import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,21 +36,36 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-ALGO_BYTES_PER_SAMPLE = 12.0  # CF32 in (8) + f32 dB out (4), SURVEY.md §8d power mode
+L3_BYTES = 256 << 20   # Infinity Cache
+
+# BASELINE.json configs -> flags (config 2 is the default command line)
+CONFIGS = {
+    1: dict(cpu_only=True),
+    2: dict(),
+    3: dict(fft=65536, frames=128, fmt="cs8", sample_rate=20_000_000, no_psd_out=True),
+    4: dict(gpus=8, shard="bands"),
+    5: dict(gpus=8, shard="frames", fft=1 << 20, frames=16, sample_rate=61_440_000, no_psd_out=True),
+}
 
 
+def algo_bytes_per_sample(fmt: str, psd_out: bool) -> float:
+    """IQ in (8 B CF32 / 2 B int8) + dB row out (4 B) in power mode; detect mode hands out candidates only."""
+    return (8.0 if fmt == "cf32" else 2.0) + (4.0 if psd_out else 0.0)
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline
 def _cpu_worker(args):
     """One host core scanning its own band with the reference's code for `budget_s` seconds."""
-    seed, n, fs, budget_s, use_ref, backend = args
+    seed, n, fs, budget_s, use_ref, backend, stages = args
     import numpy as np
     import rtl_sdr_scanner_cpp_amd as pkg
     from oracle import oracle as O
     band = pkg.synth.SyntheticBand(n, seed=seed, on_frame=130, off_frame=10_000)
-    chunk = 64
+    chunk = max(1, min(64, (1 << 19) // n))
     iq = band.frames_cf32(chunk)
     center = 145_000_000
     frames = 0
-    if use_ref:
+    if use_ref and not stages:
         O.ref().orc_set_fft_backend(backend)
         chain = O.RefChain(n, fs, center - fs // 2, center + fs // 2)
         t_ms = 0
@@ -50,7 +74,7 @@ def _cpu_worker(args):
         chain = O.oracle_chain(fs, center, fft_size=n, decim=1, max_batch=chunk)
     t0 = time.perf_counter()
     while True:
-        if use_ref:
+        if use_ref and not stages:
             chain.process(iq, t_ms + 20 * np.arange(chunk))
             t_ms += 20 * chunk
         else:
@@ -58,7 +82,16 @@ def _cpu_worker(args):
         frames += chunk
         el = time.perf_counter() - t0
         if el >= budget_s:
-            return frames, el
+            break
+    split = None
+    if stages:
+        import ctypes as C
+        buf = (C.c_double * 6)()
+        O.lib().orc_stage_seconds(chain._h, buf)
+        tot = sum(buf) or 1.0
+        names = ("window+fft+shift", "psd_db", "noise_relative", "averager_21_frames", "average_21_bins", "threshold")
+        split = {k: round(v / tot, 3) for k, v in zip(names, buf)}
+    return frames, el, split
 
 
 def usable_cores() -> int:
@@ -76,7 +109,17 @@ def usable_cores() -> int:
     return max(1, min(cores, 64))
 
 
-def cpu_baseline(n: int, fs: int, budget_s: float = 12.0):
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n: int, fs: int, budget_s: float = 12.0, stages: bool = False):
     os.environ.setdefault("MKL_NUM_THREADS", "1")  # one FFT thread per worker process, like fft_v's nthreads = 1
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     from oracle import oracle as O
@@ -85,43 +128,98 @@ def cpu_baseline(n: int, fs: int, budget_s: float = 12.0):
     backend = 2 if (O.ref() if use_ref else O.lib()).orc_set_fft_backend(2) == 0 else 0
     cores = usable_cores()
     ctx = mp.get_context("fork")
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(1000 + i, n, fs, budget_s, use_ref, backend) for i in range(cores)])
+    one_s = max(2.0, budget_s / 3.0)
+    with ctx.Pool(1) as pool:  # (i) one thread, whole chain
+        one = pool.map(_cpu_worker, [(999, n, fs, one_s, use_ref, backend, False)])[0]
+    split = None
+    if stages:
+        with ctx.Pool(1) as pool:  # per-stage split (C restatement: the reference's classes carry no stage clocks)
+            split = pool.map(_cpu_worker, [(998, n, fs, one_s, use_ref, backend, True)])[0][2]
+    with ctx.Pool(cores) as pool:  # (ii) frame-parallel over all hardware threads, one chain per thread
+        res = pool.map(_cpu_worker, [(1000 + i, n, fs, budget_s, use_ref, backend, False) for i in range(cores)])
     frames = sum(r[0] for r in res)
     wall = max(r[1] for r in res)
-    one = res[0][0] * n / res[0][1] / 1e6
-    return {
+    out = {
         "value": round(frames * n / wall / 1e6, 3), "unit": "MS/s", "cores": cores,
         "kind": "reference" if use_ref else "port",
-        "sample": (f"{frames} frames of {n} CF32 samples ({frames * n / 1e6:.0f} MS) in {wall:.1f} s: one independent band per core, "
+        "one_thread": round(one[0] * n / one[1] / 1e6, 3), "nproc": os.cpu_count(), "cpu_model": cpu_model(),
+        "sample": (f"{frames} frames of {n} CF32 samples ({frames * n / 1e6:.0f} MS) in {wall:.1f} s on {cores} threads "
+                   f"(one independent band per thread), {one[0]} frames in {one[1]:.1f} s on one thread; "
                    f"full chain window+FFT+dB+noise+21x21 mean+threshold, "
                    f"{'reference .cpp files compiled in place (oracle/_ref)' if use_ref else 'C restatement (oracle/liboracle.so)'}, "
-                   f"FFT via {'MKL FFTW3 interface' if backend == 2 else 'built-in radix-2'}; {one:.1f} MS/s per core"),
+                   f"FFT via {'MKL FFTW3 interface' if backend == 2 else 'built-in radix-2'}"),
     }
+    if split:
+        out["stage_split_one_thread"] = split
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+# ---------------------------------------------------------------------------------------------- launcher
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks, one per GPU (RCCL). On a box with fewer GPUs than
+    ranks the ranks share devices over gloo (functional only; the JSON line says so)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "SS_DIST_BACKEND" not in env:
+        ndev = 0
+        if not args.launch_check:
+            import torch
+            ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            env["SS_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--gpus", type=int, default=None)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=1024, help="frames per batch (BASELINE config 2: 1024)")
-    ap.add_argument("--fft", type=int, default=8192)
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json config number (1-5); explicit flags win over the preset")
+    ap.add_argument("--frames", type=int, default=None, help="frames per batch (BASELINE config 2: 1024)")
+    ap.add_argument("--fft", type=int, default=None)
+    ap.add_argument("--sample-rate", type=int, default=None)
+    ap.add_argument("--shard", default=None, choices=["bands", "frames"], help="N > 1: one band per rank, or contiguous frame ranges of one band")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fmt", default="cf32", choices=["cf32", "cs8", "cu8"], help="IQ sample format in HBM (the headline is cf32)")
+    ap.add_argument("--fmt", default=None, choices=["cf32", "cs8", "cu8"], help="IQ sample format in HBM (the headline is cf32)")
     ap.add_argument("--spectrogram", action="store_true", help="also run the Spectrogram side branch (SS_FLAG_SPECTROGRAM) every batch")
-    ap.add_argument("--no-psd-out", action="store_true", help="detect mode: the caller takes candidates only, no PSD plane is handed out")
+    ap.add_argument("--no-psd-out", action="store_true", default=None, help="detect mode: the caller takes candidates only, no PSD plane is handed out")
     ap.add_argument("--planes", action="store_true", help="full mode: the rel and avg planes are handed out as well (20 B/sample)")
     ap.add_argument("--decim", type=int, default=1, help="frame decimation D: items of N*D samples, the first N of each are scanned (reference: 5 at 2.048 MS/s)")
     ap.add_argument("--lanes", type=int, default=1, help="ss_pipe with this many lanes (batches of the one band in flight side by side); 1 = one context")
-    ap.add_argument("--single-buffer", action="store_true", help="one output set instead of two alternating ones")
-    ap.add_argument("--time-every", type=int, default=8, help="attach start/stop events to every k-th launch of the FFT kernel")
+    ap.add_argument("--sets", type=int, default=0, help="input batches / output sets in rotation (0 = enough to exceed 2.5x the Infinity Cache, at least 6)")
+    ap.add_argument("--time-every", type=int, default=0, help="attach start/stop events to every k-th launch of the FFT kernel (0 = pick so that >= 8 launches are timed)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not attach per-launch events to the FFT kernel (roofline omitted)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--launch-check", action="store_true", help="exercise launcher, rendezvous, config broadcast and max-over-ranks timing only (no GPU work)")
+    args = ap.parse_args(argv)
+    preset = dict(CONFIGS.get(args.config or 2, {}))
+    args.cpu_only = bool(preset.pop("cpu_only", False))
+    for k, v in preset.items():
+        if getattr(args, k, None) in (None, False):
+            setattr(args, k, v)
+    args.gpus = args.gpus or 1
+    args.frames = args.frames or 1024
+    args.fft = args.fft or 8192
+    args.fmt = args.fmt or "cf32"
+    args.shard = args.shard or "bands"
+    args.no_psd_out = bool(args.no_psd_out)
+    if args.sample_rate is None:
+        args.sample_rate = 2_048_000 * (args.fft // 8192 if args.fft >= 8192 else 1)
+    return args
 
+
+# ---------------------------------------------------------------------------------------------- the measured job
+def run(args):
     import numpy as np
-    import torch
     import rtl_sdr_scanner_cpp_amd as pkg
     from rtl_sdr_scanner_cpp_amd import dist
 
@@ -130,20 +228,42 @@ def main():
     backend = os.environ.get("SS_DIST_BACKEND", "nccl")
     rank, local_rank, world = dist.init(backend)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    device_index = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(device_index)
-    dev = torch.device("cuda", device_index)
-    coll_dev = dev if backend == "nccl" else torch.device("cpu")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    n, fs, nb = args.fft, args.sample_rate, args.frames
 
-    n, fs, nb = args.fft, 2_048_000 * (args.fft // 8192 if args.fft >= 8192 else 1), args.frames
     cfg0 = None
     if rank == 0:
         cfg0 = dict(fft_size=n, sample_rate=fs, decim=args.decim, in_format={"cf32": 0, "cs8": 1, "cu8": 2}[args.fmt], grouping_x=21, grouping_y=21,
-                    start_level_mdB=8000, learn_frames=100, learn_ms=2000, max_batch=nb, band0_center=140_000_000,
-                    band_spacing=2_000_000, n_bands=world, seed=0)
+                    start_level_mdB=8000, learn_frames=min(100, nb), learn_ms=2000, max_batch=nb, band0_center=140_000_000,
+                    band_spacing=max(2_000_000, fs), n_bands=world if args.shard == "bands" else 1, seed=0)
+
+    if args.launch_check:
+        import torch
+        cfg = dist.broadcast_config(cfg0, device="cpu")
+        dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        dist.barrier()
+        elapsed = dist.max_over_ranks(time.perf_counter() - t0, device="cpu")
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "backend": backend, "fft_size": int(cfg["fft_size"]), "n_bands": int(cfg["n_bands"]),
+                              "shard": args.shard, "elapsed_s": round(elapsed, 4)}), flush=True)
+        if world > 1:
+            import torch.distributed as td
+            td.destroy_process_group()
+        return
+
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs an MI355X: the spectral-scan engine has no CPU path")
+    device_index = local_rank % ndev
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     cfg = dist.broadcast_config(cfg0, device=coll_dev)  # the only collective of the whole job (RCCL, < 1 KiB)
-    band = dist.bands_for_rank(int(cfg["n_bands"]), rank, world)[0]
+    shard_frames = args.shard == "frames" and world > 1
+    band = 0 if args.shard == "frames" else dist.bands_for_rank(int(cfg["n_bands"]), rank, world)[0]
 
     eng_kw = dict(fft_size=int(cfg["fft_size"]), decim=int(cfg["decim"]), in_format=int(cfg["in_format"]), grouping_x=int(cfg["grouping_x"]),
                   grouping_y=int(cfg["grouping_y"]), start_level=cfg["start_level_mdB"] / 1000.0, learn_frames=int(cfg["learn_frames"]),
@@ -155,32 +275,61 @@ def main():
         args.no_kernel_timing = True  # per-launch events belong to one context; the lanes overlap each other's kernels
     else:
         eng = pkg.SpectrumEngine(int(cfg["sample_rate"]), dist.band_center(cfg, band), **eng_kw)
-    iq = dist.synthetic_batch(cfg, band, nb)
-    d_iq = torch.from_numpy(iq.view(np.float32) if iq.dtype == np.complex64 else iq).to(dev)
-    # Outputs are double-buffered the way a streaming consumer would hold them: batch k writes set k & 1 while
-    # the consumer still owns set (k - 1) & 1.
+
+    # ---- working set: `nsets` distinct input batches and output sets in rotation, well past the Infinity Cache ----
+    in_bytes = nb * n * args.decim * (8 if args.fmt == "cf32" else 2)
+    out_bytes = nb * n * 4 * ((0 if args.no_psd_out else 1) + (2 if args.planes else 0))
+    nsets = args.sets or max(6, -(-int(2.5 * L3_BYTES) // max(1, in_bytes + out_bytes)))
+    nsets = min(nsets, 64)
+    gen = dist.synthetic_stream(cfg, band)  # one continuous frame stream of the band: noise + gated wide-band transmissions
+    first = gen(nb)  # holds the learning frames; every rank of a frame-sharded band learns from these same frames
+    to_dev = lambda a: torch.from_numpy(a.view(np.float32) if a.dtype == np.complex64 else a).to(dev)  # noqa: E731
+    d_first = to_dev(first)
+    halo_frames = 0
+    if shard_frames:
+        # rank r owns frames [lo, lo + (warmup + steps) * nb) of the stream; it re-reads the halo in front of its range after
+        # an averager reset (dist.scan_frame_range: the tile boundary at or below lo - 20, so 32-47 frames), nothing is exchanged
+        lo = nb + rank * (args.warmup + args.steps) * nb
+        start = ((lo // 16) * 16 - 20) // 16 * 16
+        halo_frames = lo - start
+        gen = dist.synthetic_stream(cfg, band, start_frame=start, stream_seed=1000 + rank)
+    d_halo = [to_dev(gen(min(nb, halo_frames - p))) for p in range(0, halo_frames, nb)]
+    base = [to_dev(gen(nb)) for _ in range(min(nsets, 4))]
+    # further batches: the generated ones with their frames rotated (distinct memory, same statistics)
+    d_iq = [base[k] if k < len(base) else torch.roll(base[k % len(base)], shifts=37 * k, dims=0).contiguous() for k in range(nsets)]
     cap = nb * 1024
-    outs = [dict(psd=torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
+    nout = max(nsets, args.lanes + 1)  # a lane's outputs stay its own until its batch is done
+    outs = [dict(psd=None if args.no_psd_out else torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
                  idx=torch.empty(cap, dtype=torch.int32, device=dev), avg=torch.empty(cap, dtype=torch.float32, device=dev),
                  rel_plane=torch.empty((nb, n), dtype=torch.float32, device=dev) if args.planes else None,
                  avg_plane=torch.empty((nb, n), dtype=torch.float32, device=dev) if args.planes else None)
-            for _ in range(1 if args.single_buffer else max(2, args.lanes + 1))]  # a lane's outputs stay its own until its batch is done
+            for _ in range(nout)]
     torch.cuda.synchronize()
     counter = [0]
 
-    def step():
-        o = outs[counter[0] % len(outs)]
+    def step(iq=None):
+        k = counter[0]
         counter[0] += 1
+        o = outs[k % nout]
+        src = d_iq[k % nsets] if iq is None else iq
         if args.lanes > 1:
-            eng.process_device(d_iq, nb, psd=None if args.no_psd_out else o["psd"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
+            eng.process_device(src, src.shape[0], psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
         else:
-            eng.process_device(d_iq, nb, psd=None if args.no_psd_out else o["psd"], rel=o["rel_plane"], avg=o["avg_plane"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
+            eng.process_device(src, src.shape[0], psd=o["psd"], rel=o["rel_plane"], avg=o["avg_plane"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
 
-    for _ in range(max(args.warmup, 1)):  # first warm-up batch also absorbs the noise-learning frames
+    step(d_first)  # noise learning (identical on every rank of a frame-sharded band)
+    if shard_frames and rank > 0:
+        eng.sync()
+        eng.reset()
+        for h in d_halo:
+            step(h)
+    for _ in range(max(args.warmup, 1)):
         step()
     eng.sync()
-    if args.lanes == 1:
-        eng.kernel_timing(0 if args.no_kernel_timing else args.time_every)
+    every = 0
+    if args.lanes == 1 and not args.no_kernel_timing:
+        every = args.time_every or max(1, min(8, args.steps // 8))
+        eng.kernel_timing(every)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -191,18 +340,21 @@ def main():
     dist.barrier()
     t1 = time.perf_counter()
     kern_ms, launches = (0.0, 0)
-    if args.lanes == 1:
+    if every:
         kern_ms, launches = eng.kernel_timing_read()
         eng.kernel_timing(0)
     elapsed = dist.max_over_ranks(t1 - t0, device=coll_dev)
-    ncand = int(outs[(counter[0] - 1) % len(outs)]["off"][-1].item())
+    ncand = int(outs[(counter[0] - 1) % nout]["off"][-1].item())
 
     if rank == 0:
         samples_per_step = nb * n * world
         value = samples_per_step * args.steps / elapsed / 1e6
         kern_avg_s = kern_ms / max(launches, 1) / 1e3
-        algo_bytes = ALGO_BYTES_PER_SAMPLE if args.fmt == "cf32" else 6.0  # int8 IQ: 2 B in + 4 B out
-        achieved = algo_bytes * nb * n / kern_avg_s / 1e9 if launches else None
+        abps = algo_bytes_per_sample(args.fmt, True)  # the FFT kernel always writes its dB row
+        achieved = abps * nb * n / kern_avg_s / 1e9 if launches else None
+        chain_bps = algo_bytes_per_sample(args.fmt, not args.no_psd_out) + (8.0 if args.planes else 0.0)
+        chain_gbs = chain_bps * nb * n / (elapsed / args.steps) / 1e9  # per GPU
+        kernel_name = {8192: "k_fft8192_psd (load+window+FFT+dB)"}.get(n, "FFT+dB kernels" if n > 8192 else "k_fft256xR_psd / k_fft_psd_lds (load+window+FFT+dB)")
         out = {
             "metric": "iq_msamples_per_sec_scanned_8192pt_fft" if n == 8192 else f"iq_msamples_per_sec_scanned_{n}pt_fft",
             "value": round(value, 1), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,20 +362,23 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}-pt FFT, {fs / 1e6:.3f} MS/s, {nb}-frame batches, {args.fmt.upper()} IQ resident in HBM, full chain "
                                    "(window+FFT+dB -> noise-relative -> 21x21 mean -> threshold -> candidate lists), "
-                                   "one band per GPU",
-                       "fft_size": n, "frames_per_batch": nb, "bands": world, "candidates_per_batch": ncand,
-                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "lanes": args.lanes, "output_sets": len(outs), "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},
-            "roofline": {"bound": "hbm", "kernel": "k_fft8192_psd (load+window+FFT+dB)",
-                         "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                         "kernel_us": round(kern_avg_s * 1e6, 2), "launches": launches, "traffic": None},
+                                   + ("one band per GPU" if not shard_frames else "one band, a contiguous frame range per GPU (halo re-read, no exchange)"),
+                       "baseline_config": args.config or 2, "fft_size": n, "frames_per_batch": nb, "bands": int(cfg["n_bands"]), "shard": args.shard if world > 1 else None,
+                       "halo_frames": halo_frames, "candidates_per_batch": ncand,
+                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "lanes": args.lanes,
+                       "input_sets": nsets, "output_sets": nout, "working_set_mib": round((nsets * in_bytes + nout * out_bytes) / 2**20, 1),
+                       "dist_backend": backend if world > 1 else None, "ranks_share_devices": bool(world > ndev),
+                       "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},
+            "roofline": {"bound": "hbm", "kernel": kernel_name if n == 8192 else None,
+                         "achieved": None if (achieved is None or n != 8192) else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if (achieved is None or n != 8192) else round(achieved / HBM_PEAK_GBS, 4),
+                         "kernel_us": round(kern_avg_s * 1e6, 2) if launches and n == 8192 else None, "launches": launches if n == 8192 else 0,
+                         "algorithmic_bytes_per_launch": abps * nb * n,
+                         "traffic": None},  # PMC counters cannot be read from inside the run: see profiles/ (separate --pmc passes)
+            "roofline_chain": {"bound": "hbm", "what": "whole step (every kernel of the chain + launch gaps), per GPU",
+                               "algorithmic_bytes_per_sample": chain_bps, "achieved": round(chain_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
         }
-        traffic_file = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        if os.path.exists(traffic_file):  # HBM bytes per launch from the PMC passes (profiles/README.md), same command
-            try:
-                out["roofline"]["traffic"] = json.load(open(traffic_file)).get(f"{n}x{nb}")
-            except Exception:
-                pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, fs, args.cpu_seconds)
         elif world == 1:
@@ -233,6 +388,30 @@ def main():
     if world > 1:
         import torch.distributed as td
         td.destroy_process_group()
+
+
+def run_cpu_only(args):
+    """BASELINE config 1: the reference's CPU path on a synthetic 2.048 MS/s band, no GPU."""
+    n, fs = args.fft, args.sample_rate
+    cb = cpu_baseline(n, fs, args.cpu_seconds, stages=True)
+    out = {"metric": "iq_msamples_per_sec_scanned_8192pt_fft" if n == 8192 else f"iq_msamples_per_sec_scanned_{n}pt_fft",
+           "value": cb["value"], "unit": "MS/s", "n_gpus": 0, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{n}-pt FFT, {fs / 1e6:.3f} MS/s, CPU reference path (no GPU), {cb['cores']} threads", "baseline_config": 1},
+           "roofline": None, "cpu_baseline": cb}
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.cpu_only:
+        return run_cpu_only(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.config and "--gpus" not in " ".join(argv):
+            argv = [*argv, "--gpus", str(args.gpus)]
+        raise SystemExit(self_launch(args, argv))
+    run(args)
 
 
 if __name__ == "__main__":

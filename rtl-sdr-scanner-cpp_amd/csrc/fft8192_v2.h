@@ -1,0 +1,277 @@
+// fft8192_v2.h — second generation of the N = 8192 front end (BASELINE.json configs 1/2/4).
+//
+// Same contract and the same three register passes as k_fft8192_psd_w8 in fft8192_kernel.h (Decimator + fft_v(Hamming,
+// forward, shift) + PSD::work; reference sources/radio/blocks/decimator.h:15-22, sources/radio/sdr_device.cpp:164,
+// sources/radio/blocks/psd.cpp:18-20). What changes is WHERE the twiddle factors come from.
+//
+// Workgroup time stamps of the first-generation kernel (profiles/README.md, round 2) showed that a workgroup's second and
+// third pass take 7.0 and 3.1 us inside a full launch against 2.5 and 1.9 us alone on a CU: its 24 table loads per thread
+// (15 x W_256 for pass 2, 9 x W_8192 / W_2048 for pass 3) are ordinary vector-memory loads, and the CU's vector-memory
+// pipeline returns data in order — every table load queues behind the 64 KiB frames the other three resident workgroups
+// are streaming in from HBM. Here no pass waits on vector memory after its frame has arrived:
+//
+//   pass 2  W_256^(m r), m = t mod 16: the 256-entry table is copied into LDS once per workgroup (2 KiB).
+//   pass 3  W_8192^(j r), j = 32 w + l (w = wave, l = lane mod 32), r = 2 q + h, factored as
+//             W_8192^(j (r & 3)) * W_2048^(j (r >> 2))                                  (as before), each factor split
+//             W_8192^(j a)  = W_256^(w a)  * W_8192^(l a)      a  = r & 3
+//             W_2048^(j q2) = W_64^(w q2)  * W_2048^(l q2)     q2 = r >> 2
+//           into a wave-uniform part — scalar loads through the scalar cache into SGPRs, free VALU operands — and a
+//           per-lane part that only depends on l: 12 x 32 entries in LDS (3 KiB), read with broadcast ds_read_b64.
+//   The table loads are issued before the frame's own loads, so they return first.
+//
+// LDS: 34 KiB exchange plane + 5 KiB of tables = 39 KiB -> still four workgroups (32 waves) per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft8192_kernel.h"
+
+namespace ss {
+
+struct Fft8192V2Tables {
+  const float2* tw2;   // [16][16]  W_256^(m r) at r*16 + m
+  const float2* lane;  // [8][32] W_2048^(l q2) at q2*32 + l, then [4][32] W_8192^(l a) at 256 + a*32 + l
+  const float2* wave;  // [8 waves][12]: W_64^(w q2) at q2 = 0..7, then W_256^(w a) at 8 + a, a = 0..3
+  const float2* tw3a;  // first-generation tables (TW = 0, 1): [4][256] W_8192^(t r1)
+  const float2* tw3b;  //                                      [8][256] W_2048^(t r2)
+};
+
+constexpr int kFft8192V2PlaneBytes = (8192 + 512) * 4;
+constexpr int kFft8192V2LdsBytes = kFft8192V2PlaneBytes + (256 + 384) * 8;  // 39 936
+
+// Host side: fills the three v2 tables (double precision, rounded once).
+inline void fft8192_v2_host_tables(float2* tw2 /*256*/, float2* lane /*384*/, float2* wave /*96*/) {
+  const auto W = [](double num, double den) {
+    const double ang = -2.0 * 3.14159265358979323846 * num / den;
+    return make_float2((float)cos(ang), (float)sin(ang));
+  };
+  for (int r = 0; r < 16; ++r)
+    for (int m = 0; m < 16; ++m) tw2[r * 16 + m] = W((double)m * r, 256.0);
+  for (int q2 = 0; q2 < 8; ++q2)
+    for (int l = 0; l < 32; ++l) lane[q2 * 32 + l] = W((double)l * q2, 2048.0);
+  for (int a = 0; a < 4; ++a)
+    for (int l = 0; l < 32; ++l) lane[256 + a * 32 + l] = W((double)l * a, 8192.0);
+  for (int w = 0; w < 8; ++w) {
+    for (int q2 = 0; q2 < 8; ++q2) wave[w * 12 + q2] = W((double)w * q2, 64.0);
+    for (int a = 0; a < 4; ++a) wave[w * 12 + 8 + a] = W((double)w * a, 256.0);
+  }
+}
+
+// TW: 0 = every table from global memory (first generation), 1 = pass-2 table in LDS, 2 = all tables in LDS / SGPRs,
+//     3 = no tables at all (timing bound only: the output is meaningless).
+// SWZ: exchange 1 as four 16-byte LDS stores per plane into an unpadded, quad-rotated image instead of sixteen 4-byte
+//      stores into the 17-word pitch.
+// TWO: see Fft8192Second (ss_pipe).
+template <int FMT, int TW, bool SWZ = false, bool TWO = false, bool NOWIN = false>
+__global__ __launch_bounds__(512, 8) void k_fft8192_psd_v2(const void* __restrict__ iq_a, long long item_stride,
+                                                            const float* __restrict__ win, Fft8192V2Tables tabs, float db_off, float scale,
+                                                            float* __restrict__ psd_a, Fft8192Second second) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s = reinterpret_cast<float*>(smem_raw);
+  float2* tw2_l = reinterpret_cast<float2*>(smem_raw + kFft8192V2PlaneBytes);
+  float2* lane_l = tw2_l + 256;
+  const int t = threadIdx.x;
+  size_t frame = blockIdx.x;
+  const void* iq = iq_a;
+  float* psd = psd_a;
+  if constexpr (TWO) {
+    if ((int)blockIdx.x >= second.split) {  // block-uniform
+      frame = blockIdx.x - (size_t)second.split;
+      iq = second.iq;
+      item_stride = second.item_stride;
+      psd = second.psd;
+    }
+  }
+  const size_t in_base = frame * (size_t)item_stride;
+
+  // ---- tables first: these loads are ahead of the frame's own in the vector-memory queue ----
+  float2 tf0 = make_float2(0.f, 0.f), tf1 = make_float2(0.f, 0.f);
+  if constexpr (TW == 1) {
+    if (t < 256) tf0 = tabs.tw2[t];
+  } else if constexpr (TW == 2) {
+    tf0 = t < 256 ? tabs.tw2[t] : tabs.lane[t - 256];
+    if (t < 128) tf1 = tabs.lane[256 + t];
+  }
+
+  // ---------------- pass 1: radix 16, Ns = 1, butterfly j = t ----------------
+  float2 a[16];
+  {
+    constexpr int kSample = FMT == FMT_CF32 ? 8 : 2;  // bytes per IQ sample
+    const __amdgpu_buffer_rsrc_t rin = buffer_of(reinterpret_cast<const char*>(iq) + in_base * kSample, 8192 * kSample);
+    const __amdgpu_buffer_rsrc_t rwin = buffer_of(win, 8192 * 4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float2 x;
+      if constexpr (FMT == FMT_CF32) {
+        x = buffer_load_f2(rin, t * 8, 4096 * r);
+      } else {
+        const unsigned short raw = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rin, t * 2, 1024 * r, 0);
+        if constexpr (FMT == FMT_CS8) x = make_float2((float)(signed char)(raw & 0xff) * scale, (float)(signed char)(raw >> 8) * scale);
+        else x = make_float2(((float)(raw & 0xff) - 127.5f) * scale, ((float)(raw >> 8) - 127.5f) * scale);
+      }
+      if constexpr (NOWIN) {
+        a[r] = x;
+      } else {
+        const float w = buffer_load_f1(rwin, t * 4, 2048 * r);
+        a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
+      }
+    }
+  }
+  if constexpr (TW == 1) {
+    if (t < 256) tw2_l[t] = tf0;
+  } else if constexpr (TW == 2) {
+    tw2_l[t] = tf0;  // tw2_l and lane_l are contiguous: entries 0..511
+    if (t < 128) lane_l[256 + t] = tf1;
+  }
+  dft16(a);
+  float2 c[16];
+  if constexpr (SWZ) {
+    // exchange 1, unpadded: y[16 t + k] lives at word 16 t + 4 (((k >> 2) + (t >> 1)) & 3) + (k & 3). The 8 lanes of one
+    // 16-byte store cycle then hit 8 different bank quads; a reader's 32 consecutive elements stay a permutation of
+    // two 16-word rows.
+    const int rot = (t >> 1) & 3;
+    const int rd = ((t >> 4) << 4) + ((((t >> 2) & 3) + ((t >> 5) & 3)) & 3) * 4 + (t & 3);
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+      *reinterpret_cast<float4*>(&s[16 * t + 4 * ((c4 + rot) & 3)]) =
+          make_float4(a[slot16(4 * c4)].x, a[slot16(4 * c4 + 1)].x, a[slot16(4 * c4 + 2)].x, a[slot16(4 * c4 + 3)].x);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r].x = s[rd + 512 * r];
+    __syncthreads();
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+      *reinterpret_cast<float4*>(&s[16 * t + 4 * ((c4 + rot) & 3)]) =
+          make_float4(a[slot16(4 * c4)].y, a[slot16(4 * c4 + 1)].y, a[slot16(4 * c4 + 2)].y, a[slot16(4 * c4 + 3)].y);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r].y = s[rd + 512 * r];
+  } else {
+    // exchange 1: y[16 t + k] at word 17 t + k
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s[17 * t + k] = a[slot16(k)].x;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int e = t + 512 * r;
+      c[r].x = s[e + (e >> 4)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s[17 * t + k] = a[slot16(k)].y;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int e = t + 512 * r;
+      c[r].y = s[e + (e >> 4)];
+    }
+  }
+  // ---------------- pass 2: radix 16, Ns = 16, butterfly j = t ----------------
+  {
+    const int m = t & 15;
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+      float2 w;
+      if constexpr (TW == 0) w = tabs.tw2[r * 16 + m];
+      else if constexpr (TW == 3) w = make_float2(__int_as_float(0x3f800000 + m * r), 0.25f);
+      else w = tw2_l[r * 16 + m];
+      c[r] = cmul(c[r], w);
+    }
+  }
+  dft16(c);
+  __syncthreads();  // every read of y is done before z overwrites the plane
+  // exchange 2: z[(t/16)*256 + t%16 + 16 k]; pass 3 lane (w, l) reads z[j + 256 (2q + h)], j = 32 w + (l & 31), h = l >> 5
+  const int zbase = ((t >> 4) << 8) + (t & 15);
+  const int lane = t & 63;
+  const int h = lane >> 5;
+  const int lam = lane & 31;
+  const int j = ((t >> 6) << 5) + lam;
+  const int rbase = j + 256 * h;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s[zbase + 16 * k] = c[slot16(k)].x;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) a[q].x = s[rbase + 512 * q];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s[zbase + 16 * k] = c[slot16(k)].y;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) a[q].y = s[rbase + 512 * q];
+
+  // ---------------- pass 3: radix 32, Ns = 256, butterfly j shared by lanes l and l + 32 ----------------
+  // twiddle of input r = 2q + h:  W_8192^(j r) = W_8192^(j (r & 3)) * W_2048^(j (r >> 2)),  r & 3 = 2 (q & 1) + h,  r >> 2 = q >> 1
+  if constexpr (TW == 2) {
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const float2* __restrict__ sw = tabs.wave + w * 12;  // wave-uniform: scalar loads
+    const float2 sa0 = h ? sw[9] : sw[8];    // W_256^(w a), a = h
+    const float2 sa1 = h ? sw[11] : sw[10];  //              a = 2 + h
+    const float2 wa0 = cmul(lane_l[256 + h * 32 + lam], sa0);
+    const float2 wa1 = cmul(lane_l[256 + (2 + h) * 32 + lam], sa1);
+    a[0] = cmul(a[0], wa0);
+    a[1] = cmul(a[1], wa1);
+#pragma unroll
+    for (int q2 = 1; q2 < 8; ++q2) {
+      const float2 wb = cmul(lane_l[q2 * 32 + lam], sw[q2]);
+      a[2 * q2] = cmul(a[2 * q2], cmul(wa0, wb));
+      a[2 * q2 + 1] = cmul(a[2 * q2 + 1], cmul(wa1, wb));
+    }
+  } else {
+    float2 wa0, wa1;
+    if constexpr (TW == 3) {
+      wa0 = make_float2(__int_as_float(0x3f800000 + j + h), 0.5f);
+      wa1 = make_float2(__int_as_float(0x3f800000 + 2 * j + h), 0.75f);
+    } else {
+      wa0 = tabs.tw3a[h * 256 + j];        // r & 3 = h      (h = 0: W^0 = 1)
+      wa1 = tabs.tw3a[(2 + h) * 256 + j];  // r & 3 = 2 + h
+    }
+    a[0] = cmul(a[0], wa0);
+    a[1] = cmul(a[1], wa1);
+#pragma unroll
+    for (int q2 = 1; q2 < 8; ++q2) {
+      float2 wb;
+      if constexpr (TW == 3) wb = make_float2(__int_as_float(0x3f800000 + j * q2), 0.125f);
+      else wb = tabs.tw3b[q2 * 256 + j];
+      a[2 * q2] = cmul(a[2 * q2], cmul(wa0, wb));
+      a[2 * q2 + 1] = cmul(a[2 * q2 + 1], cmul(wa1, wb));
+    }
+  }
+  dft16(a);  // A_h[k] in slot16(k)
+  const bool odd = h != 0;
+  float2 u[16];  // u[k] = A_even[k] on the low half-wave, W_32^k A_odd[k] on the high half-wave
+  u[0] = a[slot16(0)];
+  u[1] = mulw32_if<1>(a[slot16(1)], odd);
+  u[2] = mulw32_if<2>(a[slot16(2)], odd);
+  u[3] = mulw32_if<3>(a[slot16(3)], odd);
+  u[4] = mulw32_if<4>(a[slot16(4)], odd);
+  u[5] = mulw32_if<5>(a[slot16(5)], odd);
+  u[6] = mulw32_if<6>(a[slot16(6)], odd);
+  u[7] = mulw32_if<7>(a[slot16(7)], odd);
+  u[8] = mulw32_if<8>(a[slot16(8)], odd);
+  u[9] = mulw32_if<9>(a[slot16(9)], odd);
+  u[10] = mulw32_if<10>(a[slot16(10)], odd);
+  u[11] = mulw32_if<11>(a[slot16(11)], odd);
+  u[12] = mulw32_if<12>(a[slot16(12)], odd);
+  u[13] = mulw32_if<13>(a[slot16(13)], odd);
+  u[14] = mulw32_if<14>(a[slot16(14)], odd);
+  u[15] = mulw32_if<15>(a[slot16(15)], odd);
+  float* out = psd + frame * 8192;
+  const __amdgpu_buffer_rsrc_t rout = buffer_of(out, 8192 * 4);
+  const int voff = (j + 2048 * h) * 4;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    // v_permlane32_swap(vdst, src): lanes 32..63 of vdst <-> lanes 0..31 of src. With vdst = u[k], src = u[k+8]:
+    //   low half:  (e, o) = (own u[k] = A_even[k],          partner's u[k]   = W^k A_odd[k])
+    //   high half: (e, o) = (partner's u[k+8] = A_even[k+8], own u[k+8]      = W^(k+8) A_odd[k+8])
+    const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].x), __float_as_uint(u[k + 8].x), false, false);
+    const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].y), __float_as_uint(u[k + 8].y), false, false);
+    const float2 e = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
+    const float2 o = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
+    // this lane's output index kk = k + 8 h; bin0 = j + 256 kk < 4096: the half rotation (fft_v shift = true) sends
+    // X[kk] to bin0 + 4096 and X[kk + 16] to bin0
+    buffer_store_f1(rout, voff, 1024 * k + 16384, psd_db(cadd(e, o), db_off));
+    buffer_store_f1(rout, voff, 1024 * k, psd_db(csub(e, o), db_off));
+  }
+}
+
+}  // namespace ss

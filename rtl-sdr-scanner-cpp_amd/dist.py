@@ -83,6 +83,25 @@ def synthetic_batch(cfg: dict, band: int, nframes: int) -> np.ndarray:
     return b.frames_cf32(nframes) if fmt == 0 else (b.frames_cs8(nframes) if fmt == 1 else b.frames_cu8(nframes))
 
 
+def synthetic_stream(cfg: dict, band: int, start_frame: int = 0, stream_seed: int | None = None):
+    """A continuous frame stream of one band for the benchmark: `gen(nframes)` returns the next frames in the band's sample
+    format. Transmissions switch on 30 frames after the learning phase and then toggle every 400 frames. The comb phases
+    come from the band's seed (the same transmitters for every rank that scans the band), the noise from `stream_seed`."""
+    from . import synth
+    learn = int(cfg["learn_frames"])
+    seed = int(cfg["seed"]) + band
+    b = synth.SyntheticBand(int(cfg["fft_size"]), decim=int(cfg["decim"]), seed=seed, on_frame=learn + 30, off_frame=learn + 430, period=800,
+                            start_frame=start_frame)
+    if stream_seed is not None:
+        b.rng = np.random.default_rng(stream_seed)
+    fmt = int(cfg.get("in_format", 0))
+
+    def gen(nframes: int) -> np.ndarray:
+        return b.frames_cf32(nframes) if fmt == 0 else (b.frames_cs8(nframes) if fmt == 1 else b.frames_cu8(nframes))
+
+    return gen
+
+
 def scan_frame_range(chain, frames, lo: int, hi: int, learn_frames: int, max_batch: int, align: int = 16, halo: int = 20):
     """One rank's share of a recorded band, frames [lo, hi) of ``frames`` ([nframes, N*D] items), with no exchange between
     ranks (BASELINE config 5): every rank first runs the learning prefix [0, learn_frames) itself so that

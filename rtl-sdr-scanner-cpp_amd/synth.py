@@ -24,14 +24,16 @@ class SyntheticBand:
     """Deterministic generator of `fft_size*decim`-sample items for one band."""
 
     def __init__(self, fft_size: int, decim: int = 1, seed: int = 0, sigma: float = 0.05, comb_width: int = 48,
-                 rel_db: float = 25.0, on_frame: int = 130, off_frame: int = 330, centres=COMB_CENTRES):
+                 rel_db: float = 25.0, on_frame: int = 130, off_frame: int = 330, centres=COMB_CENTRES, period: int = 0,
+                 start_frame: int = 0):
         self.n = int(fft_size)
         self.decim = int(decim)
         self.sigma = float(sigma)
         self.rng = np.random.default_rng(seed)
         self.on_frame = int(on_frame)
         self.off_frame = int(off_frame)
-        self.frame = 0
+        self.period = int(period)  # > 0: the on/off gate repeats every `period` frames (a long stream for the benchmark)
+        self.frame = int(start_frame)
         n = self.n
         w = min(comb_width, max(2, n // 32))
         amp = comb_amplitude(n, sigma, rel_db)
@@ -47,6 +49,8 @@ class SyntheticBand:
             self.comb_bins.append(np.sort((ks + n // 2) % n))
 
     def active(self, frame: int) -> bool:
+        if self.period > 0:
+            frame %= self.period
         return self.on_frame <= frame < self.off_frame
 
     def frames_cf32(self, nframes: int) -> np.ndarray:
