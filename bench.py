@@ -194,11 +194,12 @@ def parse_args(argv):
     ap.add_argument("--no-psd-out", action="store_true", default=None, help="detect mode: the caller takes candidates only, no PSD plane is handed out")
     ap.add_argument("--planes", action="store_true", help="full mode: the rel and avg planes are handed out as well (20 B/sample)")
     ap.add_argument("--decim", type=int, default=1, help="frame decimation D: items of N*D samples, the first N of each are scanned (reference: 5 at 2.048 MS/s)")
-    ap.add_argument("--lanes", type=int, default=1, help="ss_pipe with this many lanes (batches of the one band in flight side by side); 1 = one context")
+    ap.add_argument("--sync-every-step", action="store_true", help="ss_sync after every step: no overlap between consecutive calls (what a caller that reads every result before the next call sees)")
     ap.add_argument("--sets", type=int, default=0, help="input batches / output sets in rotation (0 = enough to exceed 2.5x the Infinity Cache, at least 6)")
     ap.add_argument("--time-every", type=int, default=0, help="attach start/stop events to every k-th launch of the FFT kernel (0 = pick so that >= 8 launches are timed)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not attach per-launch events to the FFT kernel (roofline omitted)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--diag-lib", action="store_true", help="load libspecscan_diag.so (-DSS_DIAG: SS_* environment variables select alternative implementations; measurement runs only)")
     ap.add_argument("--launch-check", action="store_true", help="exercise launcher, rendezvous, config broadcast and max-over-ranks timing only (no GPU work)")
     args = ap.parse_args(argv)
     preset = dict(CONFIGS.get(args.config or 2, {}))
@@ -268,13 +269,9 @@ def run(args):
     eng_kw = dict(fft_size=int(cfg["fft_size"]), decim=int(cfg["decim"]), in_format=int(cfg["in_format"]), grouping_x=int(cfg["grouping_x"]),
                   grouping_y=int(cfg["grouping_y"]), start_level=cfg["start_level_mdB"] / 1000.0, learn_frames=int(cfg["learn_frames"]),
                   max_batch=nb, device_id=device_index, flags=pkg.abi.SS_FLAG_SPECTROGRAM if args.spectrogram else 0)
-    if args.lanes > 1:
-        if args.planes or args.spectrogram:
-            raise SystemExit("--lanes: candidates and the PSD plane only")
-        eng = pkg.engine.Pipe(int(cfg["sample_rate"]), dist.band_center(cfg, band), lanes=args.lanes, **eng_kw)
-        args.no_kernel_timing = True  # per-launch events belong to one context; the lanes overlap each other's kernels
-    else:
-        eng = pkg.SpectrumEngine(int(cfg["sample_rate"]), dist.band_center(cfg, band), **eng_kw)
+    if args.diag_lib:
+        pkg.engine.use_diag_library(True)
+    eng = pkg.SpectrumEngine(int(cfg["sample_rate"]), dist.band_center(cfg, band), **eng_kw)
 
     # ---- working set: `nsets` distinct input batches and output sets in rotation, well past the Infinity Cache ----
     in_bytes = nb * n * args.decim * (8 if args.fmt == "cf32" else 2)
@@ -298,7 +295,7 @@ def run(args):
     # further batches: the generated ones with their frames rotated (distinct memory, same statistics)
     d_iq = [base[k] if k < len(base) else torch.roll(base[k % len(base)], shifts=37 * k, dims=0).contiguous() for k in range(nsets)]
     cap = nb * 1024
-    nout = max(nsets, args.lanes + 1)  # a lane's outputs stay its own until its batch is done
+    nout = nsets  # (the stages of up to three consecutive calls are in flight at once: every call has its own output set)
     outs = [dict(psd=None if args.no_psd_out else torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
                  idx=torch.empty(cap, dtype=torch.int32, device=dev), avg=torch.empty(cap, dtype=torch.float32, device=dev),
                  rel_plane=torch.empty((nb, n), dtype=torch.float32, device=dev) if args.planes else None,
@@ -312,10 +309,9 @@ def run(args):
         counter[0] += 1
         o = outs[k % nout]
         src = d_iq[k % nsets] if iq is None else iq
-        if args.lanes > 1:
-            eng.process_device(src, src.shape[0], psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
-        else:
-            eng.process_device(src, src.shape[0], psd=o["psd"], rel=o["rel_plane"], avg=o["avg_plane"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
+        eng.process_device(src, src.shape[0], psd=o["psd"], rel=o["rel_plane"], avg=o["avg_plane"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
+        if args.sync_every_step:
+            eng.sync()
 
     step(d_first)  # noise learning (identical on every rank of a frame-sharded band)
     if shard_frames and rank > 0:
@@ -327,7 +323,7 @@ def run(args):
         step()
     eng.sync()
     every = 0
-    if args.lanes == 1 and not args.no_kernel_timing:
+    if not args.no_kernel_timing:
         every = args.time_every or max(1, min(8, args.steps // 8))
         eng.kernel_timing(every)
     dist.barrier()
@@ -335,7 +331,9 @@ def run(args):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    eng.flush()  # the deferred detect / emit stages of the last two steps belong to the timed work
     t_enq = time.perf_counter()
+    eng.sync()
     torch.cuda.synchronize()
     dist.barrier()
     t1 = time.perf_counter()
@@ -354,7 +352,8 @@ def run(args):
         achieved = abps * nb * n / kern_avg_s / 1e9 if launches else None
         chain_bps = algo_bytes_per_sample(args.fmt, not args.no_psd_out) + (8.0 if args.planes else 0.0)
         chain_gbs = chain_bps * nb * n / (elapsed / args.steps) / 1e9  # per GPU
-        kernel_name = {8192: "k_fft8192_psd (load+window+FFT+dB)"}.get(n, "FFT+dB kernels" if n > 8192 else "k_fft256xR_psd / k_fft_psd_lds (load+window+FFT+dB)")
+        kernel_name = ("k_scan_step: load+window+FFT+dB of call k, carrying the 21x21 mean + threshold of call k-1 and the candidate lists "
+                       "of call k-2 as further roles of the same launch") if n == 8192 else None
         out = {
             "metric": "iq_msamples_per_sec_scanned_8192pt_fft" if n == 8192 else f"iq_msamples_per_sec_scanned_{n}pt_fft",
             "value": round(value, 1), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -365,7 +364,7 @@ def run(args):
                                    + ("one band per GPU" if not shard_frames else "one band, a contiguous frame range per GPU (halo re-read, no exchange)"),
                        "baseline_config": args.config or 2, "fft_size": n, "frames_per_batch": nb, "bands": int(cfg["n_bands"]), "shard": args.shard if world > 1 else None,
                        "halo_frames": halo_frames, "candidates_per_batch": ncand,
-                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "lanes": args.lanes,
+                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "sync_every_step": bool(args.sync_every_step), "diag_lib": bool(args.diag_lib),
                        "input_sets": nsets, "output_sets": nout, "working_set_mib": round((nsets * in_bytes + nout * out_bytes) / 2**20, 1),
                        "dist_backend": backend if world > 1 else None, "ranks_share_devices": bool(world > ndev),
                        "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},

@@ -127,11 +127,21 @@ int ss_process(ss_ctx* ctx, const void* iq, int32_t nframes, const int64_t* t_ms
 
 /* Same call on DEVICE buffers (hipMalloc'd on cfg.device_id), enqueued on the context's stream and
  * NOT synchronised: call ss_sync before reading results. n_learn = how many leading frames of this
- * batch belong to the noise-learning phase is decided on the host from learn_frames. */
+ * batch belong to the noise-learning phase is decided on the host from learn_frames.
+ *
+ * Stage pipelining (8192-point frames, 21 x 21 grouping): like the reference's flowgraph, whose blocks each work on a
+ * different frame at any moment (sdr_device.cpp:161-171), consecutive calls overlap on the device — the launch of call k
+ * carries the FFT + dB stage of call k, the averaging / threshold stage of call k-1 and the candidate-list stage of call
+ * k-2 (csrc/scan_step.h). The results of a call are therefore complete only after ss_sync, or after ss_flush followed by
+ * any synchronisation of ss_stream; every buffer passed to a call (d_iq included) must stay valid and untouched until
+ * then. Results are bit-identical to running the three stages back to back. The host-buffer entry points (ss_process,
+ * ss_feed_*) and every call that reads or changes state (ss_set_frequency_range, ss_reset, ss_reset_noise,
+ * ss_read_window, ss_read_noise, ss_spectrogram_read) drain the deferred stages themselves. */
 int ss_process_device(ss_ctx* ctx, const void* d_iq, int32_t nframes,
                       float* d_psd_db, float* d_rel_db, float* d_avg_db,
                       int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int32_t cand_cap);
-int ss_sync(ss_ctx* ctx);
+int ss_flush(ss_ctx* ctx); /* enqueue the deferred stages of earlier ss_process_device calls (asynchronous) */
+int ss_sync(ss_ctx* ctx);  /* ss_flush + wait for the context's stream */
 void* ss_stream(ss_ctx* ctx); /* the hipStream_t ss_process_device enqueues on */
 
 /* Measurement aid (bench.py): when enabled (enable = 1: every launch, enable = k > 1: every k-th launch, to keep
@@ -211,41 +221,6 @@ int ss_feed_acquire(ss_feed* feed, void** frames);
 int ss_feed_submit(ss_feed* feed, int32_t nframes, const int64_t* t_ms, int64_t user_tag);
 int ss_feed_collect(ss_feed* feed, ss_feed_result* out);
 int ss_feed_pending(const ss_feed* feed);
-
-/* ---- lanes: one band, several batches in flight on the device (SURVEY.md 8e-2 applied inside one GPU) ---------
- * The kernels of one batch run one after the other, each in lock step across the chip; a second batch could use what
- * they leave idle, but batch k+1 of the SAME context depends on batch k (the 21-frame averager, averager.cpp:14-25).
- * A pipe therefore owns `lanes` contexts with identical configuration and hands consecutive calls to them in turn. A
- * lane that did not see the previous call first restarts its averager (Averager::reset) and re-scans a halo of the
- * 32..47 frames before the call (the GROUPING_Y - 1 = 20 frames of history, sources/config.h:29, of the first frame of the
- * call's first 16-frame tile, from a tile boundary — the engine's sliding sums restart per tile), whose input the pipe keeps
- * from call to call; the halo's outputs are dropped. This is frame-range sharding with recomputed halos: every frame past the averager's warm-up gets the same
- * candidates and planes, bit for bit, as from ss_process_device on one context (tests/test_gpu_pipe.py). While a centre
- * frequency is still learning its noise ceiling (noise_learner.cpp:36-52), and for calls shorter than 64 frames, every lane
- * processes the call, so that all lanes hold the same ceiling and stay contiguous.
- *
- * Device pointers in, device pointers out, asynchronous like ss_process_device: the outputs of a call are complete
- * after ss_pipe_sync. d_iq must stay intact until ss_pipe_sync. Learning counts frames (learn_frames), as ss_process_device does. SS_FLAG_SPECTROGRAM and
- * SS_FLAG_KEEP_PLANES are per-context features and are refused here.
- *
- * What a turn costs the host decides whether lanes pay (a HIP call is 3-4 us here, a batch ~35 us on the device), so a turn
- * is a handful of launches and no events: the tail of call k is copied on the stream of the lane that takes call k + 1 —
- * which is why d_iq has to stay intact until ss_pipe_sync, not just until the call's own work is done —, the restart is
- * bookkeeping only, and for 8192-point frames the halo and the call go through the chain as ONE batch (the FFT and detect
- * kernels read the halo's rows from the lane's own copies and the rest from the caller; only the caller's frames report
- * candidates): four launches per turn. Other sizes run the halo as a batch of its own for the ring alone (six launches).
- * 8192 points, 1024-frame calls (bench.py --lanes): 218 / 248 / 212 GS/s with two / three / four lanes against 188 for one
- * context (int8 IQ, three lanes: 271). The halo is 32..47 frames whatever the call's size: lanes are for calls of many
- * hundreds of frames (65536 points, 128-frame calls: 97 GS/s against 128 for one context). */
-typedef struct ss_pipe ss_pipe;
-int ss_pipe_create(const ss_config* cfg, int32_t lanes, ss_pipe** out); /* lanes 1..4; cfg->max_batch >= 64 */
-void ss_pipe_destroy(ss_pipe* pipe);
-const char* ss_pipe_last_error(const ss_pipe* pipe);
-int ss_pipe_process_device(ss_pipe* pipe, const void* d_iq, int32_t nframes, float* d_psd_db, int32_t* d_cand_off, int32_t* d_cand_idx,
-                           float* d_cand_avg, int32_t cand_cap);
-int ss_pipe_sync(ss_pipe* pipe);
-int ss_pipe_set_frequency_range(ss_pipe* pipe, int32_t lo_hz, int32_t hi_hz); /* SdrDevice::setFrequencyRange, every lane */
-int ss_pipe_reset(ss_pipe* pipe);                                             /* Transmission::resetBuffers, every lane */
 
 #ifdef __cplusplus
 }

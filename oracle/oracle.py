@@ -63,6 +63,7 @@ def lib() -> C.CDLL:
         L.orc_spectrogram_size.argtypes = [C.c_void_p]
         L.orc_spectrogram_process.argtypes = [C.c_void_p, c_float_p]
         L.orc_spectrogram_send.argtypes = [C.c_void_p, C.POINTER(C.c_int8), c_float_p]
+        L.orc_spectrogram_payload.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         # channeliser oracle (channelizer_oracle.h)
         c_int_p = C.POINTER(C.c_int)
         L.cho_resampler_factors.argtypes = [C.c_int32, C.c_int32, C.c_int, c_int_p, c_int_p, C.c_int]
@@ -175,6 +176,15 @@ def ref() -> C.CDLL:
         R.ref_averager_average.argtypes = [C.c_void_p, c_float_p]
         R.ref_averager_row.argtypes = [C.c_void_p, C.c_int, c_float_p]
         R.orc_set_fft_backend.argtypes = [C.c_int]
+        R.ref_spectrogram_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        R.ref_spectrogram_create.restype = C.c_void_p
+        R.ref_spectrogram_destroy.argtypes = [C.c_void_p]
+        R.ref_spectrogram_size.argtypes = [C.c_void_p]
+        R.ref_spectrogram_set_frequency.argtypes = [C.c_void_p, C.c_int]
+        R.ref_spectrogram_work.argtypes = [C.c_void_p, c_float_p, C.c_int]
+        R.ref_spectrogram_container.argtypes = [C.c_void_p, c_float_p]
+        R.ref_spectrogram_pop.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        R.ref_transmission_payload.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     return _ref
 
 
@@ -190,6 +200,56 @@ def oracle_chain(sample_rate: int, center_hz: int, **overrides):
     """The oracle behind the same numpy wrapper the engine uses (prefix orc_)."""
     import rtl_sdr_scanner_cpp_amd as pkg
     return pkg.abi.Chain(lib(), "orc_", sample_rate, center_hz, **overrides)
+
+
+class RefSpectrogram:
+    """The reference's own Spectrogram block + DataController (oracle/_ref: radio/blocks/spectrogram.cpp and
+    network/data_controller.cpp compiled in place; Mqtt is a stub that keeps what is published)."""
+
+    def __init__(self, item_size: int, sample_rate: int, frequency: int):
+        self._h = ref().ref_spectrogram_create(item_size, sample_rate, frequency)
+        self.size = ref().ref_spectrogram_size(self._h)
+
+    def close(self):
+        if self._h:
+            ref().ref_spectrogram_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_frequency(self, frequency: int):
+        ref().ref_spectrogram_set_frequency(self._h, int(frequency))
+
+    def work(self, psd_rows: np.ndarray, now_ms: int) -> int:
+        """Spectrogram::work over the rows with getTime() == now_ms; returns the number of payloads waiting."""
+        rows = np.ascontiguousarray(psd_rows, dtype=np.float32)
+        ref().ref_set_time(int(now_ms))
+        return ref().ref_spectrogram_work(self._h, fp(rows), rows.shape[0])
+
+    def container(self):
+        """(m_sum, m_counter) of the current centre frequency's container."""
+        out = np.empty(self.size, np.float32)
+        cnt = ref().ref_spectrogram_container(self._h, fp(out))
+        return out, cnt
+
+    def pop(self):
+        """Oldest published payload as bytes, or None."""
+        buf = np.empty(64 + self.size, np.uint8)
+        n = ref().ref_spectrogram_pop(self._h, buf.ctypes.data, buf.size)
+        return None if n <= 0 else buf[:n].tobytes()
+
+
+def ref_transmission_payload(time_ms: int, frequency: int, sample_rate: int, iq_i8: np.ndarray) -> bytes:
+    """DataController::pushTransmission's bytes for [n, 2] int8 samples (the reference's own code)."""
+    a = np.ascontiguousarray(iq_i8, dtype=np.int8).reshape(-1, 2)
+    out = np.empty(32 + a.size, np.uint8)
+    n = ref().ref_transmission_payload(int(time_ms), int(frequency), int(sample_rate), a.ctypes.data, a.shape[0], out.ctypes.data, out.size)
+    assert n > 0
+    return out[:n].tobytes()
 
 
 class RefChain:

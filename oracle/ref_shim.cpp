@@ -4,6 +4,8 @@
 //   radio/blocks/psd.cpp  radio/blocks/noise_learner.cpp  radio/blocks/transmission.cpp
 //   radio/averager.cpp    radio/signal.cpp   utils/utils.cpp   utils/radio_utils.cpp
 //   performance_logger.cpp            (+ header-only utils/collection_utils.h, notification.h)
+//   radio/blocks/spectrogram.cpp      network/data_controller.cpp   (against stubs/network/mqtt.h, which keeps what
+//                                     DataController publishes)
 // against oracle/stubs/ (stand-ins for the GNU Radio / spdlog / nlohmann / boost headers) and links them
 // with this file into oracle/_ref/libref_specscan.so. Nothing of the reference is copied into the repo;
 // the .so is git-ignored.
@@ -47,6 +49,7 @@
 #include <radio/averager.h>
 #include <radio/blocks/noise_learner.h>
 #include <radio/blocks/psd.h>
+#include <radio/blocks/spectrogram.h>
 #include <radio/blocks/transmission.h>
 #include <radio/signal.h>
 #include <utils/collection_utils.h>
@@ -289,6 +292,80 @@ void ref_psd(const float* spectrum, float* out, int n, int sample_rate) {
   gr_vector_const_void_star in{spectrum};
   gr_vector_void_star o{out};
   psd.work(1, in, o);
+}
+
+// ---- the Spectrogram block and DataController's framing, on the reference's own code ----
+// Spectrogram::work (spectrogram.cpp:29-43) per frame: accumulate into the container of the current centre frequency,
+// then send() — which publishes through DataController::pushSpectrogram (data_controller.cpp:44-57) once more than
+// SPECTROGRAM_SEND_INTERVAL has passed on the injected clock (ref_set_time) since the container's last send.
+namespace {
+struct RefSpectrogram {
+  Mqtt mqtt;
+  DataController controller;
+  Frequency frequency;
+  Spectrogram block;
+  RefSpectrogram(int item_size, Frequency sample_rate, Frequency f)
+      : mqtt(), controller(mqtt, "ref"), frequency(f), block(item_size, sample_rate, controller, [this]() { return frequency; }) {}
+};
+}  // namespace
+
+void* ref_spectrogram_create(int item_size, int sample_rate, int frequency) {
+  ensureLogger();
+  auto* g = new RefSpectrogram(item_size, sample_rate, frequency);
+  return g;
+}
+void ref_spectrogram_destroy(void* h) { delete static_cast<RefSpectrogram*>(h); }
+int ref_spectrogram_size(void* h) { return static_cast<RefSpectrogram*>(h)->block.m_outputSize; }
+// Retune. The reference's Container constructor leaves m_counter uninitialised (spectrogram.cpp:9; whatever the heap
+// holds): the shim creates the container of a new centre frequency itself — exactly as work() would, spectrogram.cpp:34-37 —
+// and zeroes that one field, so that the comparison is deterministic.
+void ref_spectrogram_set_frequency(void* h, int frequency) {
+  auto* g = static_cast<RefSpectrogram*>(h);
+  g->frequency = frequency;
+  auto it = g->block.m_containers.find(frequency);
+  if (it == g->block.m_containers.end()) {
+    it = g->block.m_containers.emplace(frequency, g->block.m_outputSize).first;
+    it->second.m_counter = 0;
+  }
+}
+// nframes PSD rows through Spectrogram::work at the current injected time; returns how many payloads are waiting
+int ref_spectrogram_work(void* h, const float* psd_rows, int nframes) {
+  auto* g = static_cast<RefSpectrogram*>(h);
+  ref_spectrogram_set_frequency(h, g->frequency);
+  gr_vector_const_void_star in{psd_rows};
+  gr_vector_void_star out{};
+  g->block.work(nframes, in, out);
+  return (int)g->mqtt.m_sent.size();
+}
+// container of the current centre frequency: m_sum (m_outputSize floats) and m_counter
+int ref_spectrogram_container(void* h, float* sum_out) {
+  auto* g = static_cast<RefSpectrogram*>(h);
+  const auto it = g->block.m_containers.find(g->frequency);
+  if (it == g->block.m_containers.end()) return -1;
+  if (sum_out) std::memcpy(sum_out, it->second.m_sum.data(), sizeof(float) * it->second.m_sum.size());
+  return it->second.m_counter;
+}
+// oldest published payload (bytes as handed to Mqtt::publish); returns its size, 0 when none, -1 when cap is short
+int ref_spectrogram_pop(void* h, uint8_t* out, int cap) {
+  auto* g = static_cast<RefSpectrogram*>(h);
+  if (g->mqtt.m_sent.empty()) return 0;
+  const auto& p = g->mqtt.m_sent.front().second;
+  if ((int)p.size() > cap) return -1;
+  std::memcpy(out, p.data(), p.size());
+  const int n = (int)p.size();
+  g->mqtt.m_sent.pop_front();
+  return n;
+}
+// DataController::pushTransmission (data_controller.cpp:27-42) for `size` complex int8 samples
+int ref_transmission_payload(uint64_t time_ms, int frequency, int sample_rate, const int8_t* iq_pairs, int size, uint8_t* out, int cap) {
+  ensureLogger();
+  Mqtt mqtt;
+  DataController controller(mqtt, "ref");
+  controller.pushTransmission(std::chrono::milliseconds(time_ms), frequency, sample_rate, reinterpret_cast<const SimpleComplex*>(iq_pairs), size);
+  const auto& p = mqtt.m_sent.front().second;
+  if ((int)p.size() > cap) return -1;
+  std::memcpy(out, p.data(), p.size());
+  return (int)p.size();
 }
 
 void* ref_averager_create(int size, int group) { return new Averager(size, group); }

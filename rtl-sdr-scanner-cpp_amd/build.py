@@ -8,9 +8,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libspecscan.so")
+# the same sources with -DSS_DIAG: implementation choices can be overridden from the environment at ss_create / sc_create.
+# Used by the A/B tests and the measurement scripts only; the product library never reads the environment.
+LIB_DIAG = os.path.join(CSRC, "libspecscan_diag.so")
 SOURCES = ["specscan.hip", "channelizer.hip"]
-HEADERS = ["fft_kernels.h", "fft8192_kernel.h", "fft256_kernels.h", "detect_kernels.h", "detect_fused.h", "specscan_pipe_impl.h", os.path.join("..", "..", "include", "specscan.h"),
-           os.path.join("..", "..", "include", "specscan_channelizer.h")]
+HEADERS = ["fft_kernels.h", "fft8192_kernel.h", "fft8192_v2.h", "scan_step.h", "fft256_kernels.h", "detect_kernels.h", "detect_fused.h",
+           os.path.join("..", "..", "include", "specscan.h"), os.path.join("..", "..", "include", "specscan_channelizer.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 
 
@@ -21,21 +24,22 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP engine cannot be built (there is no CPU fallback)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def needs_build(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if force or needs_build():
-        cmd = [_hipcc(), *FLAGS, "-o", LIB, *[os.path.join(CSRC, s) for s in SOURCES]]
+def build_lib(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    lib = LIB_DIAG if diag else LIB
+    if force or needs_build(lib):
+        cmd = [_hipcc(), *FLAGS, *(["-DSS_DIAG"] if diag else []), "-o", lib, *[os.path.join(CSRC, s) for s in SOURCES]]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB
+    return lib
 
 
 HOST_DIR = os.path.join(HERE, "host")
@@ -75,5 +79,6 @@ def build_replay_tool(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
+    print(build_lib(force=True, verbose=True, diag=True))
     print(build_host_lib(force=True, verbose=True))
     print(build_replay_tool(force=True, verbose=True))

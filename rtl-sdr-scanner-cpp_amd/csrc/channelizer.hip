@@ -731,8 +731,13 @@ int sc_create(const sc_config* cfg, sc_ctx** out) {
       st.tile /= 2;
     }
     // first stage, interpolation 1, at most 33 taps per branch (GNU Radio's design always gives 33): branch kernel
-    const char* force_generic = getenv("SC_GENERIC");  // A/B measurements
-    if (c->stages.empty() && st.interp == 1 && st.decim <= 128 && st.ntaps <= kDecA * st.decim && !(force_generic && force_generic[0] == '1')) {
+#ifdef SS_DIAG
+    const char* force_generic_env = getenv("SC_GENERIC");  // A/B measurements, libspecscan_diag.so only
+    const bool force_generic = force_generic_env && force_generic_env[0] == '1';
+#else
+    const bool force_generic = false;
+#endif
+    if (c->stages.empty() && st.interp == 1 && st.decim <= 128 && st.ntaps <= kDecA * st.decim && !force_generic) {
       const int generic_tile = st.tile, generic_lds = st.lds_floats2;
       st.fast = true;
       st.passes = st.decim > 64 ? 2 : 1;

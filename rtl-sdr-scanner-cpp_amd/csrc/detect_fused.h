@@ -73,17 +73,12 @@ struct DetectArgs {
   float* rel_out;
   float* avg_out;
   float* avg_sparse;
-  long long* dbg;  // diagnostic (SS_DEBUG_TIMING): per-workgroup wall_clock64 stamps {start, mid, end, class}, or null
   // Spectrogram side branch (k_detect_fused<..., SPEC = true> only; spectrogram.cpp:45-60)
   float* spec_partial;             // [frame tile][spec_n]: the tile's frames, bin-decimated and summed in frame order
   const float* spec_prev_partial;  // the previous launch's partial sums, not yet added to their container (or null)
   float* spec_prev_sum;            // [spec_n] Container::m_sum they belong to
   int spec_prev_tiles;
   int spec_m, spec_n;              // m_decimatorFactor (a power of two <= 256), m_outputSize
-  // k_detect_fused<..., TWO = true> (ss_pipe): PSD rows of batch frames >= split live in psd_b (row 0 = frame split); frames
-  // below split are a re-scanned halo and report no candidates
-  const float* psd_b;
-  int split;
 };
 
 // plane[row][byte offset coff]: block-uniform row base (scalar registers) + one 32-bit per-thread offset
@@ -186,37 +181,36 @@ __device__ __forceinline__ void spectrogram_fold(const DetectArgs& a, int tid, i
   a.spec_prev_sum[ob] = acc;
 }
 
-template <int G, int GX, int TF, int TB_ = 256, bool SPEC = false, bool TWO = false>
-__global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k_detect_fused(DetectArgs a) {
+// One tile of the fused back end. `block` = tile number (what blockIdx.x is for the stand-alone kernel), `tid` = 0..TB-1,
+// `tile` / `cnt` = this tile's LDS (TF * P floats, TF ints). `valid` = false: the caller has no tile for these threads (odd
+// tile count in a two-tile workgroup) — they only keep the workgroup's barriers company. Every __syncthreads() below is
+// reached by all threads of the workgroup whatever `valid`, `steady` or `interior` are.
+template <int G, int GX, int TF, int TB_ = 256, bool SPEC = false>
+__device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int tid, float* __restrict__ tile, int* __restrict__ cnt, bool valid) {
   using T = DetectTile<G, GX, TF, TB_>;
   constexpr int A = T::A, TB = T::TB, P = T::P, ROWS = T::ROWS, H = T::H, SEGW = T::SEGW, NSEG = T::NSEG, YW = T::YW;
-  __shared__ __attribute__((aligned(16))) float tile[TF * P];
-  __shared__ int cnt[TF];
-
-  const int tid = threadIdx.x;
-  long long t_start = 0, t_mid = 0;
-  if (a.dbg && tid == 0) t_start = wall_clock64();
   const int n = a.n, nframes = a.nframes;
   const int tiles_per_row = (n + TB - 1) / TB;
   // Frame tiles are dispatched rotated by one: the ragged last tile and the tiles that read ring rows take the
   // slower general path, so they go first and the straight-line tiles fill in behind them instead of leaving a tail.
   const int nft = (nframes + a.shift + TF - 1) / TF;
-  const int ft = (blockIdx.x / tiles_per_row + nft - 1) % nft;
+  const int ft = (block / tiles_per_row + nft - 1) % nft;
   const int f0 = ft * TF - a.shift;  // batch-relative frame of the tile's first row of outputs; may be negative
-  const int b0 = (blockIdx.x % tiles_per_row) * TB;
+  const int b0 = (block % tiles_per_row) * TB;
   if (tid < TF) cnt[tid] = 0;
   if constexpr (SPEC) {
-    if (a.spec_prev_partial && blockIdx.x < (unsigned)tiles_per_row) spectrogram_fold<TB>(a, tid, b0);
+    if (valid && a.spec_prev_partial && block < tiles_per_row) spectrogram_fold<TB>(a, tid, b0);
   }
   // block-uniform classification
   const bool interior = (b0 - A >= 0) && (b0 + TB + A <= n);
-  bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes);
-  if constexpr (TWO) steady = steady && (f0 - (G - 1) >= a.split || f0 + TF <= a.split);  // all rows of the tile in one plane
+  const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes);
   const int first_hist = nframes - H;  // batch frames >= first_hist become the ring rows [frame - first_hist]
   const bool writes_hist = f0 + TF > first_hist;
 
   // ---------------- phase 1: time means, thread = column ----------------
-  if (steady) {
+  if (!valid) {
+    // nothing
+  } else if (steady) {
     // straight line: ROWS independent, unconditional loads per column; 276 columns over 256 threads.
     // Columns outside the band (first / last tile of a row) read a clamped address and contribute 0.0f.
 #pragma unroll
@@ -225,23 +219,20 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
       if (pass_c == 0 || tid < 2 * A) {
         const int col = b0 - A + c;
         const int colc = min(max(col, 0), n - 1);
-        const bool valid = col == colc;
+        const bool in_band = col == colc;
         const float t = a.thr[colc];
         // block-uniform row base (scalar registers) + one 32-bit per-thread byte offset
         const char* p = reinterpret_cast<const char*>(a.psd + (size_t)(f0 - (G - 1)) * n);
-        if constexpr (TWO) {
-          if (f0 - (G - 1) >= a.split) p = reinterpret_cast<const char*>(a.psd_b + (size_t)(f0 - (G - 1) - a.split) * n);
-        }
         const uint32_t coff = (uint32_t)colc * 4u;
         float x[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) x[r] = *reinterpret_cast<const float*>(p + (size_t)r * n * 4 + coff) - t;
         if (!interior) {
 #pragma unroll
-          for (int r = 0; r < ROWS; ++r) x[r] = valid ? x[r] : 0.0f;
+          for (int r = 0; r < ROWS; ++r) x[r] = in_band ? x[r] : 0.0f;
         }
         time_means_to_tile<G, TF, P, false>(x, &tile[c], 0);
-        if (valid && c >= A && c < A + TB) {
+        if (in_band && c >= A && c < A + TB) {
           if (a.rel_out) {
 #pragma unroll
             for (int j = 0; j < TF; ++j) store_row(a.rel_out, f0 + j, n, coff, x[G - 1 + j]);
@@ -280,9 +271,6 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
         for (int r = 0; r < ROWS; ++r) {
           const int fr = f0 - (G - 1) + r;
           const float* src = fr < 0 ? a.hist_in + (size_t)max(H + fr, 0) * n : a.psd + (size_t)min(fr, nframes - 1) * n;
-          if constexpr (TWO) {
-            if (fr >= a.split) src = a.psd_b + (size_t)(min(fr, nframes - 1) - a.split) * n;
-          }
           x[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + coff);
         }
 #pragma unroll
@@ -306,7 +294,6 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
     }
   }
   __syncthreads();
-  if (a.dbg && tid == 0) t_mid = wall_clock64();
 
   // ---------------- phase 2: frequency means + threshold, thread = (frame, 16-bin segment) ----------------
 #pragma unroll
@@ -316,7 +303,7 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
     const int seg = q / TF;
     const int f = f0 + fj;
     const int i0 = b0 + seg * SEGW;  // first bin of the segment
-    const bool live = f >= 0 && f < nframes && i0 < n;
+    const bool live = valid && f >= 0 && f < nframes && i0 < n;
     uint32_t bits = 0;
     if (live) {
       float outv[SEGW];
@@ -372,9 +359,6 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
           if (bits & (1u << o)) dst[o] = outv[o];
       }
     }
-    if constexpr (TWO) {
-      if (f < a.split) bits = 0;  // halo frames: for the ring only
-    }
     // lanes q and q + TF hold the same frame, segments seg and seg + 1: together one 32-bit mask word
     const uint32_t hi_bits = __shfl_down(bits, TF);
     if ((seg & 1) == 0 && live) {
@@ -384,19 +368,23 @@ __global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k
     }
   }
   __syncthreads();
-  if (tid < TF && cnt[tid] != 0) atomicAdd(&a.counts[f0 + tid], cnt[tid]);
+  if (valid && tid < TF && cnt[tid] != 0) atomicAdd(&a.counts[f0 + tid], cnt[tid]);
   if constexpr (SPEC) {
     // (the __syncthreads above freed the avgY tile)
-    spectrogram_tile_means<TF, TB>(a, tile, tid, f0, b0);
+    if (valid) spectrogram_tile_means<TF, TB>(a, tile, tid, f0, b0);
     __syncthreads();
-    spectrogram_tile_sum<TF, TB>(a, tile, tid, ft, f0, b0);
+    if (valid) spectrogram_tile_sum<TF, TB>(a, tile, tid, ft, f0, b0);
   }
-  if (a.dbg && tid == 0) {
-    a.dbg[4 * blockIdx.x] = t_start;
-    a.dbg[4 * blockIdx.x + 1] = t_mid;
-    a.dbg[4 * blockIdx.x + 2] = wall_clock64();
-    a.dbg[4 * blockIdx.x + 3] = steady ? (interior ? 1 : 3) : 2;
-  }
+}
+
+// Stand-alone launch: one tile per workgroup of TB threads (FFT sizes other than 8192; the 8192-point chain runs the same
+// tile code as a role of k_scan_step, scan_step.h).
+template <int G, int GX, int TF, int TB_ = 256, bool SPEC = false>
+__global__ __launch_bounds__(TB_) __attribute__((amdgpu_waves_per_eu(8))) void k_detect_fused(DetectArgs a) {
+  using T = DetectTile<G, GX, TF, TB_>;
+  __shared__ __attribute__((aligned(16))) float tile[TF * T::P];
+  __shared__ int cnt[TF];
+  detect_tile<G, GX, TF, TB_, SPEC>(a, (int)blockIdx.x, (int)threadIdx.x, tile, cnt, true);
 }
 
 // Row copy used when the sliding ring window reaches the end of its buffer and moves back to the front
@@ -409,21 +397,35 @@ __global__ void k_hist_shift(const float* __restrict__ hist_in, float* __restric
 }
 
 // Candidate lists (CSR) from the mask bits: one wave per frame. The frame's offset is the sum of the
-// counts of the frames before it (16 counts per lane per trip of 1024 frames). The wave pulls 256 mask words
+// counts of the frames before it (8 counts per lane per trip of 512 frames). The wave pulls 256 mask words
 // per trip (one 16-byte load per lane), ranks them with one wave scan, expands the set bits into an LDS
 // list at their ranks, then streams the list out with coalesced stores — ascending bins, frames in
-// order, deterministic. counts_next (the other half of the double-buffered counters, last used by the previous
-// batch with clear_n frames) is cleared for the next batch. Everything a trip needs from global memory is requested before anything is waited for.
-__global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ maskbits, int words_per_row, int n, int nframes,
-                                                  const int* __restrict__ counts, int* __restrict__ counts_next, int clear_n,
-                                                  const float* __restrict__ avg, int cap, int* __restrict__ off_int,
-                                                  int* __restrict__ off_out, int* __restrict__ cand_idx, float* __restrict__ cand_avg,
-                                                  int out_shift /* frames below it (ss_pipe halo) have no entry in off_out */) {
-  constexpr int LIST = 2048;
-  __shared__ int list[LIST];
-  const int f = blockIdx.x;
-  const int lane = threadIdx.x;
-  const uint32_t* row = maskbits + (size_t)f * words_per_row;
+// order, deterministic. counts_clear (the counter buffer a later batch will accumulate into, last used by a batch of
+// clear_n frames) is zeroed on the way. Everything a trip needs from global memory is requested before anything is
+// waited for. The wave synchronises with nobody: its LDS list is private (LDS operations of one wave complete in
+// order), so eight frames can share a workgroup (k_scan_step) without a barrier in sight.
+struct EmitArgs {
+  const uint32_t* maskbits;
+  int words_per_row, n, nframes;
+  const int* counts;
+  int* counts_clear;
+  int clear_n;
+  const float* avg;  // avg[f * n + bin] for every hit bin (the sparse plane, or the caller's full avg plane)
+  int cap;
+  int* off_int;      // [nframes + 1] the library's own copy of the offsets
+  int* off_out;      // caller's cand_off or null
+  int* cand_idx;     // null: offsets only
+  float* cand_avg;
+};
+
+constexpr int kEmitList = 1024;  // ints of LDS per wave
+
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void cand_emit_frame(const EmitArgs& a, int f, int lane, int* __restrict__ list) {
+  constexpr int LIST = kEmitList;
+  const int words_per_row = a.words_per_row, nframes = a.nframes, n = a.n;
+  const uint32_t* row = a.maskbits + (size_t)f * words_per_row;
   // first trip's mask words (words_per_row is a multiple of 2; rows of >= 256 words are 16-byte aligned)
   const bool wide = (words_per_row & 3) == 0;
   uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
@@ -432,31 +434,30 @@ __global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ m
   } else if (lane < words_per_row) {
     w4.x = row[lane];  // N = 64: two words per row, one per lane
   }
-  // offset of this frame = sum of counts[0..f): 16 ints per lane per trip, all loads independent
+  // offset of this frame = sum of counts[0..f): 8 ints per lane per trip, all loads independent
   int part = 0;
-  for (int base = 0; base < f; base += 1024) {
-    int v[16];
+  for (int base = 0; base < f; base += 512) {
+    int v[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = counts[min(base + k * 64 + lane, nframes - 1)];
+    for (int k = 0; k < 8; ++k) v[k] = a.counts[min(base + k * 64 + lane, nframes - 1)];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) part += (base + k * 64 + lane) < f ? v[k] : 0;
+    for (int k = 0; k < 8; ++k) part += (base + k * 64 + lane) < f ? v[k] : 0;
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
   const int begin = part;
-  const int mine = counts[f];
+  const int mine = a.counts[f];
   if (lane == 0) {
-    off_int[f] = begin;
-    if (off_out && f >= out_shift) off_out[f - out_shift] = begin;
+    a.off_int[f] = begin;
+    if (a.off_out) a.off_out[f] = begin;
     if (f == nframes - 1) {
-      off_int[nframes] = begin + mine;
-      if (off_out) off_out[nframes - out_shift] = begin + mine;
+      a.off_int[nframes] = begin + mine;
+      if (a.off_out) a.off_out[nframes] = begin + mine;
     }
-    // the other half of the double-buffered counters held the PREVIOUS batch (clear_n frames, possibly more than this one)
-    for (int g = f; g < clear_n; g += nframes) counts_next[g] = 0;
+    for (int g = f; g < a.clear_n; g += nframes) a.counts_clear[g] = 0;
   }
-  if (mine == 0 || !cand_idx) return;
-  const float* arow = avg + (size_t)f * n;
+  if (mine == 0 || !a.cand_idx) return;
+  const float* arow = a.avg + (size_t)f * n;
   const int words_per_trip = wide ? 256 : 64;
   int carry = begin;
   for (int base = 0; base < words_per_row; base += words_per_trip) {
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ m
           if (on && pos >= 0 && pos < LIST) list[pos] = word * 32 + bit;
         }
       }
-      __syncthreads();  // one wave per block: orders the LDS writes before the reads
+      wave_lds_fence();  // this wave's list writes have landed
       const int cnt = min(LIST, total - lo);
       for (int p0 = 0; p0 < cnt; p0 += 256) {
         int idx[4];
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ m
           const int p = p0 + k * 64 + lane;
           idx[k] = p < cnt ? list[p] : 0;
         }
-        if (cand_avg) {
+        if (a.cand_avg) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) av[k] = arow[idx[k]];  // four independent loads in flight
         }
@@ -525,16 +526,22 @@ __global__ __launch_bounds__(64) void k_cand_emit(const uint32_t* __restrict__ m
         for (int k = 0; k < 4; ++k) {
           const int p = p0 + k * 64 + lane;
           const int dst = carry + lo + p;
-          if (p < cnt && dst < cap) {
-            cand_idx[dst] = idx[k];
-            if (cand_avg) cand_avg[dst] = av[k];
+          if (p < cnt && dst < a.cap) {
+            a.cand_idx[dst] = idx[k];
+            if (a.cand_avg) a.cand_avg[dst] = av[k];
           }
         }
       }
-      __syncthreads();
+      wave_lds_fence();  // the list has been read before the next piece overwrites it
     }
     carry += total;
   }
+}
+
+// Stand-alone launch: one wave per workgroup (FFT sizes other than 8192).
+__global__ __launch_bounds__(64) void k_cand_emit(EmitArgs a) {
+  __shared__ int list[kEmitList];
+  cand_emit_frame(a, (int)blockIdx.x, (int)threadIdx.x, list);
 }
 
 }  // namespace ss

@@ -57,32 +57,31 @@ inline void fft8192_v2_host_tables(float2* tw2 /*256*/, float2* lane /*384*/, fl
   }
 }
 
+struct Fft8192Args {
+  const void* iq;         // frames of item_stride samples each; the first 8192 of each are transformed (Decimator)
+  long long item_stride;
+  const float* win;
+  Fft8192V2Tables tabs;
+  float db_off, scale;
+  float* psd;             // [frames][8192] dB rows, DC at bin 4096
+};
+
 // TW: 0 = every table from global memory (first generation), 1 = pass-2 table in LDS, 2 = all tables in LDS / SGPRs,
 //     3 = no tables at all (timing bound only: the output is meaningless).
 // SWZ: exchange 1 as four 16-byte LDS stores per plane into an unpadded, quad-rotated image instead of sixteen 4-byte
 //      stores into the 17-word pitch.
-// TWO: see Fft8192Second (ss_pipe).
-template <int FMT, int TW, bool SWZ = false, bool TWO = false, bool NOWIN = false>
-__global__ __launch_bounds__(512, 8) void k_fft8192_psd_v2(const void* __restrict__ iq_a, long long item_stride,
-                                                            const float* __restrict__ win, Fft8192V2Tables tabs, float db_off, float scale,
-                                                            float* __restrict__ psd_a, Fft8192Second second) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+// One frame by one workgroup of 512 threads; `smem_raw` = kFft8192V2LdsBytes of LDS, `t` = threadIdx.x.
+template <int FMT, int TW, bool SWZ = false, bool NOWIN = false>
+__device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t frame, unsigned char* __restrict__ smem_raw, int t) {
   float* s = reinterpret_cast<float*>(smem_raw);
   float2* tw2_l = reinterpret_cast<float2*>(smem_raw + kFft8192V2PlaneBytes);
   float2* lane_l = tw2_l + 256;
-  const int t = threadIdx.x;
-  size_t frame = blockIdx.x;
-  const void* iq = iq_a;
-  float* psd = psd_a;
-  if constexpr (TWO) {
-    if ((int)blockIdx.x >= second.split) {  // block-uniform
-      frame = blockIdx.x - (size_t)second.split;
-      iq = second.iq;
-      item_stride = second.item_stride;
-      psd = second.psd;
-    }
-  }
-  const size_t in_base = frame * (size_t)item_stride;
+  const Fft8192V2Tables& tabs = g.tabs;
+  const void* iq = g.iq;
+  const float* win = g.win;
+  const float db_off = g.db_off, scale = g.scale;
+  float* psd = g.psd;
+  const size_t in_base = frame * (size_t)g.item_stride;
 
   // ---- tables first: these loads are ahead of the frame's own in the vector-memory queue ----
   float2 tf0 = make_float2(0.f, 0.f), tf1 = make_float2(0.f, 0.f);
@@ -272,6 +271,14 @@ __global__ __launch_bounds__(512, 8) void k_fft8192_psd_v2(const void* __restric
     buffer_store_f1(rout, voff, 1024 * k + 16384, psd_db(cadd(e, o), db_off));
     buffer_store_f1(rout, voff, 1024 * k, psd_db(csub(e, o), db_off));
   }
+}
+
+// Stand-alone launch, one frame per workgroup (scripts/ubench/fft8192_lab; the product runs fft8192_v2_frame as a role of
+// k_scan_step, scan_step.h).
+template <int FMT, int TW, bool SWZ = false, bool NOWIN = false>
+__global__ __launch_bounds__(512, 8) void k_fft8192_psd_v2(Fft8192Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  fft8192_v2_frame<FMT, TW, SWZ, NOWIN>(g, blockIdx.x, smem_raw, (int)threadIdx.x);
 }
 
 }  // namespace ss

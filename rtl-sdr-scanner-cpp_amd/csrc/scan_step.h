@@ -1,0 +1,114 @@
+// scan_step.h — the 8192-point chain as ONE launch per call: k_scan_step.
+//
+// The reference runs its stages as a pipeline of blocks, each on its own thread, every block working on a different frame
+// at any moment (sources/radio/sdr_device.cpp:161-171: blocker -> decimator -> fft -> psd -> noiseLearner -> transmission).
+// The first generation of this engine ran them as three dependent launches per batch — FFT+dB, detect, emit — and each
+// launch has its own fill and drain: the FFT kernel waits ~4 us for its first frames and leaves the vector pipe idle
+// meanwhile, the detect kernel's tiles all load and then all compute, the emit kernel is one latency chain per frame, and
+// every dependent launch boundary costs 1.5-2 us. What depends on what, across CALLS, is:
+//
+//     FFT+dB(k)  ->  detect(k)  ->  emit(k)            and            detect(k-1) -> detect(k)   (the averager ring)
+//
+// so FFT+dB(k), detect(k-1) and emit(k-2) are independent of each other. k_scan_step carries all three as ROLES of one
+// launch: every workgroup takes one work item — one frame of call k through the FFT, two 16-frame x 256-bin detect tiles
+// of call k-1, or the candidate lists of eight frames of call k-2 — and whatever one role leaves idle (the FFT role's
+// wait for HBM, the detect role's dependence on L2 latency) the others use. No workgroup ever waits for another: all
+// dependencies are launch boundaries, so there is nothing to spin on and nothing to deadlock. The host side (specscan.hip)
+// keeps the deferred stages' arguments and drains them — two more launches with the finished roles empty — whenever a
+// result is asked for (ss_sync, ss_flush, the host-buffer entry points, retunes and resets): results are exactly those of
+// the three-launch chain, bit for bit, because every role runs the same code on the same data.
+//
+// Workgroup = 512 threads, <= 64 VGPRs, 39 KiB of LDS (the FFT role's; two detect tiles need 35 KiB, eight emit lists
+// 32 KiB): four workgroups per CU whatever their roles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "detect_fused.h"
+#include "fft8192_v2.h"
+
+namespace ss {
+
+struct StepArgs {
+  Fft8192Args fft;
+  DetectArgs det;
+  EmitArgs emit;
+  int n_fft;   // frames of the FFT role (0: role absent)
+  int n_det;   // detect TILES (two per workgroup)
+  int n_emit;  // frames of the emit role (eight per workgroup)
+  // One workgroup per work item, dispatched in blockIdx order, four resident per CU. WHICH item a workgroup takes decides
+  // what shares a CU when: `order` (device memory, one word per workgroup: role << 24 | item, built by the host once per
+  // launch shape — step_order() below) or, when null, emit first, then runs of run_det / run_fft alternating.
+  const uint32_t* order;
+  int run_det, run_fft, mixed_runs;
+};
+
+constexpr int kStepThreads = 512;
+constexpr int kStepLdsBytes = kFft8192V2LdsBytes;
+static_assert(2 * (16 * DetectTile<21, 21, 16, 256>::P * 4 + 64) <= kFft8192V2LdsBytes, "two detect tiles per workgroup");
+static_assert(8 * kEmitList * 4 <= kFft8192V2LdsBytes, "eight emit lists per workgroup");
+
+inline int step_items(const StepArgs& a) { return a.n_fft + (a.n_det + 1) / 2 + (a.n_emit + 7) / 8; }
+
+enum { ROLE_NONE = 0, ROLE_FFT = 1, ROLE_DET = 2, ROLE_EMIT = 3 };
+
+template <int FMT, bool SPEC, int TW, bool SWZ>
+__device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int item, unsigned char* smem_raw, int tid) {
+  if (role == ROLE_EMIT) {
+    // ---- emit role: one wave per frame ----
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = item * 8 + w;
+    if (f < a.n_emit) cand_emit_frame(a.emit, f, tid & 63, reinterpret_cast<int*>(smem_raw) + w * kEmitList);
+  } else if (role == ROLE_DET) {
+    // ---- detect role: two tiles, threads 0..255 and 256..511 ----
+    using T = DetectTile<21, 21, 16, 256>;
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int tile_no = 2 * item + half;
+    float* tile = reinterpret_cast<float*>(smem_raw) + half * (16 * T::P + 16);
+    int* cnt = reinterpret_cast<int*>(tile + 16 * T::P);
+    detect_tile<21, 21, 16, 256, SPEC>(a.det, min(tile_no, a.n_det - 1), tid & 255, tile, cnt, tile_no < a.n_det);
+  } else {
+    // ---- FFT role: one frame ----
+    fft8192_v2_frame<FMT, TW, SWZ>(a.fft, (size_t)item, smem_raw, tid);
+  }
+}
+
+template <int FMT, bool SPEC, int TW = 2, bool SWZ = true>
+__global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  int role, item;
+  if (a.order) {
+    const uint32_t w = a.order[blockIdx.x];
+    role = (int)(w >> 24);
+    item = (int)(w & 0xffffffu);
+  } else {
+    const int wg_emit = (a.n_emit + 7) >> 3;
+    const int wg_det = (a.n_det + 1) >> 1;
+    int b = blockIdx.x;
+    if (b < wg_emit) {
+      role = ROLE_EMIT;
+      item = b;
+    } else {
+      b -= wg_emit;
+      // runs of run_det detect workgroups and run_fft FFT workgroups alternate `mixed_runs` times, then the leftovers
+      const int period = a.run_det + a.run_fft;
+      const int mixed = a.mixed_runs * period;
+      bool is_det;
+      if (b < mixed) {
+        const int g = b / period, r = b - g * period;
+        is_det = r < a.run_det;
+        item = is_det ? g * a.run_det + r : g * a.run_fft + (r - a.run_det);
+      } else {
+        const int rest = b - mixed;
+        const int det_left = wg_det - a.mixed_runs * a.run_det;
+        is_det = rest < det_left;
+        item = is_det ? a.mixed_runs * a.run_det + rest : a.mixed_runs * a.run_fft + (rest - det_left);
+      }
+      role = is_det ? ROLE_DET : ROLE_FFT;
+    }
+  }
+  step_run_item<FMT, SPEC, TW, SWZ>(a, role, item, smem_raw, tid);
+}
+
+}  // namespace ss

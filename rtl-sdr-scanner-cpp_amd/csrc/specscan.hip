@@ -22,8 +22,8 @@
 #include "detect_fused.h"
 #include "detect_kernels.h"
 #include "fft256_kernels.h"
-#include "fft8192_kernel.h"
 #include "fft_kernels.h"
+#include "scan_step.h"
 
 namespace {
 
@@ -61,27 +61,27 @@ struct ss_ctx {
   // constants
   float* d_win = nullptr;
   float2* d_tw = nullptr;
-  float2* d_tw8k = nullptr;  // tables of k_fft8192_psd: tw2[256] ++ tw3a[1024] ++ tw3b[2048]
+  float2* d_tw8k = nullptr;   // 8192 points: tw2[256] ++ tw3a[1024] ++ tw3b[2048] (first-generation tables, SS_DIAG A/B runs)
+  float2* d_tw8v2 = nullptr;  // 8192 points: tw2[256] ++ lane[384] ++ wave[96] (fft8192_v2.h)
   bool use_fft8192 = false;
-  int fft8192_variant = 0;  // 0 = eight-wave kernel (default); 2 = four-wave variant (SS_FFT_IMPL=wide, A/B runs)
-  // development diagnostics, read from the environment once at ss_create and owned by the context:
-  //   SS_DEBUG_TIMING_FFT=<file> / SS_DEBUG_TIMING=<file>: per-workgroup clock stamps of the 20th FFT / detect launch
-  //   SS_FFT_ABLATE=1|2: memory-only / transform-only variant of the 8192-point kernel (profiles/README.md)
-  // Measurement hooks, read from the environment once, in ss_create (Diag::read); none of them changes results beyond
-  // the parity contract, all of them exist to time one implementation against another (DESIGN.md "Measurement hooks").
+  // Implementation choices. The shipped library fixes them here; a build with -DSS_DIAG (libspecscan_diag.so, used by
+  // the A/B tests and the measurement scripts only) lets the environment override them once, at ss_create.
   struct Diag {
-    std::string fft_stamp_path, detect_stamp_path;  // SS_DEBUG_TIMING_FFT / SS_DEBUG_TIMING: files for per-workgroup clock stamps
-    long long* d_fft_stamps = nullptr;              // 8 stamps x up to 8192 workgroups
-    long long* d_detect_stamps = nullptr;           // 4 stamps x up to 65536 workgroups
-    int fft_calls = 0, detect_calls = 0;
-    int fft_ablate = 0;            // SS_FFT_ABLATE: 1 = memory traffic only, 2 = transform only, 3 / 4 = traffic with wider accesses (8192-point kernel; results are garbage)
-    bool backend_unfused = false;  // SS_BACKEND=unfused: per-stage back-end kernels also for the 21 x 21 grouping
-    bool fft_generic = false;      // SS_FFT_IMPL=generic: radix-4 LDS kernels instead of the register-pass ones
-    bool fft_wide = false;         // SS_FFT_IMPL=wide: the four-wave 8192-point kernel instead of the eight-wave one
-    int fft_rows_r = -1;           // SS_FFT_ROWSR: 0 never / 1 always use k_fft_rows256xR_psd for N2 = 512..4096 (-1: up to 2048)
-    int fft_sub = -1;              // SS_FFT_SUB: 0 never / 1 always split N2 > 256 rows into radix-A step + 256-point rows (-1: from 2048)
-    bool fft_xcd_map = true;       // SS_FFT_XCDMAP=0: plain tile order in k_fft_rows256xR_psd
-    bool spec_standalone = false;  // SS_SPEC_IMPL=standalone: spectrogram by its own two kernels instead of inside k_detect_fused
+    bool backend_unfused = false;  // per-stage back-end kernels also for the 21 x 21 grouping
+    bool fft_generic = false;      // radix-4 LDS kernels instead of the register-pass ones
+    int fft_rows_r = -1;           // 0 never / 1 always use k_fft_rows256xR_psd for N2 = 512..4096 (-1: up to 2048)
+    int fft_sub = -1;              // 0 never / 1 always split N2 > 256 rows into radix-A step + 256-point rows (-1: from 2048)
+    bool fft_xcd_map = true;       // XCD-aware tile order in k_fft_rows256xR_psd
+    bool spec_standalone = false;  // spectrogram by its own two kernels instead of inside the detect tiles
+    bool pipeline = true;          // 8192 points: defer detect / emit of a call into the next calls' launches (scan_step.h)
+    int fft_tw = 2;                // 8192 points: where the twiddles come from (fft8192_v2.h: 0 global, 1 pass-2 table in LDS, 2 LDS + SGPRs)
+    bool fft_swz = true;           // 8192 points: 16-byte swizzled first exchange
+    int run_det = 128, run_fft = 128;  // dispatch order of k_scan_step's roles when no order table is used
+    // Dispatch order of k_scan_step's work items when all three roles ride one launch: "prefix|cycle", comma-separated
+    // segments of a role letter (E emit, D detect, F FFT) and a workgroup count ('*' = all that are left); the cycle repeats
+    // until every item is placed, a role that has run out is skipped. Empty = the run_det / run_fft formula.
+    std::string step_order = "E*|D128,F128";
+#ifdef SS_DIAG
     void read() {
       const auto is = [](const char* name, const char* value) {
         const char* v = getenv(name);
@@ -91,17 +91,26 @@ struct ss_ctx {
         const char* v = getenv(name);
         return !v ? -1 : (v[0] == '1' ? 1 : 0);
       };
-      if (const char* pth = getenv("SS_DEBUG_TIMING_FFT")) fft_stamp_path = pth;
-      if (const char* pth = getenv("SS_DEBUG_TIMING")) detect_stamp_path = pth;
-      if (const char* ab = getenv("SS_FFT_ABLATE")) fft_ablate = atoi(ab);
+      const auto num = [](const char* name, int dflt) {
+        const char* v = getenv(name);
+        return v ? atoi(v) : dflt;
+      };
       backend_unfused = is("SS_BACKEND", "unfused");
       fft_generic = is("SS_FFT_IMPL", "generic");
-      fft_wide = is("SS_FFT_IMPL", "wide");
       fft_rows_r = tri("SS_FFT_ROWSR");
       fft_sub = tri("SS_FFT_SUB");
       fft_xcd_map = tri("SS_FFT_XCDMAP") != 0;
       spec_standalone = is("SS_SPEC_IMPL", "standalone");
+      pipeline = tri("SS_PIPELINE") != 0;
+      fft_tw = num("SS_FFT_TW", 2);
+      fft_swz = tri("SS_FFT_SWZ") != 0;
+      run_det = num("SS_STEP_RUN_DET", run_det);
+      run_fft = num("SS_STEP_RUN_FFT", run_fft);
+      if (const char* v = getenv("SS_STEP_ORDER")) step_order = v;
     }
+#else
+    void read() {}
+#endif
   } diag;
   uint8_t* d_pass = nullptr;
   bool pass_dirty = true;
@@ -130,28 +139,40 @@ struct ss_ctx {
   int hist_rows = 0;   // capacity in rows
   int hist_start = 0;
   long long abs_frames = 0;               // frames since the last reset: frame tiles are aligned to this index
-  int* d_cnt2[2] = {nullptr, nullptr};    // per-frame candidate counts; the emit kernel clears the other half
+  // per-frame candidate counts, three buffers in rotation: batch k accumulates into [k % 3]; its emit stage — which may
+  // run two launches later, next to the detect stage of batch k + 1 — reads them and zeroes [(k + 2) % 3] for batch k + 2
+  int* d_cnt3[3] = {nullptr, nullptr, nullptr};
   int cnt_cur = 0;
-  int cnt_frames[2] = {0, 0};             // how many entries of each half may be non-zero
+  int cnt_frames[3] = {0, 0, 0};          // how many entries of each buffer may be non-zero
   float* d_relplane = nullptr;            // full rel plane, only when a caller asks for it (lazy)
   int last_n_learn = 0;
-  bool history_only = false;  // ss_pipe halo: run the chain for the averager ring only (no candidates, no emit)
-  // ss_pipe, 8192 points: one launch over [halo | batch] — frames >= split are read from / written to a second place and
-  // only they report candidates (transient: set around one run_batch call)
-  struct Two {
-    const void* iq_b = nullptr;
-    long long stride_b = 0;
-    float* psd_b = nullptr;
-    int split = 0;
-  } two;
+  // Stage pipelining (8192 points, scan_step.h): the detect stage of the last call and the emit stage of the call before
+  // it are kept as arguments until the next launch carries them (or flush_stages drains them). Buffers a deferred stage
+  // reads while a later call already writes its own are doubled: mask bits, sparse avg plane, internal PSD plane.
+  bool step_path = false;
+  bool have_det = false, have_emit = false;
+  ss::DetectArgs pend_det{};
+  int pend_det_tiles = 0;
+  bool pend_det_spec = false;
+  ss::EmitArgs pend_det_emit{};  // the emit stage that follows pend_det
+  ss::EmitArgs pend_emit{};
+  int buf_cur = 0;               // which of the doubled buffers the NEXT batch writes
+  // k_scan_step's dispatch-order table for the current launch shape (rebuilt when the shape changes; two buffers so that a
+  // launch still in flight keeps the table it was given)
+  uint32_t* d_step_order[2] = {nullptr, nullptr};
+  std::vector<uint32_t> h_step_order[2];
+  int step_order_cur = 0;
+  int step_order_key[3] = {-1, -1, -1};
+  uint32_t* d_mask2[2] = {nullptr, nullptr};
+  float* d_avg2[2] = {nullptr, nullptr};
+  float* d_psd2[2] = {nullptr, nullptr};
+  const float* last_avg = nullptr;  // the avg plane (sparse or kept) of the last batch
   const float* last_hist = nullptr;       // ring rows as they were before the last batch
   float* last_thr = nullptr;
   // back end, unfused path (any other grouping): one buffer holds the ring rows + the batch rows
   float* d_rel = nullptr;   // (G-1) history rows + max_batch rows
   float* d_hist_tmp = nullptr;
-  float* d_psd = nullptr;   // internal PSD plane (used when the caller passes none)
   float* d_avgy = nullptr;
-  float* d_avg = nullptr;
   float2* d_work = nullptr;  // four-step intermediate (N > 8192)
   float2* d_tw256 = nullptr; // W_256^(m r), r*16 + m: second pass of the 256-point register FFTs (N >= 65536)
   float2* d_tw_rowsR = nullptr;  // N = 2^17 .. 2^19: [q][k'] W_N2^(q k') for k_fft_rows256xR_psd (N2 = 512 .. 2048)
@@ -159,7 +180,6 @@ struct ss_ctx {
   float2* d_tw_sub = nullptr;   // N = 2^19, 2^20: [c][b] W_N2^(b c) for k_fft_sub_dft (N2 = N / 256 = 256 A)
   float2* d_tw_cols = nullptr;  // N >= 65536: step-A twiddle factored for k_fft_cols256, [j][n2] W_N^(n2 j) then [k][n2] W_N^(16 n2 k)
   bool use_fft256 = false;
-  uint32_t* d_mask = nullptr;
   int* d_counts = nullptr;
   int* d_off = nullptr;
   // host-entry staging
@@ -318,62 +338,138 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
   }
 }
 
-template <int FMT>
-void launch_fft8192(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
-  ss::Fft8192Tables tabs{c->d_tw8k, c->d_tw8k + 256, c->d_tw8k + 256 + 1024, nullptr};
-  if (c->diag.d_fft_stamps && nframes <= 8192) tabs.dbg = c->diag.d_fft_stamps;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  const bool timed = prof_pair(c, &e0, &e1);
-  auto launch = [&](auto kernel, int lds_bytes) {
-    if (timed) {
-      hipExtLaunchKernelGGL(kernel, dim3(nframes), dim3(256), lds_bytes, c->stream, e0, e1, 0, d_iq, item_stride, (const float*)c->d_win, tabs,
-                            c->db_off, c->cfg.int_scale, d_psd);
-    } else {
-      hipLaunchKernelGGL(kernel, dim3(nframes), dim3(256), lds_bytes, c->stream, d_iq, item_stride, (const float*)c->d_win, tabs, c->db_off,
-                         c->cfg.int_scale, d_psd);
-    }
+// ---- k_scan_step (8192 points): any subset of the three roles in one launch ------------------------------------------
+// Dispatch-order table from the pattern in diag.step_order (see there). Returns the device table for this launch shape.
+const uint32_t* step_order_table(ss_ctx* c, int n_fft, int wg_det, int wg_emit) {
+  if (c->step_order_key[0] == n_fft && c->step_order_key[1] == wg_det && c->step_order_key[2] == wg_emit) return c->d_step_order[c->step_order_cur];
+  struct Seg {
+    int role, count;
   };
-  const ss::Fft8192Second second{c->two.iq_b, c->two.stride_b, c->two.psd_b, c->two.split};
-  auto launch8 = [&](auto kernel, int lds_bytes) {
-    if (timed) {
-      hipExtLaunchKernelGGL(kernel, dim3(nframes), dim3(512), lds_bytes, c->stream, e0, e1, 0, d_iq, item_stride, (const float*)c->d_win, tabs,
-                            c->db_off, c->cfg.int_scale, d_psd, second);
-    } else {
-      hipLaunchKernelGGL(kernel, dim3(nframes), dim3(512), lds_bytes, c->stream, d_iq, item_stride, (const float*)c->d_win, tabs, c->db_off,
-                         c->cfg.int_scale, d_psd, second);
-    }
-  };
-  if (c->fft8192_variant == 2) launch(ss::k_fft8192_psd<FMT>, ss::kFft8192LdsBytes);
-  else if (tabs.dbg) launch8(ss::k_fft8192_psd_w8<FMT, 8, true>, ss::kFft8192W8LdsBytes);
-  else {
-    const int ablate = c->diag.fft_ablate;
-    if (ablate == 1) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 1>, ss::kFft8192W8LdsBytes);
-    else if (ablate == 2) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 2>, ss::kFft8192W8LdsBytes);
-    else if (ablate == 3) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 3>, ss::kFft8192W8LdsBytes);
-    else if (ablate == 4 && FMT == ss::FMT_CF32) launch8(ss::k_fft8192_psd_w8<ss::FMT_CF32, 8, false, 4>, ss::kFft8192W8LdsBytes);
-    // (int8 IQ ran best at 6 waves per SIMD, 80 registers, while the compiler packed fp32 pairs: 23.0 vs 27.7 us; built
-    // without the SLP vectorizer the 64-register form does not spill and wins, 21.4 vs 22.4 us)
-    else if (c->two.split > 0) launch8(ss::k_fft8192_psd_w8<FMT, 8, false, 0, true>, ss::kFft8192W8LdsBytes);
-    else launch8(ss::k_fft8192_psd_w8<FMT, 8>, ss::kFft8192W8LdsBytes);
-  }
-  if (tabs.dbg && ++c->diag.fft_calls == 20) {
-    std::vector<long long> h((size_t)8 * nframes);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipMemcpy(h.data(), c->diag.d_fft_stamps, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-    if (FILE* fp = fopen(c->diag.fft_stamp_path.c_str(), "w")) {
-      for (int b = 0; b < nframes; ++b) {
-        for (int k = 0; k < 8; ++k) fprintf(fp, "%lld ", h[(size_t)8 * b + k]);
-        fprintf(fp, "\n");
+  std::vector<Seg> prefix, cycle;
+  {
+    std::vector<Seg>* into = &prefix;
+    const std::string& sp = c->diag.step_order;
+    for (size_t i = 0; i < sp.size();) {
+      const char ch = sp[i];
+      if (ch == '|') {
+        into = &cycle;
+        ++i;
+        continue;
       }
-      fclose(fp);
+      const int role = ch == 'F' ? ss::ROLE_FFT : ch == 'D' ? ss::ROLE_DET : ch == 'E' ? ss::ROLE_EMIT : ss::ROLE_NONE;
+      ++i;
+      int count = 0;
+      if (i < sp.size() && sp[i] == '*') {
+        count = 1 << 30;
+        ++i;
+      } else {
+        while (i < sp.size() && sp[i] >= '0' && sp[i] <= '9') count = count * 10 + (sp[i++] - '0');
+      }
+      if (role != ss::ROLE_NONE && count > 0) into->push_back(Seg{role, count});
+      while (i < sp.size() && sp[i] != '|' && !(sp[i] >= 'A' && sp[i] <= 'Z')) ++i;  // separators
     }
+  }
+  const int total[4] = {0, n_fft, wg_det, wg_emit};
+  int next[4] = {0, 0, 0, 0};
+  const int buf = c->step_order_cur ^ 1;
+  std::vector<uint32_t>& out = c->h_step_order[buf];
+  out.clear();
+  const auto place = [&](const Seg& sg) {
+    for (int k = 0; k < sg.count && next[sg.role] < total[sg.role]; ++k) out.push_back((uint32_t)sg.role << 24 | (uint32_t)next[sg.role]++);
+  };
+  for (const Seg& sg : prefix) place(sg);
+  const size_t want = (size_t)n_fft + (size_t)wg_det + (size_t)wg_emit;
+  while (out.size() < want) {
+    const size_t before = out.size();
+    for (const Seg& sg : cycle) place(sg);
+    if (out.size() == before) {  // the cycle does not reach what is left: whatever remains, FFT first
+      place(Seg{ss::ROLE_FFT, 1 << 30});
+      place(Seg{ss::ROLE_DET, 1 << 30});
+      place(Seg{ss::ROLE_EMIT, 1 << 30});
+    }
+  }
+  if (hipMemcpyAsync(c->d_step_order[buf], out.data(), sizeof(uint32_t) * out.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) return nullptr;
+  c->step_order_cur = buf;
+  c->step_order_key[0] = n_fft;
+  c->step_order_key[1] = wg_det;
+  c->step_order_key[2] = wg_emit;
+  return c->d_step_order[buf];
+}
+
+template <int FMT, bool SPEC>
+void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEvent_t e1) {
+  const dim3 grid((unsigned)ss::step_items(a)), block(ss::kStepThreads);
+  auto go = [&](auto kernel) {
+    if (e0) hipExtLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, c->stream, e0, e1, 0, a);
+    else hipLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, c->stream, a);
+  };
+#ifdef SS_DIAG
+  if (c->diag.fft_tw == 0) return go(ss::k_scan_step<FMT, SPEC, 0, false>);
+  if (c->diag.fft_tw == 1) return go(ss::k_scan_step<FMT, SPEC, 1, false>);
+  if (!c->diag.fft_swz) return go(ss::k_scan_step<FMT, SPEC, 2, false>);
+#endif
+  go(ss::k_scan_step<FMT, SPEC, 2, true>);
+}
+
+// fft / det / emit: null = role absent. Start/stop events ride on launches that carry an FFT role (the dominant work).
+void launch_step(ss_ctx* c, const ss::Fft8192Args* fft, int n_fft, const ss::DetectArgs* det, int n_det_tiles, bool spec, const ss::EmitArgs* emit) {
+  ss::StepArgs a{};
+  if (fft) {
+    a.fft = *fft;
+    a.n_fft = n_fft;
+  }
+  if (det) {
+    a.det = *det;
+    a.n_det = n_det_tiles;
+  }
+  if (emit) {
+    a.emit = *emit;
+    a.n_emit = emit->nframes;
+  }
+  if (ss::step_items(a) == 0) return;
+  if (fft && det && !c->diag.step_order.empty()) a.order = step_order_table(c, a.n_fft, (a.n_det + 1) / 2, (a.n_emit + 7) / 8);
+  a.run_det = c->diag.run_det > 0 ? c->diag.run_det : 0;
+  a.run_fft = c->diag.run_fft > 0 ? c->diag.run_fft : 0;
+  const int wg_det = (a.n_det + 1) / 2;
+  a.mixed_runs = (a.run_det > 0 && a.run_fft > 0) ? std::min(wg_det / a.run_det, a.n_fft / a.run_fft) : 0;
+  if (a.mixed_runs == 0) a.run_det = a.run_fft = 1;  // (unused; keeps the period non-zero)
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (fft && !prof_pair(c, &e0, &e1)) e0 = e1 = nullptr;
+  const bool sp = spec && det;
+  switch (c->cfg.in_format) {
+    case SS_FMT_CF32: sp ? launch_step_variant<ss::FMT_CF32, true>(c, a, e0, e1) : launch_step_variant<ss::FMT_CF32, false>(c, a, e0, e1); break;
+    case SS_FMT_CS8: sp ? launch_step_variant<ss::FMT_CS8, true>(c, a, e0, e1) : launch_step_variant<ss::FMT_CS8, false>(c, a, e0, e1); break;
+    default: sp ? launch_step_variant<ss::FMT_CU8, true>(c, a, e0, e1) : launch_step_variant<ss::FMT_CU8, false>(c, a, e0, e1); break;
+  }
+}
+
+ss::Fft8192Args fft8192_args(ss_ctx* c, const void* d_iq, long long item_stride, float* d_psd) {
+  ss::Fft8192Args g{};
+  g.iq = d_iq;
+  g.item_stride = item_stride;
+  g.win = c->d_win;
+  g.tabs = ss::Fft8192V2Tables{c->d_tw8v2, c->d_tw8v2 + 256, c->d_tw8v2 + 256 + 384, c->d_tw8k + 256, c->d_tw8k + 256 + 1024};
+  g.db_off = c->db_off;
+  g.scale = c->cfg.int_scale;
+  g.psd = d_psd;
+  return g;
+}
+
+// Drain the deferred stages: detect (+ the emit stage before it), then the last emit. Nothing is synchronised.
+void flush_stages(ss_ctx* c) {
+  while (c->have_det || c->have_emit) {
+    launch_step(c, nullptr, 0, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
+    c->have_emit = c->have_det;
+    c->pend_emit = c->pend_det_emit;
+    c->have_det = false;
   }
 }
 
 template <int FMT>
 int launch_fft_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
-  if (c->use_fft8192) {
-    launch_fft8192<FMT>(c, d_iq, item_stride, nframes, d_psd);
+  if (c->use_fft8192) {  // (only reached without the fused back end; with it run_batch builds the step itself)
+    const ss::Fft8192Args g = fft8192_args(c, d_iq, item_stride, d_psd);
+    launch_step(c, &g, nframes, nullptr, 0, false, nullptr);
     return SS_OK;
   }
   switch (c->logn) {
@@ -463,31 +559,35 @@ int run_backend_unfused(ss_ctx* c, const float* d_psd, int nframes, int n_learn,
   const int a = c->cfg.grouping_x / 2;
   const int blocks_per_row = (n + 255) / 256;
   hipLaunchKernelGGL(ss::k_freq_mean_detect, dim3(nframes * blocks_per_row), dim3(256), sizeof(float) * (256 + 2 * a), c->stream, c->d_avgy,
-                     n, nframes, c->cfg.grouping_x, c->cfg.start_level, c->d_pass, c->d_avg, d_avg_out, c->d_mask);
+                     n, nframes, c->cfg.grouping_x, c->cfg.start_level, c->d_pass, c->d_avg2[0], d_avg_out, c->d_mask2[0]);
   const int wpr = n / 32;
-  hipLaunchKernelGGL(ss::k_cand_count, dim3(nframes), dim3(256), 0, c->stream, c->d_mask, wpr, c->d_counts);
+  hipLaunchKernelGGL(ss::k_cand_count, dim3(nframes), dim3(256), 0, c->stream, c->d_mask2[0], wpr, c->d_counts);
   hipLaunchKernelGGL(ss::k_cand_scan, dim3(1), dim3(256), 0, c->stream, c->d_counts, nframes, c->d_off, d_cand_off);
   if (d_cand_idx && cand_cap > 0) {
-    hipLaunchKernelGGL(ss::k_cand_write, dim3(nframes), dim3(256), 0, c->stream, c->d_mask, wpr, n, c->d_off, c->d_avg, cand_cap, d_cand_idx,
+    hipLaunchKernelGGL(ss::k_cand_write, dim3(nframes), dim3(256), 0, c->stream, c->d_mask2[0], wpr, n, c->d_off, c->d_avg2[0], cand_cap, d_cand_idx,
                        d_cand_avg);
   }
   c->rot_frames = nframes;
+  c->last_avg = c->d_avg2[0];
   return SS_OK;
 }
 
-// Back end for the reference's grouping (21 x 21): two launches, the PSD plane is read once.
+// Back end for the reference's grouping (21 x 21): a detect stage that reads the PSD plane once and an emit stage.
+// Builds the two stages' arguments and advances the host-side state (ring window, counter rotation, buffer rotation);
+// launches them at once (deferred = false: FFT sizes other than 8192) or leaves them in *det_out / *emit_out for the
+// caller to schedule (k_scan_step).
 int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, NoiseState* z, SpecState* spec, float* d_rel_out,
-                      float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
+                      float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap, bool deferred,
+                      ss::DetectArgs* det_out, int* det_tiles_out, ss::EmitArgs* emit_out) {
   const int n = c->n;
   constexpr int G = 21, GX = 21, TF = kFusedTF, TB = 256;  // measured against 32-frame and 128-bin tiles: 16 x 256 is fastest
   constexpr int H = kHistRows;
   static_assert(H == ss::DetectTile<G, GX, TF, TB>::H, "ring depth");
-  if (n_learn > 0) {
-    hipLaunchKernelGGL(ss::k_noise_learn, dim3((n + 255) / 256), dim3(256), 0, c->stream, d_psd, n, n_learn, z->d_thr);
-  }
-  // The kernel writes the batch's newest min(nframes, H) rel rows to the LAST rows of hist_out[0..H).
+  // The detect stage writes the batch's newest min(nframes, H) rel rows to the LAST rows of hist_out[0..H).
   if (nframes < H && c->hist_start + H + nframes > c->hist_rows) {
-    // end of the buffer: move the window to the front once (rare: every (hist_rows - H) / nframes batches)
+    // end of the buffer: move the window to the front once (rare: every (hist_rows - H) / nframes batches).
+    // (stream order: a deferred detect stage that still has to write this window must go first)
+    flush_stages(c);
     hipLaunchKernelGGL(ss::k_hist_shift, dim3(grid_for((size_t)H * n, 256)), dim3(256), 0, c->stream,
                        (const float*)(c->d_hist + (size_t)c->hist_start * n), c->d_hist, n, H, 0);
     c->hist_start = 0;
@@ -497,18 +597,30 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   if (nframes < H) next_start = c->hist_start + nframes;  // old rows [nframes, H) stay where they are, new ones land behind them
   else next_start = c->hist_start >= H ? 0 : c->hist_start + H;  // a whole new window, clear of the one being read
   float* hist_out = c->d_hist + (size_t)next_start * n;
-  int* counts = c->d_cnt2[c->cnt_cur];
-  int* counts_next = c->d_cnt2[c->cnt_cur ^ 1];
+  const int cur = c->cnt_cur, clr = (c->cnt_cur + 2) % 3;
+  int* counts = c->d_cnt3[cur];
+  const int b = c->buf_cur;
   const bool keep_planes = (c->cfg.flags & SS_FLAG_KEEP_PLANES) != 0;
-  float* avg_full = d_avg_out ? d_avg_out : (keep_planes ? c->d_avg : nullptr);
+  float* avg_full = d_avg_out ? d_avg_out : (keep_planes ? c->d_avg2[b] : nullptr);
   const int shift = (int)(c->abs_frames % TF);
   const int tiles = ((nframes + shift + TF - 1) / TF) * ((n + TB - 1) / TB);
-  ss::DetectArgs da{d_psd, z->d_thr,           hist_in,   hist_out,  n,      nframes,   n_learn,  c->frames_pushed,
-                    shift, c->cfg.start_level, c->d_pass, c->d_mask, counts, d_rel_out, avg_full, c->d_avg,         nullptr,
-                    nullptr, nullptr,          nullptr,   0,         0,      0,         c->two.psd_b, c->two.split};
-  if (c->diag.d_detect_stamps && tiles <= 65536) da.dbg = c->diag.d_detect_stamps;
-  const bool history_only = c->history_only;
-  if (history_only) da.start_level = NAN;  // startLevel <= avg is false for every avg: no hits, the counters stay clean
+  ss::DetectArgs da{};
+  da.psd = d_psd;
+  da.thr = z->d_thr;
+  da.hist_in = hist_in;
+  da.hist_out = hist_out;
+  da.n = n;
+  da.nframes = nframes;
+  da.n_learn = n_learn;
+  da.pushed_before = c->frames_pushed;
+  da.shift = shift;
+  da.start_level = c->cfg.start_level;
+  da.pass = c->d_pass;
+  da.maskbits = c->d_mask2[b];
+  da.counts = counts;
+  da.rel_out = d_rel_out;
+  da.avg_out = avg_full;
+  da.avg_sparse = c->d_avg2[b];
   if (spec) {
     da.spec_partial = c->d_spec_part2[c->spec_cur];
     da.spec_m = c->spec_m;
@@ -518,37 +630,42 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
       da.spec_prev_sum = c->spec_pending_sum;
       da.spec_prev_tiles = c->spec_pending_tiles;
     }
-    hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, true>), dim3(tiles), dim3(TB), 0, c->stream, da);
     c->spec_pending_sum = spec->d_sum;  // (the containers live until the context is destroyed)
     c->spec_pending_tiles = (nframes + shift + TF - 1) / TF;
     c->spec_cur ^= 1;
-  } else if (c->two.split > 0) {
-    hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, false, true>), dim3(tiles), dim3(TB), 0, c->stream, da);
-  } else {
-    hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, false>), dim3(tiles), dim3(TB), 0, c->stream, da);
   }
-  if (da.dbg && ++c->diag.detect_calls == 20) {
-    std::vector<long long> h((size_t)4 * tiles);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipMemcpy(h.data(), c->diag.d_detect_stamps, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
-    if (FILE* fp = fopen(c->diag.detect_stamp_path.c_str(), "w")) {
-      for (int b = 0; b < tiles; ++b) fprintf(fp, "%d %lld %lld %lld %lld\n", b, h[4 * b], h[4 * b + 1], h[4 * b + 2], h[4 * b + 3]);
-      fclose(fp);
-    }
-  }
-  if (!history_only) {
-    hipLaunchKernelGGL(ss::k_cand_emit, dim3(nframes), dim3(64), 0, c->stream, (const uint32_t*)c->d_mask, n / 32, n, nframes,
-                       (const int*)counts, counts_next, c->cnt_frames[c->cnt_cur ^ 1], (const float*)(avg_full ? avg_full : c->d_avg), cand_cap,
-                       c->d_off, d_cand_off,
-                       (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr, d_cand_avg, c->two.split);
-    c->cnt_frames[c->cnt_cur] = nframes;   // this half now holds nframes counts (read by the emit above, cleared by the next one)
-    c->cnt_frames[c->cnt_cur ^ 1] = 0;     // just cleared
-    c->cnt_cur ^= 1;
-  }
+  ss::EmitArgs ea{};
+  ea.maskbits = c->d_mask2[b];
+  ea.words_per_row = n / 32;
+  ea.n = n;
+  ea.nframes = nframes;
+  ea.counts = counts;
+  ea.counts_clear = c->d_cnt3[clr];
+  ea.clear_n = c->cnt_frames[clr];
+  ea.avg = avg_full ? avg_full : c->d_avg2[b];
+  ea.cap = cand_cap;
+  ea.off_int = c->d_off;
+  ea.off_out = d_cand_off;
+  ea.cand_idx = (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr;
+  ea.cand_avg = d_cand_avg;
+  c->cnt_frames[cur] = nframes;  // this buffer now holds nframes counts (read by the emit stage, zeroed two batches on)
+  c->cnt_frames[clr] = 0;
+  c->cnt_cur = (cur + 1) % 3;
+  c->buf_cur = b ^ 1;
+  c->last_avg = ea.avg;
   c->last_hist = hist_in;
   c->hist_start = next_start;
   c->last_n_learn = n_learn;
   c->last_thr = z->d_thr;
+  if (deferred) {
+    *det_out = da;
+    *det_tiles_out = tiles;
+    *emit_out = ea;
+    return SS_OK;
+  }
+  if (spec) hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, true>), dim3(tiles), dim3(TB), 0, c->stream, da);
+  else hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, false>), dim3(tiles), dim3(TB), 0, c->stream, da);
+  hipLaunchKernelGGL(ss::k_cand_emit, dim3(nframes), dim3(64), 0, c->stream, ea);
   return SS_OK;
 }
 
@@ -591,33 +708,66 @@ int spectrogram_accumulate(ss_ctx* c, SpecState* g, const float* d_psd, int nfra
 
 // The chain for one batch, everything on c->stream, nothing synchronised.
 // n_learn = leading frames that belong to the noise-learning phase (decided by the caller).
+// 8192 points with the fused back end (c->step_path): the call's FFT stage is launched together with the deferred detect
+// stage of the previous call and the emit stage of the one before (scan_step.h); this call's own detect and emit stages
+// stay deferred until the next call or flush_stages.
 int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int n_learn, NoiseState* z, float* d_psd_out,
               float* d_rel_out, float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
   const int G = c->cfg.grouping_y;
   if (c->pass_dirty) {
+    flush_stages(c);  // (ss_set_frequency_range drained them already; the mask a deferred stage reads must not change under it)
     std::vector<uint8_t> pass;
     build_pass_mask(c, pass);
     SS_HIP(c, hipMemcpyAsync(c->d_pass, pass.data(), pass.size(), hipMemcpyHostToDevice, c->stream));
     SS_HIP(c, hipStreamSynchronize(c->stream));  // `pass` is pageable and dies at scope end
     c->pass_dirty = false;
   }
-  float* d_psd = d_psd_out ? d_psd_out : c->d_psd;
-  int st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
-  if (st != SS_OK) return st;
+  float* d_psd = d_psd_out ? d_psd_out : c->d_psd2[c->buf_cur];
+  int st = SS_OK;
   SpecState* spec = nullptr;
   if (c->spec_n > 0) {
     spec = spectrogram_container(c);
     if (!spec) return fail(c, SS_ERR_NOMEM, "spectrogram container");
-    if (!c->spec_in_detect) {
+  }
+  if (c->step_path) {
+    const ss::Fft8192Args g = fft8192_args(c, d_iq, item_stride, d_psd);
+    const bool overlap = c->diag.pipeline && n_learn == 0;
+    if (!overlap) flush_stages(c);
+    launch_step(c, &g, nframes, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
+    c->have_emit = c->have_det;
+    c->pend_emit = c->pend_det_emit;
+    c->have_det = false;
+    if (spec && !c->spec_in_detect) {
       st = spectrogram_accumulate(c, spec, d_psd, nframes);
       if (st != SS_OK) return st;
     }
-    spec->count += nframes;
+    if (spec) spec->count += nframes;
+    if (n_learn > 0) hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
+    st = run_backend_fused(c, d_psd, nframes, n_learn, z, c->spec_in_detect ? spec : nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg,
+                           cand_cap, true, &c->pend_det, &c->pend_det_tiles, &c->pend_det_emit);
+    if (st != SS_OK) return st;
+    c->have_det = true;
+    c->pend_det_spec = c->spec_in_detect && spec != nullptr;
+    if (!overlap) flush_stages(c);
+  } else {
+    st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
+    if (st != SS_OK) return st;
+    if (spec) {
+      if (!c->spec_in_detect) {
+        st = spectrogram_accumulate(c, spec, d_psd, nframes);
+        if (st != SS_OK) return st;
+      }
+      spec->count += nframes;
+    }
+    if (c->fused) {
+      if (n_learn > 0) hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
+      st = run_backend_fused(c, d_psd, nframes, n_learn, z, c->spec_in_detect ? spec : nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg,
+                             cand_cap, false, nullptr, nullptr, nullptr);
+    } else {
+      st = run_backend_unfused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap);
+    }
+    if (st != SS_OK) return st;
   }
-  st = c->fused ? run_backend_fused(c, d_psd, nframes, n_learn, z, c->spec_in_detect ? spec : nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx,
-                                    d_cand_avg, cand_cap)
-                : run_backend_unfused(c, d_psd, nframes, n_learn, z, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap);
-  if (st != SS_OK) return st;
   ++c->batch_no;
   SS_HIP(c, hipGetLastError());
   c->frames_pushed = c->frames_pushed + nframes < G ? c->frames_pushed + nframes : G;
@@ -671,16 +821,19 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_tw8k);
   (void)hipFree(c->d_pass);
   (void)hipFree(c->d_rel);
-  (void)hipFree(c->diag.d_fft_stamps);
-  (void)hipFree(c->diag.d_detect_stamps);
+  (void)hipFree(c->d_tw8v2);
+  (void)hipFree(c->d_step_order[0]);
+  (void)hipFree(c->d_step_order[1]);
   (void)hipFree(c->d_hist);
-  (void)hipFree(c->d_cnt2[0]);
-  (void)hipFree(c->d_cnt2[1]);
+  for (int k = 0; k < 3; ++k) (void)hipFree(c->d_cnt3[k]);
+  for (int k = 0; k < (c->step_path ? 2 : 1); ++k) {
+    (void)hipFree(c->d_mask2[k]);
+    (void)hipFree(c->d_avg2[k]);
+    (void)hipFree(c->d_psd2[k]);
+  }
   (void)hipFree(c->d_relplane);
   (void)hipFree(c->d_hist_tmp);
-  (void)hipFree(c->d_psd);
   (void)hipFree(c->d_avgy);
-  (void)hipFree(c->d_avg);
   (void)hipFree(c->d_work);
   (void)hipFree(c->d_tw256);
   (void)hipFree(c->d_tw_cols);
@@ -689,7 +842,6 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_tw_rowsR);
   (void)hipFree(c->d_spec_part2[0]);
   (void)hipFree(c->d_spec_part2[1]);
-  (void)hipFree(c->d_mask);
   (void)hipFree(c->d_counts);
   (void)hipFree(c->d_off);
   (void)hipFree(c->d_in);
@@ -804,8 +956,6 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   CREATE_HIP(hipMalloc(&c->d_tw, sizeof(float2) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_pass, (size_t)n));
   c->diag.read();
-  if (!c->diag.fft_stamp_path.empty()) CREATE_HIP(hipMalloc(&c->diag.d_fft_stamps, sizeof(long long) * 8 * 8192));
-  if (!c->diag.detect_stamp_path.empty()) CREATE_HIP(hipMalloc(&c->diag.d_detect_stamps, sizeof(long long) * 4 * 65536));
   c->fused = G == 21 && cfg->grouping_x == 21 && cfg->max_batch <= 65536 && !c->diag.backend_unfused;
   if (c->fused) {
     {
@@ -818,9 +968,9 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       CREATE_HIP(hipMalloc(&c->d_hist, sizeof(float) * (size_t)n * (size_t)rows));
       CREATE_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(float) * (size_t)n * (size_t)kHistRows, c->stream));  // Averager ctor, averager.cpp:7-12
     }
-    for (int k = 0; k < 2; ++k) {
-      CREATE_HIP(hipMalloc(&c->d_cnt2[k], sizeof(int) * (size_t)cfg->max_batch));
-      CREATE_HIP(hipMemsetAsync(c->d_cnt2[k], 0, sizeof(int) * (size_t)cfg->max_batch, c->stream));
+    for (int k = 0; k < 3; ++k) {
+      CREATE_HIP(hipMalloc(&c->d_cnt3[k], sizeof(int) * (size_t)cfg->max_batch));
+      CREATE_HIP(hipMemsetAsync(c->d_cnt3[k], 0, sizeof(int) * (size_t)cfg->max_batch, c->stream));
     }
   } else {
     CREATE_HIP(hipMalloc(&c->d_rel, sizeof(float) * (size_t)n * (size_t)(G - 1 + cfg->max_batch)));
@@ -828,9 +978,23 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipMalloc(&c->d_avgy, plane));
     CREATE_HIP(hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)n * (size_t)(G - 1 + cfg->max_batch), c->stream));
   }
-  CREATE_HIP(hipMalloc(&c->d_psd, plane));
-  CREATE_HIP(hipMalloc(&c->d_avg, plane));
-  CREATE_HIP(hipMalloc(&c->d_mask, sizeof(uint32_t) * (size_t)(n / 32) * (size_t)cfg->max_batch));
+  // 8192 points with the fused back end: stages of consecutive calls overlap (scan_step.h), so what a deferred stage reads
+  // is doubled; every other configuration uses set 0 only
+  c->step_path = c->fused && n == 8192 && !c->diag.fft_generic;
+  for (int k = 0; k < (c->step_path ? 2 : 1); ++k) {
+    CREATE_HIP(hipMalloc(&c->d_psd2[k], plane));
+    CREATE_HIP(hipMalloc(&c->d_avg2[k], plane));
+    CREATE_HIP(hipMalloc(&c->d_mask2[k], sizeof(uint32_t) * (size_t)(n / 32) * (size_t)cfg->max_batch));
+  }
+  if (c->step_path) {
+    const size_t max_items = (size_t)cfg->max_batch + ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256) / 2 + (size_t)cfg->max_batch / 8 + 4;
+    for (int k = 0; k < 2; ++k) CREATE_HIP(hipMalloc(&c->d_step_order[k], sizeof(uint32_t) * max_items));
+  }
+  if (!c->step_path) {
+    c->d_psd2[1] = c->d_psd2[0];
+    c->d_avg2[1] = c->d_avg2[0];
+    c->d_mask2[1] = c->d_mask2[0];
+  }
   CREATE_HIP(hipMalloc(&c->d_counts, sizeof(int) * (size_t)cfg->max_batch));
   CREATE_HIP(hipMalloc(&c->d_off, sizeof(int) * ((size_t)cfg->max_batch + 1)));
   if (cfg->flags & SS_FLAG_SPECTROGRAM) {
@@ -933,7 +1097,6 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     }
     if (n == 8192) {
       c->use_fft8192 = !c->diag.fft_generic;
-      if (c->diag.fft_wide) c->fft8192_variant = 2;
       std::vector<float2> t8((size_t)(256 + 1024 + 2048));
       auto W = [](double num, double den) {
         const double ang = -2.0 * M_PI * num / den;
@@ -947,6 +1110,10 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
         for (int t = 0; t < 256; ++t) t8[(size_t)(256 + 1024 + r2 * 256 + t)] = W((double)t * r2, 2048.0);
       CREATE_HIP(hipMalloc(&c->d_tw8k, sizeof(float2) * t8.size()));
       CREATE_HIP(hipMemcpy(c->d_tw8k, t8.data(), sizeof(float2) * t8.size(), hipMemcpyHostToDevice));
+      std::vector<float2> v2((size_t)(256 + 384 + 96));
+      ss::fft8192_v2_host_tables(v2.data(), v2.data() + 256, v2.data() + 256 + 384);
+      CREATE_HIP(hipMalloc(&c->d_tw8v2, sizeof(float2) * v2.size()));
+      CREATE_HIP(hipMemcpy(c->d_tw8v2, v2.data(), sizeof(float2) * v2.size(), hipMemcpyHostToDevice));
     }
     CREATE_HIP(hipMemcpy(c->d_win, win.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
@@ -964,9 +1131,20 @@ const char* ss_last_error(const ss_ctx* ctx) { return ctx ? ctx->err : g_create_
 
 void* ss_stream(ss_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int ss_flush(ss_ctx* ctx) {
+  if (!ctx) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mtx);
+  SS_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+  flush_stages(ctx);
+  SS_HIP(ctx, hipGetLastError());
+  return SS_OK;
+}
+
 int ss_sync(ss_ctx* ctx) {
   if (!ctx) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(ctx->mtx);
   SS_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+  flush_stages(ctx);
   SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SS_OK;
 }
@@ -1057,16 +1235,17 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
     if (!c->d_relplane) SS_HIP(c, hipMalloc(&c->d_relplane, sizeof(float) * (size_t)n * (size_t)c->cfg.max_batch));
     d_rel_plane = c->d_relplane;
   }
-  st = run_batch(c, c->d_in, (long long)n, nframes, n_learn, z, nullptr, d_rel_plane, (c->fused && avg_db) ? c->d_avg : nullptr, nullptr,
+  st = run_batch(c, c->d_in, (long long)n, nframes, n_learn, z, nullptr, d_rel_plane, (c->fused && avg_db) ? c->d_avg2[c->buf_cur] : nullptr, nullptr,
                  want_cands ? c->d_cand_idx : nullptr, want_cands && cand_avg ? c->d_cand_avg : nullptr, cand_cap);
   if (st != SS_OK) return st;
+  flush_stages(c);  // a work() call hands its results back before it returns
   const size_t plane = sizeof(float) * (size_t)n * (size_t)nframes;
   if (psd_db) SS_HIP(c, hipMemcpyAsync(psd_db, c->last_psd, plane, hipMemcpyDeviceToHost, c->stream));
   if (rel_db) {
     const float* src = c->fused ? c->d_relplane : c->d_rel + (size_t)(c->cfg.grouping_y - 1) * n;
     SS_HIP(c, hipMemcpyAsync(rel_db, src, plane, hipMemcpyDeviceToHost, c->stream));
   }
-  if (avg_db) SS_HIP(c, hipMemcpyAsync(avg_db, c->d_avg, plane, hipMemcpyDeviceToHost, c->stream));
+  if (avg_db) SS_HIP(c, hipMemcpyAsync(avg_db, c->last_avg, plane, hipMemcpyDeviceToHost, c->stream));
   std::vector<int> off((size_t)nframes + 1);
   SS_HIP(c, hipMemcpyAsync(off.data(), c->d_off, sizeof(int) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, c->stream));
   SS_HIP(c, hipStreamSynchronize(c->stream));
@@ -1086,6 +1265,8 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
 int ss_set_frequency_range(ss_ctx* c, int32_t lo_hz, int32_t hi_hz) {
   if (!c) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  flush_stages(c);  // deferred stages belong to the old range (pass mask, noise ceiling)
   c->range_lo = lo_hz;
   c->range_hi = hi_hz;
   c->pass_dirty = true;
@@ -1096,6 +1277,7 @@ int ss_reset(ss_ctx* c) {  // Transmission::resetBuffers -> Averager::reset: row
   if (!c) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  flush_stages(c);  // deferred stages still read and write the ring
   const int G = c->cfg.grouping_y;
   if (c->fused) {
     c->hist_start = 0;
@@ -1114,9 +1296,12 @@ int ss_reset_noise(ss_ctx* c) {
   if (!c) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  flush_stages(c);
   SS_HIP(c, hipStreamSynchronize(c->stream));
   for (auto& z : c->noise) (void)hipFree(z.d_thr);
   c->noise.clear();
+  c->last_thr = nullptr;  // ss_read_window(SS_PLANE_REL) of the last batch has nothing to subtract any more
+  c->last_n = 0;
   return SS_OK;
 }
 
@@ -1125,8 +1310,9 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
   std::lock_guard<std::mutex> lock(c->mtx);
   const int n = c->n;
   const int G = c->cfg.grouping_y;
-  if (lo < 0 || hi > n || lo > hi || frame >= c->last_n) return fail(c, SS_ERR_INVALID, "window out of range");
+  if (lo < 0 || hi > n || lo > hi || frame >= c->last_n || c->last_n <= 0 || !c->last_psd) return fail(c, SS_ERR_INVALID, "window out of range (or no batch processed yet)");
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  flush_stages(c);
   const size_t cnt = (size_t)(hi - lo);
   if (c->fused && plane == SS_PLANE_REL && frame >= 0) {
     // the fused back end never stores rel: rebuild the window as the kernel computes it,
@@ -1147,7 +1333,7 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
     if (plane == SS_PLANE_PSD) src = c->last_psd + (size_t)frame * n;
     if (plane == SS_PLANE_AVG) {
       if (c->fused && !(c->cfg.flags & SS_FLAG_KEEP_PLANES)) return fail(c, SS_ERR_INVALID, "SS_PLANE_AVG needs SS_FLAG_KEEP_PLANES at ss_create");
-      src = c->d_avg + (size_t)frame * n;
+      src = c->last_avg + (size_t)frame * n;
     }
     if (plane == SS_PLANE_REL && !c->fused) src = c->d_rel + (size_t)(G - 1 + frame) * n;
   } else if (plane == SS_PLANE_REL && frame >= -(G - 1)) {
@@ -1176,6 +1362,7 @@ int ss_spectrogram_read(ss_ctx* c, int8_t* out, float* mean_out) {
   for (auto& s : c->spec)
     if (s.center == center) g = &s;
   if (!g || g->count == 0) return 0;
+  flush_stages(c);
   spectrogram_flush(c);
   std::vector<float> sum((size_t)c->spec_n);
   SS_HIP(c, hipMemcpyAsync(sum.data(), g->d_sum, sizeof(float) * sum.size(), hipMemcpyDeviceToHost, c->stream));
@@ -1378,6 +1565,7 @@ int ss_feed_submit(ss_feed* f, int32_t nframes, const int64_t* t_ms, int64_t use
   st = run_batch(c, s.d_in, (long long)n, nframes, n_learn, z, nullptr, nullptr, nullptr, s.d_off, want_cands ? s.d_idx : nullptr,
                  want_cands ? s.d_avg : nullptr, f->cand_cap);
   if (st != SS_OK) return st;
+  flush_stages(c);  // the slot's results are copied out right behind the batch
   SS_HIP(c, hipMemcpyAsync(s.h_off, s.d_off, sizeof(int32_t) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, c->stream));
   if (f->want_psd) SS_HIP(c, hipMemcpyAsync(s.h_psd, c->last_psd, sizeof(float) * (size_t)n * (size_t)nframes, hipMemcpyDeviceToHost, c->stream));
   SS_HIP(c, hipEventRecord(s.ev_done, c->stream));
@@ -1422,7 +1610,5 @@ int ss_feed_collect(ss_feed* f, ss_feed_result* out) {
   --f->pending;
   return SS_OK;
 }
-
-#include "specscan_pipe_impl.h"  // ss_pipe_*: several lanes taking the calls of one band in turn
 
 }  // extern "C"

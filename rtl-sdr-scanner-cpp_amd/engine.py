@@ -13,19 +13,28 @@ import os
 import numpy as np
 
 from . import abi
-from .build import LIB
+from .build import LIB, LIB_DIAG
 
-_lib = None
+_libs = {}
+_use_diag = False  # tests / measurement scripts: route new engines to libspecscan_diag.so (use_diag_library)
 
 
-def load_library() -> C.CDLL:
+def use_diag_library(on: bool = True) -> None:
+    """Engines created from now on load csrc/libspecscan_diag.so — the same sources built with -DSS_DIAG, the only build
+    that lets SS_* / SC_* environment variables pick one implementation of a step over another (A/B tests)."""
+    global _use_diag
+    _use_diag = bool(on)
+
+
+def load_library(diag: bool | None = None) -> C.CDLL:
     """dlopen csrc/libspecscan.so (built by build.build_lib / __graft_entry__.build). Raises if absent."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB):
-            raise RuntimeError(f"{LIB} is missing: run `python __graft_entry__.py build` (hipcc, gfx950). "
+    diag = _use_diag if diag is None else diag
+    path = LIB_DIAG if diag else LIB
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python __graft_entry__.py build` (hipcc, gfx950). "
                                "The spectral-scan engine has no CPU fallback.")
-        lib = C.CDLL(LIB)
+        lib = C.CDLL(path)
         abi.bind(lib, "ss_")
         lib.ss_device_count.restype = C.c_int
         lib.ss_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -33,6 +42,8 @@ def load_library() -> C.CDLL:
         lib.ss_process_device.restype = C.c_int
         lib.ss_sync.argtypes = [C.c_void_p]
         lib.ss_sync.restype = C.c_int
+        lib.ss_flush.argtypes = [C.c_void_p]
+        lib.ss_flush.restype = C.c_int
         lib.ss_stream.argtypes = [C.c_void_p]
         lib.ss_stream.restype = C.c_void_p
         lib.ss_kernel_timing.argtypes = [C.c_void_p, C.c_int]
@@ -59,15 +70,14 @@ def load_library() -> C.CDLL:
         lib.ss_feed_collect.restype = C.c_int
         lib.ss_feed_pending.argtypes = [C.c_void_p]
         lib.ss_feed_pending.restype = C.c_int
-        _lib = lib
-    return _lib
+        _libs[path] = lib
+    return _libs[path]
 
 
 EXPORTS = ("ss_default_config", "ss_device_count", "ss_create", "ss_destroy", "ss_last_error", "ss_process",
-           "ss_process_device", "ss_sync", "ss_stream", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
+           "ss_process_device", "ss_flush", "ss_sync", "ss_stream", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
            "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read",
-           "ss_spectrogram_payload", "ss_pipe_create", "ss_pipe_destroy", "ss_pipe_last_error", "ss_pipe_process_device", "ss_pipe_sync",
-           "ss_pipe_set_frequency_range", "ss_pipe_reset", "ss_feed_create", "ss_feed_destroy", "ss_feed_acquire", "ss_feed_submit", "ss_feed_collect", "ss_feed_pending")
+           "ss_spectrogram_payload", "ss_feed_create", "ss_feed_destroy", "ss_feed_acquire", "ss_feed_submit", "ss_feed_collect", "ss_feed_pending")
 
 
 def _ptr(t):
@@ -107,7 +117,12 @@ class SpectrumEngine(abi.Chain):
         self._check(st)
 
     def sync(self):
+        """Drain the deferred stages of earlier process_device calls and wait for the chain's stream."""
         self._check(self._lib.ss_sync(self._h))
+
+    def flush(self):
+        """Enqueue the deferred stages of earlier process_device calls without waiting."""
+        self._check(self._lib.ss_flush(self._h))
 
     def spectrogram_read(self):
         """(int8 spectrogram row, float means, frames accumulated) for the current centre; clears the accumulator."""
@@ -193,60 +208,3 @@ class Feed:
         if r.psd_db:
             out["psd"] = np.ctypeslib.as_array(r.psd_db, shape=(nf, self._e.n))
         return out
-
-
-class Pipe:
-    """One band, several lanes (contexts) taking its calls in turn — ss_pipe_* of include/specscan.h. Device tensors in and
-    out, asynchronous; results equal SpectrumEngine.process_device on one context (past the averager's warm-up)."""
-
-    def __init__(self, sample_rate: int, center_hz: int, lanes: int = 2, **overrides):
-        self._lib = load_library()
-        L = self._lib
-        L.ss_pipe_create.argtypes = [C.POINTER(abi.SsConfig), C.c_int32, C.POINTER(C.c_void_p)]
-        L.ss_pipe_destroy.argtypes = [C.c_void_p]
-        L.ss_pipe_destroy.restype = None
-        L.ss_pipe_last_error.argtypes = [C.c_void_p]
-        L.ss_pipe_last_error.restype = C.c_char_p
-        L.ss_pipe_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
-        L.ss_pipe_sync.argtypes = [C.c_void_p]
-        L.ss_pipe_set_frequency_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
-        L.ss_pipe_reset.argtypes = [C.c_void_p]
-        abi.bind(L, "ss_")
-        cfg = abi.SsConfig()
-        L.ss_default_config(C.byref(cfg), int(sample_rate), int(center_hz))
-        keep = abi.apply_overrides(cfg, overrides)
-        self._keep = keep
-        self.n = cfg.fft_size
-        h = C.c_void_p()
-        st = L.ss_pipe_create(C.byref(cfg), int(lanes), C.byref(h))
-        if st != 0:
-            raise abi.SpecscanError(st, (L.ss_pipe_last_error(None) or b"").decode())
-        self._h = h
-
-    def _check(self, st):
-        if st != 0 and st != abi.SS_ERR_CAND_OVERFLOW:
-            raise abi.SpecscanError(st, (self._lib.ss_pipe_last_error(self._h) or b"").decode())
-
-    def process_device(self, iq, nframes: int, psd=None, cand_off=None, cand_idx=None, cand_avg=None):
-        cap = 0 if cand_idx is None else int(cand_idx.numel())
-        self._check(self._lib.ss_pipe_process_device(self._h, _ptr(iq), int(nframes), _ptr(psd), _ptr(cand_off), _ptr(cand_idx), _ptr(cand_avg), cap))
-
-    def sync(self):
-        self._check(self._lib.ss_pipe_sync(self._h))
-
-    def set_frequency_range(self, lo: int, hi: int):
-        self._check(self._lib.ss_pipe_set_frequency_range(self._h, int(lo), int(hi)))
-
-    def reset(self):
-        self._check(self._lib.ss_pipe_reset(self._h))
-
-    def close(self):
-        if getattr(self, "_h", None):
-            self._lib.ss_pipe_destroy(self._h)
-            self._h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass

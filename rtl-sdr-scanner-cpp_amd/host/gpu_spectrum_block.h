@@ -21,7 +21,9 @@
 // looked at once per work() call (the reference looks after every frame), so a row closes at a batch boundary.
 //
 // Control calls mirror what SdrDevice does to the blocks it owns: setFrequencyRange (sdr_device.cpp:54-80)
-// -> set_frequency_range() + reset_buffers(); they are serialised against work() inside the library.
+// -> set_frequency_range() + reset_buffers(). They come from the Scanner's thread while work() runs on the flowgraph's:
+// the library serialises its own entry points, and m_mutex does for the host-side tracker what Transmission::m_mutex does
+// in the reference (taken in work() and in resetBuffers(), transmission.cpp:35,43).
 #pragma once
 #include <gnuradio/sync_block.h>
 #include <specscan.h>
@@ -34,6 +36,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -94,7 +97,17 @@ class GpuSpectrum : virtual public gr::sync_block {
     const int status = ss_process(m_ctx, input_items[0], nframes, m_times.data(), static_cast<float*>(output_items[0]),
                                   m_tracker ? m_rel.data() : nullptr, m_tracker ? m_avgPlane.data() : nullptr, m_offsets.data(), m_bins.data(),
                                   m_avg.data(), static_cast<int32_t>(m_bins.size()));
-    if (status != SS_OK && status != SS_ERR_CAND_OVERFLOW) {
+    size_t grow_to = 0;
+    if (status == SS_ERR_CAND_OVERFLOW) {
+      // More candidates than the lists hold (the reference never drops one): the offsets are exact, so once this call's
+      // own lists — truncated, later frames incomplete — have been handed on, the lists are grown to fit; the call is
+      // flagged (lastError, candidateOverflows) and the next one fits.
+      const size_t need = static_cast<size_t>(m_offsets[static_cast<size_t>(nframes)]);
+      const size_t per_frame = (need + static_cast<size_t>(nframes) - 1) / static_cast<size_t>(nframes);
+      grow_to = static_cast<size_t>(m_config.max_batch) * (per_frame + 64);
+      m_lastError = "candidate lists overflowed; capacity raised to " + std::to_string(grow_to);
+      ++m_overflows;
+    } else if (status != SS_OK) {
       // work() has no error channel in the reference either (sdr_source.cpp:37-41 logs and exits): produce nothing
       m_lastError = ss_last_error(m_ctx);
       return 0;
@@ -108,6 +121,7 @@ class GpuSpectrum : virtual public gr::sync_block {
       }
     }
     if (m_tracker) {
+      std::lock_guard<std::mutex> lock(m_mutex);
       const int32_t cap = static_cast<int32_t>(m_bins.size());
       const size_t n = static_cast<size_t>(m_config.fft_size);
       for (int f = 0; f < nframes; ++f) {
@@ -129,6 +143,10 @@ class GpuSpectrum : virtual public gr::sync_block {
         it->second = now;
       }
     }
+    if (grow_to > m_bins.size()) {
+      m_bins.resize(grow_to);
+      m_avg.resize(grow_to);
+    }
     return nframes;
   }
 
@@ -139,9 +157,11 @@ class GpuSpectrum : virtual public gr::sync_block {
   }
   void resetBuffers() {  // Transmission::resetBuffers, transmission.cpp:42-55: signals cleared, averager reset
     ss_reset(m_ctx);
+    std::lock_guard<std::mutex> lock(m_mutex);
     if (m_tracker) m_tracker->reset();
   }
   const std::string& lastError() const { return m_lastError; }
+  int candidateOverflows() const { return m_overflows; }  // work() calls whose lists were cut (capacity grows each time)
 
  private:
   ss_config m_config;
@@ -159,4 +179,6 @@ class GpuSpectrum : virtual public gr::sync_block {
   std::vector<int8_t> m_spectrogramRow;
   std::map<int32_t, int64_t> m_spectrogramSent;  // Container::m_lastDataSendTime per centre frequency
   std::atomic<int32_t> m_center{0};  // written by the retuning thread (setFrequencyRange), read by work()
+  std::mutex m_mutex;                // the tracker: work() on the flowgraph thread, resetBuffers() on the Scanner's
+  int m_overflows = 0;
 };

@@ -146,21 +146,17 @@ class RawFileSink {
   }
 
  private:
+  // Append whole items; the file is opened on the first write of a recording.
   void save(const void* data, int nitems) {
-    if (!m_file) {
-      m_file = fopen(m_filename.c_str(), "wb");
-      if (!m_file) throw std::runtime_error("open file failed: " + m_filename);
-    }
-    const char* p = static_cast<const char*>(data);
-    int nwritten = 0;
-    while (nwritten < nitems) {
-      const size_t count = fwrite(p, m_itemBytes, (size_t)(nitems - nwritten), m_file);
-      if (count == 0) {
-        if (ferror(m_file)) throw std::runtime_error("write file failed: " + m_filename);
-        break;
+    if (!m_file && !(m_file = fopen(m_filename.c_str(), "wb"))) throw std::runtime_error("cannot create " + m_filename);
+    const auto* bytes = static_cast<const unsigned char*>(data);
+    for (size_t done = 0, total = static_cast<size_t>(nitems); done < total;) {
+      const size_t n = fwrite(bytes + done * m_itemBytes, m_itemBytes, total - done, m_file);
+      done += n;
+      if (n == 0) {  // short write: a device error is fatal, anything else ends the append quietly (as the reference's sink does)
+        if (ferror(m_file)) throw std::runtime_error("cannot append to " + m_filename);
+        return;
       }
-      nwritten += (int)count;
-      p += count * m_itemBytes;
     }
   }
   const size_t m_itemBytes;

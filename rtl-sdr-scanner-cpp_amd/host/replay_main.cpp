@@ -156,7 +156,17 @@ int main(int argc, char** argv) {
         cv.notify_all();
         break;
       }
-      if (want_power) power.work(r.psd_db, r.nframes);
+      if (want_power) {
+        try {
+          power.work(r.psd_db, r.nframes);
+        } catch (const std::exception& e) {  // the producer thread is still joinable: report, wake it, fall through to the join
+          std::lock_guard<std::mutex> lock(mtx);
+          failed = true;
+          error = e.what();
+          cv.notify_all();
+          break;
+        }
+      }
       frames += r.nframes;
       candidates += r.cand_off[r.nframes];
       ++batches;

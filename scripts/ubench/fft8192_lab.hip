@@ -85,19 +85,18 @@ int main(int argc, char** argv) {
   const ss::Fft8192Second none{nullptr, 0, nullptr, 0};
   const float db_off = (float)(10.0 * log10(2048000.0));
 
-  // rotating working set
-  const size_t in_set = (size_t)max_frames * n * 8, out_set = (size_t)max_frames * n * 4;
-  int nsets = (int)(((size_t)704 << 20) / in_set) + 1;
-  if (nsets < 3) nsets = 3;
-  std::vector<void*> d_in(nsets);
-  std::vector<float*> d_out(nsets);
-  for (int k = 0; k < nsets; ++k) {
-    CK(hipMalloc(&d_in[k], in_set));
-    CK(hipMalloc((void**)&d_out[k], out_set));
-    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (float*)d_in[k], in_set / 4, 12345u + 977u * k);
-  }
+  // rotating working set: one pool, cut into as many sets as the batch size allows (>= 3 sets, >= 768 MiB of input)
+  size_t pool_in = (size_t)768 << 20;
+  if (pool_in < (size_t)3 * max_frames * n * 8) pool_in = (size_t)3 * max_frames * n * 8;
+  const size_t pool_out = pool_in / 2;
+  char *pool_in_d, *pool_out_d;
+  CK(hipMalloc((void**)&pool_in_d, pool_in));
+  CK(hipMalloc((void**)&pool_out_d, pool_out));
+  hipLaunchKernelGGL(k_fill, dim3(8192), dim3(256), 0, 0, (float*)pool_in_d, pool_in / 4, 12345u);
   CK(hipDeviceSynchronize());
-  printf("# %d sets of %zu MiB in + %zu MiB out\n", nsets, in_set >> 20, out_set >> 20);
+  int nsets = 0;
+  std::vector<void*> d_in;
+  std::vector<float*> d_out;
 
   hipStream_t st;
   CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -109,8 +108,8 @@ int main(int argc, char** argv) {
   }
 #define V2(...)                                                                                                                          \
   [&](const void* in, float* out, int frames, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {                                             \
-    hipExtLaunchKernelGGL((ss::k_fft8192_psd_v2<__VA_ARGS__>), dim3(frames), dim3(512), ss::kFft8192V2LdsBytes, s, e0, e1, 0, in,       \
-                          (long long)8192, (const float*)d_win, tabs2, db_off, 1.0f, out, none);                                         \
+    const ss::Fft8192Args g{in, (long long)8192, (const float*)d_win, tabs2, db_off, 1.0f, out};                                         \
+    hipExtLaunchKernelGGL((ss::k_fft8192_psd_v2<__VA_ARGS__>), dim3(frames), dim3(512), ss::kFft8192V2LdsBytes, s, e0, e1, 0, g);       \
   }
   std::vector<Variant> variants = {
       {"w8 (first generation)", W8(ss::FMT_CF32, 8), true},
@@ -123,8 +122,8 @@ int main(int argc, char** argv) {
       {"v2 TW3 (no tables, bound)", V2(ss::FMT_CF32, 3), false},
       {"v2 TW0 + swizzled exchange", V2(ss::FMT_CF32, 0, true), true},
       {"v2 TW2 + swizzled exchange", V2(ss::FMT_CF32, 2, true), true},
-      {"v2 TW2, no window (bound)", V2(ss::FMT_CF32, 2, false, false, true), false},
-      {"v2 TW3, no window (bound)", V2(ss::FMT_CF32, 3, false, false, true), false},
+      {"v2 TW2, no window (bound)", V2(ss::FMT_CF32, 2, false, true), false},
+      {"v2 TW3, no window (bound)", V2(ss::FMT_CF32, 3, false, true), false},
   };
 
   const int iters = 48;
@@ -136,6 +135,14 @@ int main(int argc, char** argv) {
   std::vector<float> ref((size_t)1024 * n), got((size_t)1024 * n);
 
   for (int frames : frame_counts) {
+    nsets = (int)(pool_in / ((size_t)frames * n * 8));
+    d_in.assign(nsets, nullptr);
+    d_out.assign(nsets, nullptr);
+    for (int k = 0; k < nsets; ++k) {
+      d_in[k] = pool_in_d + (size_t)k * frames * n * 8;
+      d_out[k] = reinterpret_cast<float*>(pool_out_d + (size_t)k * frames * n * 4);
+    }
+    printf("\n# %d sets of %d MiB in + %d MiB out in rotation\n", nsets, frames * n * 8 >> 20, frames * n * 4 >> 20);
     printf("\n## %d frames per launch (%.1f MB algorithmic)\n", frames, 12.0 * frames * n / 1e6);
     printf("%-32s %9s %9s %9s %7s %9s  %s\n", "variant", "kern us", "min us", "loop us", "GB/s", "% 8TB/s", "max |dB diff| vs w8");
     bool have_ref = false;

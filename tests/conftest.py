@@ -36,3 +36,13 @@ def ref_mod(oracle_mod):
         pytest.skip("oracle/_ref/libref_specscan.so not built (needs /root/reference)")
     oracle_mod.ref()
     return oracle_mod
+
+
+@pytest.fixture
+def diag_lib():
+    """Engines created inside the test load libspecscan_diag.so — the -DSS_DIAG build, the only one that lets SS_* / SC_*
+    environment variables select an alternative implementation (the product library never reads the environment)."""
+    import rtl_sdr_scanner_cpp_amd as pkg
+    pkg.engine.use_diag_library(True)
+    yield
+    pkg.engine.use_diag_library(False)

@@ -150,7 +150,7 @@ def test_result_does_not_depend_on_the_call_sizes():
 
 
 @pytest.mark.parametrize("fs,bw", [(2_048_000, 32_000), (2_000_000, 20_000), (2_048_000, 16_000), (250_000, 25_000)])
-def test_branch_kernel_equals_the_generic_stage_kernel(fs, bw, monkeypatch):
+def test_branch_kernel_equals_the_generic_stage_kernel(fs, bw, monkeypatch, diag_lib):
     """The polyphase-by-branch first stage (full-tile and edge code) against the one-output-per-lane kernel (SC_GENERIC=1)
     on the same stream cut into the same ragged calls: two summation orders of the same fp32 products."""
     n = 140_000

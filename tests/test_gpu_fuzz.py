@@ -194,7 +194,7 @@ def test_entry_points_agree(seed):
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SS_FUZZ_SEEDS4", "6"))))
 @pytest.mark.parametrize("impl", ["detect", "standalone"])
-def test_random_spectrogram_sessions(oracle_mod, seed, impl, monkeypatch):
+def test_random_spectrogram_sessions(oracle_mod, seed, impl, monkeypatch, diag_lib):
     """The spectrogram side branch under random sizes (its output size follows min(16384, getFft(fs, 1000))), call sizes,
     send times and a retune (the accumulator is per centre frequency, spectrogram.cpp:29-60); accumulated inside the
     detect kernel (decimation factors up to 64) or by the stand-alone kernels."""

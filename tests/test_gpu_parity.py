@@ -95,7 +95,10 @@ def test_engine_matches_oracle(oracle_mod, n, fs, decim, fmt, nframes, chunk, le
 ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurement hook of DESIGN.md 6f meets the same contract
     ({"SS_BACKEND": "unfused"}, 8192, 2_048_000, "cf32"),
     ({"SS_FFT_IMPL": "generic"}, 8192, 2_048_000, "cf32"),
-    ({"SS_FFT_IMPL": "wide"}, 8192, 2_048_000, "cs8"),
+    ({"SS_FFT_TW": "0", "SS_FFT_SWZ": "0"}, 8192, 2_048_000, "cs8"),
+    ({"SS_FFT_TW": "1"}, 8192, 2_048_000, "cu8"),
+    ({"SS_PIPELINE": "0"}, 8192, 2_048_000, "cf32"),
+    ({"SS_STEP_RUN_DET": "3", "SS_STEP_RUN_FFT": "5"}, 8192, 2_048_000, "cf32"),
     ({"SS_FFT_IMPL": "generic"}, 2048, 512_000, "cf32"),
     ({"SS_FFT_IMPL": "generic"}, 65536, 20_000_000, "cs8"),
     ({"SS_FFT_ROWSR": "0", "SS_FFT_SUB": "1"}, 131072, 20_000_000, "cf32"),
@@ -104,7 +107,7 @@ ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurem
 
 
 @pytest.mark.parametrize("env,n,fs,fmt", ALTERNATIVES, ids=lambda v: "-".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
-def test_alternative_implementations_meet_the_contract(oracle_mod, monkeypatch, env, n, fs, fmt):
+def test_alternative_implementations_meet_the_contract(oracle_mod, monkeypatch, diag_lib, env, n, fs, fmt):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     nframes, learn = 48, 6
@@ -164,7 +167,7 @@ def test_gpu_fft_is_as_accurate_as_the_cpu_fp32_ffts(oracle_mod):
 
 
 @pytest.mark.parametrize("logn,rows", [(20, ""), (20, "1"), (19, ""), (19, "0"), (18, ""), (18, "0"), (17, "0")])
-def test_one_million_point_frames(oracle_mod, logn, rows, monkeypatch):
+def test_one_million_point_frames(oracle_mod, logn, rows, monkeypatch, diag_lib):
     """BASELINE config 5 frame size (2^20) and the sizes below it, detect chain on a few frames. Rows of the four-step
     transform: one register-pass kernel per row of 512 .. 2048 points (default up to 2^19; forced for 2^20 with
     SS_FFT_ROWSR=1), or radix-A step + 256-point rows (default at 2^20, forced with "0"; generic LDS rows below 2^19)."""
@@ -389,7 +392,7 @@ def test_contexts_on_their_own_threads_with_control_calls_from_a_third():
 
 
 @pytest.mark.parametrize("impl", ["detect", "standalone"])
-def test_spectrogram_side_branch(oracle_mod, impl, monkeypatch):
+def test_spectrogram_side_branch(oracle_mod, impl, monkeypatch, diag_lib):
     """Spectrogram::process/send (spectrogram.cpp:45-75) on the raw PSD: bin-decimated mean accumulated over frames,
     published as int8 by the C++ float -> int8 conversion. The float means agree to 1e-4 dB; the int8 bytes are
     identical wherever the reference's own mean is not within 1e-3 of an integer (there truncation decides)."""

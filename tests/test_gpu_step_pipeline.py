@@ -1,0 +1,140 @@
+"""k_scan_step's stage pipelining (csrc/scan_step.h, 8192-point frames): the launch of call k carries the FFT + dB stage of
+call k, the averaging / threshold stage of call k-1 and the candidate-list stage of call k-2. Results must be those of the
+stages run back to back — bit for bit, whatever the call sizes, through learning, retunes, resets and reads in between.
+Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+import rtl_sdr_scanner_cpp_amd as pkg
+
+pytestmark = pytest.mark.gpu
+
+N, FS, CENTER = 8192, 2_048_000, 145_000_000
+
+
+def _device_outputs(torch, dev, s_, want_planes):
+    o = dict(psd=torch.full((s_, N), -7.0, dtype=torch.float32, device=dev), off=torch.full((s_ + 1,), -1, dtype=torch.int32, device=dev),
+             idx=torch.full((s_ * 512,), -1, dtype=torch.int32, device=dev), cav=torch.full((s_ * 512,), -7.0, dtype=torch.float32, device=dev))
+    o["rel"] = torch.full((s_, N), -7.0, dtype=torch.float32, device=dev) if want_planes else None
+    o["avg"] = torch.full((s_, N), -7.0, dtype=torch.float32, device=dev) if want_planes else None
+    return o
+
+
+def _call(eng, d_iq, s_, o):
+    eng.process_device(d_iq, s_, psd=o["psd"], rel=o["rel"], avg=o["avg"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["cav"])
+
+
+def _same(a, b, what):
+    for k in ("psd", "off", "rel", "avg"):
+        if a[k] is not None:
+            np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), err_msg=f"{what}: {k}")
+    total = int(a["off"][-1])
+    assert total == int(b["off"][-1])
+    np.testing.assert_array_equal(a["idx"][:total].cpu().numpy(), b["idx"][:total].cpu().numpy(), err_msg=f"{what}: cand_idx")
+    np.testing.assert_array_equal(a["cav"][:total].cpu().numpy(), b["cav"][:total].cpu().numpy(), err_msg=f"{what}: cand_avg")
+    return total
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_overlapped_calls_equal_call_by_call(seed):
+    """Engine A waits after every call (no stage ever overlaps another call), engine B is only synchronised at the very end
+    (up to three calls in flight). Same stream, same random cut into calls, a retune with reset and a plain reset on the way,
+    sometimes int8 IQ, the spectrogram branch or full planes."""
+    import torch
+    rng = np.random.default_rng(4200 + seed)
+    dev = torch.device("cuda:0")
+    fmt = [pkg.abi.SS_FMT_CF32, pkg.abi.SS_FMT_CS8, pkg.abi.SS_FMT_CU8][seed % 3]
+    want_planes = seed % 4 == 1
+    flags = pkg.abi.SS_FLAG_SPECTROGRAM if seed % 4 == 2 else 0
+    nframes, learn, max_batch = 420, int(rng.integers(10, 40)), int(rng.choice([64, 100, 128]))
+    band = pkg.synth.SyntheticBand(N, seed=70 + seed, on_frame=learn + 25, off_frame=250, period=300)
+    iq = band.frames_cf32(nframes) if fmt == pkg.abi.SS_FMT_CF32 else (band.frames_cs8(nframes) if fmt == pkg.abi.SS_FMT_CS8 else band.frames_cu8(nframes))
+    kw = dict(fft_size=N, decim=1, in_format=fmt, learn_frames=learn, max_batch=max_batch, flags=flags)
+    a, b = pkg.SpectrumEngine(FS, CENTER, **kw), pkg.SpectrumEngine(FS, CENTER, **kw)
+    sizes, pos = [], 0
+    while pos < nframes:
+        s_ = int(min(nframes - pos, rng.choice([1, 3, 16, 17, 40, max_batch, int(rng.integers(1, max_batch + 1))])))
+        sizes.append(s_)
+        pos += s_
+    retune_at, reset_at = len(sizes) // 3, 2 * len(sizes) // 3
+    outs_a, outs_b, keep, pos = [], [], [], 0
+    for k, s_ in enumerate(sizes):
+        if k == retune_at:  # SdrDevice::setFrequencyRange: new centre, buffers reset, noise learned afresh there
+            for e in (a, b):
+                e.set_frequency_range(CENTER + 1_000_000 - FS // 2, CENTER + 1_000_000 + FS // 2)
+                e.reset()
+        if k == reset_at:
+            for e in (a, b):
+                e.reset()
+        chunk = iq[pos:pos + s_]
+        d_iq = torch.from_numpy(np.ascontiguousarray(chunk).view(np.float32) if chunk.dtype == np.complex64 else np.ascontiguousarray(chunk)).to(dev)
+        keep.append(d_iq)  # inputs stay untouched until the final sync
+        oa, ob = _device_outputs(torch, dev, s_, want_planes), _device_outputs(torch, dev, s_, want_planes)
+        _call(a, d_iq, s_, oa)
+        a.sync()
+        _call(b, d_iq, s_, ob)
+        outs_a.append(oa)
+        outs_b.append(ob)
+        pos += s_
+    b.sync()
+    total = sum(_same(oa, ob, f"call {k} ({sizes[k]} frames)") for k, (oa, ob) in enumerate(zip(outs_a, outs_b)))
+    assert total > 500
+    if flags:
+        ra, rb = a.spectrogram_read(), b.spectrogram_read()
+        assert ra[2] == rb[2] > 0
+        np.testing.assert_array_equal(ra[0], rb[0])
+        np.testing.assert_array_equal(ra[1], rb[1])
+
+
+def test_flush_then_stream_sync_completes_the_results():
+    """ss_flush enqueues the deferred stages; after it any synchronisation of the stream (here: of the device) will do."""
+    import torch
+    dev = torch.device("cuda:0")
+    band = pkg.synth.SyntheticBand(N, seed=5, on_frame=40, off_frame=10_000)
+    iq = band.frames_cf32(192)
+    kw = dict(fft_size=N, decim=1, learn_frames=16, max_batch=64)
+    host = pkg.SpectrumEngine(FS, CENTER, **kw)
+    eng = pkg.SpectrumEngine(FS, CENTER, **kw)
+    outs, keep = [], []
+    for k in range(3):
+        d_iq = torch.from_numpy(iq[64 * k:64 * k + 64].view(np.float32).copy()).to(dev)
+        keep.append(d_iq)
+        o = _device_outputs(torch, dev, 64, False)
+        _call(eng, d_iq, 64, o)
+        outs.append(o)
+    assert int(outs[2]["off"][0]) == -1  # (the last call's candidate stage has not even been launched yet)
+    eng.flush()
+    torch.cuda.synchronize()
+    for k in range(3):
+        h = host.process(iq[64 * k:64 * k + 64])
+        np.testing.assert_array_equal(outs[k]["off"].cpu().numpy(), h["cand_off"])
+        np.testing.assert_array_equal(outs[k]["psd"].cpu().numpy(), h["psd"])
+        t = int(h["cand_off"][-1])
+        np.testing.assert_array_equal(outs[k]["idx"][:t].cpu().numpy(), h["cand_idx"])
+        np.testing.assert_array_equal(outs[k]["cav"][:t].cpu().numpy(), h["cand_avg"])
+    assert int(outs[2]["off"][-1]) > 100
+
+
+def test_reads_between_overlapped_calls_see_finished_state():
+    """ss_read_window / ss_read_noise in the middle of a run of device calls drain the deferred stages first."""
+    import torch
+    dev = torch.device("cuda:0")
+    band = pkg.synth.SyntheticBand(N, seed=6, on_frame=30, off_frame=10_000)
+    iq = band.frames_cf32(160)
+    kw = dict(fft_size=N, decim=1, learn_frames=12, max_batch=32, flags=pkg.abi.SS_FLAG_KEEP_PLANES)
+    host = pkg.SpectrumEngine(FS, CENTER, **kw)
+    eng = pkg.SpectrumEngine(FS, CENTER, **kw)
+    keep = []
+    for k in range(5):
+        chunk = iq[32 * k:32 * k + 32]
+        h = host.process(chunk)
+        d_iq = torch.from_numpy(chunk.view(np.float32).copy()).to(dev)
+        keep.append(d_iq)
+        o = _device_outputs(torch, dev, 32, False)
+        _call(eng, d_iq, 32, o)
+        keep.append(o)
+        if k >= 2:
+            for plane, key in ((pkg.abi.SS_PLANE_PSD, "psd"), (pkg.abi.SS_PLANE_REL, "rel"), (pkg.abi.SS_PLANE_AVG, "avg")):
+                np.testing.assert_array_equal(eng.read_window(plane, 7, 100, 900), h[key][7, 100:900])
+            np.testing.assert_array_equal(eng.read_window(pkg.abi.SS_PLANE_REL, -3, 0, N), host.read_window(pkg.abi.SS_PLANE_REL, -3, 0, N))
+    np.testing.assert_array_equal(eng.read_noise()[0], host.read_noise()[0])
