@@ -125,6 +125,13 @@ int ss_process(ss_ctx* ctx, const void* iq, int32_t nframes, const int64_t* t_ms
                float* psd_db, float* rel_db, float* avg_db,
                int32_t* cand_off, int32_t* cand_idx, float* cand_avg, int32_t cand_cap);
 
+/* Degenerate input. A frame of exact zeros gives -inf in every PSD bin, as PSD::work does (log10f(0), psd.cpp:19). The
+ * reference then never detects again until the next resetBuffers: -inf - (-inf) = NaN when the row leaves the Averager's
+ * window (averager.cpp:40-50) and average() carries NaN along each row (utils.cpp:39-48). This library is blind exactly
+ * while the -inf row is inside the 21-frame window — like the reference — and detects again at most 15 frames later (its
+ * sliding sums restart every 16 frames and every 16 bins). Pinned, with the frames where the two part, by
+ * tests/test_gpu_degenerate_input.py. */
+
 /* Same call on DEVICE buffers (hipMalloc'd on cfg.device_id), enqueued on the context's stream and
  * NOT synchronised: call ss_sync before reading results. n_learn = how many leading frames of this
  * batch belong to the noise-learning phase is decided on the host from learn_frames.

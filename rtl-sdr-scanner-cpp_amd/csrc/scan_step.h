@@ -37,10 +37,12 @@ struct StepArgs {
   int n_det;   // detect TILES (two per workgroup)
   int n_emit;  // frames of the emit role (eight per workgroup)
   // One workgroup per work item, dispatched in blockIdx order, four resident per CU. WHICH item a workgroup takes decides
-  // what shares a CU when: `order` (device memory, one word per workgroup: role << 24 | item, built by the host once per
-  // launch shape — step_order() below) or, when null, emit first, then runs of run_det / run_fft alternating.
+  // what shares a CU when: `order` (device memory, one word per workgroup: role << 24 | item) is built by the host once
+  // per launch shape. A launch with one role only passes null (items in blockIdx order). (Tried and dropped: the order as
+  // a run-length list in the kernel arguments, decoded with scalar instructions — ~800 of them per wave: 40 against 35 us
+  // per step.)
   const uint32_t* order;
-  int run_det, run_fft, mixed_runs;
+  int prio_fft, prio_other;  // s_setprio of the roles' waves (0..3)
 };
 
 constexpr int kStepThreads = 512;
@@ -73,7 +75,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
   }
 }
 
-template <int FMT, bool SPEC, int TW = 2, bool SWZ = true>
+template <int FMT, bool SPEC, int TW = 2, bool SWZ = true, bool PRIO = false>
 __global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -82,31 +84,15 @@ __global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a) {
     const uint32_t w = a.order[blockIdx.x];
     role = (int)(w >> 24);
     item = (int)(w & 0xffffffu);
-  } else {
-    const int wg_emit = (a.n_emit + 7) >> 3;
-    const int wg_det = (a.n_det + 1) >> 1;
-    int b = blockIdx.x;
-    if (b < wg_emit) {
-      role = ROLE_EMIT;
-      item = b;
-    } else {
-      b -= wg_emit;
-      // runs of run_det detect workgroups and run_fft FFT workgroups alternate `mixed_runs` times, then the leftovers
-      const int period = a.run_det + a.run_fft;
-      const int mixed = a.mixed_runs * period;
-      bool is_det;
-      if (b < mixed) {
-        const int g = b / period, r = b - g * period;
-        is_det = r < a.run_det;
-        item = is_det ? g * a.run_det + r : g * a.run_fft + (r - a.run_det);
-      } else {
-        const int rest = b - mixed;
-        const int det_left = wg_det - a.mixed_runs * a.run_det;
-        is_det = rest < det_left;
-        item = is_det ? a.mixed_runs * a.run_det + rest : a.mixed_runs * a.run_fft + (rest - det_left);
-      }
-      role = is_det ? ROLE_DET : ROLE_FFT;
-    }
+  } else {  // a single role
+    role = a.n_fft ? ROLE_FFT : a.n_det ? ROLE_DET : ROLE_EMIT;
+    item = blockIdx.x;
+  }
+  if constexpr (PRIO) {  // (s_setprio takes an immediate)
+    const int p = role == ROLE_FFT ? a.prio_fft : a.prio_other;
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 3) __builtin_amdgcn_s_setprio(3);
   }
   step_run_item<FMT, SPEC, TW, SWZ>(a, role, item, smem_raw, tid);
 }

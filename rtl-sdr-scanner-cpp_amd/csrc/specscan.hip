@@ -76,11 +76,11 @@ struct ss_ctx {
     bool pipeline = true;          // 8192 points: defer detect / emit of a call into the next calls' launches (scan_step.h)
     int fft_tw = 2;                // 8192 points: where the twiddles come from (fft8192_v2.h: 0 global, 1 pass-2 table in LDS, 2 LDS + SGPRs)
     bool fft_swz = true;           // 8192 points: 16-byte swizzled first exchange
-    int run_det = 128, run_fft = 128;  // dispatch order of k_scan_step's roles when no order table is used
+    int prio_fft = 0, prio_other = 0;  // s_setprio of k_scan_step's roles
     // Dispatch order of k_scan_step's work items when all three roles ride one launch: "prefix|cycle", comma-separated
     // segments of a role letter (E emit, D detect, F FFT) and a workgroup count ('*' = all that are left); the cycle repeats
-    // until every item is placed, a role that has run out is skipped. Empty = the run_det / run_fft formula.
-    std::string step_order = "E*|D128,F128";
+    // until every item is placed, a role that has run out is skipped.
+    std::string step_order = "E*|D128,F1024";
 #ifdef SS_DIAG
     void read() {
       const auto is = [](const char* name, const char* value) {
@@ -104,8 +104,8 @@ struct ss_ctx {
       pipeline = tri("SS_PIPELINE") != 0;
       fft_tw = num("SS_FFT_TW", 2);
       fft_swz = tri("SS_FFT_SWZ") != 0;
-      run_det = num("SS_STEP_RUN_DET", run_det);
-      run_fft = num("SS_STEP_RUN_FFT", run_fft);
+      prio_fft = num("SS_STEP_PRIO_FFT", 0);
+      prio_other = num("SS_STEP_PRIO_OTHER", 0);
       if (const char* v = getenv("SS_STEP_ORDER")) step_order = v;
     }
 #else
@@ -339,9 +339,18 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
 }
 
 // ---- k_scan_step (8192 points): any subset of the three roles in one launch ------------------------------------------
-// Dispatch-order table from the pattern in diag.step_order (see there). Returns the device table for this launch shape.
-const uint32_t* step_order_table(ss_ctx* c, int n_fft, int wg_det, int wg_emit) {
-  if (c->step_order_key[0] == n_fft && c->step_order_key[1] == wg_det && c->step_order_key[2] == wg_emit) return c->d_step_order[c->step_order_cur];
+// Dispatch order of a launch that carries more than one role, from the pattern in diag.step_order (see there): one word per
+// workgroup (role << 24 | item) in device memory, rebuilt only when the launch shape changes.
+void step_order(ss_ctx* c, ss::StepArgs& a) {
+  const int n_fft = a.n_fft, wg_det = (a.n_det + 1) / 2, wg_emit = (a.n_emit + 7) / 8;
+  a.order = nullptr;
+  a.prio_fft = c->diag.prio_fft;
+  a.prio_other = c->diag.prio_other;
+  if ((n_fft > 0) + (wg_det > 0) + (wg_emit > 0) < 2) return;
+  if (c->step_order_key[0] == n_fft && c->step_order_key[1] == wg_det && c->step_order_key[2] == wg_emit) {
+    a.order = c->d_step_order[c->step_order_cur];
+    return;
+  }
   struct Seg {
     int role, count;
   };
@@ -360,7 +369,7 @@ const uint32_t* step_order_table(ss_ctx* c, int n_fft, int wg_det, int wg_emit) 
       ++i;
       int count = 0;
       if (i < sp.size() && sp[i] == '*') {
-        count = 1 << 30;
+        count = 1 << 27;
         ++i;
       } else {
         while (i < sp.size() && sp[i] >= '0' && sp[i] <= '9') count = count * 10 + (sp[i++] - '0');
@@ -383,17 +392,17 @@ const uint32_t* step_order_table(ss_ctx* c, int n_fft, int wg_det, int wg_emit) 
     const size_t before = out.size();
     for (const Seg& sg : cycle) place(sg);
     if (out.size() == before) {  // the cycle does not reach what is left: whatever remains, FFT first
-      place(Seg{ss::ROLE_FFT, 1 << 30});
-      place(Seg{ss::ROLE_DET, 1 << 30});
-      place(Seg{ss::ROLE_EMIT, 1 << 30});
+      place(Seg{ss::ROLE_FFT, 1 << 27});
+      place(Seg{ss::ROLE_DET, 1 << 27});
+      place(Seg{ss::ROLE_EMIT, 1 << 27});
     }
   }
-  if (hipMemcpyAsync(c->d_step_order[buf], out.data(), sizeof(uint32_t) * out.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) return nullptr;
+  if (hipMemcpyAsync(c->d_step_order[buf], out.data(), sizeof(uint32_t) * out.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) return;
   c->step_order_cur = buf;
   c->step_order_key[0] = n_fft;
   c->step_order_key[1] = wg_det;
   c->step_order_key[2] = wg_emit;
-  return c->d_step_order[buf];
+  a.order = c->d_step_order[buf];
 }
 
 template <int FMT, bool SPEC>
@@ -407,6 +416,7 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
   if (c->diag.fft_tw == 0) return go(ss::k_scan_step<FMT, SPEC, 0, false>);
   if (c->diag.fft_tw == 1) return go(ss::k_scan_step<FMT, SPEC, 1, false>);
   if (!c->diag.fft_swz) return go(ss::k_scan_step<FMT, SPEC, 2, false>);
+  if (c->diag.prio_fft || c->diag.prio_other) return go(ss::k_scan_step<FMT, SPEC, 2, true, true>);
 #endif
   go(ss::k_scan_step<FMT, SPEC, 2, true>);
 }
@@ -427,12 +437,7 @@ void launch_step(ss_ctx* c, const ss::Fft8192Args* fft, int n_fft, const ss::Det
     a.n_emit = emit->nframes;
   }
   if (ss::step_items(a) == 0) return;
-  if (fft && det && !c->diag.step_order.empty()) a.order = step_order_table(c, a.n_fft, (a.n_det + 1) / 2, (a.n_emit + 7) / 8);
-  a.run_det = c->diag.run_det > 0 ? c->diag.run_det : 0;
-  a.run_fft = c->diag.run_fft > 0 ? c->diag.run_fft : 0;
-  const int wg_det = (a.n_det + 1) / 2;
-  a.mixed_runs = (a.run_det > 0 && a.run_fft > 0) ? std::min(wg_det / a.run_det, a.n_fft / a.run_fft) : 0;
-  if (a.mixed_runs == 0) a.run_det = a.run_fft = 1;  // (unused; keeps the period non-zero)
+  step_order(c, a);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (fft && !prof_pair(c, &e0, &e1)) e0 = e1 = nullptr;
   const bool sp = spec && det;
@@ -732,7 +737,17 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
   if (c->step_path) {
     const ss::Fft8192Args g = fft8192_args(c, d_iq, item_stride, d_psd);
     const bool overlap = c->diag.pipeline && n_learn == 0;
-    if (!overlap) flush_stages(c);
+    // A caller that hands the same PSD or avg plane to consecutive calls would have this call's stages write what a
+    // deferred stage of the previous call still has to read in the same launch: drain first (no overlap for such callers).
+    const size_t plane_bytes = sizeof(float) * (size_t)nframes * (size_t)c->n;
+    const auto clash = [](const void* a, size_t abytes, const void* b, size_t bbytes) {
+      const char *pa = static_cast<const char*>(a), *pb = static_cast<const char*>(b);
+      return a && b && pa < pb + bbytes && pb < pa + abytes;
+    };
+    const size_t pend_bytes = sizeof(float) * (size_t)c->pend_det.nframes * (size_t)c->n;
+    const bool reused = c->have_det && (clash(d_psd, plane_bytes, c->pend_det.psd, pend_bytes) || clash(d_avg_out, plane_bytes, c->pend_det_emit.avg, pend_bytes) ||
+                                         clash(d_psd, plane_bytes, c->pend_det.rel_out, pend_bytes) || clash(d_rel_out, plane_bytes, c->pend_det.psd, pend_bytes));
+    if (!overlap || reused) flush_stages(c);
     launch_step(c, &g, nframes, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     c->have_emit = c->have_det;
     c->pend_emit = c->pend_det_emit;

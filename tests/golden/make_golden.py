@@ -4,8 +4,9 @@ the restated fft_v (built-in fp32 FFT back end). Run in the build container:
 
     python tests/golden/make_golden.py
 
-The fixtures are small (N = 256) so they can be committed; they pin the C oracle on machines where
-/root/reference — and therefore oracle/_ref — does not exist."""
+The fixtures are small (N = 256, and one at the headline N = 8192 that keeps int8 IQ, full candidate lists and every 8th
+bin of the planes) so they can be committed; they pin the C oracle on machines where /root/reference — and therefore
+oracle/_ref — does not exist."""
 import os
 import sys
 
@@ -49,6 +50,28 @@ def chain_case(name, n, fs, seed, nframes, dt_ms, ignored=(), retune_at=None):
     print(name, "frames", nframes, "candidates", int(off[-1]))
 
 
+def chain_case_cs8(name, n, fs, seed, nframes, dt_ms, on_frame, sub=8):
+    """A fixture at the headline size (N = 8192) that stays committable: int8 IQ (HackRF-shaped, converted exactly like the
+    engine's load stage: int8 / 128), the reference's candidate lists in full, its PSD / rel / avg planes at every `sub`-th bin,
+    and the learned noise ceiling."""
+    center = 145_000_000
+    band = pkg.synth.SyntheticBand(n, seed=seed, on_frame=on_frame, off_frame=nframes - 6)
+    iq8 = band.frames_cs8(nframes)
+    iq = (iq8[..., 0].astype(np.float32) / np.float32(128.0) + 1j * (iq8[..., 1].astype(np.float32) / np.float32(128.0))).astype(np.complex64)
+    t = (1_000_000 + dt_ms * np.arange(nframes)).astype(np.int64)
+    O.ref().orc_set_fft_backend(0)
+    ref = O.RefChain(n, fs, center - fs // 2, center + fs // 2)
+    r = ref.process(iq, t)
+    off = np.zeros(nframes + 1, np.int32)
+    off[1:] = np.cumsum([len(c) for c in r["cands"]])
+    idx = np.concatenate(r["cands"]).astype(np.int32)
+    thr, ready = ref.noise()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), iq8=iq8, t_ms=t, psd_sub=r["psd"][:, ::sub], rel_sub=r["rel"][:, ::sub],
+                        avg_sub=r["avg"][:, ::sub], cand_off=off, cand_idx=idx, cand_avg=r["avg"][np.repeat(np.arange(nframes), np.diff(off)), idx],
+                        thr=thr, n=n, fs=fs, center=center, sub=sub)
+    print(name, "frames", nframes, "candidates", int(off[-1]), "noise ready", ready)
+
+
 def tracker_case(name, n, fs, seed, nframes, dt_ms, min_ms, timeout_ms):
     """Per-frame output of the reference's Transmission/Signal bookkeeping: the notified (shift Hz, flush) list and
     the keys of m_signals."""
@@ -79,3 +102,5 @@ if __name__ == "__main__":
                ignored=[145_000_000 + 9000, 145_000_000 + 13000])
     chain_case("ref_chain_n256_retune", 256, 64000, seed=5, nframes=220, dt_ms=40, retune_at=100)
     tracker_case("ref_tracker_n256", 256, 64000, seed=6, nframes=300, dt_ms=40, min_ms=800, timeout_ms=1200)
+    # the headline size: 2.048 MS/s, N = 8192; dt = 100 ms -> learning ends after 21 frames, the averager is full 20 frames on
+    chain_case_cs8("ref_big_n8192_cs8", 8192, 2_048_000, seed=7, nframes=72, dt_ms=100, on_frame=46)

@@ -103,6 +103,29 @@ def propagated_floor(floor, gy=21, gx=21):
     return (cx[:, r + 1] - cx[:, l]) / (r - l + 1)[None, :]
 
 
+def error_quantiles(got, ref, planes=("psd", "rel", "avg")):
+    """Achieved |got - ref| in dB per plane over the ordinary bins (finite, not the -100 sentinel): p50, p99.9, max — so that
+    the slack the tolerances leave is visible next to every verdict."""
+    out = {}
+    for k in planes:
+        if k in got and k in ref:
+            fin = np.isfinite(ref[k]) & (ref[k] != -100.0) & np.isfinite(got[k])
+            if fin.any():
+                e = np.abs(got[k][fin].astype(np.float64) - ref[k][fin].astype(np.float64))
+                out[k] = {"p50": float(np.quantile(e, 0.5)), "p99.9": float(np.quantile(e, 0.999)), "max": float(e.max())}
+    return out
+
+
+def format_quantiles(q):
+    return "; ".join(f"{k} p50 {v['p50']:.1e} p99.9 {v['p99.9']:.1e} max {v['max']:.1e}" for k, v in q.items())
+
+
+def dont_care_limit(ncand):
+    """How many candidates may sit inside the +-1e-3 dB band around start_level (decided by fp32 rounding, counted, not
+    compared): 2, or one per 2000 reference candidates for the very long vectors."""
+    return max(2, ncand // 2000)
+
+
 def check_all(got, ref, start_level=8.0, gy=21, gx=21):
     floor = floor_tolerance(ref["psd"]) if "psd" in ref else None
     errs = {}

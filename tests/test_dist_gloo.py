@@ -82,3 +82,22 @@ def test_two_rank_band_sharding_over_gloo(oracle_mod, tmp_path):
     for r in res:
         assert r["shard"]["frames_equal"] >= (r["shard"]["hi"] - r["shard"]["lo"]) - 3, r["shard"]
     assert res[0]["shard"]["cands"] + res[1]["shard"]["cands"] > 500
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (one rank per GPU; gloo
+    where the box has fewer GPUs than ranks): launcher, rendezvous on 127.0.0.1, config broadcast from rank 0, barrier and
+    max-over-ranks timing are exercised end to end by --launch-check, which stops short of the GPU work."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for argv, want in ((["--gpus", "2", "--launch-check"], dict(n_gpus=2, n_bands=2, shard="bands", fft_size=8192)),
+                       (["--config", "5", "--gpus", "4", "--launch-check"], dict(n_gpus=4, n_bands=1, shard="frames", fft_size=1 << 20))):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+        d = json.loads(lines[0])
+        assert d["launch_check"] is True and d["backend"] == "gloo"
+        for k, v in want.items():
+            assert d[k] == v, (k, d)

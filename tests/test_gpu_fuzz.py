@@ -62,7 +62,7 @@ def test_random_scenario(oracle_mod, seed):
 
     got, ref = cat(outs_g), cat(outs_o)
     errs, ncand, ndc = check_all(got, ref)
-    assert ndc <= max(2, ncand // 100), (seed, ncand, ndc)
+    assert ndc <= max(3, ncand // 1000), (seed, ncand, ndc)
     # (a draw may produce no detection at all: bursts shorter than the 21-frame mean, or a retune right after they start)
 
 
@@ -115,7 +115,7 @@ def test_random_scenario_variants(oracle_mod, seed):
     got["cand_off"] = np.concatenate([[0], np.cumsum(cg)]).astype(np.int32)
     ref["cand_off"] = np.concatenate([[0], np.cumsum(co)]).astype(np.int32)
     errs, ncand, ndc = check_all(got, ref, gy=gy, gx=gx)
-    assert ndc <= max(2, ncand // 100), (seed, ncand, ndc)
+    assert ndc <= max(3, ncand // 1000), (seed, ncand, ndc)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SS_FUZZ_SEEDS3", "8"))))

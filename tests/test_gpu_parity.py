@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import rtl_sdr_scanner_cpp_amd as pkg
-from parity import check_all, check_plane
+from parity import check_all, check_plane, dont_care_limit
 
 pytestmark = pytest.mark.gpu
 
@@ -50,7 +50,7 @@ def test_engine_matches_reference_made_golden(path, chunk):
     got = _run(eng, g["iq"], chunk, t_ms=g["t_ms"], hooks=hooks)
     ref = {k: g[k] for k in ("psd", "rel", "avg", "cand_off", "cand_idx")}
     errs, ncand, ndc = check_all(got, ref)
-    assert ncand > 100 and ndc <= max(2, ncand // 200), (ncand, ndc, errs)
+    assert ncand > 100 and ndc <= dont_care_limit(ncand), (ncand, ndc, errs)
 
 
 CASES = [
@@ -85,7 +85,7 @@ def test_engine_matches_oracle(oracle_mod, n, fs, decim, fmt, nframes, chunk, le
     got, ref = _run(eng, iq, chunk), _run(orc, iq, chunk)
     errs, ncand, ndc = check_all(got, ref)
     assert ncand > (50 if n >= 256 else 5), "the test vector must produce detections"
-    assert ndc <= max(2, ncand // 200), (ncand, ndc)
+    assert ndc <= dont_care_limit(ncand), (ncand, ndc)
     thr_g, ready_g = eng.read_noise()
     thr_o, ready_o = orc.read_noise()
     assert ready_g and ready_o
@@ -98,7 +98,8 @@ ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurem
     ({"SS_FFT_TW": "0", "SS_FFT_SWZ": "0"}, 8192, 2_048_000, "cs8"),
     ({"SS_FFT_TW": "1"}, 8192, 2_048_000, "cu8"),
     ({"SS_PIPELINE": "0"}, 8192, 2_048_000, "cf32"),
-    ({"SS_STEP_RUN_DET": "3", "SS_STEP_RUN_FFT": "5"}, 8192, 2_048_000, "cf32"),
+    ({"SS_STEP_ORDER": "|F5,D3,E1"}, 8192, 2_048_000, "cf32"),
+    ({"SS_STEP_ORDER": "E*|D77,F99", "SS_STEP_PRIO_FFT": "2", "SS_STEP_PRIO_OTHER": "1"}, 8192, 2_048_000, "cf32"),
     ({"SS_FFT_IMPL": "generic"}, 2048, 512_000, "cf32"),
     ({"SS_FFT_IMPL": "generic"}, 65536, 20_000_000, "cs8"),
     ({"SS_FFT_ROWSR": "0", "SS_FFT_SUB": "1"}, 131072, 20_000_000, "cf32"),
@@ -117,7 +118,7 @@ def test_alternative_implementations_meet_the_contract(oracle_mod, monkeypatch, 
     got = _run(pkg.SpectrumEngine(fs, 145_000_000, **kw), iq, 20)
     ref = _run(oracle_mod.oracle_chain(fs, 145_000_000, **kw), iq, 20)
     errs, ncand, ndc = check_all(got, ref)
-    assert ncand > 50 and ndc <= max(2, ncand // 200), (ncand, ndc)
+    assert ncand > 50 and ndc <= dont_care_limit(ncand), (ncand, ndc)
 
 
 @pytest.mark.parametrize("n,fmt", [(512, "cs8"), (1024, "cf32"), (2048, "cs8"), (2048, "cf32"), (4096, "cu8"), (8192, "cf32"), (16384, "cs8"),

@@ -138,3 +138,31 @@ def test_reads_between_overlapped_calls_see_finished_state():
                 np.testing.assert_array_equal(eng.read_window(plane, 7, 100, 900), h[key][7, 100:900])
             np.testing.assert_array_equal(eng.read_window(pkg.abi.SS_PLANE_REL, -3, 0, N), host.read_window(pkg.abi.SS_PLANE_REL, -3, 0, N))
     np.testing.assert_array_equal(eng.read_noise()[0], host.read_noise()[0])
+
+
+def test_caller_reusing_its_planes_every_call_is_safe():
+    """The same PSD / avg planes handed to every call, never synchronised in between: the library notices that this call's
+    stages would overwrite what a deferred stage of the previous call still reads, and drains first."""
+    import torch
+    dev = torch.device("cuda:0")
+    band = pkg.synth.SyntheticBand(N, seed=9, on_frame=40, off_frame=10_000)
+    iq = band.frames_cf32(320)
+    kw = dict(fft_size=N, decim=1, learn_frames=16, max_batch=64)
+    host = pkg.SpectrumEngine(FS, CENTER, **kw)
+    eng = pkg.SpectrumEngine(FS, CENTER, **kw)
+    o = _device_outputs(torch, dev, 64, True)
+    keep = []
+    for k in range(5):
+        chunk = iq[64 * k:64 * k + 64]
+        h = host.process(chunk)
+        d_iq = torch.from_numpy(chunk.view(np.float32).copy()).to(dev)
+        keep.append(d_iq)
+        _call(eng, d_iq, 64, o)
+    eng.sync()
+    for key, name in (("psd", "psd"), ("rel", "rel"), ("avg", "avg")):
+        np.testing.assert_array_equal(o[key].cpu().numpy(), h[name])
+    np.testing.assert_array_equal(o["off"].cpu().numpy(), h["cand_off"])
+    t = int(h["cand_off"][-1])
+    assert t > 1000
+    np.testing.assert_array_equal(o["idx"][:t].cpu().numpy(), h["cand_idx"])
+    np.testing.assert_array_equal(o["cav"][:t].cpu().numpy(), h["cand_avg"])

@@ -164,3 +164,22 @@ def test_empty_batch_and_overflow(oracle_mod):
     np.testing.assert_array_equal(small["cand_idx"], full["cand_idx"][:10])
     with pytest.raises(pkg.abi.SpecscanError):
         ch.process(np.zeros((65, n), np.complex64))
+
+
+def test_oracle_matches_the_headline_size_golden(oracle_mod):
+    """N = 8192 at 2.048 MS/s on int8 IQ (tests/golden/ref_big_n8192_cs8.npz: the reference's candidate lists in full, its
+    planes at every 8th bin, its noise ceiling), wall-clock learning included."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_big_n8192_cs8.npz"))
+    n, fs, center, sub = int(g["n"]), int(g["fs"]), int(g["center"]), int(g["sub"])
+    oracle_mod.lib().orc_set_fft_backend(0)
+    ch = oracle_mod.oracle_chain(fs, center, fft_size=n, decim=1, in_format=pkg.abi.SS_FMT_CS8, max_batch=32)
+    iq8, t = g["iq8"], g["t_ms"]
+    outs = [ch.process(iq8[a:a + 32], t_ms=t[a:a + 32]) for a in range(0, iq8.shape[0], 32)]
+    for k in ("psd", "rel", "avg"):
+        np.testing.assert_array_equal(np.concatenate([o[k] for o in outs])[:, ::sub], g[k + "_sub"])
+    counts = np.concatenate([np.diff(o["cand_off"]) for o in outs])
+    np.testing.assert_array_equal(np.concatenate([[0], np.cumsum(counts)]), g["cand_off"])
+    np.testing.assert_array_equal(np.concatenate([o["cand_idx"] for o in outs]), g["cand_idx"])
+    np.testing.assert_array_equal(np.concatenate([o["cand_avg"] for o in outs]), g["cand_avg"])
+    np.testing.assert_array_equal(ch.read_noise()[0], g["thr"])
+    assert g["cand_off"][-1] > 1000
