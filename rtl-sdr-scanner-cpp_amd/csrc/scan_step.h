@@ -34,6 +34,7 @@ struct StepArgs {
   DetectArgs det;
   EmitArgs emit;
   int n_fft;   // frames of the FFT role (0: role absent)
+  int fft_per_wg;  // consecutive frames one FFT workgroup transforms, one after the other (see below)
   int n_det;   // detect TILES (two per workgroup)
   int n_emit;  // frames of the emit role (eight per workgroup)
   // One workgroup per work item, dispatched in blockIdx order, four resident per CU. WHICH item a workgroup takes decides
@@ -44,13 +45,21 @@ struct StepArgs {
   const uint32_t* order;
   int prio_fft, prio_other;  // s_setprio of the roles' waves (0..3)
 };
+// Why an FFT workgroup takes SEVERAL frames. A CU holds four workgroups. Four FFT workgroups on a CU are four frames
+// waiting for HBM with the vector pipe idle and no slot left for anything else; but two FFT workgroups per CU already keep
+// the memory pipe as busy (1024 frames alone: 27.2 us with two per CU, 27.0 with three, 24.2 with four — fft8192_lab). So a
+// batch is cut into only as many FFT workgroups as fill TWO slots of every CU (2 x CUs), each transforming
+// fft_per_wg = nframes / (2 x CUs) frames in turn and living as long as the launch, and the order table hands the other two
+// slots of every CU to the short-lived detect and emit workgroups, which then run inside the FFT role's memory waits
+// instead of behind it.
 
 constexpr int kStepThreads = 512;
 constexpr int kStepLdsBytes = kFft8192V2LdsBytes;
 static_assert(2 * (16 * DetectTile<21, 21, 16, 256>::P * 4 + 64) <= kFft8192V2LdsBytes, "two detect tiles per workgroup");
 static_assert(8 * kEmitList * 4 <= kFft8192V2LdsBytes, "eight emit lists per workgroup");
 
-inline int step_items(const StepArgs& a) { return a.n_fft + (a.n_det + 1) / 2 + (a.n_emit + 7) / 8; }
+inline int step_fft_wgs(const StepArgs& a) { return a.n_fft ? (a.n_fft + a.fft_per_wg - 1) / a.fft_per_wg : 0; }
+inline int step_items(const StepArgs& a) { return step_fft_wgs(a) + (a.n_det + 1) / 2 + (a.n_emit + 7) / 8; }
 
 enum { ROLE_NONE = 0, ROLE_FFT = 1, ROLE_DET = 2, ROLE_EMIT = 3 };
 
@@ -70,8 +79,14 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     int* cnt = reinterpret_cast<int*>(tile + 16 * T::P);
     detect_tile<21, 21, 16, 256, SPEC>(a.det, min(tile_no, a.n_det - 1), tid & 255, tile, cnt, tile_no < a.n_det);
   } else {
-    // ---- FFT role: one frame ----
-    fft8192_v2_frame<FMT, TW, SWZ>(a.fft, (size_t)item, smem_raw, tid);
+    // ---- FFT role: fft_per_wg consecutive frames, one after the other ----
+    const int f0 = item * a.fft_per_wg, f1 = min(f0 + a.fft_per_wg, a.n_fft);
+    for (int f = f0; f < f1; ++f) {
+      if (f > f0) __syncthreads();  // the previous frame's last LDS reads are done
+      int t = tid;
+      asm volatile("" : "+v"(t));  // the per-thread offsets are cheap to rebuild per frame and expensive to keep alive across the loop (64 VGPRs)
+      fft8192_v2_frame<FMT, TW, SWZ>(a.fft, (size_t)f, smem_raw, t);
+    }
   }
 }
 
@@ -85,7 +100,7 @@ __global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a) {
     role = (int)(w >> 24);
     item = (int)(w & 0xffffffu);
   } else {  // a single role
-    role = a.n_fft ? ROLE_FFT : a.n_det ? ROLE_DET : ROLE_EMIT;
+    role = a.n_fft ? ROLE_FFT : a.n_det ? ROLE_DET : ROLE_EMIT;  // (fft_per_wg frames per workgroup for the FFT role)
     item = blockIdx.x;
   }
   if constexpr (PRIO) {  // (s_setprio takes an immediate)

@@ -77,6 +77,7 @@ struct ss_ctx {
     int fft_tw = 2;                // 8192 points: where the twiddles come from (fft8192_v2.h: 0 global, 1 pass-2 table in LDS, 2 LDS + SGPRs)
     bool fft_swz = true;           // 8192 points: 16-byte swizzled first exchange
     int prio_fft = 0, prio_other = 0;  // s_setprio of k_scan_step's roles
+    int fft_per_wg = 0;            // frames per FFT workgroup of k_scan_step: 0 = one; -1 = as many as leave the FFT role two slots per CU (scan_step.h)
     // Dispatch order of k_scan_step's work items when all three roles ride one launch: "prefix|cycle", comma-separated
     // segments of a role letter (E emit, D detect, F FFT) and a workgroup count ('*' = all that are left); the cycle repeats
     // until every item is placed, a role that has run out is skipped.
@@ -106,6 +107,7 @@ struct ss_ctx {
       fft_swz = tri("SS_FFT_SWZ") != 0;
       prio_fft = num("SS_STEP_PRIO_FFT", 0);
       prio_other = num("SS_STEP_PRIO_OTHER", 0);
+      fft_per_wg = num("SS_FFT_PER_WG", fft_per_wg);
       if (const char* v = getenv("SS_STEP_ORDER")) step_order = v;
     }
 #else
@@ -163,6 +165,7 @@ struct ss_ctx {
   std::vector<uint32_t> h_step_order[2];
   int step_order_cur = 0;
   int step_order_key[3] = {-1, -1, -1};
+  int n_cus = 256;
   uint32_t* d_mask2[2] = {nullptr, nullptr};
   float* d_avg2[2] = {nullptr, nullptr};
   float* d_psd2[2] = {nullptr, nullptr};
@@ -342,7 +345,7 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
 // Dispatch order of a launch that carries more than one role, from the pattern in diag.step_order (see there): one word per
 // workgroup (role << 24 | item) in device memory, rebuilt only when the launch shape changes.
 void step_order(ss_ctx* c, ss::StepArgs& a) {
-  const int n_fft = a.n_fft, wg_det = (a.n_det + 1) / 2, wg_emit = (a.n_emit + 7) / 8;
+  const int n_fft = ss::step_fft_wgs(a), wg_det = (a.n_det + 1) / 2, wg_emit = (a.n_emit + 7) / 8;  // (FFT WORKGROUPS)
   a.order = nullptr;
   a.prio_fft = c->diag.prio_fft;
   a.prio_other = c->diag.prio_other;
@@ -424,9 +427,13 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
 // fft / det / emit: null = role absent. Start/stop events ride on launches that carry an FFT role (the dominant work).
 void launch_step(ss_ctx* c, const ss::Fft8192Args* fft, int n_fft, const ss::DetectArgs* det, int n_det_tiles, bool spec, const ss::EmitArgs* emit) {
   ss::StepArgs a{};
+  a.fft_per_wg = 1;
   if (fft) {
     a.fft = *fft;
     a.n_fft = n_fft;
+    // with other roles in the launch the FFT role keeps to two of every CU's four workgroup slots (scan_step.h)
+    if (c->diag.fft_per_wg > 0) a.fft_per_wg = c->diag.fft_per_wg;
+    else if (c->diag.fft_per_wg < 0 && (det || emit)) a.fft_per_wg = std::max(1, (n_fft + 2 * c->n_cus - 1) / (2 * c->n_cus));
   }
   if (det) {
     a.det = *det;
@@ -1002,6 +1009,9 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipMalloc(&c->d_mask2[k], sizeof(uint32_t) * (size_t)(n / 32) * (size_t)cfg->max_batch));
   }
   if (c->step_path) {
+    hipDeviceProp_t prop;
+    CREATE_HIP(hipGetDeviceProperties(&prop, cfg->device_id));
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t max_items = (size_t)cfg->max_batch + ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256) / 2 + (size_t)cfg->max_batch / 8 + 4;
     for (int k = 0; k < 2; ++k) CREATE_HIP(hipMalloc(&c->d_step_order[k], sizeof(uint32_t) * max_items));
   }

@@ -106,6 +106,11 @@ int main(int argc, char** argv) {
     hipExtLaunchKernelGGL((ss::k_fft8192_psd_w8<__VA_ARGS__>), dim3(frames), dim3(512), ss::kFft8192W8LdsBytes, s, e0, e1, 0, in,       \
                           (long long)8192, (const float*)d_win, tabs1, db_off, 1.0f, out, none);                                         \
   }
+#define V2L(LDSB, ...)                                                                                                                   \
+  [&](const void* in, float* out, int frames, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {                                             \
+    const ss::Fft8192Args g{in, (long long)8192, (const float*)d_win, tabs2, db_off, 1.0f, out};                                         \
+    hipExtLaunchKernelGGL((ss::k_fft8192_psd_v2<__VA_ARGS__>), dim3(frames), dim3(512), LDSB, s, e0, e1, 0, g);                         \
+  }
 #define V2(...)                                                                                                                          \
   [&](const void* in, float* out, int frames, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {                                             \
     const ss::Fft8192Args g{in, (long long)8192, (const float*)d_win, tabs2, db_off, 1.0f, out};                                         \
@@ -122,6 +127,8 @@ int main(int argc, char** argv) {
       {"v2 TW3 (no tables, bound)", V2(ss::FMT_CF32, 3), false},
       {"v2 TW0 + swizzled exchange", V2(ss::FMT_CF32, 0, true), true},
       {"v2 TW2 + swizzled exchange", V2(ss::FMT_CF32, 2, true), true},
+      {"v2 TW2+swz, 3 workgroups per CU", V2L(53 * 1024, ss::FMT_CF32, 2, true), true},
+      {"v2 TW2+swz, 2 workgroups per CU", V2L(80 * 1024, ss::FMT_CF32, 2, true), true},
       {"v2 TW2, no window (bound)", V2(ss::FMT_CF32, 2, false, true), false},
       {"v2 TW3, no window (bound)", V2(ss::FMT_CF32, 3, false, true), false},
   };
