@@ -154,6 +154,45 @@ def cpu_baseline(n: int, fs: int, budget_s: float = 12.0, stages: bool = False):
     return out
 
 
+def parity_sample(n: int, fs: int, fmt: str):
+    """A small parity check beside the numbers (the checker leg, like cpu_baseline): 96 frames through the engine and through
+    the reference's own code (oracle/_ref; the C restatement where that is absent), same contract as tests/parity.py;
+    reports the achieved error quantiles per plane and the candidate counts."""
+    import numpy as np
+    import rtl_sdr_scanner_cpp_amd as pkg
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity import check_all, dont_care_limit, error_quantiles
+    nframes = 96 if n <= 16384 else 48
+    band = pkg.synth.SyntheticBand(n, seed=77, on_frame=nframes // 2, off_frame=nframes - 4)
+    center = 145_000_000
+    in_format = {"cf32": 0, "cs8": 1, "cu8": 2}[fmt]
+    iq = band.frames_cf32(nframes) if fmt == "cf32" else (band.frames_cs8(nframes) if fmt == "cs8" else band.frames_cu8(nframes))
+    t = (1_000 + 100 * np.arange(nframes)).astype(np.int64)  # learning: the first 21 frames
+    chunk = min(nframes, 48)
+    eng = pkg.SpectrumEngine(fs, center, fft_size=n, decim=1, in_format=in_format, max_batch=chunk)
+    outs = [eng.process(iq[a:a + chunk], t_ms=t[a:a + chunk]) for a in range(0, nframes, chunk)]
+    got = {k: np.concatenate([o[k] for o in outs]) for k in ("psd", "rel", "avg", "cand_idx", "cand_avg")}
+    got["cand_off"] = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o["cand_off"]) for o in outs]))]).astype(np.int32)
+    if O.have_ref() and fmt == "cf32":
+        O.ref().orc_set_fft_backend(0)
+        r = O.RefChain(n, fs, center - fs // 2, center + fs // 2).process(iq, t)
+        off = np.zeros(nframes + 1, np.int32)
+        off[1:] = np.cumsum([len(c) for c in r["cands"]])
+        ref = {"psd": r["psd"], "rel": r["rel"], "avg": r["avg"], "cand_off": off, "cand_idx": np.concatenate(r["cands"]).astype(np.int32)}
+        against = "reference .cpp files compiled in place (oracle/_ref)"
+    else:
+        O.lib().orc_set_fft_backend(0)
+        ch = O.oracle_chain(fs, center, fft_size=n, decim=1, in_format=in_format, max_batch=chunk)
+        routs = [ch.process(iq[a:a + chunk], t_ms=t[a:a + chunk]) for a in range(0, nframes, chunk)]
+        ref = {k: np.concatenate([o[k] for o in routs]) for k in ("psd", "rel", "avg", "cand_idx")}
+        ref["cand_off"] = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o["cand_off"]) for o in routs]))]).astype(np.int32)
+        against = "C restatement (oracle/liboracle.so)"
+    errs, ncand, ndc = check_all(got, ref)  # raises when the contract is broken
+    return {"against": against, "frames": nframes, "reference_candidates": ncand, "inside_1e-3_dB_band": ndc, "band_limit": dont_care_limit(ncand),
+            "abs_err_dB": {k: {q: float(f"{v:.3g}") for q, v in d.items()} for k, d in error_quantiles(got, ref).items()}}
+
+
 # ---------------------------------------------------------------------------------------------- launcher
 def free_port() -> int:
     with socket.socket() as s:
@@ -388,6 +427,10 @@ def run(args):
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, fs, args.cpu_seconds)
+            try:
+                out["parity"] = parity_sample(n, fs, args.fmt)
+            except AssertionError as e:
+                out["parity"] = {"failed": str(e)[:300]}
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

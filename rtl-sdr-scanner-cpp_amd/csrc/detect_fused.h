@@ -194,12 +194,16 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
   // Frame tiles are dispatched rotated by one: the ragged last tile and the tiles that read ring rows take the
   // slower general path, so they go first and the straight-line tiles fill in behind them instead of leaving a tail.
   const int nft = (nframes + a.shift + TF - 1) / TF;
-  const int ft = (block / tiles_per_row + nft - 1) % nft;
+  // (Tried for long rows and dropped: an XCD-aware column-major order — each XCD walking the frame tiles of one column
+  // group after the other so that a tile finds its predecessor's halo rows in that XCD's L2. 65536 points x 128 frames:
+  // the kernel went from 19.6 to 26.7 us.)
+  const int ft_seq = block / tiles_per_row, bt = block % tiles_per_row;
+  const int ft = (ft_seq + nft - 1) % nft;
   const int f0 = ft * TF - a.shift;  // batch-relative frame of the tile's first row of outputs; may be negative
-  const int b0 = (block % tiles_per_row) * TB;
+  const int b0 = bt * TB;
   if (tid < TF) cnt[tid] = 0;
   if constexpr (SPEC) {
-    if (valid && a.spec_prev_partial && block < tiles_per_row) spectrogram_fold<TB>(a, tid, b0);
+    if (valid && a.spec_prev_partial && ft_seq == 0) spectrogram_fold<TB>(a, tid, b0);  // the first-dispatched tile of each bin column
   }
   // block-uniform classification
   const bool interior = (b0 - A >= 0) && (b0 + TB + A <= n);
@@ -422,21 +426,12 @@ constexpr int kEmitList = 1024;  // ints of LDS per wave
 
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-__device__ __forceinline__ void cand_emit_frame(const EmitArgs& a, int f, int lane, int* __restrict__ list) {
-  constexpr int LIST = kEmitList;
-  const int words_per_row = a.words_per_row, nframes = a.nframes, n = a.n;
-  const uint32_t* row = a.maskbits + (size_t)f * words_per_row;
-  // first trip's mask words (words_per_row is a multiple of 2; rows of >= 256 words are 16-byte aligned)
-  const bool wide = (words_per_row & 3) == 0;
-  uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
-  if (wide) {
-    if (4 * lane < words_per_row) w4 = *reinterpret_cast<const uint4*>(row + 4 * lane);
-  } else if (lane < words_per_row) {
-    w4.x = row[lane];  // N = 64: two words per row, one per lane
-  }
-  // offset of this frame = sum of counts[0..f): 8 ints per lane per trip, all loads independent
+// offset of frame f = sum of counts[0..f); lane 0 records it (and the grand total behind the last frame) and zeroes this
+// frame's share of the counter buffer a later batch will use. Returns the offset to every lane.
+__device__ __forceinline__ int emit_frame_offset(const EmitArgs& a, int f, int lane, int mine) {
+  const int nframes = a.nframes;
   int part = 0;
-  for (int base = 0; base < f; base += 512) {
+  for (int base = 0; base < f; base += 512) {  // 8 ints per lane per trip, all loads independent
     int v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = a.counts[min(base + k * 64 + lane, nframes - 1)];
@@ -446,7 +441,6 @@ __device__ __forceinline__ void cand_emit_frame(const EmitArgs& a, int f, int la
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
   const int begin = part;
-  const int mine = a.counts[f];
   if (lane == 0) {
     a.off_int[f] = begin;
     if (a.off_out) a.off_out[f] = begin;
@@ -456,14 +450,27 @@ __device__ __forceinline__ void cand_emit_frame(const EmitArgs& a, int f, int la
     }
     for (int g = f; g < a.clear_n; g += nframes) a.counts_clear[g] = 0;
   }
-  if (mine == 0 || !a.cand_idx) return;
+  return begin;
+}
+
+// The candidates of mask words [word_lo, word_hi) of frame f, written from list position `carry` on. `w4` holds the first
+// trip's words when `preloaded` (requested before the offsets were summed, so the two latencies overlap).
+__device__ __forceinline__ void emit_span(const EmitArgs& a, int f, int lane, int* __restrict__ list, int word_lo, int word_hi, int carry, uint4 w4,
+                                          bool preloaded) {
+  constexpr int LIST = kEmitList;
+  const int words_per_row = a.words_per_row, n = a.n;
+  const uint32_t* row = a.maskbits + (size_t)f * words_per_row;
+  const bool wide = (words_per_row & 3) == 0;
   const float* arow = a.avg + (size_t)f * n;
   const int words_per_trip = wide ? 256 : 64;
-  int carry = begin;
-  for (int base = 0; base < words_per_row; base += words_per_trip) {
-    if (base > 0) {
+  for (int base = word_lo; base < word_hi; base += words_per_trip) {
+    if (base > word_lo || !preloaded) {
       w4 = make_uint4(0u, 0u, 0u, 0u);
-      if (base + 4 * lane < words_per_row) w4 = *reinterpret_cast<const uint4*>(row + base + 4 * lane);
+      if (wide) {
+        if (base + 4 * lane < word_hi) w4 = *reinterpret_cast<const uint4*>(row + base + 4 * lane);
+      } else if (base + lane < word_hi) {
+        w4.x = row[base + lane];
+      }
     }
     const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
     const int c = __popc(wv[0]) + __popc(wv[1]) + __popc(wv[2]) + __popc(wv[3]);
@@ -536,6 +543,58 @@ __device__ __forceinline__ void cand_emit_frame(const EmitArgs& a, int f, int la
     }
     carry += total;
   }
+}
+
+__device__ __forceinline__ void cand_emit_frame(const EmitArgs& a, int f, int lane, int* __restrict__ list) {
+  const int words_per_row = a.words_per_row;
+  const uint32_t* row = a.maskbits + (size_t)f * words_per_row;
+  // first trip's mask words (words_per_row is a multiple of 2; rows of >= 256 words are 16-byte aligned)
+  uint4 w4 = make_uint4(0u, 0u, 0u, 0u);
+  if ((words_per_row & 3) == 0) {
+    if (4 * lane < words_per_row) w4 = *reinterpret_cast<const uint4*>(row + 4 * lane);
+  } else if (lane < words_per_row) {
+    w4.x = row[lane];  // N = 64: two words per row, one per lane
+  }
+  const int mine = a.counts[f];
+  const int begin = emit_frame_offset(a, f, lane, mine);
+  if (mine == 0 || !a.cand_idx) return;
+  emit_span(a, f, lane, list, 0, words_per_row, begin, w4, true);
+}
+
+// Long rows (n >= 16384: 512 .. 32768 mask words per frame): W waves per frame, each taking a contiguous slice of the row —
+// a count pass over its slice (the words come back from L2 for the expansion), a prefix over the W slice counts in LDS,
+// then the same expansion from the slice's own start. One wave per frame walks 2^20-point rows in 128 serial trips (38 us
+// per 16-frame batch); eight waves take 16 each.
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_cand_emit_wide(EmitArgs a) {
+  __shared__ int list[W][kEmitList];
+  __shared__ int slice_cnt[W];
+  const int f = blockIdx.x, lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int words_per_row = a.words_per_row;
+  const int per = words_per_row / W;  // a multiple of 256 (the host picks W accordingly)
+  const int lo = w * per, hi = lo + per;
+  const uint32_t* row = a.maskbits + (size_t)f * words_per_row;
+  const int mine = a.counts[f];
+  int begin = 0;
+  if (w == 0) begin = emit_frame_offset(a, f, lane, mine);
+  int cnt = 0;
+  if (mine != 0 && a.cand_idx) {
+    for (int base = lo; base < hi; base += 256) {
+      const uint4 q = *reinterpret_cast<const uint4*>(row + base + 4 * lane);
+      cnt += __popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+  }
+  if (lane == 0) slice_cnt[w] = cnt;
+  __shared__ int frame_begin;
+  if (w == 0 && lane == 0) frame_begin = begin;
+  __syncthreads();
+  if (mine == 0 || !a.cand_idx) return;
+  int carry = frame_begin;
+  for (int k = 0; k < w; ++k) carry += slice_cnt[k];
+  if (cnt == 0) return;  // wave-uniform
+  emit_span(a, f, lane, list[w], lo, hi, carry, make_uint4(0u, 0u, 0u, 0u), false);
 }
 
 // Stand-alone launch: one wave per workgroup (FFT sizes other than 8192).

@@ -77,6 +77,7 @@ struct ss_ctx {
     int fft_tw = 2;                // 8192 points: where the twiddles come from (fft8192_v2.h: 0 global, 1 pass-2 table in LDS, 2 LDS + SGPRs)
     bool fft_swz = true;           // 8192 points: 16-byte swizzled first exchange
     int prio_fft = 0, prio_other = 0;  // s_setprio of k_scan_step's roles
+    bool emit_wide = true;         // long rows (n >= 16384): several waves per frame in the emit stage
     int fft_per_wg = 0;            // frames per FFT workgroup of k_scan_step: 0 = one; -1 = as many as leave the FFT role two slots per CU (scan_step.h)
     // Dispatch order of k_scan_step's work items when all three roles ride one launch: "prefix|cycle", comma-separated
     // segments of a role letter (E emit, D detect, F FFT) and a workgroup count ('*' = all that are left); the cycle repeats
@@ -108,6 +109,7 @@ struct ss_ctx {
       prio_fft = num("SS_STEP_PRIO_FFT", 0);
       prio_other = num("SS_STEP_PRIO_OTHER", 0);
       fft_per_wg = num("SS_FFT_PER_WG", fft_per_wg);
+      emit_wide = tri("SS_EMIT_WIDE") != 0;
       if (const char* v = getenv("SS_STEP_ORDER")) step_order = v;
     }
 #else
@@ -677,7 +679,12 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   }
   if (spec) hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, true>), dim3(tiles), dim3(TB), 0, c->stream, da);
   else hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, false>), dim3(tiles), dim3(TB), 0, c->stream, da);
-  hipLaunchKernelGGL(ss::k_cand_emit, dim3(nframes), dim3(64), 0, c->stream, ea);
+  // long rows: several waves per frame (slices of at least 256 mask words)
+  const int words = n / 32;
+  if (c->diag.emit_wide && words >= 2048) hipLaunchKernelGGL(ss::k_cand_emit_wide<8>, dim3(nframes), dim3(512), 0, c->stream, ea);
+  else if (c->diag.emit_wide && words >= 1024) hipLaunchKernelGGL(ss::k_cand_emit_wide<4>, dim3(nframes), dim3(256), 0, c->stream, ea);
+  else if (c->diag.emit_wide && words >= 512) hipLaunchKernelGGL(ss::k_cand_emit_wide<2>, dim3(nframes), dim3(128), 0, c->stream, ea);
+  else hipLaunchKernelGGL(ss::k_cand_emit, dim3(nframes), dim3(64), 0, c->stream, ea);
   return SS_OK;
 }
 
@@ -983,8 +990,11 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     {
       // ring capacity: at least three windows (a long batch needs a free one next to the one it reads), more when rows
       // are small, so that short batches slide for a long time before the window is moved back to the front
+      // (the window slides by a batch's frames; when it reaches the end, kHistRows rows are copied back to the front:
+      // 147 MB for 2^20-point rows, so long rows get at least ten windows — one copy per ~20 sixteen-frame batches)
       long long rows = (64ll << 20) / ((long long)n * 4);
-      if (rows < 3 * kHistRows) rows = 3 * kHistRows;
+      const long long min_rows = (long long)n >= 65536 ? 10 * kHistRows : 3 * kHistRows;
+      if (rows < min_rows) rows = min_rows;
       if (rows > 64 * kHistRows) rows = 64 * kHistRows;
       c->hist_rows = (int)rows;
       CREATE_HIP(hipMalloc(&c->d_hist, sizeof(float) * (size_t)n * (size_t)rows));
