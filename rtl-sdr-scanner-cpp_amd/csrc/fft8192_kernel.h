@@ -1,23 +1,11 @@
-// fft8192_kernel.h — the N = 8192 front end (BASELINE.json configs 1/2/4: 2.048 MS/s, 250 Hz bins).
+// fft8192_kernel.h — butterflies and addressing helpers of the N = 8192 front end, plus the ROUND-1 kernel
+// k_fft8192_psd_w8 kept as the reference point of scripts/ubench/fft8192_lab (and its memory-only / transform-only
+// ablations, which compute garbage by design). The product does not launch anything from this file: the 8192-point
+// transform that ships is fft8192_v2_frame (fft8192_v2.h), a role of k_scan_step (scan_step.h).
 //
 // Same contract as k_fft_psd_lds in fft_kernels.h (Decimator + fft_v(Hamming, forward, shift) + PSD::work,
 // reference sources/radio/blocks/decimator.h:15-22, sources/radio/sdr_device.cpp:164,
-// sources/radio/blocks/psd.cpp:18-20), restructured for the CU:
-//
-//   one workgroup (256 threads = 4 waves, one per SIMD) per frame, 32 points per thread in VGPRs,
-//   8192 = 16 x 16 x 32: three register-resident Stockham passes and only TWO trips through LDS
-//   (the generic kernel makes seven), 64.5 KiB of LDS per workgroup -> two frames in flight per CU, so
-//   one frame's HBM loads overlap the other's butterflies.
-//
-//   pass 1  radix 16, Ns = 1    thread t: butterflies j = 2t, 2t+1  <- 16 x float4 global loads
-//           y[16 j + k]                               -> LDS (33-element pitch per thread, conflict-free)
-//   pass 2  radix 16, Ns = 16   thread t: butterflies j = t, t+256, twiddle W_256^((j%16) r)
-//           z[(j/16) 256 + j%16 + 16 k]               -> LDS (linear, conflict-free)
-//   pass 3  radix 32, Ns = 256  thread t: butterfly j = t, twiddle W_8192^(t r) = W_8192^(t (r&3)) * W_2048^(t (r>>2))
-//           X[t + 256 k] -> 10 log10(|X|^2) - 10 log10(fs) -> psd[(t + 256 k) ^ 4096]   (half rotation in the index)
-//
-// HBM traffic per frame: 64 KiB in (CF32) + 32 KiB out; window taps (32 KiB) and twiddle tables
-// (2 KiB + 20 KiB) are shared by every workgroup and stay in L2.
+// sources/radio/blocks/psd.cpp:18-20).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -153,130 +141,11 @@ struct Fft8192Tables {
   const float2* tw2;
   const float2* tw3a;
   const float2* tw3b;
-  long long* dbg;  // diagnostic (SS_DEBUG_TIMING_FFT): per-workgroup s_memtime stamps of the phases, or null
+  long long* unused;  // (round 1: debug stamps)
 };
 
-constexpr int kFft8192LdsBytes = (8192 + 256) * 8;  // exchange 1 uses a 33-element pitch per 32 elements
-
-// Four-wave variant (256 threads, 32 points per thread, float2 exchanges, 66 KiB LDS, ~14 KiB of straight-line code):
-// kept as the A/B reference for the eight-wave kernel below (SS_FFT_IMPL=wide).
-template <int FMT>
-__global__ __launch_bounds__(256, 2) void k_fft8192_psd(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
-                                                         Fft8192Tables tabs, float db_off, float scale, float* __restrict__ psd) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float2* s = reinterpret_cast<float2*>(smem_raw);
-  const int t = threadIdx.x;
-  const size_t frame = blockIdx.x;
-  const size_t in_base = frame * (size_t)item_stride;
-  long long ts[8];
-  if (tabs.dbg && t == 0) ts[0] = wall_clock64();
-
-  // ---------------- pass 1: radix 16, Ns = 1, butterflies j = 2t and 2t+1 ----------------
-  float2 a[16], b[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e = 2 * t + 512 * r;
-    float2 x0, x1;
-    if constexpr (FMT == FMT_CF32) {
-      const float4 q = *reinterpret_cast<const float4*>(reinterpret_cast<const float2*>(iq) + in_base + e);
-      x0 = make_float2(q.x, q.y);
-      x1 = make_float2(q.z, q.w);
-    } else if constexpr (FMT == FMT_CS8) {
-      const char4 q = *reinterpret_cast<const char4*>(reinterpret_cast<const char2*>(iq) + in_base + e);
-      x0 = make_float2((float)q.x * scale, (float)q.y * scale);
-      x1 = make_float2((float)q.z * scale, (float)q.w * scale);
-    } else {
-      const uchar4 q = *reinterpret_cast<const uchar4*>(reinterpret_cast<const uchar2*>(iq) + in_base + e);
-      x0 = make_float2(((float)q.x - 127.5f) * scale, ((float)q.y - 127.5f) * scale);
-      x1 = make_float2(((float)q.z - 127.5f) * scale, ((float)q.w - 127.5f) * scale);
-    }
-    const float2 w = *reinterpret_cast<const float2*>(win + e);
-    a[r] = make_float2(x0.x * w.x, x0.y * w.x);  // volk_32fc_32f_multiply_32fc
-    b[r] = make_float2(x1.x * w.y, x1.y * w.y);
-  }
-  if (tabs.dbg && t == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[1] = wall_clock64(); }
-  dft16(a);
-  dft16(b);
-  // y[16 j + k]: thread t owns y[32 t .. 32 t + 31]; LDS pitch 33 elements per thread
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    s[33 * t + k] = a[slot16(k)];
-    s[33 * t + 16 + k] = b[slot16(k)];
-  }
-  __syncthreads();
-  if (tabs.dbg && t == 0) ts[2] = wall_clock64();
-
-  // ---------------- pass 2: radix 16, Ns = 16, butterflies j = t and t + 256 ----------------
-  {
-    const int m = t & 15;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int e0 = t + 512 * r;  // element index in y
-      const int e1 = e0 + 256;
-      float2 x0 = s[e0 + (e0 >> 5)];
-      float2 x1 = s[e1 + (e1 >> 5)];
-      if (r > 0) {
-        const float2 w = tabs.tw2[r * 16 + m];
-        x0 = cmul(x0, w);
-        x1 = cmul(x1, w);
-      }
-      a[r] = x0;
-      b[r] = x1;
-    }
-  }
-  __syncthreads();  // every read of y is done before z overwrites the buffer
-  if (tabs.dbg && t == 0) ts[3] = wall_clock64();
-  dft16(a);
-  dft16(b);
-  {
-    // z[(j/16)*256 + j%16 + 16 k]
-    const int base0 = ((t >> 4) << 8) + (t & 15);
-    const int base1 = base0 + 4096;  // j = t + 256 -> (j/16) = t/16 + 16
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      s[base0 + 16 * k] = a[slot16(k)];
-      s[base1 + 16 * k] = b[slot16(k)];
-    }
-  }
-  __syncthreads();
-  if (tabs.dbg && t == 0) ts[4] = wall_clock64();
-
-  // ---------------- pass 3: radix 32, Ns = 256, butterfly j = t ----------------
-  float2 v[32];
-  {
-    float2 wa[4], wb[8];
-#pragma unroll
-    for (int r1 = 1; r1 < 4; ++r1) wa[r1] = tabs.tw3a[r1 * 256 + t];
-#pragma unroll
-    for (int r2 = 1; r2 < 8; ++r2) wb[r2] = tabs.tw3b[r2 * 256 + t];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      float2 x = s[t + 256 * r];
-      const int r1 = r & 3, r2 = r >> 2;
-      if (r1 != 0 && r2 != 0) x = cmul(x, cmul(wa[r1], wb[r2]));
-      else if (r1 != 0) x = cmul(x, wa[r1]);
-      else if (r2 != 0) x = cmul(x, wb[r2]);
-      v[r] = x;
-    }
-  }
-  if (tabs.dbg && t == 0) ts[5] = wall_clock64();
-  dft32(v);
-  if (tabs.dbg && t == 0) ts[6] = wall_clock64();
-  float* out = psd + frame * 8192;
-#pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    const int bin = t + 256 * k;
-    out[bin ^ 4096] = psd_db(v[slot32(k)], db_off);
-  }
-  if (tabs.dbg && t == 0) {
-    ts[7] = wall_clock64();
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tabs.dbg[8 * blockIdx.x + k] = ts[k];
-  }
-}
-
 // =================================================================================================
-// Eight-wave kernel (the default): 512 threads, 16 points per thread. Half the per-thread work of the four-wave
+// Eight-wave kernel (round 1): 512 threads, 16 points per thread. Half the per-thread work of the four-wave
 // variant, 7 KiB of code instead of 14 (instruction fetch falls off a cliff between 8 and 16 KiB of hot code,
 // scripts/ubench/ifetch2), 64 VGPRs and 34 KiB of LDS: four frames and 32 waves per CU.
 //
@@ -330,8 +199,6 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
     }
   }
   const size_t in_base = frame * (size_t)item_stride;
-  long long ts[DBG ? 8 : 1] = {};  // DBG: per-workgroup wall_clock64 stamps of the phases (SS_DEBUG_TIMING_FFT)
-  if constexpr (DBG) if (t == 0) ts[0] = wall_clock64();
 
   if constexpr (ABLATE == 3 || ABLATE == 4) {
     // what the same bytes cost with wider accesses: 3 = the kernel's own 8-byte loads + 16-byte stores, 4 = 16-byte loads too
@@ -387,10 +254,6 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
       if constexpr (ABLATE == 2) a[r] = make_float2(__int_as_float(0x3f800000 + e), db_off * (float)r);  // no global loads
     }
   }
-  if constexpr (DBG) if (t == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ts[1] = wall_clock64();
-  }
   if constexpr (ABLATE == 1) {  // memory traffic only: same loads, same number of stores, no transform
 #pragma unroll
     for (int r = 0; r < 16; ++r) psd[frame * 8192 + t + 512 * r] = a[r].x + a[r].y;
@@ -416,7 +279,6 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
     const int e = t + 512 * r;
     c[r].y = s[e + (e >> 4)];
   }
-  if constexpr (DBG) if (t == 0) ts[2] = wall_clock64();
   // ---------------- pass 2: radix 16, Ns = 16, butterfly j = t ----------------
   {
     const int m = t & 15;
@@ -443,7 +305,6 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
 #pragma unroll
   for (int q = 0; q < 16; ++q) a[q].y = s[rbase + 512 * q];
 
-  if constexpr (DBG) if (t == 0) ts[3] = wall_clock64();
   // ---------------- pass 3: radix 32, Ns = 256, butterfly j shared by lanes l and l + 32 ----------------
   // twiddle of input r = 2q + h:  W_8192^(j r) = W_8192^(j (r & 3)) * W_2048^(j (r >> 2)),  r & 3 = 2 (q & 1) + h,  r >> 2 = q >> 1
   {
@@ -505,19 +366,6 @@ __global__ __launch_bounds__(512, WAVES_PER_SIMD) void k_fft8192_psd_w8(const vo
       out[bin0 ^ 4096] = psd_db(cadd(e, o), db_off);
       out[bin1 ^ 4096] = psd_db(csub(e, o), db_off);
     }
-  }
-  if constexpr (DBG) if (t == 0) {
-    ts[4] = wall_clock64();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ts[5] = wall_clock64();
-    // where the workgroup ran: HW_ID (wave, SIMD, CU, SH, SE) and XCC_ID, for dispatch-order analysis
-    unsigned hw_id = 0, xcc_id = 0;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-    ts[6] = hw_id;
-    ts[7] = xcc_id;
-#pragma unroll
-    for (int k = 0; k < (DBG ? 8 : 1); ++k) tabs.dbg[8 * blockIdx.x + k] = ts[k];
   }
 }
 
