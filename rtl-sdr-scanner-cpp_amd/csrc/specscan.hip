@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -223,6 +224,19 @@ int fail(ss_ctx* c, int status, const char* fmt, ...) {
   } while (0)
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// Wait for a stream. A blocking hipStreamSynchronize wakes the caller tens of microseconds after the work has finished — as
+// long as a whole 1024-frame step, several times a work() call of a few frames — so the wait polls first (the scanner's
+// calls finish within a few hundred microseconds) and only then blocks.
+hipError_t stream_wait(hipStream_t stream) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(stream);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) break;
+  }
+  return hipStreamSynchronize(stream);
+}
 
 size_t in_bytes_per_sample(int fmt) { return fmt == SS_FMT_CF32 ? 8 : 2; }
 
@@ -1180,7 +1194,7 @@ int ss_sync(ss_ctx* ctx) {
   std::lock_guard<std::mutex> lock(ctx->mtx);
   SS_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
   flush_stages(ctx);
-  SS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SS_HIP(ctx, stream_wait(ctx->stream));
   return SS_OK;
 }
 
@@ -1283,7 +1297,7 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
   if (avg_db) SS_HIP(c, hipMemcpyAsync(avg_db, c->last_avg, plane, hipMemcpyDeviceToHost, c->stream));
   std::vector<int> off((size_t)nframes + 1);
   SS_HIP(c, hipMemcpyAsync(off.data(), c->d_off, sizeof(int) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, c->stream));
-  SS_HIP(c, hipStreamSynchronize(c->stream));
+  SS_HIP(c, stream_wait(c->stream));
   if (cand_off) memcpy(cand_off, off.data(), sizeof(int) * ((size_t)nframes + 1));
   const int total = off[(size_t)nframes];
   if (want_cands) {
