@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--realloc", action="store_true", help="new device buffers (behind a dummy allocation of random size) for every engine")
     ap.add_argument("--env", action="append", default=[], help="KEY=VALUE set for every engine")
+    ap.add_argument("--lib", action="append", default=[], help="NAME=path/to/libspecscan_diag.so: alternate engines between these builds (A/B of two source states in one process)")
     args = ap.parse_args()
     import torch
     import rtl_sdr_scanner_cpp_amd as pkg
@@ -50,7 +51,11 @@ def main():
 
     d_iq, outs = buffers()
     print(f"# {nb} frames x {n}, {args.chunks} chunks of {args.steps} steps per engine; us per step", flush=True)
+    libs = [kv.split("=", 1) for kv in args.lib] or [("", None)]
     for rnd in range(args.rounds):
+      for lib_name, lib_path in libs:
+        if lib_path:
+            pkg.engine.LIB_DIAG = os.path.abspath(lib_path)
         for order in args.orders:
             os.environ["SS_STEP_ORDER"] = order
             if args.realloc:
@@ -73,7 +78,7 @@ def main():
                 eng.sync()
                 res.append((time.perf_counter() - t0) / args.steps * 1e6)
             ncand = int(outs[(k - 1) % 7]["off"][-1].item())
-            print(f"round {rnd} {order:34s} " + " ".join(f"{r:6.2f}" for r in res) + f"   cand {ncand}", flush=True)
+            print(f"round {rnd} {lib_name:6s} {order:30s} " + " ".join(f"{r:6.2f}" for r in res) + f"   cand {ncand}", flush=True)
             eng.close()
 
 
