@@ -79,6 +79,9 @@ struct DetectArgs {
   float* spec_prev_sum;            // [spec_n] Container::m_sum they belong to
   int spec_prev_tiles;
   int spec_m, spec_n;              // m_decimatorFactor (a power of two <= 256), m_outputSize
+#ifdef SS_DIAG
+  long long* stamp_mid;  // measurement builds: wall clock after phase 1 (loads + time means) and after phase 2, per tile
+#endif
 };
 
 // plane[row][byte offset coff]: block-uniform row base (scalar registers) + one 32-bit per-thread offset
@@ -298,6 +301,9 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
     }
   }
   __syncthreads();
+#ifdef SS_DIAG
+  if (a.stamp_mid && valid && tid == 0) a.stamp_mid[2 * (size_t)block] = wall_clock64();
+#endif
 
   // ---------------- phase 2: frequency means + threshold, thread = (frame, 16-bin segment) ----------------
 #pragma unroll
@@ -372,6 +378,9 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
     }
   }
   __syncthreads();
+#ifdef SS_DIAG
+  if (a.stamp_mid && valid && tid == 0) a.stamp_mid[2 * (size_t)block + 1] = wall_clock64();
+#endif
   if (valid && tid < TF && cnt[tid] != 0) atomicAdd(&a.counts[f0 + tid], cnt[tid]);
   if constexpr (SPEC) {
     // (the __syncthreads above freed the avgY tile)

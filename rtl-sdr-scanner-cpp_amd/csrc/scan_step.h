@@ -44,6 +44,9 @@ struct StepArgs {
   // per step.)
   const uint32_t* order;
   int prio_fft, prio_other;  // s_setprio of the roles' waves (0..3)
+#ifdef SS_DIAG
+  long long* stamps;  // measurement builds only: {start, end (100 MHz wall clock), role << 32 | item, XCC_ID << 32 | HW_ID} per workgroup
+#endif
 };
 // Why an FFT workgroup takes SEVERAL frames. A CU holds four workgroups. Four FFT workgroups on a CU are four frames
 // waiting for HBM with the vector pipe idle and no slot left for anything else; but two FFT workgroups per CU already keep
@@ -109,7 +112,23 @@ __global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a) {
     else if (p == 2) __builtin_amdgcn_s_setprio(2);
     else if (p == 3) __builtin_amdgcn_s_setprio(3);
   }
+#ifdef SS_DIAG
+  long long t_start = 0;
+  if (a.stamps && tid == 0) t_start = wall_clock64();
+#endif
   step_run_item<FMT, SPEC, TW, SWZ>(a, role, item, smem_raw, tid);
+#ifdef SS_DIAG
+  if (a.stamps && tid == 0) {
+    unsigned hw_id = 0, xcc_id = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    long long* d = a.stamps + 4 * (size_t)blockIdx.x;
+    d[0] = t_start;
+    d[1] = wall_clock64();
+    d[2] = ((long long)role << 32) | (unsigned)item;
+    d[3] = ((long long)xcc_id << 32) | hw_id;
+  }
+#endif
 }
 
 }  // namespace ss

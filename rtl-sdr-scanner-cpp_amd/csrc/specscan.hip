@@ -78,6 +78,9 @@ struct ss_ctx {
     int fft_tw = 2;                // 8192 points: where the twiddles come from (fft8192_v2.h: 0 global, 1 pass-2 table in LDS, 2 LDS + SGPRs)
     bool fft_swz = true;           // 8192 points: 16-byte swizzled first exchange
     int prio_fft = 0, prio_other = 0;  // s_setprio of k_scan_step's roles
+    std::string stamp_path;        // SS_DIAG only: dump per-workgroup start / end stamps of the 40th full k_scan_step launch here
+    long long* d_stamps = nullptr;
+    int stamp_launches = 0;
     bool emit_wide = true;         // long rows (n >= 16384): several waves per frame in the emit stage
     int fft_per_wg = 0;            // frames per FFT workgroup of k_scan_step: 0 = one; -1 = as many as leave the FFT role two slots per CU (scan_step.h)
     // Dispatch order of k_scan_step's work items when all three roles ride one launch: "prefix|cycle", comma-separated
@@ -109,6 +112,7 @@ struct ss_ctx {
       fft_swz = tri("SS_FFT_SWZ") != 0;
       prio_fft = num("SS_STEP_PRIO_FFT", 0);
       prio_other = num("SS_STEP_PRIO_OTHER", 0);
+      if (const char* v = getenv("SS_STEP_STAMPS")) stamp_path = v;
       fft_per_wg = num("SS_FFT_PER_WG", fft_per_wg);
       emit_wide = tri("SS_EMIT_WIDE") != 0;
       if (const char* v = getenv("SS_STEP_ORDER")) step_order = v;
@@ -461,6 +465,17 @@ void launch_step(ss_ctx* c, const ss::Fft8192Args* fft, int n_fft, const ss::Det
   }
   if (ss::step_items(a) == 0) return;
   step_order(c, a);
+#ifdef SS_DIAG
+  bool dump_stamps = false;
+  if (!c->diag.stamp_path.empty() && fft && det && emit && ss::step_items(a) <= 4096 && a.n_det <= 4096) {
+    if (!c->diag.d_stamps) (void)hipMalloc(&c->diag.d_stamps, sizeof(long long) * 4 * 8192);
+    if (c->diag.d_stamps && ++c->diag.stamp_launches == 40) {
+      a.stamps = c->diag.d_stamps;
+      a.det.stamp_mid = c->diag.d_stamps + 4 * 4096;  // (2 per tile, behind the per-workgroup stamps)
+      dump_stamps = true;
+    }
+  }
+#endif
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (fft && !prof_pair(c, &e0, &e1)) e0 = e1 = nullptr;
   const bool sp = spec && det;
@@ -469,6 +484,25 @@ void launch_step(ss_ctx* c, const ss::Fft8192Args* fft, int n_fft, const ss::Det
     case SS_FMT_CS8: sp ? launch_step_variant<ss::FMT_CS8, true>(c, a, e0, e1) : launch_step_variant<ss::FMT_CS8, false>(c, a, e0, e1); break;
     default: sp ? launch_step_variant<ss::FMT_CU8, true>(c, a, e0, e1) : launch_step_variant<ss::FMT_CU8, false>(c, a, e0, e1); break;
   }
+#ifdef SS_DIAG
+  if (dump_stamps) {
+    const int wgs = ss::step_items(a);
+    std::vector<long long> h((size_t)4 * wgs);  // (wgs <= 4096 here)
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(h.data(), c->diag.d_stamps, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+    if (FILE* fp = fopen(c->diag.stamp_path.c_str(), "w")) {
+      for (int b = 0; b < wgs; ++b)
+        fprintf(fp, "%d %lld %lld %lld %lld %lld %lld\n", b, h[4 * b], h[4 * b + 1], h[4 * b + 2] >> 32, h[4 * b + 2] & 0xffffffff, h[4 * b + 3] >> 32, h[4 * b + 3] & 0xffffffff);
+      fclose(fp);
+      std::vector<long long> m((size_t)2 * a.n_det);
+      (void)hipMemcpy(m.data(), c->diag.d_stamps + 4 * 4096, sizeof(long long) * m.size(), hipMemcpyDeviceToHost);
+      if (FILE* fm = fopen((c->diag.stamp_path + ".det").c_str(), "w")) {
+        for (int t = 0; t < a.n_det; ++t) fprintf(fm, "%d %lld %lld\n", t, m[2 * t], m[2 * t + 1]);
+        fclose(fm);
+      }
+    }
+  }
+#endif
 }
 
 ss::Fft8192Args fft8192_args(ss_ctx* c, const void* d_iq, long long item_stride, float* d_psd) {
@@ -865,6 +899,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_pass);
   (void)hipFree(c->d_rel);
   (void)hipFree(c->d_tw8v2);
+  (void)hipFree(c->diag.d_stamps);
   (void)hipFree(c->d_step_order[0]);
   (void)hipFree(c->d_step_order[1]);
   (void)hipFree(c->d_hist);
