@@ -166,3 +166,41 @@ def test_caller_reusing_its_planes_every_call_is_safe():
     assert t > 1000
     np.testing.assert_array_equal(o["idx"][:t].cpu().numpy(), h["cand_idx"])
     np.testing.assert_array_equal(o["cav"][:t].cpu().numpy(), h["cand_avg"])
+
+
+@pytest.mark.parametrize("n,fs,max_batch,fmt", [(65536, 20_000_000, 64, "cs8"), (4096, 1_024_000, 1024, "cf32"), (1 << 18, 61_440_000, 16, "cf32")])
+def test_other_sizes_asynchronous_calls_equal_call_by_call(n, fs, max_batch, fmt):
+    """FFT sizes other than 8192 (three to six launches per call, no stage pipelining): an engine that is synchronised after
+    every call against one that is synchronised once at the end; a retune with reset and a short call on the way. (A two-stream
+    form — FFT kernels of call k beside detect + emit of call k-1, ordered by events — was built against this test and
+    measured: 65536 x 128 int8 119.9 vs 121.2 GS/s, 2^20 x 16 77.3 vs 77.5: kernels of two streams do not overlap here; dropped.)"""
+    import torch
+    dev = torch.device("cuda:0")
+    in_format = pkg.abi.SS_FMT_CS8 if fmt == "cs8" else pkg.abi.SS_FMT_CF32
+    ncalls = 7
+    band = pkg.synth.SyntheticBand(n, seed=31, on_frame=max_batch + max_batch // 2, off_frame=10_000_000)
+    kw = dict(fft_size=n, decim=1, in_format=in_format, learn_frames=max_batch // 2, max_batch=max_batch)
+    a, b = pkg.SpectrumEngine(fs, CENTER, **kw), pkg.SpectrumEngine(fs, CENTER, **kw)
+    sizes = [max_batch, max_batch, max_batch, 3, max_batch, max_batch, max_batch][:ncalls]
+    outs_a, outs_b, keep = [], [], []
+    for k, s_ in enumerate(sizes):
+        if k == 4:
+            for e in (a, b):
+                e.set_frequency_range(CENTER + fs - fs // 2, CENTER + fs + fs // 2)
+                e.reset()
+        chunk = band.frames_cs8(s_) if fmt == "cs8" else band.frames_cf32(s_)
+        d_iq = torch.from_numpy(np.ascontiguousarray(chunk).view(np.float32) if chunk.dtype == np.complex64 else np.ascontiguousarray(chunk)).to(dev)
+        keep.append(d_iq)
+
+        def outputs():
+            return dict(psd=torch.full((s_, n), -7.0, dtype=torch.float32, device=dev), off=torch.full((s_ + 1,), -1, dtype=torch.int32, device=dev),
+                        idx=torch.full((s_ * 2048,), -1, dtype=torch.int32, device=dev), cav=torch.full((s_ * 2048,), -7.0, dtype=torch.float32, device=dev), rel=None, avg=None)
+        oa, ob = outputs(), outputs()
+        _call(a, d_iq, s_, oa)
+        a.sync()
+        _call(b, d_iq, s_, ob)
+        outs_a.append(oa)
+        outs_b.append(ob)
+    b.sync()
+    total = sum(_same(oa, ob, f"call {k}") for k, (oa, ob) in enumerate(zip(outs_a, outs_b)))
+    assert total > 200
