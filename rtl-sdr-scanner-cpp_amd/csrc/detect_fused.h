@@ -574,11 +574,12 @@ __device__ __forceinline__ void cand_emit_frame(const EmitArgs& a, int f, int la
 // a count pass over its slice (the words come back from L2 for the expansion), a prefix over the W slice counts in LDS,
 // then the same expansion from the slice's own start. One wave per frame walks 2^20-point rows in 128 serial trips (38 us
 // per 16-frame batch); eight waves take 16 each.
+// `lds` = (W * kEmitList + W + 1) ints; one frame per call, 64 * W threads.
 template <int W>
-__global__ __launch_bounds__(64 * W) void k_cand_emit_wide(EmitArgs a) {
-  __shared__ int list[W][kEmitList];
-  __shared__ int slice_cnt[W];
-  const int f = blockIdx.x, lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+__device__ __forceinline__ void cand_emit_frame_wide(const EmitArgs& a, int f, int tid, int* __restrict__ lds) {
+  int* slice_cnt = lds + W * kEmitList;
+  int* frame_begin = slice_cnt + W;
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int words_per_row = a.words_per_row;
   const int per = words_per_row / W;  // a multiple of 256 (the host picks W accordingly)
   const int lo = w * per, hi = lo + per;
@@ -596,14 +597,19 @@ __global__ __launch_bounds__(64 * W) void k_cand_emit_wide(EmitArgs a) {
     for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
   }
   if (lane == 0) slice_cnt[w] = cnt;
-  __shared__ int frame_begin;
-  if (w == 0 && lane == 0) frame_begin = begin;
+  if (w == 0 && lane == 0) *frame_begin = begin;
   __syncthreads();
   if (mine == 0 || !a.cand_idx) return;
-  int carry = frame_begin;
+  int carry = *frame_begin;
   for (int k = 0; k < w; ++k) carry += slice_cnt[k];
   if (cnt == 0) return;  // wave-uniform
-  emit_span(a, f, lane, list[w], lo, hi, carry, make_uint4(0u, 0u, 0u, 0u), false);
+  emit_span(a, f, lane, lds + w * kEmitList, lo, hi, carry, make_uint4(0u, 0u, 0u, 0u), false);
+}
+
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_cand_emit_wide(EmitArgs a) {
+  __shared__ int lds[W * kEmitList + W + 1];
+  cand_emit_frame_wide<W>(a, (int)blockIdx.x, (int)threadIdx.x, lds);
 }
 
 // Stand-alone launch: one wave per workgroup (FFT sizes other than 8192).

@@ -59,39 +59,48 @@ __device__ __forceinline__ void fft256_passes(float2 (&a)[16], float2 (&c)[16], 
   dft16(c);  // X[j + 16 k] in c[slot16(k)]
 }
 
+struct ColsArgs {
+  const void* iq;
+  long long item_stride;
+  const float* win;
+  const float2* tw256;
+  const float2* twc;
+  float scale;
+  float2* work;
+  int logn2;
+};
+
+// One column tile (32 columns x 256 rows) by one workgroup of 512 threads; `block` = frame * (N2 / 32) + tile.
 template <int FMT>
-__global__ __launch_bounds__(512, 8) void k_fft_cols256(const void* __restrict__ iq, long long item_stride, const float* __restrict__ win,
-                                                        const float2* __restrict__ tw256, const float2* __restrict__ twc, float scale,
-                                                        float2* __restrict__ work, int logn2) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void fft_cols256_tile(const ColsArgs& g, int block, unsigned char* __restrict__ smem_raw, int t) {
   float* s = reinterpret_cast<float*>(smem_raw);
-  const int t = threadIdx.x;
+  const int logn2 = g.logn2;
   const int q = t & 31, j = t >> 5;
   const int n2size = 1 << logn2;
   const int tiles_per_frame = n2size >> 5;
-  const int f = blockIdx.x / tiles_per_frame;
-  const int n2 = ((blockIdx.x % tiles_per_frame) << 5) + q;
+  const int f = block / tiles_per_frame;
+  const int n2 = ((block % tiles_per_frame) << 5) + q;
   // sample n = (j + 16 r) N2 + n2: block-uniform part (frame, 16 r N2) in scalar registers, per-thread part one 32-bit offset
   constexpr uint32_t kInBytes = FMT == FMT_CF32 ? 8u : 2u;
-  const char* in_frame = reinterpret_cast<const char*>(iq) + (size_t)f * (size_t)item_stride * kInBytes;
-  const char* win_b = reinterpret_cast<const char*>(win);
+  const char* in_frame = reinterpret_cast<const char*>(g.iq) + (size_t)f * (size_t)g.item_stride * kInBytes;
+  const char* win_b = reinterpret_cast<const char*>(g.win);
   const uint32_t tn = ((uint32_t)j << logn2) + (uint32_t)n2;
   float2 a[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const size_t un = (size_t)(16 * r) << logn2;
-    const float2 x = load_iq<FMT>(in_frame + un * kInBytes + tn * kInBytes, 0, scale);
+    const float2 x = load_iq<FMT>(in_frame + un * kInBytes + tn * kInBytes, 0, g.scale);
     const float w = *reinterpret_cast<const float*>(win_b + un * 4 + tn * 4u);
     a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
   }
   float2 c[16];
-  fft256_passes<kFft256PitchCols>(a, c, s, tw256, q, j);
+  fft256_passes<kFft256PitchCols>(a, c, s, g.tw256, q, j);
   // step-A twiddle W_N^(n2 k1), k1 = j + 16 k, as W_N^(n2 j) * W_N^(16 n2 k) from two tables laid out [j][n2] and [k][n2]:
   // the lanes of a wave (consecutive n2) read consecutive entries (a gather from the N-entry table W_N^m at m = n2 k1
   // costs as much as the whole transform). work[k1 * N2 + n2]: block-uniform base + one 32-bit offset per access.
-  char* wf = reinterpret_cast<char*>(work + ((size_t)f << (8 + logn2)));
-  const char* t1 = reinterpret_cast<const char*>(twc);
-  const char* t2 = reinterpret_cast<const char*>(twc + ((size_t)16 << logn2));
+  char* wf = reinterpret_cast<char*>(g.work + ((size_t)f << (8 + logn2)));
+  const char* t1 = reinterpret_cast<const char*>(g.twc);
+  const char* t2 = reinterpret_cast<const char*>(g.twc + ((size_t)16 << logn2));
   const float2 tj = *reinterpret_cast<const float2*>(t1 + 8u * (((uint32_t)j << logn2) + (uint32_t)n2));
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
@@ -100,6 +109,13 @@ __global__ __launch_bounds__(512, 8) void k_fft_cols256(const void* __restrict__
     if (k > 0) y = cmul(y, *reinterpret_cast<const float2*>(t2 + 8u * (((uint32_t)k << logn2) + (uint32_t)n2)));
     *reinterpret_cast<float2*>(wf + 8u * ((k1 << logn2) + (uint32_t)n2)) = y;
   }
+}
+
+// Stand-alone launch (learning batches are launched this way too; otherwise the tiles run as a role of k_scan_step).
+template <int FMT>
+__global__ __launch_bounds__(512, 8) void k_fft_cols256(ColsArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  fft_cols256_tile<FMT>(g, (int)blockIdx.x, smem_raw, (int)threadIdx.x);
 }
 
 // Rows of 256 points spaced row_stride apart: N2 = 256 (row_stride 256, nsub 1) directly after the columns pass, or

@@ -1,4 +1,5 @@
-// scan_step.h — the 8192-point chain as ONE launch per call: k_scan_step.
+// scan_step.h — the chain's stages of three consecutive calls as ONE launch: k_scan_step (8192 points: the whole FFT + dB
+// stage; 16384 points and more: the column half of the four-step FFT, the row half follows as its own launch).
 //
 // The reference runs its stages as a pipeline of blocks, each on its own thread, every block working on a different frame
 // at any moment (sources/radio/sdr_device.cpp:161-171: blocker -> decimator -> fft -> psd -> noiseLearner -> transmission).
@@ -18,6 +19,10 @@
 // result is asked for (ss_sync, ss_flush, the host-buffer entry points, retunes and resets): results are exactly those of
 // the three-launch chain, bit for bit, because every role runs the same code on the same data.
 //
+// Transforms of 16384 points and more are four-step (fft256_kernels.h): their column half — tiles of 32 columns x 256 rows,
+// one per 512-thread workgroup — takes the FFT role's place (KIND 1, 2), the row half follows as a launch of its own, and
+// the deferred stages ride on the column launch in the same way.
+//
 // Workgroup = 512 threads, <= 64 VGPRs, 39 KiB of LDS (the FFT role's; two detect tiles need 35 KiB, eight emit lists
 // 32 KiB): four workgroups per CU whatever their roles.
 #pragma once
@@ -25,18 +30,21 @@
 #include <stdint.h>
 
 #include "detect_fused.h"
+#include "fft256_kernels.h"
 #include "fft8192_v2.h"
 
 namespace ss {
 
 struct StepArgs {
-  Fft8192Args fft;
+  Fft8192Args fft;  // KIND 0: 8192-point frames
+  ColsArgs cols;    // KIND 1, 2: 256-point column tiles of a long transform (fft256_kernels.h)
   DetectArgs det;
   EmitArgs emit;
-  int n_fft;   // frames of the FFT role (0: role absent)
-  int fft_per_wg;  // consecutive frames one FFT workgroup transforms, one after the other (see below)
+  int n_fft;   // frames (KIND 0) or column tiles (KIND 1) of the FFT role (0: role absent)
+  int fft_per_wg;  // consecutive frames one FFT workgroup transforms, one after the other (see below; 1 for KIND 1)
   int n_det;   // detect TILES (two per workgroup)
-  int n_emit;  // frames of the emit role (eight per workgroup)
+  int n_emit;  // frames of the emit role
+  int emit_per_wg;  // 8: one wave per frame; 1 (KIND 2): rows of 2048 mask words and more, the eight waves share one frame
   // One workgroup per work item, dispatched in blockIdx order, four resident per CU. WHICH item a workgroup takes decides
   // what shares a CU when: `order` (device memory, one word per workgroup: role << 24 | item) is built by the host once
   // per launch shape. A launch with one role only passes null (items in blockIdx order). (Tried and dropped: the order as
@@ -59,20 +67,27 @@ struct StepArgs {
 constexpr int kStepThreads = 512;
 constexpr int kStepLdsBytes = kFft8192V2LdsBytes;
 static_assert(2 * (16 * DetectTile<21, 21, 16, 256>::P * 4 + 64) <= kFft8192V2LdsBytes, "two detect tiles per workgroup");
-static_assert(8 * kEmitList * 4 <= kFft8192V2LdsBytes, "eight emit lists per workgroup");
+static_assert((8 * kEmitList + 9) * 4 <= kFft8192V2LdsBytes, "eight emit lists per workgroup");
+static_assert(kFft256LdsBytes <= kFft8192V2LdsBytes, "a column tile");
 
 inline int step_fft_wgs(const StepArgs& a) { return a.n_fft ? (a.n_fft + a.fft_per_wg - 1) / a.fft_per_wg : 0; }
-inline int step_items(const StepArgs& a) { return step_fft_wgs(a) + (a.n_det + 1) / 2 + (a.n_emit + 7) / 8; }
+inline int step_emit_wgs(const StepArgs& a) { return a.emit_per_wg == 1 ? a.n_emit : (a.n_emit + 7) / 8; }
+inline int step_items(const StepArgs& a) { return step_fft_wgs(a) + (a.n_det + 1) / 2 + step_emit_wgs(a); }
 
 enum { ROLE_NONE = 0, ROLE_FFT = 1, ROLE_DET = 2, ROLE_EMIT = 3 };
 
-template <int FMT, bool SPEC, int TW, bool SWZ>
+template <int FMT, bool SPEC, int TW, bool SWZ, int KIND>
 __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int item, unsigned char* smem_raw, int tid) {
   if (role == ROLE_EMIT) {
-    // ---- emit role: one wave per frame ----
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int f = item * 8 + w;
-    if (f < a.n_emit) cand_emit_frame(a.emit, f, tid & 63, reinterpret_cast<int*>(smem_raw) + w * kEmitList);
+    if constexpr (KIND == 2) {
+      // ---- emit role, long rows: the eight waves share one frame ----
+      cand_emit_frame_wide<8>(a.emit, item, tid, reinterpret_cast<int*>(smem_raw));
+    } else {
+      // ---- emit role: one wave per frame ----
+      const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int f = item * 8 + w;
+      if (f < a.n_emit) cand_emit_frame(a.emit, f, tid & 63, reinterpret_cast<int*>(smem_raw) + w * kEmitList);
+    }
   } else if (role == ROLE_DET) {
     // ---- detect role: two tiles, threads 0..255 and 256..511 ----
     using T = DetectTile<21, 21, 16, 256>;
@@ -81,6 +96,9 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     float* tile = reinterpret_cast<float*>(smem_raw) + half * (16 * T::P + 16);
     int* cnt = reinterpret_cast<int*>(tile + 16 * T::P);
     detect_tile<21, 21, 16, 256, SPEC>(a.det, min(tile_no, a.n_det - 1), tid & 255, tile, cnt, tile_no < a.n_det);
+  } else if constexpr (KIND >= 1) {
+    // ---- FFT role, long transforms: one tile of 32 columns ----
+    fft_cols256_tile<FMT>(a.cols, item, smem_raw, tid);
   } else {
     // ---- FFT role: fft_per_wg consecutive frames, one after the other ----
     const int f0 = item * a.fft_per_wg, f1 = min(f0 + a.fft_per_wg, a.n_fft);
@@ -93,7 +111,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
   }
 }
 
-template <int FMT, bool SPEC, int TW = 2, bool SWZ = true, bool PRIO = false>
+template <int FMT, bool SPEC, int TW = 2, bool SWZ = true, bool PRIO = false, int KIND = 0>
 __global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -116,7 +134,7 @@ __global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a) {
   long long t_start = 0;
   if (a.stamps && tid == 0) t_start = wall_clock64();
 #endif
-  step_run_item<FMT, SPEC, TW, SWZ>(a, role, item, smem_raw, tid);
+  step_run_item<FMT, SPEC, TW, SWZ, KIND>(a, role, item, smem_raw, tid);
 #ifdef SS_DIAG
   if (a.stamps && tid == 0) {
     unsigned hw_id = 0, xcc_id = 0;

@@ -82,11 +82,15 @@ struct ss_ctx {
     long long* d_stamps = nullptr;
     int stamp_launches = 0;
     bool emit_wide = true;         // long rows (n >= 16384): several waves per frame in the emit stage
+    bool step_long = true;         // n >= 16384: the column half of the FFT as the FFT role of k_scan_step (false: one launch per stage)
     int fft_per_wg = 0;            // frames per FFT workgroup of k_scan_step: 0 = one; -1 = as many as leave the FFT role two slots per CU (scan_step.h)
     // Dispatch order of k_scan_step's work items when all three roles ride one launch: "prefix|cycle", comma-separated
     // segments of a role letter (E emit, D detect, F FFT) and a workgroup count ('*' = all that are left); the cycle repeats
     // until every item is placed, a role that has run out is skipped.
     std::string step_order = "E*|D128,F1024";
+    // n >= 16384 (the FFT role is the column half, short workgroups): detect first. 65536 x 128 frames: 63.3 us per step
+    // against 64.7 with the order above and 70.7 with one launch per stage; 2^20 x 16: 216.8 / 235 / 216.9 (profiles/r02/s18).
+    std::string step_order_long = "E*|D*,F*";
 #ifdef SS_DIAG
     void read() {
       const auto is = [](const char* name, const char* value) {
@@ -115,7 +119,8 @@ struct ss_ctx {
       if (const char* v = getenv("SS_STEP_STAMPS")) stamp_path = v;
       fft_per_wg = num("SS_FFT_PER_WG", fft_per_wg);
       emit_wide = tri("SS_EMIT_WIDE") != 0;
-      if (const char* v = getenv("SS_STEP_ORDER")) step_order = v;
+      step_long = tri("SS_STEP_LONG") != 0;
+      if (const char* v = getenv("SS_STEP_ORDER")) step_order = step_order_long = v;
     }
 #else
     void read() {}
@@ -323,11 +328,25 @@ void launch_four_step(ss_ctx* c, const void* d_iq, long long item_stride, int nf
 }
 
 // N >= 16384: N = 256 x N2. Columns: 256-point register FFTs; rows: the same for N2 = 256, the generic LDS kernel otherwise.
+ss::ColsArgs cols256_args(ss_ctx* c, const void* d_iq, long long item_stride) {
+  ss::ColsArgs g{};
+  g.iq = d_iq;
+  g.item_stride = item_stride;
+  g.win = c->d_win;
+  g.tw256 = c->d_tw256;
+  g.twc = c->d_tw_cols;
+  g.scale = c->cfg.int_scale;
+  g.work = c->d_work;
+  g.logn2 = c->logn - 8;
+  return g;
+}
+
+// with_cols = false: the column half ran as a role of k_scan_step (run_batch), only the row half is launched here
 template <int LOGN2, int FMT>
-void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
+void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd, bool with_cols = true) {
   constexpr int N2 = 1 << LOGN2;
-  hipLaunchKernelGGL((ss::k_fft_cols256<FMT>), dim3(nframes * (N2 / 32)), dim3(512), ss::kFft256LdsBytes, c->stream, d_iq, item_stride,
-                     (const float*)c->d_win, (const float2*)c->d_tw256, (const float2*)c->d_tw_cols, c->cfg.int_scale, c->d_work, LOGN2);
+  if (with_cols)
+    hipLaunchKernelGGL((ss::k_fft_cols256<FMT>), dim3(nframes * (N2 / 32)), dim3(512), ss::kFft256LdsBytes, c->stream, cols256_args(c, d_iq, item_stride));
   if constexpr (LOGN2 == 8) {
     hipLaunchKernelGGL(ss::k_fft_rows256_psd, dim3(nframes * 8), dim3(512), ss::kFft256LdsBytes, c->stream, (const float2*)c->d_work,
                        (const float2*)c->d_tw256, c->db_off, d_psd, 16, 0);
@@ -365,7 +384,7 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
 // Dispatch order of a launch that carries more than one role, from the pattern in diag.step_order (see there): one word per
 // workgroup (role << 24 | item) in device memory, rebuilt only when the launch shape changes.
 void step_order(ss_ctx* c, ss::StepArgs& a) {
-  const int n_fft = ss::step_fft_wgs(a), wg_det = (a.n_det + 1) / 2, wg_emit = (a.n_emit + 7) / 8;  // (FFT WORKGROUPS)
+  const int n_fft = ss::step_fft_wgs(a), wg_det = (a.n_det + 1) / 2, wg_emit = ss::step_emit_wgs(a);  // (FFT WORKGROUPS)
   a.order = nullptr;
   a.prio_fft = c->diag.prio_fft;
   a.prio_other = c->diag.prio_other;
@@ -380,7 +399,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a) {
   std::vector<Seg> prefix, cycle;
   {
     std::vector<Seg>* into = &prefix;
-    const std::string& sp = c->diag.step_order;
+    const std::string& sp = c->use_fft8192 ? c->diag.step_order : c->diag.step_order_long;
     for (size_t i = 0; i < sp.size();) {
       const char ch = sp[i];
       if (ch == '|') {
@@ -435,6 +454,7 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
     if (e0) hipExtLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, c->stream, e0, e1, 0, a);
     else hipLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, c->stream, a);
   };
+  if (!c->use_fft8192) return a.emit_per_wg == 1 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 2>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 1>);
 #ifdef SS_DIAG
   if (c->diag.fft_tw == 0) return go(ss::k_scan_step<FMT, SPEC, 0, false>);
   if (c->diag.fft_tw == 1) return go(ss::k_scan_step<FMT, SPEC, 1, false>);
@@ -444,16 +464,28 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
   go(ss::k_scan_step<FMT, SPEC, 2, true>);
 }
 
+// The FFT role of a launch: 8192-point frames, or the column tiles of a long transform.
+struct FftRole {
+  const ss::Fft8192Args* frames = nullptr;
+  const ss::ColsArgs* cols = nullptr;
+  int n = 0;  // frames / column tiles
+};
+
 // fft / det / emit: null = role absent. Start/stop events ride on launches that carry an FFT role (the dominant work).
-void launch_step(ss_ctx* c, const ss::Fft8192Args* fft, int n_fft, const ss::DetectArgs* det, int n_det_tiles, bool spec, const ss::EmitArgs* emit) {
+void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n_det_tiles, bool spec, const ss::EmitArgs* emit) {
   ss::StepArgs a{};
   a.fft_per_wg = 1;
-  if (fft) {
-    a.fft = *fft;
+  a.emit_per_wg = (!c->use_fft8192 && c->diag.emit_wide && c->n / 32 >= 2048) ? 1 : 8;
+  if (fft && fft->frames) {
+    const int n_fft = fft->n;
+    a.fft = *fft->frames;
     a.n_fft = n_fft;
     // with other roles in the launch the FFT role keeps to two of every CU's four workgroup slots (scan_step.h)
     if (c->diag.fft_per_wg > 0) a.fft_per_wg = c->diag.fft_per_wg;
     else if (c->diag.fft_per_wg < 0 && (det || emit)) a.fft_per_wg = std::max(1, (n_fft + 2 * c->n_cus - 1) / (2 * c->n_cus));
+  } else if (fft && fft->cols) {
+    a.cols = *fft->cols;
+    a.n_fft = fft->n;
   }
   if (det) {
     a.det = *det;
@@ -520,7 +552,7 @@ ss::Fft8192Args fft8192_args(ss_ctx* c, const void* d_iq, long long item_stride,
 // Drain the deferred stages: detect (+ the emit stage before it), then the last emit. Nothing is synchronised.
 void flush_stages(ss_ctx* c) {
   while (c->have_det || c->have_emit) {
-    launch_step(c, nullptr, 0, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
+    launch_step(c, nullptr, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     c->have_emit = c->have_det;
     c->pend_emit = c->pend_det_emit;
     c->have_det = false;
@@ -531,7 +563,10 @@ template <int FMT>
 int launch_fft_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd) {
   if (c->use_fft8192) {  // (only reached without the fused back end; with it run_batch builds the step itself)
     const ss::Fft8192Args g = fft8192_args(c, d_iq, item_stride, d_psd);
-    launch_step(c, &g, nframes, nullptr, 0, false, nullptr);
+    FftRole role;
+    role.frames = &g;
+    role.n = nframes;
+    launch_step(c, &role, nullptr, 0, false, nullptr);
     return SS_OK;
   }
   switch (c->logn) {
@@ -581,6 +616,22 @@ int launch_fft(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, 
     case SS_FMT_CS8: return launch_fft_fmt<ss::FMT_CS8>(c, d_iq, item_stride, nframes, d_psd);
     default: return launch_fft_fmt<ss::FMT_CU8>(c, d_iq, item_stride, nframes, d_psd);
   }
+}
+
+// Row half of the four-step transform whose column half ran as a role of k_scan_step.
+int launch_fft_rows(ss_ctx* c, int nframes, float* d_psd) {
+  constexpr int F = ss::FMT_CF32;  // (the rows read the work buffer, whatever the input format was)
+  switch (c->logn) {
+    case 14: launch_four_step256<6, F>(c, nullptr, 0, nframes, d_psd, false); break;
+    case 15: launch_four_step256<7, F>(c, nullptr, 0, nframes, d_psd, false); break;
+    case 16: launch_four_step256<8, F>(c, nullptr, 0, nframes, d_psd, false); break;
+    case 17: launch_four_step256<9, F>(c, nullptr, 0, nframes, d_psd, false); break;
+    case 18: launch_four_step256<10, F>(c, nullptr, 0, nframes, d_psd, false); break;
+    case 19: launch_four_step256<11, F>(c, nullptr, 0, nframes, d_psd, false); break;
+    case 20: launch_four_step256<12, F>(c, nullptr, 0, nframes, d_psd, false); break;
+    default: return fail(c, SS_ERR_INVALID, "fft_size 2^%d has no column / row split", c->logn);
+  }
+  return SS_OK;
 }
 
 int grid_for(size_t work_items, int block) {
@@ -797,7 +848,18 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     if (!spec) return fail(c, SS_ERR_NOMEM, "spectrogram container");
   }
   if (c->step_path) {
-    const ss::Fft8192Args g = fft8192_args(c, d_iq, item_stride, d_psd);
+    ss::Fft8192Args g{};
+    ss::ColsArgs gc{};
+    FftRole role;
+    if (c->use_fft8192) {
+      g = fft8192_args(c, d_iq, item_stride, d_psd);
+      role.frames = &g;
+      role.n = nframes;
+    } else {  // N = 256 x N2: the column half here, the row half right behind it
+      gc = cols256_args(c, d_iq, item_stride);
+      role.cols = &gc;
+      role.n = nframes * (c->n >> 13);
+    }
     const bool overlap = c->diag.pipeline && n_learn == 0;
     // A caller that hands the same PSD or avg plane to consecutive calls would have this call's stages write what a
     // deferred stage of the previous call still has to read in the same launch: drain first (no overlap for such callers).
@@ -810,10 +872,14 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     const bool reused = c->have_det && (clash(d_psd, plane_bytes, c->pend_det.psd, pend_bytes) || clash(d_avg_out, plane_bytes, c->pend_det_emit.avg, pend_bytes) ||
                                          clash(d_psd, plane_bytes, c->pend_det.rel_out, pend_bytes) || clash(d_rel_out, plane_bytes, c->pend_det.psd, pend_bytes));
     if (!overlap || reused) flush_stages(c);
-    launch_step(c, &g, nframes, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
+    launch_step(c, &role, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     c->have_emit = c->have_det;
     c->pend_emit = c->pend_det_emit;
     c->have_det = false;
+    if (!c->use_fft8192) {
+      st = launch_fft_rows(c, nframes, d_psd);
+      if (st != SS_OK) return st;
+    }
     if (spec && !c->spec_in_detect) {
       st = spectrogram_accumulate(c, spec, d_psd, nframes);
       if (st != SS_OK) return st;
@@ -1061,7 +1127,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   }
   // 8192 points with the fused back end: stages of consecutive calls overlap (scan_step.h), so what a deferred stage reads
   // is doubled; every other configuration uses set 0 only
-  c->step_path = c->fused && n == 8192 && !c->diag.fft_generic;
+  c->step_path = c->fused && !c->diag.fft_generic && (n == 8192 || (n >= 16384 && c->diag.step_long));
   for (int k = 0; k < (c->step_path ? 2 : 1); ++k) {
     CREATE_HIP(hipMalloc(&c->d_psd2[k], plane));
     CREATE_HIP(hipMalloc(&c->d_avg2[k], plane));
@@ -1071,7 +1137,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, cfg->device_id));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const size_t max_items = (size_t)cfg->max_batch + ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256) / 2 + (size_t)cfg->max_batch / 8 + 4;
+    const size_t max_items = (size_t)cfg->max_batch * (size_t)(n / 8192) + ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256) / 2 + (size_t)cfg->max_batch + 4;
     for (int k = 0; k < 2; ++k) CREATE_HIP(hipMalloc(&c->d_step_order[k], sizeof(uint32_t) * max_items));
   }
   if (!c->step_path) {

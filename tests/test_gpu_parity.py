@@ -107,6 +107,8 @@ ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurem
     ({"SS_FFT_ROWSR": "0", "SS_FFT_SUB": "1"}, 131072, 20_000_000, "cf32"),
     ({"SS_FFT_XCDMAP": "0"}, 262144, 20_000_000, "cf32"),
     ({"SS_EMIT_WIDE": "0"}, 65536, 20_000_000, "cs8"),
+    ({"SS_STEP_LONG": "0"}, 65536, 20_000_000, "cs8"),
+    ({"SS_STEP_LONG": "0"}, 16384, 4_000_000, "cf32"),
 ]
 
 
