@@ -38,6 +38,19 @@ def ref_mod(oracle_mod):
     return oracle_mod
 
 
+@pytest.fixture(autouse=True)
+def _whole_suite_on_the_diagnostics_build():
+    """SS_TEST_USE_DIAG_LIB=1 (with SS_* variables of one's choice) runs every test against libspecscan_diag.so: an
+    alternative implementation meets the whole suite, not only tests/test_gpu_parity.py's ALTERNATIVES."""
+    if not os.environ.get("SS_TEST_USE_DIAG_LIB"):
+        yield
+        return
+    import rtl_sdr_scanner_cpp_amd as pkg
+    pkg.engine.use_diag_library(True)
+    yield
+    pkg.engine.use_diag_library(False)
+
+
 @pytest.fixture
 def diag_lib():
     """Engines created inside the test load libspecscan_diag.so — the -DSS_DIAG build, the only one that lets SS_* / SC_*
