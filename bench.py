@@ -318,6 +318,7 @@ def run(args):
     out_bytes = nb * n * 4 * ((0 if args.no_psd_out else 1) + (2 if args.planes else 0))
     nsets = args.sets or max(6, -(-int(2.5 * L3_BYTES) // max(1, in_bytes + out_bytes)))
     nsets = min(nsets, 64)
+    nsets += nsets & 1  # an even number of sets: the library's two launch queues then order every buffer reuse by stream order alone (include/specscan.h)
     gen = dist.synthetic_stream(cfg, band)  # one continuous frame stream of the band: noise + gated wide-band transmissions
     first = gen(nb)  # holds the learning frames; every rank of a frame-sharded band learns from these same frames
     to_dev = lambda a: torch.from_numpy(a.view(np.float32) if a.dtype == np.complex64 else a).to(dev)  # noqa: E731
@@ -335,7 +336,7 @@ def run(args):
     # further batches: the generated ones with their frames rotated (distinct memory, same statistics)
     d_iq = [base[k] if k < len(base) else torch.roll(base[k % len(base)], shifts=37 * k, dims=0).contiguous() for k in range(nsets)]
     cap = nb * 1024
-    nout = nsets  # (the stages of up to three consecutive calls are in flight at once: every call has its own output set)
+    nout = nsets  # (the stages of up to five consecutive calls are in flight at once: every call has its own output set)
     outs = [dict(psd=None if args.no_psd_out else torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
                  idx=torch.empty(cap, dtype=torch.int32, device=dev), avg=torch.empty(cap, dtype=torch.float32, device=dev),
                  rel_plane=torch.empty((nb, n), dtype=torch.float32, device=dev) if args.planes else None,

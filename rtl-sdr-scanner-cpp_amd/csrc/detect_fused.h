@@ -64,6 +64,12 @@ struct DetectArgs {
   const float* thr;
   const float* hist_in;
   float* hist_out;
+  // Rows before the batch straight from the PREVIOUS call's PSD plane instead of the ring (null: the ring). rel = psd - thr is
+  // the same fp32 subtraction either way, so the results are the same bits; what changes is the dependence: the ring was
+  // written by the previous call's detect stage, the plane by its FFT stage (specscan.hip, deep pipelining). Only between
+  // calls without learning frames; halo_rows = frames of that plane (>= H).
+  const float* halo_psd;
+  int halo_rows;
   int n, nframes, n_learn, pushed_before;
   int shift;  // (frames since reset, before this batch) mod TF: tile t covers batch frames [t*TF - shift, t*TF - shift + TF)
   float start_level;
@@ -212,6 +218,8 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
   const bool interior = (b0 - A >= 0) && (b0 + TB + A <= n);
   const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes);
   const int first_hist = nframes - H;  // batch frames >= first_hist become the ring rows [frame - first_hist]
+  const float* before_base = a.halo_psd ? a.halo_psd : a.hist_in;  // rows before the batch: the previous call's last frames, or the ring
+  const int before_rows = a.halo_psd ? a.halo_rows : H;
   const bool writes_hist = f0 + TF > first_hist;
 
   // ---------------- phase 1: time means, thread = column ----------------
@@ -277,14 +285,15 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
           const int fr = f0 - (G - 1) + r;
-          const float* src = fr < 0 ? a.hist_in + (size_t)max(H + fr, 0) * n : a.psd + (size_t)min(fr, nframes - 1) * n;
+          const float* src = fr < 0 ? before_base + (size_t)max(before_rows + fr, 0) * n : a.psd + (size_t)min(fr, nframes - 1) * n;
           x[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + coff);
         }
+        const float t_before = a.halo_psd ? t : 0.0f;  // ring rows already hold rel values (x - 0.0f is x, bit for bit); plane rows are PSD
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
           const int fr = f0 - (G - 1) + r;
           const float v = fr < a.n_learn ? kNoData : x[r] - t;  // noise_learner.cpp:49 / :55
-          x[r] = fr < 0 ? x[r] : (fr < nframes ? v : 0.0f);     // ring rows already hold rel values
+          x[r] = fr < 0 ? x[r] - t_before : (fr < nframes ? v : 0.0f);
         }
         if (main_col) {
 #pragma unroll

@@ -37,10 +37,15 @@ namespace ss {
 
 struct StepArgs {
   Fft8192Args fft;  // KIND 0: 8192-point frames
+  // KIND 0, deep pipelining (specscan.hip): FFT role frames [0, n_halo) are the last n_halo frames of the PREVIOUS call,
+  // transformed again into a buffer of this launch's own, so that no stage has to read what the launch before wrote
+  const void* halo_iq;  // first of those frames
+  float* halo_psd;      // [n_halo][8192]
+  int n_halo;
   ColsArgs cols;    // KIND 1, 2: 256-point column tiles of a long transform (fft256_kernels.h)
   DetectArgs det;
   EmitArgs emit;
-  int n_fft;   // frames (KIND 0) or column tiles (KIND 1) of the FFT role (0: role absent)
+  int n_fft;   // frames (KIND 0, n_halo included) or column tiles (KIND 1) of the FFT role (0: role absent)
   int fft_per_wg;  // consecutive frames one FFT workgroup transforms, one after the other (see below; 1 for KIND 1)
   int n_det;   // detect TILES (two per workgroup)
   int n_emit;  // frames of the emit role
@@ -106,7 +111,12 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       if (f > f0) __syncthreads();  // the previous frame's last LDS reads are done
       int t = tid;
       asm volatile("" : "+v"(t));  // the per-thread offsets are cheap to rebuild per frame and expensive to keep alive across the loop (64 VGPRs)
-      fft8192_v2_frame<FMT, TW, SWZ>(a.fft, (size_t)f, smem_raw, t);
+      const int fu = __builtin_amdgcn_readfirstlane(f);  // (workgroup-uniform: keep the selects in scalar registers)
+      const bool halo = fu < a.n_halo;
+      Fft8192Args g = a.fft;
+      g.iq = halo ? a.halo_iq : a.fft.iq;
+      g.psd = halo ? a.halo_psd : a.fft.psd;
+      fft8192_v2_frame<FMT, TW, SWZ>(g, (size_t)(halo ? fu : fu - a.n_halo), smem_raw, t);
     }
   }
 }

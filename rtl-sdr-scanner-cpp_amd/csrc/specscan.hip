@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <string>
@@ -32,6 +33,9 @@ thread_local char g_create_err[512] = "";
 
 // fused back end (grouping 21 x 21): frames per tile, and the ring rows kept between batches
 constexpr int kFusedTF = 16;
+// Deep pipelining (ss_ctx::deep): a call's last stage runs four launches after its first; the two queues synchronise once in
+// sixteen launches on the launch three back: everything launched more than 4 + 16 + 3 launches ago has finished.
+constexpr int kDeepHorizon = 24;
 constexpr int kHistRows = ss::DetectTile<21, 21, kFusedTF, 256>::H;  // 35
 
 struct SpecState {  // Spectrogram::Container, sources/radio/blocks/spectrogram.h:10-16, one per centre frequency
@@ -82,6 +86,7 @@ struct ss_ctx {
     long long* d_stamps = nullptr;
     int stamp_launches = 0;
     bool emit_wide = true;         // long rows (n >= 16384): several waves per frame in the emit stage
+    bool deep = true;              // 8192 points: consecutive step launches independent of each other, alternating over two queues (see ss_ctx::deep)
     bool step_long = true;         // n >= 16384: the column half of the FFT as the FFT role of k_scan_step (false: one launch per stage)
     int fft_per_wg = 0;            // frames per FFT workgroup of k_scan_step: 0 = one; -1 = as many as leave the FFT role two slots per CU (scan_step.h)
     // Dispatch order of k_scan_step's work items when all three roles ride one launch: "prefix|cycle", comma-separated
@@ -120,6 +125,7 @@ struct ss_ctx {
       fft_per_wg = num("SS_FFT_PER_WG", fft_per_wg);
       emit_wide = tri("SS_EMIT_WIDE") != 0;
       step_long = tri("SS_STEP_LONG") != 0;
+      deep = tri("SS_DEEP") != 0;
       if (const char* v = getenv("SS_STEP_ORDER")) step_order = step_order_long = v;
     }
 #else
@@ -155,9 +161,12 @@ struct ss_ctx {
   long long abs_frames = 0;               // frames since the last reset: frame tiles are aligned to this index
   // per-frame candidate counts, three buffers in rotation: batch k accumulates into [k % 3]; its emit stage — which may
   // run two launches later, next to the detect stage of batch k + 1 — reads them and zeroes [(k + 2) % 3] for batch k + 2
-  int* d_cnt3[3] = {nullptr, nullptr, nullptr};
+  // (deep pipelining, below: six buffers, the emit stage of batch k runs four launches after its FFT stage and zeroes
+  // [(k + 4) % 6], whose last reader ran two launches earlier on the same queue)
+  int* d_cnt3[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int cnt_cur = 0;
-  int cnt_frames[3] = {0, 0, 0};          // how many entries of each buffer may be non-zero
+  int cnt_frames[6] = {0, 0, 0, 0, 0, 0};  // how many entries of each buffer may be non-zero
+  int ncnt = 3, nbuf = 1, npsd = 1, lag = 1;  // buffers in rotation: counters, mask / avg planes / offsets, internal PSD planes; launches between a call's stages
   float* d_relplane = nullptr;            // full rel plane, only when a caller asks for it (lazy)
   int last_n_learn = 0;
   // Stage pipelining (8192 points, scan_step.h): the detect stage of the last call and the emit stage of the call before
@@ -170,17 +179,73 @@ struct ss_ctx {
   bool pend_det_spec = false;
   ss::EmitArgs pend_det_emit{};  // the emit stage that follows pend_det
   ss::EmitArgs pend_emit{};
-  int buf_cur = 0;               // which of the doubled buffers the NEXT batch writes
+  int buf_cur = 0;               // which of the rotating buffers the NEXT batch writes
+  int psd_cur = 0;
+  // Deep pipelining (8192 points, no spectrogram branch; diag.deep). With the stages of three consecutive calls in one
+  // launch, launch k + 1 still depends on launch k (detect(k) needs FFT(k)), so every launch runs its ramp and its tail
+  // alone — a quarter of a 1024-frame launch (scripts/ubench/launch_overlap_lab.hip). Independent launches on two
+  // hardware queues fill each other's tails. Launch L therefore carries FFT(L), detect(L - 2) and emit(L - 4), and
+  // launches alternate over two side streams, so that launch L follows launch L - 2 in stream order and never waits for
+  // launch L - 1. What detect(L) needs from BEFORE its batch — the ring rows its predecessor writes, one launch earlier —
+  // it gets without that predecessor: launch L's FFT role transforms the last kHistRows frames of call L - 1 once more
+  // (3 % more FFT work; same kernel, same input: the same bits) into a buffer of its own (d_halo), which detect(L) reads
+  // as DetectArgs::halo_psd. No launch reads anything an odd number of launches back, so no events are needed between
+  // the two queues (an event record + wait per launch cost 3.7 us per step, more than the overlap gains). The context's
+  // public stream only forks (ev_in, when it holds work) and joins (flush_stages: both side streams, then the remaining
+  // stages in order on the public stream). Calls that cannot overlap (learning frames, fewer frames than the ring
+  // holds, a caller reusing a plane that is still in use) drain first and run their three stages in order on the public
+  // stream.
+  bool deep = false;
+  hipStream_t s_ab[2] = {nullptr, nullptr};
+  hipEvent_t ev_launch[8] = {}, ev_in[4] = {}, ev_join[2] = {};
+  float* d_halo[4] = {nullptr, nullptr, nullptr, nullptr};  // [kHistRows][n] each: written by launch L, read by detect(L) in launch L + 2
+  const void* deep_prev_iq = nullptr;  // the previous call's frames (caller's buffer: untouched until ss_sync by contract)
+  long long deep_prev_stride = 0;
+  long deep_L = 0;             // launches since the last drain
+  long deep_barrier = -10;     // a launch whose detect role read the ring: the next launch waits for it
+  unsigned deep_forks = 0;
+  struct PendDet {
+    ss::DetectArgs a;
+    int tiles;
+    ss::EmitArgs emit;
+    long ready;  // first launch that may carry it
+  };
+  struct PendEmit {
+    ss::EmitArgs a;
+    long ready;
+  };
+  std::deque<PendDet> pd;
+  std::deque<PendEmit> pe;
+  bool deep_prev_ok = false;   // the previous call overlapped: its PSD plane serves as this call's halo
+  int deep_prev_frames = 0;
+  // The caller's buffers of the last calls, which stages still in flight may read or write. A buffer handed to a later call
+  // again is safe without further ado when the launches that touch it for the two calls share a queue (an even number of
+  // launches apart, the earlier one at least two back); an odd distance needs an event from the other queue — recorded
+  // after every launch from the first time a caller is seen rotating an odd number of buffer sets (about 1 us per step, plus
+  // 2 us for the wait) — and anything closer drains the pipeline first.
+  struct Buffers {
+    const void* p[6];  // psd, rel | avg, cand_off, cand_idx, cand_avg
+    size_t bytes[6];
+    long launch;       // the call's FFT launch; its detect stage runs in launch + 2 (last to touch psd / rel), its emit stage in launch + 4
+  };
+  std::deque<Buffers> deep_buffers;
+  bool deep_events = false;   // record ev_launch after every launch
+  long deep_events_from = 0;  // first launch of this run of launches that has its event
   // k_scan_step's dispatch-order table for the current launch shape (rebuilt when the shape changes; two buffers so that a
   // launch still in flight keeps the table it was given)
-  uint32_t* d_step_order[2] = {nullptr, nullptr};
-  std::vector<uint32_t> h_step_order[2];
-  int step_order_cur = 0;
-  int step_order_key[3] = {-1, -1, -1};
+  struct OrderTable {
+    int key[3];  // FFT / detect / emit workgroups of the launch shape
+    uint32_t* d;
+    unsigned long long used;
+  };
+  std::vector<OrderTable> order_tables;  // one per launch shape met so far (a handful: steady state, pipeline fill, drain)
+  size_t order_capacity = 0;
+  unsigned long long order_clock = 0;
   int n_cus = 256;
-  uint32_t* d_mask2[2] = {nullptr, nullptr};
-  float* d_avg2[2] = {nullptr, nullptr};
-  float* d_psd2[2] = {nullptr, nullptr};
+  uint32_t* d_mask2[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* d_avg2[4] = {nullptr, nullptr, nullptr, nullptr};
+  int* d_off4[4] = {nullptr, nullptr, nullptr, nullptr};  // the library's copy of the candidate offsets, per rotating set (d_off = the latest)
+  float* d_psd2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   const float* last_avg = nullptr;  // the avg plane (sparse or kept) of the last batch
   const float* last_hist = nullptr;       // ring rows as they were before the last batch
   float* last_thr = nullptr;
@@ -383,16 +448,18 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
 // ---- k_scan_step (8192 points): any subset of the three roles in one launch ------------------------------------------
 // Dispatch order of a launch that carries more than one role, from the pattern in diag.step_order (see there): one word per
 // workgroup (role << 24 | item) in device memory, rebuilt only when the launch shape changes.
-void step_order(ss_ctx* c, ss::StepArgs& a) {
+void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
   const int n_fft = ss::step_fft_wgs(a), wg_det = (a.n_det + 1) / 2, wg_emit = ss::step_emit_wgs(a);  // (FFT WORKGROUPS)
   a.order = nullptr;
   a.prio_fft = c->diag.prio_fft;
   a.prio_other = c->diag.prio_other;
   if ((n_fft > 0) + (wg_det > 0) + (wg_emit > 0) < 2) return;
-  if (c->step_order_key[0] == n_fft && c->step_order_key[1] == wg_det && c->step_order_key[2] == wg_emit) {
-    a.order = c->d_step_order[c->step_order_cur];
-    return;
-  }
+  for (auto& t : c->order_tables)
+    if (t.key[0] == n_fft && t.key[1] == wg_det && t.key[2] == wg_emit) {
+      t.used = ++c->order_clock;
+      a.order = t.d;
+      return;
+    }
   struct Seg {
     int role, count;
   };
@@ -422,8 +489,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a) {
   }
   const int total[4] = {0, n_fft, wg_det, wg_emit};
   int next[4] = {0, 0, 0, 0};
-  const int buf = c->step_order_cur ^ 1;
-  std::vector<uint32_t>& out = c->h_step_order[buf];
+  std::vector<uint32_t> out;
   out.clear();
   const auto place = [&](const Seg& sg) {
     for (int k = 0; k < sg.count && next[sg.role] < total[sg.role]; ++k) out.push_back((uint32_t)sg.role << 24 | (uint32_t)next[sg.role]++);
@@ -439,20 +505,40 @@ void step_order(ss_ctx* c, ss::StepArgs& a) {
       place(Seg{ss::ROLE_EMIT, 1 << 27});
     }
   }
-  if (hipMemcpyAsync(c->d_step_order[buf], out.data(), sizeof(uint32_t) * out.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess) return;
-  c->step_order_cur = buf;
-  c->step_order_key[0] = n_fft;
-  c->step_order_key[1] = wg_det;
-  c->step_order_key[2] = wg_emit;
-  a.order = c->d_step_order[buf];
+  // A new shape: a table of its own, copied synchronously — launches of other shapes, on any of the context's streams, keep
+  // theirs, and every later launch sees this one complete. Shapes are few (steady state, pipeline fill, drain); when the
+  // cache is full the least recently used table is recycled after everything in flight has finished.
+  if (out.size() > c->order_capacity) return;  // (capacity is sized from max_batch; launch_step then runs the roles one after the other)
+  ss_ctx::OrderTable* slot = nullptr;
+  if (c->order_tables.size() < 8) {
+    ss_ctx::OrderTable t{};
+    if (hipMalloc(&t.d, sizeof(uint32_t) * c->order_capacity) != hipSuccess) return;
+    c->order_tables.push_back(t);
+    slot = &c->order_tables.back();
+  } else {
+    for (hipStream_t q : {c->s_ab[0], c->s_ab[1], c->stream})
+      if (q) (void)hipStreamSynchronize(q);
+    slot = &c->order_tables[0];
+    for (auto& t : c->order_tables)
+      if (t.used < slot->used) slot = &t;
+  }
+  if (hipMemcpy(slot->d, out.data(), sizeof(uint32_t) * out.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    slot->key[0] = -1;
+    return;
+  }
+  slot->key[0] = n_fft;
+  slot->key[1] = wg_det;
+  slot->key[2] = wg_emit;
+  slot->used = ++c->order_clock;
+  a.order = slot->d;
 }
 
 template <int FMT, bool SPEC>
-void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEvent_t e1) {
+void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEvent_t e1, hipStream_t stream) {
   const dim3 grid((unsigned)ss::step_items(a)), block(ss::kStepThreads);
   auto go = [&](auto kernel) {
-    if (e0) hipExtLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, c->stream, e0, e1, 0, a);
-    else hipLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, c->stream, a);
+    if (e0) hipExtLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, stream, e0, e1, 0, a);
+    else hipLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, stream, a);
   };
   if (!c->use_fft8192) return a.emit_per_wg == 1 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 2>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 1>);
 #ifdef SS_DIAG
@@ -469,17 +555,24 @@ struct FftRole {
   const ss::Fft8192Args* frames = nullptr;
   const ss::ColsArgs* cols = nullptr;
   int n = 0;  // frames / column tiles
+  const void* halo_iq = nullptr;  // deep pipelining: n_halo frames of the previous call go through the FFT again, into halo_psd
+  float* halo_psd = nullptr;
+  int n_halo = 0;
 };
 
 // fft / det / emit: null = role absent. Start/stop events ride on launches that carry an FFT role (the dominant work).
-void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n_det_tiles, bool spec, const ss::EmitArgs* emit) {
+void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n_det_tiles, bool spec, const ss::EmitArgs* emit, hipStream_t stream = nullptr) {
+  if (!stream) stream = c->stream;
   ss::StepArgs a{};
   a.fft_per_wg = 1;
   a.emit_per_wg = (!c->use_fft8192 && c->diag.emit_wide && c->n / 32 >= 2048) ? 1 : 8;
   if (fft && fft->frames) {
-    const int n_fft = fft->n;
+    const int n_fft = fft->n + fft->n_halo;
     a.fft = *fft->frames;
     a.n_fft = n_fft;
+    a.halo_iq = fft->halo_iq;
+    a.halo_psd = fft->halo_psd;
+    a.n_halo = fft->n_halo;
     // with other roles in the launch the FFT role keeps to two of every CU's four workgroup slots (scan_step.h)
     if (c->diag.fft_per_wg > 0) a.fft_per_wg = c->diag.fft_per_wg;
     else if (c->diag.fft_per_wg < 0 && (det || emit)) a.fft_per_wg = std::max(1, (n_fft + 2 * c->n_cus - 1) / (2 * c->n_cus));
@@ -496,7 +589,14 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
     a.n_emit = emit->nframes;
   }
   if (ss::step_items(a) == 0) return;
-  step_order(c, a);
+  step_order(c, a, stream);
+  if (!a.order && (fft != nullptr) + (det != nullptr) + (emit != nullptr) > 1) {
+    // no order table to be had (out of device memory): the roles one launch after the other, oldest call first
+    if (emit) launch_step(c, nullptr, nullptr, 0, false, emit, stream);
+    if (det) launch_step(c, nullptr, det, n_det_tiles, spec, nullptr, stream);
+    if (fft) launch_step(c, fft, nullptr, 0, false, nullptr, stream);
+    return;
+  }
 #ifdef SS_DIAG
   bool dump_stamps = false;
   if (!c->diag.stamp_path.empty() && fft && det && emit && ss::step_items(a) <= 4096 && a.n_det <= 4096) {
@@ -512,15 +612,15 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   if (fft && !prof_pair(c, &e0, &e1)) e0 = e1 = nullptr;
   const bool sp = spec && det;
   switch (c->cfg.in_format) {
-    case SS_FMT_CF32: sp ? launch_step_variant<ss::FMT_CF32, true>(c, a, e0, e1) : launch_step_variant<ss::FMT_CF32, false>(c, a, e0, e1); break;
-    case SS_FMT_CS8: sp ? launch_step_variant<ss::FMT_CS8, true>(c, a, e0, e1) : launch_step_variant<ss::FMT_CS8, false>(c, a, e0, e1); break;
-    default: sp ? launch_step_variant<ss::FMT_CU8, true>(c, a, e0, e1) : launch_step_variant<ss::FMT_CU8, false>(c, a, e0, e1); break;
+    case SS_FMT_CF32: sp ? launch_step_variant<ss::FMT_CF32, true>(c, a, e0, e1, stream) : launch_step_variant<ss::FMT_CF32, false>(c, a, e0, e1, stream); break;
+    case SS_FMT_CS8: sp ? launch_step_variant<ss::FMT_CS8, true>(c, a, e0, e1, stream) : launch_step_variant<ss::FMT_CS8, false>(c, a, e0, e1, stream); break;
+    default: sp ? launch_step_variant<ss::FMT_CU8, true>(c, a, e0, e1, stream) : launch_step_variant<ss::FMT_CU8, false>(c, a, e0, e1, stream); break;
   }
 #ifdef SS_DIAG
   if (dump_stamps) {
     const int wgs = ss::step_items(a);
     std::vector<long long> h((size_t)4 * wgs);  // (wgs <= 4096 here)
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(stream);
     (void)hipMemcpy(h.data(), c->diag.d_stamps, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
     if (FILE* fp = fopen(c->diag.stamp_path.c_str(), "w")) {
       for (int b = 0; b < wgs; ++b)
@@ -549,8 +649,55 @@ ss::Fft8192Args fft8192_args(ss_ctx* c, const void* d_iq, long long item_stride,
   return g;
 }
 
+// Deep pipelining: the stages still owed, then the public stream waits for both side streams. Each stage goes to the queue
+// its launch would have used (detect(j) behind launch j, emit(j) behind detect(j): the parity of `ready`), so the two queues
+// drain side by side; a detect stage that reads the ring (the first of an overlapped run) has its successor wait, so then —
+// and after a call that did not overlap at all — everything runs in order on the public stream instead.
+void drain_deep(ss_ctx* c) {
+  bool in_order = c->deep_L == 0;
+  for (const auto& d : c->pd) in_order = in_order || d.a.halo_psd == nullptr;
+  const auto join = [&]() {
+    for (int q = 0; q < 2; ++q) {
+      (void)hipEventRecord(c->ev_join[q], c->s_ab[q]);
+      (void)hipStreamWaitEvent(c->stream, c->ev_join[q], 0);
+    }
+  };
+  if (in_order && c->deep_L > 0) join();
+  for (int parity = 0; parity < (in_order ? 1 : 2); ++parity) {
+    hipStream_t q = in_order ? c->stream : c->s_ab[parity];
+    const auto mine = [&](long ready) { return in_order || (int)(ready & 1) == parity; };
+    for (;;) {
+      auto d = c->pd.begin();
+      while (d != c->pd.end() && !mine(d->ready)) ++d;
+      auto e = c->pe.begin();
+      while (e != c->pe.end() && !mine(e->ready)) ++e;  // (an emit stage in the queue belongs to a detect stage launched earlier)
+      const bool has_det = d != c->pd.end(), has_emit = e != c->pe.end();
+      if (!has_det && !has_emit) break;
+      ss_ctx::PendDet dd{};
+      ss_ctx::PendEmit ee{};
+      if (has_det) {
+        dd = *d;
+        c->pd.erase(d);
+      }
+      if (has_emit) {
+        ee = *e;
+        c->pe.erase(e);
+      }
+      launch_step(c, nullptr, has_det ? &dd.a : nullptr, dd.tiles, false, has_emit ? &ee.a : nullptr, q);
+      if (has_det) c->pe.push_back(ss_ctx::PendEmit{dd.emit, dd.ready});
+    }
+  }
+  if (!in_order) join();
+  c->deep_L = 0;
+  c->deep_barrier = -10;
+  c->deep_prev_ok = false;  // after a drain the caller may reuse its planes: the next call takes its rows from the ring
+  c->deep_buffers.clear();
+  c->deep_events_from = 0;
+}
+
 // Drain the deferred stages: detect (+ the emit stage before it), then the last emit. Nothing is synchronised.
 void flush_stages(ss_ctx* c) {
+  if (c->deep) return drain_deep(c);
   while (c->have_det || c->have_emit) {
     launch_step(c, nullptr, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     c->have_emit = c->have_det;
@@ -710,7 +857,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   if (nframes < H) next_start = c->hist_start + nframes;  // old rows [nframes, H) stay where they are, new ones land behind them
   else next_start = c->hist_start >= H ? 0 : c->hist_start + H;  // a whole new window, clear of the one being read
   float* hist_out = c->d_hist + (size_t)next_start * n;
-  const int cur = c->cnt_cur, clr = (c->cnt_cur + 2) % 3;
+  const int cur = c->cnt_cur, clr = (c->cnt_cur + c->ncnt - c->lag) % c->ncnt;
   int* counts = c->d_cnt3[cur];
   const int b = c->buf_cur;
   const bool keep_planes = (c->cfg.flags & SS_FLAG_KEEP_PLANES) != 0;
@@ -757,14 +904,15 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   ea.clear_n = c->cnt_frames[clr];
   ea.avg = avg_full ? avg_full : c->d_avg2[b];
   ea.cap = cand_cap;
-  ea.off_int = c->d_off;
+  ea.off_int = c->d_off4[b];
+  c->d_off = c->d_off4[b];
   ea.off_out = d_cand_off;
   ea.cand_idx = (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr;
   ea.cand_avg = d_cand_avg;
   c->cnt_frames[cur] = nframes;  // this buffer now holds nframes counts (read by the emit stage, zeroed two batches on)
   c->cnt_frames[clr] = 0;
-  c->cnt_cur = (cur + 1) % 3;
-  c->buf_cur = b ^ 1;
+  c->cnt_cur = (cur + 1) % c->ncnt;
+  c->buf_cur = (b + 1) % c->nbuf;
   c->last_avg = ea.avg;
   c->last_hist = hist_in;
   c->hist_start = next_start;
@@ -830,7 +978,8 @@ int spectrogram_accumulate(ss_ctx* c, SpecState* g, const float* d_psd, int nfra
 // stage of the previous call and the emit stage of the one before (scan_step.h); this call's own detect and emit stages
 // stay deferred until the next call or flush_stages.
 int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int n_learn, NoiseState* z, float* d_psd_out,
-              float* d_rel_out, float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap) {
+              float* d_rel_out, float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap,
+              bool allow_overlap = false) {
   const int G = c->cfg.grouping_y;
   if (c->pass_dirty) {
     flush_stages(c);  // (ss_set_frequency_range drained them already; the mask a deferred stage reads must not change under it)
@@ -840,14 +989,112 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     SS_HIP(c, hipStreamSynchronize(c->stream));  // `pass` is pageable and dies at scope end
     c->pass_dirty = false;
   }
-  float* d_psd = d_psd_out ? d_psd_out : c->d_psd2[c->buf_cur];
+  float* d_psd = d_psd_out ? d_psd_out : c->d_psd2[c->psd_cur];
+  if (!d_psd_out) c->psd_cur = (c->psd_cur + 1) % c->npsd;
   int st = SS_OK;
   SpecState* spec = nullptr;
   if (c->spec_n > 0) {
     spec = spectrogram_container(c);
     if (!spec) return fail(c, SS_ERR_NOMEM, "spectrogram container");
   }
-  if (c->step_path) {
+  if (c->deep) {
+    const ss::Fft8192Args g = fft8192_args(c, d_iq, item_stride, d_psd);
+    FftRole role;
+    role.frames = &g;
+    role.n = nframes;
+    const bool overlap = allow_overlap && c->diag.pipeline && n_learn == 0 && nframes >= kHistRows;
+    const size_t plane_bytes = sizeof(float) * (size_t)nframes * (size_t)c->n;
+    const auto clash = [](const void* a, size_t abytes, const void* b, size_t bbytes) {
+      const char *pa = static_cast<const char*>(a), *pb = static_cast<const char*>(b);
+      return a && b && abytes && bbytes && pa < pb + bbytes && pb < pa + abytes;
+    };
+    ss_ctx::Buffers mine{{d_psd_out, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg},
+                         {plane_bytes, plane_bytes, plane_bytes, sizeof(int32_t) * ((size_t)nframes + 1), sizeof(int32_t) * (size_t)cand_cap, sizeof(float) * (size_t)cand_cap},
+                         0};
+    // how this call's launches relate to the stages of earlier calls that touch the same buffers (ss_ctx::Buffers)
+    bool must_drain = !overlap, wait_other_queue = false;
+    if (overlap) {
+      const long L = c->deep_L;
+      for (const auto& b : c->deep_buffers)
+        for (int x = 0; x < 6 && !must_drain; ++x)
+          for (int y = 0; y < 6 && !must_drain; ++y)
+            if (clash(mine.p[x], mine.bytes[x], b.p[y], b.bytes[y])) {
+              const long last = b.launch + (y < 2 ? 2 : 4);  // the last launch that touches b.p[y]
+              if (last > L - 2) must_drain = true;                      // too close: not even stream order helps
+              else if (((L - last) & 1) == 0) continue;                 // same queue, earlier: stream order
+              else if (c->deep_events && L - 3 >= c->deep_events_from) wait_other_queue = true;  // (last <= L - 3: the other queue's launch L - 3 is at or behind it)
+              else must_drain = true;
+              if (((L - last) & 1) != 0) c->deep_events = true;         // a caller rotating an odd number of sets: keep events from now on
+            }
+    }
+    if (must_drain) flush_stages(c);
+    hipStream_t q = c->stream;
+    ss_ctx::PendDet d{};
+    ss_ctx::PendEmit e{};
+    bool has_det = false, has_emit = false;
+    long L = -1;
+    if (overlap) {
+      L = c->deep_L++;
+      q = c->s_ab[L & 1];
+      // whatever the public stream holds (the caller's producers, a drain, a learning call) comes first
+      if (L < 2 || hipStreamQuery(c->stream) != hipSuccess) {
+        hipEvent_t ev = c->ev_in[c->deep_forks++ & 3];
+        SS_HIP(c, hipEventRecord(ev, c->stream));
+        SS_HIP(c, hipStreamWaitEvent(q, ev, 0));
+      }
+      // The two queues never wait for each other otherwise, so nothing bounds how far one may run ahead: once in sixteen
+      // launches each waits for the other's launch three back. Whatever a launch older than kDeepHorizon touched is then
+      // finished for both queues, and the buffers of older calls need no tracking.
+      const int phase = (int)(L & 15);
+      if ((wait_other_queue && !must_drain) || (L >= 3 && (phase == 0 || phase == 1))) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 3) & 7], 0));
+      if (c->deep_barrier == L - 1) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 1) & 7], 0));  // a detect role that read the ring goes before the next one writes it (once per drain)
+      if (c->deep_prev_ok) {  // this call's detect stage will want the rows before the batch: the previous call's last frames, once more
+        role.n_halo = kHistRows;
+        role.halo_iq = static_cast<const char*>(c->deep_prev_iq) +
+                       (size_t)(c->deep_prev_frames - kHistRows) * (size_t)c->deep_prev_stride * in_bytes_per_sample(c->cfg.in_format);
+        role.halo_psd = c->d_halo[L & 3];
+      }
+      if (!c->pd.empty() && c->pd.front().ready <= L) {
+        d = c->pd.front();
+        c->pd.pop_front();
+        has_det = true;
+      }
+      if (!c->pe.empty() && c->pe.front().ready <= L) {
+        e = c->pe.front();
+        c->pe.pop_front();
+        has_emit = true;
+      }
+    }
+    launch_step(c, &role, has_det ? &d.a : nullptr, d.tiles, false, has_emit ? &e.a : nullptr, q);
+    if (overlap) {
+      const bool ring_reader = has_det && !d.a.halo_psd;
+      if (c->deep_events || ring_reader || (L & 15) == 13 || (L & 15) == 14) SS_HIP(c, hipEventRecord(c->ev_launch[L & 7], q));
+      if (has_det) c->pe.push_back(ss_ctx::PendEmit{d.emit, L + 2});
+      if (ring_reader) c->deep_barrier = L;
+    }
+    if (n_learn > 0) hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
+    ss_ctx::PendDet mine_det{};
+    st = run_backend_fused(c, d_psd, nframes, n_learn, z, nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap, true,
+                           &mine_det.a, &mine_det.tiles, &mine_det.emit);
+    if (st != SS_OK) return st;
+    if (role.n_halo) {
+      mine_det.a.halo_psd = role.halo_psd;
+      mine_det.a.halo_rows = role.n_halo;
+    }
+    mine_det.ready = L + 2;
+    c->pd.push_back(mine_det);
+    if (overlap) {
+      c->deep_prev_ok = true;
+      c->deep_prev_iq = d_iq;
+      c->deep_prev_stride = item_stride;
+      c->deep_prev_frames = nframes;
+      mine.launch = L;
+      c->deep_buffers.push_back(mine);
+      if (c->deep_buffers.size() > (size_t)kDeepHorizon) c->deep_buffers.pop_front();
+    } else {
+      flush_stages(c);
+    }
+  } else if (c->step_path) {
     ss::Fft8192Args g{};
     ss::ColsArgs gc{};
     FftRole role;
@@ -954,7 +1201,17 @@ int get_noise(ss_ctx* c, NoiseState** out) {
 void free_ctx(ss_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device_id);
+  for (hipStream_t q : c->s_ab)
+    if (q) (void)hipStreamSynchronize(q);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (hipStream_t q : c->s_ab)
+    if (q) (void)hipStreamDestroy(q);
+  for (hipEvent_t e : c->ev_launch)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_in)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_join)
+    if (e) (void)hipEventDestroy(e);
   for (auto& z : c->noise) (void)hipFree(z.d_thr);
   for (auto& g : c->spec) (void)hipFree(g.d_sum);
   (void)hipFree(c->d_spec_partial);
@@ -966,15 +1223,14 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_rel);
   (void)hipFree(c->d_tw8v2);
   (void)hipFree(c->diag.d_stamps);
-  (void)hipFree(c->d_step_order[0]);
-  (void)hipFree(c->d_step_order[1]);
+  for (auto& t : c->order_tables) (void)hipFree(t.d);
   (void)hipFree(c->d_hist);
-  for (int k = 0; k < 3; ++k) (void)hipFree(c->d_cnt3[k]);
-  for (int k = 0; k < (c->step_path ? 2 : 1); ++k) {
-    (void)hipFree(c->d_mask2[k]);
-    (void)hipFree(c->d_avg2[k]);
-    (void)hipFree(c->d_psd2[k]);
-  }
+  for (auto p : c->d_cnt3) (void)hipFree(p);
+  for (auto p : c->d_mask2) (void)hipFree(p);
+  for (auto p : c->d_avg2) (void)hipFree(p);
+  for (auto p : c->d_off4) (void)hipFree(p);
+  for (auto p : c->d_psd2) (void)hipFree(p);
+  for (auto p : c->d_halo) (void)hipFree(p);
   (void)hipFree(c->d_relplane);
   (void)hipFree(c->d_hist_tmp);
   (void)hipFree(c->d_avgy);
@@ -987,7 +1243,6 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_spec_part2[0]);
   (void)hipFree(c->d_spec_part2[1]);
   (void)hipFree(c->d_counts);
-  (void)hipFree(c->d_off);
   (void)hipFree(c->d_in);
   (void)hipFree(c->d_cand_idx);
   (void)hipFree(c->d_cand_avg);
@@ -1101,6 +1356,14 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   CREATE_HIP(hipMalloc(&c->d_pass, (size_t)n));
   c->diag.read();
   c->fused = G == 21 && cfg->grouping_x == 21 && cfg->max_batch <= 65536 && !c->diag.backend_unfused;
+  // 8192 points (and the four-step sizes) with the fused back end: stages of consecutive calls overlap (scan_step.h), so
+  // what a deferred stage reads rotates over several buffers; every other configuration uses set 0 only
+  c->step_path = c->fused && !c->diag.fft_generic && (n == 8192 || (n >= 16384 && c->diag.step_long));
+  c->deep = c->step_path && n == 8192 && c->diag.deep && !(cfg->flags & SS_FLAG_SPECTROGRAM) && cfg->max_batch >= kHistRows;
+  c->lag = c->deep ? 2 : 1;
+  c->ncnt = c->deep ? 6 : 3;
+  c->nbuf = c->deep ? 4 : (c->step_path ? 2 : 1);
+  c->npsd = c->deep ? 4 : (c->step_path ? 2 : 1);  // (deep: written by launch L, read by launch L + 2, written again by launch L + 4 on the same queue)
   if (c->fused) {
     {
       // ring capacity: at least three windows (a long batch needs a free one next to the one it reads), more when rows
@@ -1115,7 +1378,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       CREATE_HIP(hipMalloc(&c->d_hist, sizeof(float) * (size_t)n * (size_t)rows));
       CREATE_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(float) * (size_t)n * (size_t)kHistRows, c->stream));  // Averager ctor, averager.cpp:7-12
     }
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < c->ncnt; ++k) {
       CREATE_HIP(hipMalloc(&c->d_cnt3[k], sizeof(int) * (size_t)cfg->max_batch));
       CREATE_HIP(hipMemsetAsync(c->d_cnt3[k], 0, sizeof(int) * (size_t)cfg->max_batch, c->stream));
     }
@@ -1125,28 +1388,28 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipMalloc(&c->d_avgy, plane));
     CREATE_HIP(hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)n * (size_t)(G - 1 + cfg->max_batch), c->stream));
   }
-  // 8192 points with the fused back end: stages of consecutive calls overlap (scan_step.h), so what a deferred stage reads
-  // is doubled; every other configuration uses set 0 only
-  c->step_path = c->fused && !c->diag.fft_generic && (n == 8192 || (n >= 16384 && c->diag.step_long));
-  for (int k = 0; k < (c->step_path ? 2 : 1); ++k) {
-    CREATE_HIP(hipMalloc(&c->d_psd2[k], plane));
+  for (int k = 0; k < c->npsd; ++k) CREATE_HIP(hipMalloc(&c->d_psd2[k], plane));
+  for (int k = 0; k < c->nbuf; ++k) {
     CREATE_HIP(hipMalloc(&c->d_avg2[k], plane));
     CREATE_HIP(hipMalloc(&c->d_mask2[k], sizeof(uint32_t) * (size_t)(n / 32) * (size_t)cfg->max_batch));
+    CREATE_HIP(hipMalloc(&c->d_off4[k], sizeof(int) * ((size_t)cfg->max_batch + 1)));
+  }
+  c->d_off = c->d_off4[0];
+  if (c->deep) {
+    for (auto& q : c->s_ab) CREATE_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    for (auto& h : c->d_halo) CREATE_HIP(hipMalloc(&h, sizeof(float) * (size_t)n * (size_t)kHistRows));
+    for (auto& e : c->ev_launch) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : c->ev_in) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : c->ev_join) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   if (c->step_path) {
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, cfg->device_id));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const size_t max_items = (size_t)cfg->max_batch * (size_t)(n / 8192) + ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256) / 2 + (size_t)cfg->max_batch + 4;
-    for (int k = 0; k < 2; ++k) CREATE_HIP(hipMalloc(&c->d_step_order[k], sizeof(uint32_t) * max_items));
-  }
-  if (!c->step_path) {
-    c->d_psd2[1] = c->d_psd2[0];
-    c->d_avg2[1] = c->d_avg2[0];
-    c->d_mask2[1] = c->d_mask2[0];
+    const size_t max_items = (size_t)(cfg->max_batch + kHistRows) * (size_t)(n / 8192) + ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256) / 2 + (size_t)cfg->max_batch + 4;
+    c->order_capacity = max_items;
   }
   CREATE_HIP(hipMalloc(&c->d_counts, sizeof(int) * (size_t)cfg->max_batch));
-  CREATE_HIP(hipMalloc(&c->d_off, sizeof(int) * ((size_t)cfg->max_batch + 1)));
   if (cfg->flags & SS_FLAG_SPECTROGRAM) {
     // output size rule of the Spectrogram block: min(SPECTROGRAM_MAX_FFT, getFft(fs, SPECTROGRAM_PREFERRED_MAX_STEP)),
     // sources/radio/blocks/spectrogram.cpp:14, config.h:36-37
@@ -1313,6 +1576,7 @@ int ss_kernel_timing_read(ss_ctx* c, double* total_ms, int32_t* launches) {
   if (!c || !total_ms || !launches) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  flush_stages(c);  // (timed launches may sit on the side streams of the deep pipelining)
   SS_HIP(c, hipStreamSynchronize(c->stream));
   double sum = 0.0;
   for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
@@ -1343,7 +1607,7 @@ int ss_process_device(ss_ctx* c, const void* d_iq, int32_t nframes, float* d_psd
   if (st != SS_OK) return st;
   const int n_learn = plan_learning(c, z, nframes, nullptr);
   return run_batch(c, d_iq, (long long)c->n * c->cfg.decim, nframes, n_learn, z, d_psd_db, d_rel_db, d_avg_db, d_cand_off, d_cand_idx,
-                   d_cand_avg, cand_cap);
+                   d_cand_avg, cand_cap, true);
 }
 
 int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, float* psd_db, float* rel_db, float* avg_db,

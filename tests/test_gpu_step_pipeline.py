@@ -86,6 +86,82 @@ def test_overlapped_calls_equal_call_by_call(seed):
         np.testing.assert_array_equal(ra[1], rb[1])
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_long_runs_of_overlapped_calls_equal_call_by_call(seed):
+    """Deep pipelining (specscan.hip): with calls of at least 35 frames and no learning in between, launch L carries FFT(L),
+    detect(L - 2) and emit(L - 4) and launches alternate over two queues; five calls are in flight. Long runs of such calls —
+    sizes that are and are not multiples of the 16-frame tiles, now and then a short call, a flush, a read or a producer on
+    the public stream — against an engine that waits after every call. Plane sets rotate over `sets` buffers: fewer than
+    five make the library drain instead of overlapping; the results are the same bits either way."""
+    import torch
+    rng = np.random.default_rng(9100 + seed)
+    dev = torch.device("cuda:0")
+    fmt = [pkg.abi.SS_FMT_CF32, pkg.abi.SS_FMT_CS8][seed % 2]
+    want_planes = seed % 3 == 1
+    sets = [8, 8, 5, 3, 2, 8][seed]
+    nframes, learn, max_batch = 1400, 20, 128
+    band = pkg.synth.SyntheticBand(N, seed=170 + seed, on_frame=60, off_frame=900, period=1000)
+    iq = band.frames_cf32(nframes) if fmt == pkg.abi.SS_FMT_CF32 else band.frames_cs8(nframes)
+    kw = dict(fft_size=N, decim=1, in_format=fmt, learn_frames=learn, max_batch=max_batch)
+    a, b = pkg.SpectrumEngine(FS, CENTER, **kw), pkg.SpectrumEngine(FS, CENTER, **kw)
+    pub = torch.cuda.ExternalStream(b.stream_handle, device=dev)
+    sizes, pos = [], 0
+    while pos < nframes:
+        s_ = int(min(nframes - pos, rng.choice([35, 37, 48, 64, 99, 128, int(rng.integers(35, 129)), int(rng.integers(35, 129)), int(rng.integers(1, 35))])))
+        sizes.append(s_)
+        pos += s_
+    ring_b = [_device_outputs(torch, dev, max_batch, want_planes) for _ in range(sets)]
+    outs_a = [_device_outputs(torch, dev, max_batch, want_planes) for _ in sizes]
+    torch.cuda.synchronize()  # (torch fills these on ITS stream: they must have landed before an engine writes on its own)
+    snap_b, keep, pos = [], [], 0
+    pending = []  # (call index, set index) whose results of engine B have not been copied out yet
+    def collect():
+        b.sync()
+        for k, j in pending:
+            snap_b.append((k, {key: (v.clone() if v is not None else None) for key, v in ring_b[j].items()}))
+        pending.clear()
+    for k, s_ in enumerate(sizes):
+        chunk = np.ascontiguousarray(iq[pos:pos + s_])
+        host_t = torch.from_numpy(chunk.view(np.float32) if chunk.dtype == np.complex64 else chunk)
+        d_iq = host_t.to(dev)
+        keep.append(d_iq)
+        _call(a, d_iq, s_, outs_a[k])
+        a.sync()
+        what = rng.integers(0, 12)
+        if what == 0:
+            b.flush()
+        elif what == 1:
+            np.testing.assert_array_equal(b.read_noise()[0], a.read_noise()[0])
+        elif what == 2:  # the caller produces this call's input on the public stream: the library's side queues must wait for it
+            d_iq2 = torch.empty_like(d_iq)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(pub):
+                big = torch.ones(1 << 24, device=dev)
+                for _ in range(6):
+                    big = big * 1.0001 + 0.5  # a few hundred microseconds of work ahead of the copy
+                d_iq2.copy_(d_iq)
+            keep.append(d_iq2)
+            keep.append(big)
+            d_iq = d_iq2
+        j = k % sets
+        if any(jj == j for _, jj in pending):  # the caller is about to reuse a set it has not read yet: read first
+            if sets >= 5 or rng.integers(0, 2):
+                collect()
+            else:  # ... or not: the library must notice the reuse itself; only the newest contents of the set can be compared
+                pending[:] = [(kk, jj) for kk, jj in pending if jj != j]
+        _call(b, d_iq, s_, ring_b[j])
+        pending.append((k, j))
+        pos += s_
+    collect()
+    assert len(snap_b) >= len(sizes) // 2
+    total = 0
+    for k, ob in snap_b:
+        s_ = sizes[k]
+        cut = lambda o: {key: (v[:s_] if key in ("psd", "rel", "avg") and v is not None else (v[:s_ + 1] if key == "off" else v)) for key, v in o.items()}
+        total += _same(cut(outs_a[k]), cut(ob), f"call {k} ({s_} frames)")
+    assert total > 2000
+
+
 def test_flush_then_stream_sync_completes_the_results():
     """ss_flush enqueues the deferred stages; after it any synchronisation of the stream (here: of the device) will do."""
     import torch
