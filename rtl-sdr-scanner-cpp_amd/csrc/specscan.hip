@@ -229,6 +229,11 @@ struct ss_ctx {
     long launch;       // the call's FFT launch; its detect stage runs in launch + 2 (last to touch psd / rel), its emit stage in launch + 4
   };
   std::deque<Buffers> deep_buffers;
+  // A caller that waits after every call gains nothing from queues and deferred stages and pays for the fork and the join:
+  // once ss_sync / ss_flush has come after a single call, calls run their three stages in order on the public stream
+  // until two calls arrive without one in between.
+  int deep_calls_since_sync = 0;
+  bool deep_eager = false;
   bool deep_events = false;   // record ev_launch after every launch
   long deep_events_from = 0;  // first launch of this run of launches that has its event
   // k_scan_step's dispatch-order table for the current launch shape (rebuilt when the shape changes; two buffers so that a
@@ -1002,7 +1007,8 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     FftRole role;
     role.frames = &g;
     role.n = nframes;
-    const bool overlap = allow_overlap && c->diag.pipeline && n_learn == 0 && nframes >= kHistRows;
+    if (allow_overlap && ++c->deep_calls_since_sync >= 2) c->deep_eager = false;
+    const bool overlap = allow_overlap && !c->deep_eager && c->diag.pipeline && n_learn == 0 && nframes >= kHistRows;
     const size_t plane_bytes = sizeof(float) * (size_t)nframes * (size_t)c->n;
     const auto clash = [](const void* a, size_t abytes, const void* b, size_t bbytes) {
       const char *pa = static_cast<const char*>(a), *pb = static_cast<const char*>(b);
@@ -1544,10 +1550,18 @@ const char* ss_last_error(const ss_ctx* ctx) { return ctx ? ctx->err : g_create_
 
 void* ss_stream(ss_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+// (ss_ctx::deep_eager) called by ss_flush / ss_sync: did the caller wait after a single call?
+static void note_caller_sync(ss_ctx* c) {
+  if (c->deep_calls_since_sync == 1) c->deep_eager = true;
+  else if (c->deep_calls_since_sync > 1) c->deep_eager = false;
+  c->deep_calls_since_sync = 0;
+}
+
 int ss_flush(ss_ctx* ctx) {
   if (!ctx) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(ctx->mtx);
   SS_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+  note_caller_sync(ctx);
   flush_stages(ctx);
   SS_HIP(ctx, hipGetLastError());
   return SS_OK;
@@ -1557,6 +1571,7 @@ int ss_sync(ss_ctx* ctx) {
   if (!ctx) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(ctx->mtx);
   SS_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+  note_caller_sync(ctx);
   flush_stages(ctx);
   SS_HIP(ctx, stream_wait(ctx->stream));
   return SS_OK;
