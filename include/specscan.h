@@ -136,13 +136,18 @@ int ss_process(ss_ctx* ctx, const void* iq, int32_t nframes, const int64_t* t_ms
  * NOT synchronised: call ss_sync before reading results. n_learn = how many leading frames of this
  * batch belong to the noise-learning phase is decided on the host from learn_frames.
  *
- * Stage pipelining (8192-point frames, 21 x 21 grouping): like the reference's flowgraph, whose blocks each work on a
- * different frame at any moment (sdr_device.cpp:161-171), consecutive calls overlap on the device — the launch of call k
- * carries the FFT + dB stage of call k, the averaging / threshold stage of call k-1 and the candidate-list stage of call
- * k-2 (csrc/scan_step.h). The results of a call are therefore complete only after ss_sync, or after ss_flush followed by
- * any synchronisation of ss_stream; every buffer passed to a call (d_iq included) must stay valid and untouched until
- * then. Results are bit-identical to running the three stages back to back. The host-buffer entry points (ss_process,
- * ss_feed_*) and every call that reads or changes state (ss_set_frequency_range, ss_reset, ss_reset_noise,
+ * Stage pipelining (8192-point frames and 16384 points upwards, 21 x 21 grouping): like the reference's flowgraph, whose
+ * blocks each work on a different frame at any moment (sdr_device.cpp:161-171), consecutive calls overlap on the device —
+ * a launch carries the FFT + dB stage of one call and the averaging / threshold and candidate-list stages of earlier calls
+ * (csrc/scan_step.h); for 8192-point frames up to five calls are in flight, on two hardware queues of the library's own
+ * (ss_ctx::deep in csrc/specscan.hip). The results of a call are therefore complete only after ss_sync, or after ss_flush
+ * followed by any synchronisation of ss_stream; every buffer passed to a call (d_iq included) must stay valid and
+ * untouched until then. Work the caller has enqueued on ss_stream before a call (a producer of d_iq) is waited for.
+ * Handing a plane or candidate buffer to a later call again without ss_sync in between is safe — the library orders the
+ * stages that touch it, draining its pipeline first where it has to — and costs nothing when the output sets rotate with
+ * an even period of at least six calls (four for the PSD / rel planes alone); of course only the newest contents can be
+ * read afterwards. Results are bit-identical to running the three stages back to back. The host-buffer entry points
+ * (ss_process, ss_feed_*) and every call that reads or changes state (ss_set_frequency_range, ss_reset, ss_reset_noise,
  * ss_read_window, ss_read_noise, ss_spectrogram_read) drain the deferred stages themselves. */
 int ss_process_device(ss_ctx* ctx, const void* d_iq, int32_t nframes,
                       float* d_psd_db, float* d_rel_db, float* d_avg_db,
