@@ -202,7 +202,11 @@ struct ss_ctx {
   const void* deep_prev_iq = nullptr;  // the previous call's frames (caller's buffer: untouched until ss_sync by contract)
   long long deep_prev_stride = 0;
   long deep_L = 0;             // launches since the last drain
-  long deep_barrier = -10;     // a launch whose detect role read the ring: the next launch waits for it
+  long deep_barrier = -10;     // a launch whose detect role read the ring: the next launch waits for it (only when the ring is short, see deep_ring_safe)
+  // Detect stages write their batch's newest rows to the ring window after the current one, windows rotating through the
+  // whole ring. With more windows than launches can be in flight (kDeepHorizon), the window a ring-reading detect stage
+  // reads — the first of an overlapped run — is not written again while it runs, and nobody has to wait for it.
+  bool deep_ring_safe = false;
   unsigned deep_forks = 0;
   struct PendDet {
     ss::DetectArgs a;
@@ -660,7 +664,7 @@ ss::Fft8192Args fft8192_args(ss_ctx* c, const void* d_iq, long long item_stride,
 // and after a call that did not overlap at all — everything runs in order on the public stream instead.
 void drain_deep(ss_ctx* c) {
   bool in_order = c->deep_L == 0;
-  for (const auto& d : c->pd) in_order = in_order || d.a.halo_psd == nullptr;
+  for (const auto& d : c->pd) in_order = in_order || (d.a.halo_psd == nullptr && !c->deep_ring_safe);
   const auto join = [&]() {
     for (int q = 0; q < 2; ++q) {
       (void)hipEventRecord(c->ev_join[q], c->s_ab[q]);
@@ -860,7 +864,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   const float* hist_in = c->d_hist + (size_t)c->hist_start * n;
   int next_start;
   if (nframes < H) next_start = c->hist_start + nframes;  // old rows [nframes, H) stay where they are, new ones land behind them
-  else next_start = c->hist_start >= H ? 0 : c->hist_start + H;  // a whole new window, clear of the one being read
+  else next_start = c->hist_start + 2 * H <= c->hist_rows ? c->hist_start + H : 0;  // a whole new window, clear of the one being read (the ring holds at least three)
   float* hist_out = c->d_hist + (size_t)next_start * n;
   const int cur = c->cnt_cur, clr = (c->cnt_cur + c->ncnt - c->lag) % c->ncnt;
   int* counts = c->d_cnt3[cur];
@@ -1073,7 +1077,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     }
     launch_step(c, &role, has_det ? &d.a : nullptr, d.tiles, false, has_emit ? &e.a : nullptr, q);
     if (overlap) {
-      const bool ring_reader = has_det && !d.a.halo_psd;
+      const bool ring_reader = has_det && !d.a.halo_psd && !c->deep_ring_safe;
       if (c->deep_events || ring_reader || (L & 15) == 13 || (L & 15) == 14) SS_HIP(c, hipEventRecord(c->ev_launch[L & 7], q));
       if (has_det) c->pe.push_back(ss_ctx::PendEmit{d.emit, L + 2});
       if (ring_reader) c->deep_barrier = L;
@@ -1402,6 +1406,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   }
   c->d_off = c->d_off4[0];
   if (c->deep) {
+    c->deep_ring_safe = c->hist_rows / kHistRows >= kDeepHorizon + 2;
     for (auto& q : c->s_ab) CREATE_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
     for (auto& h : c->d_halo) CREATE_HIP(hipMalloc(&h, sizeof(float) * (size_t)n * (size_t)kHistRows));
     for (auto& e : c->ev_launch) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -2,6 +2,8 @@
 call k, the averaging / threshold stage of call k-1 and the candidate-list stage of call k-2. Results must be those of the
 stages run back to back — bit for bit, whatever the call sizes, through learning, retunes, resets and reads in between.
 Needs an MI355X: run with -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -86,7 +88,7 @@ def test_overlapped_calls_equal_call_by_call(seed):
         np.testing.assert_array_equal(ra[1], rb[1])
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SS_TEST_DEEP_SEEDS", "6"))))
 def test_long_runs_of_overlapped_calls_equal_call_by_call(seed):
     """Deep pipelining (specscan.hip): with calls of at least 35 frames and no learning in between, launch L carries FFT(L),
     detect(L - 2) and emit(L - 4) and launches alternate over two queues; five calls are in flight. Long runs of such calls —
@@ -98,7 +100,7 @@ def test_long_runs_of_overlapped_calls_equal_call_by_call(seed):
     dev = torch.device("cuda:0")
     fmt = [pkg.abi.SS_FMT_CF32, pkg.abi.SS_FMT_CS8][seed % 2]
     want_planes = seed % 3 == 1
-    sets = [8, 8, 5, 3, 2, 8][seed]
+    sets = [8, 8, 5, 3, 2, 8, 6, 4, 7][seed % 9]
     nframes, learn, max_batch = 1400, 20, 128
     band = pkg.synth.SyntheticBand(N, seed=170 + seed, on_frame=60, off_frame=900, period=1000)
     iq = band.frames_cf32(nframes) if fmt == pkg.abi.SS_FMT_CF32 else band.frames_cs8(nframes)
@@ -130,7 +132,7 @@ def test_long_runs_of_overlapped_calls_equal_call_by_call(seed):
         what = rng.integers(0, 12)
         if what == 0:
             b.flush()
-        elif what == 1:
+        elif what == 1 and k > 0:  # (engine A is one call ahead here: equal once the learning call is behind both)
             np.testing.assert_array_equal(b.read_noise()[0], a.read_noise()[0])
         elif what == 2:  # the caller produces this call's input on the public stream: the library's side queues must wait for it
             d_iq2 = torch.empty_like(d_iq)
