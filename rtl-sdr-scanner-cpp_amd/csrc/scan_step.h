@@ -11,13 +11,20 @@
 //     FFT+dB(k)  ->  detect(k)  ->  emit(k)            and            detect(k-1) -> detect(k)   (the averager ring)
 //
 // so FFT+dB(k), detect(k-1) and emit(k-2) are independent of each other. k_scan_step carries all three as ROLES of one
-// launch: every workgroup takes one work item — one frame of call k through the FFT, two 16-frame x 256-bin detect tiles
-// of call k-1, or the candidate lists of eight frames of call k-2 — and whatever one role leaves idle (the FFT role's
+// launch: every workgroup takes one work item — one frame through the FFT, two 16-frame x 256-bin detect tiles of an earlier
+// call, or the candidate lists of eight frames of a still earlier one — and whatever one role leaves idle (the FFT role's
 // wait for HBM, the detect role's dependence on L2 latency) the others use. No workgroup ever waits for another: all
 // dependencies are launch boundaries, so there is nothing to spin on and nothing to deadlock. The host side (specscan.hip)
-// keeps the deferred stages' arguments and drains them — two more launches with the finished roles empty — whenever a
-// result is asked for (ss_sync, ss_flush, the host-buffer entry points, retunes and resets): results are exactly those of
-// the three-launch chain, bit for bit, because every role runs the same code on the same data.
+// keeps the deferred stages' arguments and drains them — launches with the finished roles empty — whenever a result is
+// asked for (ss_sync, ss_flush, the host-buffer entry points, retunes and resets): results are exactly those of the
+// three-launch chain, bit for bit, because every role runs the same code on the same data.
+//
+// Which calls share a launch is the host's choice. In order on one stream: FFT(k), detect(k-1), emit(k-2) — launch k + 1
+// depends on launch k, so each launch runs its ramp and its tail alone. Deep pipelining (8192 points, ss_ctx::deep):
+// FFT(L), detect(L-2), emit(L-4), launches alternating over two hardware queues; the rows detect(L) needs from before its
+// batch — which detect(L-1) would write to the ring one launch earlier — launch L's FFT role produces itself by
+// transforming the previous call's last frames once more (StepArgs::halo_*). Adjacent launches then have nothing to do
+// with each other and fill each other's ramps and tails.
 //
 // Transforms of 16384 points and more are four-step (fft256_kernels.h): their column half — tiles of 32 columns x 256 rows,
 // one per 512-thread workgroup — takes the FFT role's place (KIND 1, 2), the row half follows as a launch of its own, and
