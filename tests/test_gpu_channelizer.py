@@ -209,6 +209,7 @@ def test_device_entry_point_and_counts():
     d_iq = torch.from_numpy(x.view(np.float32).copy()).to(dev)
     d_i8 = torch.zeros((3, cap, 2), dtype=torch.int8, device=dev)
     d_cf = torch.zeros((3, cap, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()  # (torch's fills run on torch's stream, the library writes from its own)
     counts = ch.process_device(d_iq, n, d_i8, d_cf, cap)
     ch.sync()
     assert list(counts) == [0, 0, n // 64]

@@ -155,6 +155,7 @@ def test_entry_points_agree(seed):
         d_off = torch.zeros(s_ + 1, dtype=torch.int32, device=dev)
         d_idx = torch.zeros(s_ * n, dtype=torch.int32, device=dev)
         d_cav = torch.zeros(s_ * n, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()  # (torch's fills run on torch's stream, the library writes from its own)
         devc.process_device(d_iq, s_, psd=d_psd, avg=d_avg, cand_off=d_off, cand_idx=d_idx, cand_avg=d_cav)
         devc.sync()
         off = d_off.cpu().numpy()

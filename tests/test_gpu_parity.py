@@ -291,6 +291,7 @@ def test_device_resident_entry_point_matches_host_entry_point():
     cap = 100 * n
     idx = torch.empty(cap, dtype=torch.int32, device=dev)
     cav = torch.empty(cap, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()  # (torch's fills run on torch's stream, the library writes from its own)
     torch.cuda.synchronize()
     eng.process_device(d_iq, 100, *planes, off, idx, cav)
     eng.sync()

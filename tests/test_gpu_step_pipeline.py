@@ -15,6 +15,8 @@ N, FS, CENTER = 8192, 2_048_000, 145_000_000
 
 
 def _device_outputs(torch, dev, s_, want_planes):
+    """Result buffers pre-filled with values no result can have. torch fills them on its own stream: callers synchronise the
+    device once after creating them, before an engine (which has its own streams) is asked to write there."""
     o = dict(psd=torch.full((s_, N), -7.0, dtype=torch.float32, device=dev), off=torch.full((s_ + 1,), -1, dtype=torch.int32, device=dev),
              idx=torch.full((s_ * 512,), -1, dtype=torch.int32, device=dev), cav=torch.full((s_ * 512,), -7.0, dtype=torch.float32, device=dev))
     o["rel"] = torch.full((s_, N), -7.0, dtype=torch.float32, device=dev) if want_planes else None
@@ -59,7 +61,10 @@ def test_overlapped_calls_equal_call_by_call(seed):
         sizes.append(s_)
         pos += s_
     retune_at, reset_at = len(sizes) // 3, 2 * len(sizes) // 3
-    outs_a, outs_b, keep, pos = [], [], [], 0
+    outs_a = [_device_outputs(torch, dev, s_, want_planes) for s_ in sizes]
+    outs_b = [_device_outputs(torch, dev, s_, want_planes) for s_ in sizes]
+    torch.cuda.synchronize()  # (torch fills these on ITS stream: they must have landed before an engine writes on its own)
+    keep, pos = [], 0
     for k, s_ in enumerate(sizes):
         if k == retune_at:  # SdrDevice::setFrequencyRange: new centre, buffers reset, noise learned afresh there
             for e in (a, b):
@@ -71,12 +76,9 @@ def test_overlapped_calls_equal_call_by_call(seed):
         chunk = iq[pos:pos + s_]
         d_iq = torch.from_numpy(np.ascontiguousarray(chunk).view(np.float32) if chunk.dtype == np.complex64 else np.ascontiguousarray(chunk)).to(dev)
         keep.append(d_iq)  # inputs stay untouched until the final sync
-        oa, ob = _device_outputs(torch, dev, s_, want_planes), _device_outputs(torch, dev, s_, want_planes)
-        _call(a, d_iq, s_, oa)
+        _call(a, d_iq, s_, outs_a[k])
         a.sync()
-        _call(b, d_iq, s_, ob)
-        outs_a.append(oa)
-        outs_b.append(ob)
+        _call(b, d_iq, s_, outs_b[k])
         pos += s_
     b.sync()
     total = sum(_same(oa, ob, f"call {k} ({sizes[k]} frames)") for k, (oa, ob) in enumerate(zip(outs_a, outs_b)))
@@ -178,6 +180,7 @@ def test_flush_then_stream_sync_completes_the_results():
         d_iq = torch.from_numpy(iq[64 * k:64 * k + 64].view(np.float32).copy()).to(dev)
         keep.append(d_iq)
         o = _device_outputs(torch, dev, 64, False)
+        torch.cuda.synchronize()
         _call(eng, d_iq, 64, o)
         outs.append(o)
     assert int(outs[2]["off"][0]) == -1  # (the last call's candidate stage has not even been launched yet)
@@ -209,6 +212,7 @@ def test_reads_between_overlapped_calls_see_finished_state():
         d_iq = torch.from_numpy(chunk.view(np.float32).copy()).to(dev)
         keep.append(d_iq)
         o = _device_outputs(torch, dev, 32, False)
+        torch.cuda.synchronize()
         _call(eng, d_iq, 32, o)
         keep.append(o)
         if k >= 2:
@@ -229,6 +233,7 @@ def test_caller_reusing_its_planes_every_call_is_safe():
     host = pkg.SpectrumEngine(FS, CENTER, **kw)
     eng = pkg.SpectrumEngine(FS, CENTER, **kw)
     o = _device_outputs(torch, dev, 64, True)
+    torch.cuda.synchronize()
     keep = []
     for k in range(5):
         chunk = iq[64 * k:64 * k + 64]
@@ -274,6 +279,7 @@ def test_other_sizes_asynchronous_calls_equal_call_by_call(n, fs, max_batch, fmt
             return dict(psd=torch.full((s_, n), -7.0, dtype=torch.float32, device=dev), off=torch.full((s_ + 1,), -1, dtype=torch.int32, device=dev),
                         idx=torch.full((s_ * 2048,), -1, dtype=torch.int32, device=dev), cav=torch.full((s_ * 2048,), -7.0, dtype=torch.float32, device=dev), rel=None, avg=None)
         oa, ob = outputs(), outputs()
+        torch.cuda.synchronize()  # (torch's fills first: the engines write from their own streams)
         _call(a, d_iq, s_, oa)
         a.sync()
         _call(b, d_iq, s_, ob)
