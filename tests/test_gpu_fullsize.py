@@ -87,3 +87,38 @@ def test_frame_range_sharding_equals_single_rank():
     assert len(got) == nframes
     for f in range(nframes):
         np.testing.assert_array_equal(got[f], single[f], err_msg=f"frame {f}")
+
+
+def test_full_size_calls_in_flight_equal_call_by_call():
+    """The headline shape through the device entry point, the way bench.py drives it: six 1024-frame calls without a
+    synchronisation in between (deep pipelining: launches of consecutive calls overlap on two queues, five calls in flight)
+    against the same frames call by call through the host entry point. Same bits: PSD plane, offsets, candidate lists."""
+    import torch
+    dev = torch.device("cuda:0")
+    ncalls, learn = 6, 100
+    band = pkg.synth.SyntheticBand(N, seed=35, on_frame=300, off_frame=5000, period=5600)
+    kw = dict(fft_size=N, decim=1, learn_frames=learn, max_batch=B)
+    ref, eng = pkg.SpectrumEngine(FS, CENTER, **kw), pkg.SpectrumEngine(FS, CENTER, **kw)
+    d_iq, outs, want = [], [], []
+    for k in range(ncalls):
+        chunk = band.frames_cf32(B)
+        want.append(ref.process(chunk, want=("psd",)))
+        d_iq.append(torch.from_numpy(chunk.view(np.float32)).to(dev))
+        outs.append(dict(psd=torch.empty((B, N), dtype=torch.float32, device=dev), off=torch.full((B + 1,), -1, dtype=torch.int32, device=dev),
+                         idx=torch.empty(B * 512, dtype=torch.int32, device=dev), cav=torch.empty(B * 512, dtype=torch.float32, device=dev)))
+    torch.cuda.synchronize()
+    for k in range(ncalls):
+        o = outs[k]
+        eng.process_device(d_iq[k], B, psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["cav"])
+    assert int(outs[ncalls - 1]["off"][-1]) == -1  # (nothing of the last call's candidate stage has run yet)
+    eng.sync()
+    total = 0
+    for k in range(ncalls):
+        o, w = outs[k], want[k]
+        np.testing.assert_array_equal(o["off"].cpu().numpy(), w["cand_off"], err_msg=f"call {k}")
+        t = int(w["cand_off"][-1])
+        np.testing.assert_array_equal(o["idx"][:t].cpu().numpy(), w["cand_idx"], err_msg=f"call {k}")
+        np.testing.assert_array_equal(o["cav"][:t].cpu().numpy(), w["cand_avg"], err_msg=f"call {k}")
+        np.testing.assert_array_equal(o["psd"].cpu().numpy(), w["psd"], err_msg=f"call {k}")
+        total += t
+    assert total > 100_000
