@@ -7,6 +7,7 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -34,8 +35,11 @@ thread_local char g_create_err[512] = "";
 // fused back end (grouping 21 x 21): frames per tile, and the ring rows kept between batches
 constexpr int kFusedTF = 16;
 // Deep pipelining (ss_ctx::deep): a call's last stage runs four launches after its first; the two queues synchronise once in
-// sixteen launches on the launch three back: everything launched more than 4 + 16 + 3 launches ago has finished.
-constexpr int kDeepHorizon = 24;
+// kDeepSyncPeriod launches on the launch three back (a wait costs ~10 us of queue time: rarely, and not within the first 32
+// launches of a run): everything launched more than 4 + kDeepSyncPeriod + 3 launches ago has finished.
+constexpr int kDeepSyncPeriod = 64;
+constexpr int kDeepSyncPhase = 32;
+constexpr int kDeepHorizon = 4 + kDeepSyncPeriod + 3 + 1;
 constexpr int kHistRows = ss::DetectTile<21, 21, kFusedTF, 256>::H;  // 35
 
 struct SpecState {  // Spectrogram::Container, sources/radio/blocks/spectrogram.h:10-16, one per centre frequency
@@ -204,8 +208,9 @@ struct ss_ctx {
   long deep_L = 0;             // launches since the last drain
   long deep_barrier = -10;     // a launch whose detect role read the ring: the next launch waits for it (only when the ring is short, see deep_ring_safe)
   // Detect stages write their batch's newest rows to the ring window after the current one, windows rotating through the
-  // whole ring. With more windows than launches can be in flight (kDeepHorizon), the window a ring-reading detect stage
-  // reads — the first of an overlapped run — is not written again while it runs, and nobody has to wait for it.
+  // whole ring. A ring-reading detect stage — the first of an overlapped run, launch 2 — is finished for both queues by
+  // the run's first synchronisation (launch kDeepSyncPhase): with more windows than that, the window it reads is not
+  // written again while it runs, and nobody has to wait for it.
   bool deep_ring_safe = false;
   unsigned deep_forks = 0;
   struct PendDet {
@@ -231,6 +236,7 @@ struct ss_ctx {
     const void* p[6];  // psd, rel | avg, cand_off, cand_idx, cand_avg
     size_t bytes[6];
     long launch;       // the call's FFT launch; its detect stage runs in launch + 2 (last to touch psd / rel), its emit stage in launch + 4
+    uintptr_t lo, hi;  // address range that holds all of them (a cheap first test)
   };
   std::deque<Buffers> deep_buffers;
   // A caller that waits after every call gains nothing from queues and deferred stages and pays for the fork and the join:
@@ -1020,12 +1026,19 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     };
     ss_ctx::Buffers mine{{d_psd_out, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg},
                          {plane_bytes, plane_bytes, plane_bytes, sizeof(int32_t) * ((size_t)nframes + 1), sizeof(int32_t) * (size_t)cand_cap, sizeof(float) * (size_t)cand_cap},
-                         0};
+                         0, ~(uintptr_t)0, 0};
+    for (int x = 0; x < 6; ++x)
+      if (mine.p[x] && mine.bytes[x]) {
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(mine.p[x]);
+        mine.lo = std::min(mine.lo, a0);
+        mine.hi = std::max(mine.hi, a0 + mine.bytes[x]);
+      }
     // how this call's launches relate to the stages of earlier calls that touch the same buffers (ss_ctx::Buffers)
     bool must_drain = !overlap, wait_other_queue = false;
     if (overlap) {
       const long L = c->deep_L;
       for (const auto& b : c->deep_buffers)
+        if (b.lo < mine.hi && mine.lo < b.hi)
         for (int x = 0; x < 6 && !must_drain; ++x)
           for (int y = 0; y < 6 && !must_drain; ++y)
             if (clash(mine.p[x], mine.bytes[x], b.p[y], b.bytes[y])) {
@@ -1047,16 +1060,16 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       L = c->deep_L++;
       q = c->s_ab[L & 1];
       // whatever the public stream holds (the caller's producers, a drain, a learning call) comes first
-      if (L < 2 || hipStreamQuery(c->stream) != hipSuccess) {
+      if (hipStreamQuery(c->stream) != hipSuccess) {
         hipEvent_t ev = c->ev_in[c->deep_forks++ & 3];
         SS_HIP(c, hipEventRecord(ev, c->stream));
         SS_HIP(c, hipStreamWaitEvent(q, ev, 0));
       }
-      // The two queues never wait for each other otherwise, so nothing bounds how far one may run ahead: once in sixteen
-      // launches each waits for the other's launch three back. Whatever a launch older than kDeepHorizon touched is then
-      // finished for both queues, and the buffers of older calls need no tracking.
-      const int phase = (int)(L & 15);
-      if ((wait_other_queue && !must_drain) || (L >= 3 && (phase == 0 || phase == 1))) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 3) & 7], 0));
+      // The two queues never wait for each other otherwise, so nothing bounds how far one may run ahead: once in
+      // kDeepSyncPeriod launches each waits for the other's launch three back. Whatever a launch older than kDeepHorizon
+      // touched is then finished for both queues, and the buffers of older calls need no tracking.
+      const int phase = (int)(L % kDeepSyncPeriod);
+      if ((wait_other_queue && !must_drain) || phase == kDeepSyncPhase || phase == kDeepSyncPhase + 1) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 3) & 7], 0));
       if (c->deep_barrier == L - 1) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 1) & 7], 0));  // a detect role that read the ring goes before the next one writes it (once per drain)
       if (c->deep_prev_ok) {  // this call's detect stage will want the rows before the batch: the previous call's last frames, once more
         role.n_halo = kHistRows;
@@ -1078,7 +1091,8 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     launch_step(c, &role, has_det ? &d.a : nullptr, d.tiles, false, has_emit ? &e.a : nullptr, q);
     if (overlap) {
       const bool ring_reader = has_det && !d.a.halo_psd && !c->deep_ring_safe;
-      if (c->deep_events || ring_reader || (L & 15) == 13 || (L & 15) == 14) SS_HIP(c, hipEventRecord(c->ev_launch[L & 7], q));
+      const int rec_phase = (int)(L % kDeepSyncPeriod);
+      if (c->deep_events || ring_reader || rec_phase == kDeepSyncPhase - 3 || rec_phase == kDeepSyncPhase - 2) SS_HIP(c, hipEventRecord(c->ev_launch[L & 7], q));
       if (has_det) c->pe.push_back(ss_ctx::PendEmit{d.emit, L + 2});
       if (ring_reader) c->deep_barrier = L;
     }
@@ -1406,7 +1420,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   }
   c->d_off = c->d_off4[0];
   if (c->deep) {
-    c->deep_ring_safe = c->hist_rows / kHistRows >= kDeepHorizon + 2;
+    c->deep_ring_safe = c->hist_rows / kHistRows >= kDeepSyncPhase + 8;
     for (auto& q : c->s_ab) CREATE_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
     for (auto& h : c->d_halo) CREATE_HIP(hipMalloc(&h, sizeof(float) * (size_t)n * (size_t)kHistRows));
     for (auto& e : c->ev_launch) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
