@@ -987,6 +987,119 @@ int spectrogram_accumulate(ss_ctx* c, SpecState* g, const float* d_psd, int nfra
   return SS_OK;
 }
 
+// One call on a context with deep pipelining (ss_ctx::deep): launch L = FFT(L) + detect(L - 2) + emit(L - 4) on queue L & 1, or
+// — learning frames, short calls, callers that wait after every call — the three stages in order on the public stream.
+int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int n_learn, NoiseState* z, float* d_psd, float* d_psd_out,
+                  float* d_rel_out, float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap, bool allow_overlap) {
+  int st = SS_OK;
+  const ss::Fft8192Args g = fft8192_args(c, d_iq, item_stride, d_psd);
+  FftRole role;
+  role.frames = &g;
+  role.n = nframes;
+  if (allow_overlap && ++c->deep_calls_since_sync >= 2) c->deep_eager = false;
+  const bool overlap = allow_overlap && !c->deep_eager && c->diag.pipeline && n_learn == 0 && nframes >= kHistRows;
+  const size_t plane_bytes = sizeof(float) * (size_t)nframes * (size_t)c->n;
+  const auto clash = [](const void* a, size_t abytes, const void* b, size_t bbytes) {
+    const char *pa = static_cast<const char*>(a), *pb = static_cast<const char*>(b);
+    return a && b && abytes && bbytes && pa < pb + bbytes && pb < pa + abytes;
+  };
+  ss_ctx::Buffers mine{{d_psd_out, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg},
+                       {plane_bytes, plane_bytes, plane_bytes, sizeof(int32_t) * ((size_t)nframes + 1), sizeof(int32_t) * (size_t)cand_cap, sizeof(float) * (size_t)cand_cap},
+                       0, ~(uintptr_t)0, 0};
+  for (int x = 0; x < 6; ++x)
+    if (mine.p[x] && mine.bytes[x]) {
+      const uintptr_t a0 = reinterpret_cast<uintptr_t>(mine.p[x]);
+      mine.lo = std::min(mine.lo, a0);
+      mine.hi = std::max(mine.hi, a0 + mine.bytes[x]);
+    }
+  // how this call's launches relate to the stages of earlier calls that touch the same buffers (ss_ctx::Buffers)
+  bool must_drain = !overlap, wait_other_queue = false;
+  if (overlap) {
+    const long L = c->deep_L;
+    for (const auto& b : c->deep_buffers)
+      if (b.lo < mine.hi && mine.lo < b.hi)
+      for (int x = 0; x < 6 && !must_drain; ++x)
+        for (int y = 0; y < 6 && !must_drain; ++y)
+          if (clash(mine.p[x], mine.bytes[x], b.p[y], b.bytes[y])) {
+            const long last = b.launch + (y < 2 ? 2 : 4);  // the last launch that touches b.p[y]
+            if (last > L - 2) must_drain = true;                      // too close: not even stream order helps
+            else if (((L - last) & 1) == 0) continue;                 // same queue, earlier: stream order
+            else if (c->deep_events && L - 3 >= c->deep_events_from) wait_other_queue = true;  // (last <= L - 3: the other queue's launch L - 3 is at or behind it)
+            else must_drain = true;
+            if (((L - last) & 1) != 0) c->deep_events = true;         // a caller rotating an odd number of sets: keep events from now on
+          }
+  }
+  if (must_drain) flush_stages(c);
+  hipStream_t q = c->stream;
+  ss_ctx::PendDet d{};
+  ss_ctx::PendEmit e{};
+  bool has_det = false, has_emit = false;
+  long L = -1;
+  if (overlap) {
+    L = c->deep_L++;
+    q = c->s_ab[L & 1];
+    // whatever the public stream holds (the caller's producers, a drain, a learning call) comes first
+    if (hipStreamQuery(c->stream) != hipSuccess) {
+      hipEvent_t ev = c->ev_in[c->deep_forks++ & 3];
+      SS_HIP(c, hipEventRecord(ev, c->stream));
+      SS_HIP(c, hipStreamWaitEvent(q, ev, 0));
+    }
+    // The two queues never wait for each other otherwise, so nothing bounds how far one may run ahead: once in
+    // kDeepSyncPeriod launches each waits for the other's launch three back. Whatever a launch older than kDeepHorizon
+    // touched is then finished for both queues, and the buffers of older calls need no tracking.
+    const int phase = (int)(L % kDeepSyncPeriod);
+    if ((wait_other_queue && !must_drain) || phase == kDeepSyncPhase || phase == kDeepSyncPhase + 1) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 3) & 7], 0));
+    if (c->deep_barrier == L - 1) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 1) & 7], 0));  // a detect role that read the ring goes before the next one writes it (once per drain)
+    if (c->deep_prev_ok) {  // this call's detect stage will want the rows before the batch: the previous call's last frames, once more
+      role.n_halo = kHistRows;
+      role.halo_iq = static_cast<const char*>(c->deep_prev_iq) +
+                     (size_t)(c->deep_prev_frames - kHistRows) * (size_t)c->deep_prev_stride * in_bytes_per_sample(c->cfg.in_format);
+      role.halo_psd = c->d_halo[L & 3];
+    }
+    if (!c->pd.empty() && c->pd.front().ready <= L) {
+      d = c->pd.front();
+      c->pd.pop_front();
+      has_det = true;
+    }
+    if (!c->pe.empty() && c->pe.front().ready <= L) {
+      e = c->pe.front();
+      c->pe.pop_front();
+      has_emit = true;
+    }
+  }
+  launch_step(c, &role, has_det ? &d.a : nullptr, d.tiles, false, has_emit ? &e.a : nullptr, q);
+  if (overlap) {
+    const bool ring_reader = has_det && !d.a.halo_psd && !c->deep_ring_safe;
+    const int rec_phase = (int)(L % kDeepSyncPeriod);
+    if (c->deep_events || ring_reader || rec_phase == kDeepSyncPhase - 3 || rec_phase == kDeepSyncPhase - 2) SS_HIP(c, hipEventRecord(c->ev_launch[L & 7], q));
+    if (has_det) c->pe.push_back(ss_ctx::PendEmit{d.emit, L + 2});
+    if (ring_reader) c->deep_barrier = L;
+  }
+  if (n_learn > 0) hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
+  ss_ctx::PendDet mine_det{};
+  st = run_backend_fused(c, d_psd, nframes, n_learn, z, nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap, true,
+                         &mine_det.a, &mine_det.tiles, &mine_det.emit);
+  if (st != SS_OK) return st;
+  if (role.n_halo) {
+    mine_det.a.halo_psd = role.halo_psd;
+    mine_det.a.halo_rows = role.n_halo;
+  }
+  mine_det.ready = L + 2;
+  c->pd.push_back(mine_det);
+  if (overlap) {
+    c->deep_prev_ok = true;
+    c->deep_prev_iq = d_iq;
+    c->deep_prev_stride = item_stride;
+    c->deep_prev_frames = nframes;
+    mine.launch = L;
+    c->deep_buffers.push_back(mine);
+    if (c->deep_buffers.size() > (size_t)kDeepHorizon) c->deep_buffers.pop_front();
+  } else {
+    flush_stages(c);
+  }
+  return SS_OK;
+}
+
 // The chain for one batch, everything on c->stream, nothing synchronised.
 // n_learn = leading frames that belong to the noise-learning phase (decided by the caller).
 // 8192 points with the fused back end (c->step_path): the call's FFT stage is launched together with the deferred detect
@@ -1013,111 +1126,8 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     if (!spec) return fail(c, SS_ERR_NOMEM, "spectrogram container");
   }
   if (c->deep) {
-    const ss::Fft8192Args g = fft8192_args(c, d_iq, item_stride, d_psd);
-    FftRole role;
-    role.frames = &g;
-    role.n = nframes;
-    if (allow_overlap && ++c->deep_calls_since_sync >= 2) c->deep_eager = false;
-    const bool overlap = allow_overlap && !c->deep_eager && c->diag.pipeline && n_learn == 0 && nframes >= kHistRows;
-    const size_t plane_bytes = sizeof(float) * (size_t)nframes * (size_t)c->n;
-    const auto clash = [](const void* a, size_t abytes, const void* b, size_t bbytes) {
-      const char *pa = static_cast<const char*>(a), *pb = static_cast<const char*>(b);
-      return a && b && abytes && bbytes && pa < pb + bbytes && pb < pa + abytes;
-    };
-    ss_ctx::Buffers mine{{d_psd_out, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg},
-                         {plane_bytes, plane_bytes, plane_bytes, sizeof(int32_t) * ((size_t)nframes + 1), sizeof(int32_t) * (size_t)cand_cap, sizeof(float) * (size_t)cand_cap},
-                         0, ~(uintptr_t)0, 0};
-    for (int x = 0; x < 6; ++x)
-      if (mine.p[x] && mine.bytes[x]) {
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(mine.p[x]);
-        mine.lo = std::min(mine.lo, a0);
-        mine.hi = std::max(mine.hi, a0 + mine.bytes[x]);
-      }
-    // how this call's launches relate to the stages of earlier calls that touch the same buffers (ss_ctx::Buffers)
-    bool must_drain = !overlap, wait_other_queue = false;
-    if (overlap) {
-      const long L = c->deep_L;
-      for (const auto& b : c->deep_buffers)
-        if (b.lo < mine.hi && mine.lo < b.hi)
-        for (int x = 0; x < 6 && !must_drain; ++x)
-          for (int y = 0; y < 6 && !must_drain; ++y)
-            if (clash(mine.p[x], mine.bytes[x], b.p[y], b.bytes[y])) {
-              const long last = b.launch + (y < 2 ? 2 : 4);  // the last launch that touches b.p[y]
-              if (last > L - 2) must_drain = true;                      // too close: not even stream order helps
-              else if (((L - last) & 1) == 0) continue;                 // same queue, earlier: stream order
-              else if (c->deep_events && L - 3 >= c->deep_events_from) wait_other_queue = true;  // (last <= L - 3: the other queue's launch L - 3 is at or behind it)
-              else must_drain = true;
-              if (((L - last) & 1) != 0) c->deep_events = true;         // a caller rotating an odd number of sets: keep events from now on
-            }
-    }
-    if (must_drain) flush_stages(c);
-    hipStream_t q = c->stream;
-    ss_ctx::PendDet d{};
-    ss_ctx::PendEmit e{};
-    bool has_det = false, has_emit = false;
-    long L = -1;
-    if (overlap) {
-      L = c->deep_L++;
-      q = c->s_ab[L & 1];
-      // whatever the public stream holds (the caller's producers, a drain, a learning call) comes first
-      if (hipStreamQuery(c->stream) != hipSuccess) {
-        hipEvent_t ev = c->ev_in[c->deep_forks++ & 3];
-        SS_HIP(c, hipEventRecord(ev, c->stream));
-        SS_HIP(c, hipStreamWaitEvent(q, ev, 0));
-      }
-      // The two queues never wait for each other otherwise, so nothing bounds how far one may run ahead: once in
-      // kDeepSyncPeriod launches each waits for the other's launch three back. Whatever a launch older than kDeepHorizon
-      // touched is then finished for both queues, and the buffers of older calls need no tracking.
-      const int phase = (int)(L % kDeepSyncPeriod);
-      if ((wait_other_queue && !must_drain) || phase == kDeepSyncPhase || phase == kDeepSyncPhase + 1) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 3) & 7], 0));
-      if (c->deep_barrier == L - 1) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 1) & 7], 0));  // a detect role that read the ring goes before the next one writes it (once per drain)
-      if (c->deep_prev_ok) {  // this call's detect stage will want the rows before the batch: the previous call's last frames, once more
-        role.n_halo = kHistRows;
-        role.halo_iq = static_cast<const char*>(c->deep_prev_iq) +
-                       (size_t)(c->deep_prev_frames - kHistRows) * (size_t)c->deep_prev_stride * in_bytes_per_sample(c->cfg.in_format);
-        role.halo_psd = c->d_halo[L & 3];
-      }
-      if (!c->pd.empty() && c->pd.front().ready <= L) {
-        d = c->pd.front();
-        c->pd.pop_front();
-        has_det = true;
-      }
-      if (!c->pe.empty() && c->pe.front().ready <= L) {
-        e = c->pe.front();
-        c->pe.pop_front();
-        has_emit = true;
-      }
-    }
-    launch_step(c, &role, has_det ? &d.a : nullptr, d.tiles, false, has_emit ? &e.a : nullptr, q);
-    if (overlap) {
-      const bool ring_reader = has_det && !d.a.halo_psd && !c->deep_ring_safe;
-      const int rec_phase = (int)(L % kDeepSyncPeriod);
-      if (c->deep_events || ring_reader || rec_phase == kDeepSyncPhase - 3 || rec_phase == kDeepSyncPhase - 2) SS_HIP(c, hipEventRecord(c->ev_launch[L & 7], q));
-      if (has_det) c->pe.push_back(ss_ctx::PendEmit{d.emit, L + 2});
-      if (ring_reader) c->deep_barrier = L;
-    }
-    if (n_learn > 0) hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
-    ss_ctx::PendDet mine_det{};
-    st = run_backend_fused(c, d_psd, nframes, n_learn, z, nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap, true,
-                           &mine_det.a, &mine_det.tiles, &mine_det.emit);
+    st = run_call_deep(c, d_iq, item_stride, nframes, n_learn, z, d_psd, d_psd_out, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap, allow_overlap);
     if (st != SS_OK) return st;
-    if (role.n_halo) {
-      mine_det.a.halo_psd = role.halo_psd;
-      mine_det.a.halo_rows = role.n_halo;
-    }
-    mine_det.ready = L + 2;
-    c->pd.push_back(mine_det);
-    if (overlap) {
-      c->deep_prev_ok = true;
-      c->deep_prev_iq = d_iq;
-      c->deep_prev_stride = item_stride;
-      c->deep_prev_frames = nframes;
-      mine.launch = L;
-      c->deep_buffers.push_back(mine);
-      if (c->deep_buffers.size() > (size_t)kDeepHorizon) c->deep_buffers.pop_front();
-    } else {
-      flush_stages(c);
-    }
   } else if (c->step_path) {
     ss::Fft8192Args g{};
     ss::ColsArgs gc{};
