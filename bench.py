@@ -198,14 +198,14 @@ def parity_sample(n: int, fs: int, fmt: str):
 
 # ---------------------------------------------------------------------------------------------- launcher
 def traffic_from_profiles(threads_per_launch: int):
-    """Fabric bytes per launch of k_scan_step from the committed PMC passes of this command (profiles/r02/s27_pmc_*.csv:
+    """Fabric bytes per launch of k_scan_step from the committed PMC passes of this command (profiles/r02/s32_pmc_*.csv:
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, --kernel-trace only), for launches of the given
     grid size; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (round-1 calibration of gfx950's FETCH_SIZE).
     Counters cannot be collected from inside a run, so this is not a live figure: None when the files or the shape are absent."""
     import csv
     out = {}
     for kind in ("fetch", "write"):
-        path = os.path.join(ROOT, "profiles", "r02", f"s27_pmc_{kind}.csv")
+        path = os.path.join(ROOT, "profiles", "r02", f"s32_pmc_{kind}.csv")
         if not os.path.exists(path):
             return None
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
@@ -214,7 +214,7 @@ def traffic_from_profiles(threads_per_launch: int):
             return None
         out[kind] = sum(vals) / len(vals)
     return {"bytes_per_launch": round((2.0 * out["fetch"] + out["write"]) * 1024.0), "fetch_kib": round(out["fetch"], 1), "write_kib": round(out["write"], 1),
-            "source": "profiles/r02/s27_pmc_fetch.csv, s27_pmc_write.csv (rocprofv3 --pmc passes of `bench.py --steps 30`, not this run)"}
+            "source": "profiles/r02/s32_pmc_fetch.csv, s32_pmc_write.csv (rocprofv3 --pmc passes of `bench.py --steps 30`, not this run)"}
 
 
 def free_port() -> int:
@@ -452,8 +452,8 @@ def run(args):
                          "achieved_if_launches_did_not_overlap": None if (literal is None or n != 8192) else round(literal, 1),
                          "algorithmic_bytes_per_launch": abps * nb * n,
                          "traffic": None,  # PMC counters cannot be read from inside the run ...
-                         # ... the committed passes of the same command, for this launch shape (1024 + 35 FFT, 1024 detect and 128 emit workgroups of 512 threads):
-                         "traffic_from_profiles": traffic_from_profiles((nb + 35 + (nb // 16) * (n // 256) // 2 + nb // 8) * 512) if (n == 8192 and args.fmt == "cf32" and not args.no_psd_out and not args.planes) else None},
+                         # ... the committed passes of the same command, for this launch shape (1024 + 20 FFT, 1024 detect and 128 emit workgroups of 512 threads):
+                         "traffic_from_profiles": traffic_from_profiles((nb + 20 + (nb // 16) * (n // 256) // 2 + nb // 8) * 512) if (n == 8192 and args.fmt == "cf32" and not args.no_psd_out and not args.planes) else None},
             "roofline_chain": {"bound": "hbm", "what": "whole step (every kernel of the chain + launch gaps), per GPU",
                                "algorithmic_bytes_per_sample": chain_bps, "achieved": round(chain_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(chain_gbs / HBM_PEAK_GBS, 4)},

@@ -1051,9 +1051,10 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
     if ((wait_other_queue && !must_drain) || phase == kDeepSyncPhase || phase == kDeepSyncPhase + 1) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 3) & 7], 0));
     if (c->deep_barrier == L - 1) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 1) & 7], 0));  // a detect role that read the ring goes before the next one writes it (once per drain)
     if (c->deep_prev_ok) {  // this call's detect stage will want the rows before the batch: the previous call's last frames, once more
-      role.n_halo = kHistRows;
+      // (20 rows for the 21-frame mean, up to 15 more when the batch does not start on a tile boundary: two launch shapes)
+      role.n_halo = c->abs_frames % kFusedTF == 0 ? c->cfg.grouping_y - 1 : kHistRows;
       role.halo_iq = static_cast<const char*>(c->deep_prev_iq) +
-                     (size_t)(c->deep_prev_frames - kHistRows) * (size_t)c->deep_prev_stride * in_bytes_per_sample(c->cfg.in_format);
+                     (size_t)(c->deep_prev_frames - role.n_halo) * (size_t)c->deep_prev_stride * in_bytes_per_sample(c->cfg.in_format);
       role.halo_psd = c->d_halo[L & 3];
     }
     if (!c->pd.empty() && c->pd.front().ready <= L) {
