@@ -191,14 +191,14 @@ struct ss_ctx {
   // hardware queues fill each other's tails. Launch L therefore carries FFT(L), detect(L - 2) and emit(L - 4), and
   // launches alternate over two side streams, so that launch L follows launch L - 2 in stream order and never waits for
   // launch L - 1. What detect(L) needs from BEFORE its batch — the ring rows its predecessor writes, one launch earlier —
-  // it gets without that predecessor: launch L's FFT role transforms the last kHistRows frames of call L - 1 once more
-  // (3 % more FFT work; same kernel, same input: the same bits) into a buffer of its own (d_halo), which detect(L) reads
-  // as DetectArgs::halo_psd. No launch reads anything an odd number of launches back, so no events are needed between
-  // the two queues (an event record + wait per launch cost 3.7 us per step, more than the overlap gains). The context's
-  // public stream only forks (ev_in, when it holds work) and joins (flush_stages: both side streams, then the remaining
-  // stages in order on the public stream). Calls that cannot overlap (learning frames, fewer frames than the ring
-  // holds, a caller reusing a plane that is still in use) drain first and run their three stages in order on the public
-  // stream.
+  // it gets without that predecessor: launch L's FFT role transforms the last 20 frames of call L - 1 (35 when the call
+  // does not start on a tile boundary) once more — 2-3 % more FFT work; same kernel, same input: the same bits — into a
+  // buffer of its own (d_halo), which detect(L) reads as DetectArgs::halo_psd. No launch reads anything an odd number of
+  // launches back, so no events are needed between the two queues (an event record + wait per launch cost 3.7 us per
+  // step, more than the overlap gains). The context's public stream only forks (ev_in, when it holds work) and joins
+  // (flush_stages: the two queues drain their last stages side by side, then the public stream waits for both). Calls
+  // that cannot overlap (learning frames, fewer frames than the ring holds, a caller reusing a buffer too soon) drain
+  // first and run their three stages in order on the public stream.
   bool deep = false;
   hipStream_t s_ab[2] = {nullptr, nullptr};
   hipEvent_t ev_launch[8] = {}, ev_in[4] = {}, ev_join[2] = {};
