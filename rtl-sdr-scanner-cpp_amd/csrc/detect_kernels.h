@@ -236,7 +236,14 @@ __global__ __launch_bounds__(256) void k_spec_combine(const float* __restrict__ 
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= out_n) return;
   float acc = sum[j];
-  for (int c = 0; c < nchunks; ++c) acc += partial[(size_t)c * out_n + j];
+  for (int c0 = 0; c0 < nchunks; c0 += 16) {  // sixteen loads in flight, the additions one after the other in chunk order
+    float r[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = partial[(size_t)min(c0 + i, nchunks - 1) * out_n + j];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (c0 + i < nchunks) acc += r[i];
+  }
   sum[j] = acc;
 }
 

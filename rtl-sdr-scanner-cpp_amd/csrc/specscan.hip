@@ -37,6 +37,8 @@ constexpr int kFusedTF = 16;
 // Deep pipelining (ss_ctx::deep): a call's last stage runs four launches after its first; the two queues synchronise once in
 // kDeepSyncPeriod launches on the launch three back (a wait costs ~10 us of queue time: rarely, and not within the first 32
 // launches of a run): everything launched more than 4 + kDeepSyncPeriod + 3 launches ago has finished.
+constexpr int kDeepSpecSlots = 64;  // calls whose spectrogram partial sums may wait to be added to their container
+constexpr int kDeepFoldBatch = 8;   // ... added in batches of this many calls
 constexpr int kDeepSyncPeriod = 64;
 constexpr int kDeepSyncPhase = 32;
 constexpr int kDeepHorizon = 4 + kDeepSyncPeriod + 3 + 1;
@@ -147,6 +149,29 @@ struct ss_ctx {
   // spectrogram_flush); two buffers alternate
   float* d_spec_part2[2] = {nullptr, nullptr};
   int spec_cur = 0;
+  // deep pipelining: detect stages of overlapping launches cannot add to a container one after the other, so every call's
+  // partial sums keep a slot of their own until the next drain adds them, call by call and tile by tile — the same
+  // additions in the same order as the in-detect form — on the public stream (drain_deep); a full ring drains.
+  float* d_spec_ring = nullptr;
+  size_t spec_slot_floats = 0;
+  int spec_ring_next = 0;
+  struct PendFold {
+    const float* partial;
+    int tiles;
+    float* sum;
+    int slot;
+    long det_launch;  // the launch that carries (or will carry) this call's detect stage
+  };
+  std::deque<PendFold> deep_folds;
+  // The additions run on a stream of their own (the public stream stays idle, so the queues need no fork): every
+  // kDeepFoldBatch calls, behind one event from each queue, call by call in order. A slot is written again only after the
+  // host has seen the event behind its additions complete.
+  hipStream_t s_fold = nullptr;
+  hipEvent_t ev_fold_src[2] = {}, ev_fold_done[16] = {};
+  unsigned fold_batches = 0;
+  int slot_batch[kDeepSpecSlots];  // the batch (index into ev_fold_done) that added the slot's sums, -1: nothing outstanding
+  bool fold_dirty = false;         // s_fold holds work the public stream has not been made to wait for
+  int fold_last = 0;               // the newest batch
   float* spec_pending_sum = nullptr;  // container (SpecState::d_sum) the partial sums in d_spec_part2[spec_cur ^ 1] belong to
   int spec_pending_tiles = 0;
   std::vector<SpecState> spec;
@@ -218,6 +243,7 @@ struct ss_ctx {
     int tiles;
     ss::EmitArgs emit;
     long ready;  // first launch that may carry it
+    bool spec;   // with the spectrogram branch (k_scan_step<..., SPEC = true>)
   };
   struct PendEmit {
     ss::EmitArgs a;
@@ -664,6 +690,33 @@ ss::Fft8192Args fft8192_args(ss_ctx* c, const void* d_iq, long long item_stride,
   return g;
 }
 
+// Deep pipelining, spectrogram branch: add the partial sums of the oldest `count` waiting calls to their containers on
+// s_fold, call by call and tile by tile (the additions of the in-detect form, in the same order). behind_public = false:
+// behind everything the two queues hold now (the calls' detect stages are among it); true (a drain): behind the public
+// stream, which has been made to wait for both queues and may have run detect stages itself.
+void fold_spectrogram_slots(ss_ctx* c, size_t count, bool behind_public) {
+  if (count == 0) return;
+  if (behind_public) {
+    (void)hipEventRecord(c->ev_fold_src[0], c->stream);
+    (void)hipStreamWaitEvent(c->s_fold, c->ev_fold_src[0], 0);
+  } else {
+    for (int q = 0; q < 2; ++q) {
+      (void)hipEventRecord(c->ev_fold_src[q], c->s_ab[q]);
+      (void)hipStreamWaitEvent(c->s_fold, c->ev_fold_src[q], 0);
+    }
+  }
+  const int batch = (int)(c->fold_batches++ & 15);
+  for (size_t k = 0; k < count; ++k) {
+    const ss_ctx::PendFold f = c->deep_folds.front();
+    c->deep_folds.pop_front();
+    hipLaunchKernelGGL(ss::k_spec_combine, dim3((c->spec_n + 255) / 256), dim3(256), 0, c->s_fold, f.partial, f.tiles, c->spec_n, f.sum);
+    c->slot_batch[f.slot] = batch;
+  }
+  (void)hipEventRecord(c->ev_fold_done[batch], c->s_fold);
+  c->fold_last = batch;
+  c->fold_dirty = true;
+}
+
 // Deep pipelining: the stages still owed, then the public stream waits for both side streams. Each stage goes to the queue
 // its launch would have used (detect(j) behind launch j, emit(j) behind detect(j): the parity of `ready`), so the two queues
 // drain side by side; a detect stage that reads the ring (the first of an overlapped run) has its successor wait, so then —
@@ -698,11 +751,17 @@ void drain_deep(ss_ctx* c) {
         ee = *e;
         c->pe.erase(e);
       }
-      launch_step(c, nullptr, has_det ? &dd.a : nullptr, dd.tiles, false, has_emit ? &ee.a : nullptr, q);
+      launch_step(c, nullptr, has_det ? &dd.a : nullptr, dd.tiles, dd.spec, has_emit ? &ee.a : nullptr, q);
       if (has_det) c->pe.push_back(ss_ctx::PendEmit{dd.emit, dd.ready});
     }
   }
   if (!in_order) join();
+  // the spectrogram partial sums still waiting join their containers, and the public stream waits for all of them
+  fold_spectrogram_slots(c, c->deep_folds.size(), true);
+  if (c->fold_dirty) {
+    (void)hipStreamWaitEvent(c->stream, c->ev_fold_done[c->fold_last], 0);
+    c->fold_dirty = false;
+  }
   c->deep_L = 0;
   c->deep_barrier = -10;
   c->deep_prev_ok = false;  // after a drain the caller may reuse its planes: the next call takes its rows from the ring
@@ -989,8 +1048,9 @@ int spectrogram_accumulate(ss_ctx* c, SpecState* g, const float* d_psd, int nfra
 
 // One call on a context with deep pipelining (ss_ctx::deep): launch L = FFT(L) + detect(L - 2) + emit(L - 4) on queue L & 1, or
 // — learning frames, short calls, callers that wait after every call — the three stages in order on the public stream.
-int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int n_learn, NoiseState* z, float* d_psd, float* d_psd_out,
-                  float* d_rel_out, float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap, bool allow_overlap) {
+int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int n_learn, NoiseState* z, SpecState* spec, float* d_psd,
+                  float* d_psd_out, float* d_rel_out, float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap,
+                  bool allow_overlap) {
   int st = SS_OK;
   const ss::Fft8192Args g = fft8192_args(c, d_iq, item_stride, d_psd);
   FftRole role;
@@ -1028,6 +1088,14 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
             else must_drain = true;
             if (((L - last) & 1) != 0) c->deep_events = true;         // a caller rotating an odd number of sets: keep events from now on
           }
+  }
+  if (spec) {
+    // The slot this call's spectrogram partial sums will take is free once the additions of its last user, kDeepSpecSlots
+    // calls ago, have run. A host that enqueues faster than the device works gets that far ahead: it waits here (the
+    // device still has dozens of calls queued; a wait packet in a queue would cost every call ~10 us instead).
+    const int b = c->slot_batch[c->spec_ring_next];
+    if (b >= 0) SS_HIP(c, hipEventSynchronize(c->ev_fold_done[b]));
+    if ((int)c->deep_folds.size() >= kDeepSpecSlots) must_drain = true;
   }
   if (must_drain) flush_stages(c);
   hipStream_t q = c->stream;
@@ -1068,7 +1136,7 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
       has_emit = true;
     }
   }
-  launch_step(c, &role, has_det ? &d.a : nullptr, d.tiles, false, has_emit ? &e.a : nullptr, q);
+  launch_step(c, &role, has_det ? &d.a : nullptr, d.tiles, d.spec, has_emit ? &e.a : nullptr, q);
   if (overlap) {
     const bool ring_reader = has_det && !d.a.halo_psd && !c->deep_ring_safe;
     const int rec_phase = (int)(L % kDeepSyncPeriod);
@@ -1084,6 +1152,23 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   if (role.n_halo) {
     mine_det.a.halo_psd = role.halo_psd;
     mine_det.a.halo_rows = role.n_halo;
+  }
+  if (spec) {  // Spectrogram::work (spectrogram.cpp:45-60): this call's frames, bin-decimated, summed per frame tile into a slot of their own
+    const int slot_no = c->spec_ring_next;
+    float* slot = c->d_spec_ring + (size_t)slot_no * c->spec_slot_floats;
+    c->slot_batch[slot_no] = -1;
+    c->spec_ring_next = (c->spec_ring_next + 1) % kDeepSpecSlots;
+    mine_det.a.spec_partial = slot;
+    mine_det.a.spec_m = c->spec_m;
+    mine_det.a.spec_n = c->spec_n;
+    mine_det.spec = true;
+    c->deep_folds.push_back(ss_ctx::PendFold{slot, (nframes + mine_det.a.shift + kFusedTF - 1) / kFusedTF, spec->d_sum, slot_no, L + 2});
+    spec->count += nframes;
+    if (overlap) {  // calls whose detect stage is in a launch already enqueued: added in batches, beside the pipeline
+      size_t ready = 0;
+      while (ready < c->deep_folds.size() && c->deep_folds[ready].det_launch < c->deep_L) ++ready;
+      if (ready >= (size_t)kDeepFoldBatch) fold_spectrogram_slots(c, ready, false);
+    }
   }
   mine_det.ready = L + 2;
   c->pd.push_back(mine_det);
@@ -1127,7 +1212,8 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     if (!spec) return fail(c, SS_ERR_NOMEM, "spectrogram container");
   }
   if (c->deep) {
-    st = run_call_deep(c, d_iq, item_stride, nframes, n_learn, z, d_psd, d_psd_out, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap, allow_overlap);
+    st = run_call_deep(c, d_iq, item_stride, nframes, n_learn, z, spec, d_psd, d_psd_out, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap,
+                       allow_overlap);
     if (st != SS_OK) return st;
   } else if (c->step_path) {
     ss::Fft8192Args g{};
@@ -1236,11 +1322,15 @@ int get_noise(ss_ctx* c, NoiseState** out) {
 void free_ctx(ss_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device_id);
-  for (hipStream_t q : c->s_ab)
+  for (hipStream_t q : {c->s_ab[0], c->s_ab[1], c->s_fold})
     if (q) (void)hipStreamSynchronize(q);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (hipStream_t q : c->s_ab)
+  for (hipStream_t q : {c->s_ab[0], c->s_ab[1], c->s_fold})
     if (q) (void)hipStreamDestroy(q);
+  for (hipEvent_t e : c->ev_fold_src)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_fold_done)
+    if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_launch)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_in)
@@ -1275,6 +1365,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_tw_sub);
   (void)hipFree(c->d_tw_small);
   (void)hipFree(c->d_tw_rowsR);
+  (void)hipFree(c->d_spec_ring);
   (void)hipFree(c->d_spec_part2[0]);
   (void)hipFree(c->d_spec_part2[1]);
   (void)hipFree(c->d_counts);
@@ -1394,7 +1485,19 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   // 8192 points (and the four-step sizes) with the fused back end: stages of consecutive calls overlap (scan_step.h), so
   // what a deferred stage reads rotates over several buffers; every other configuration uses set 0 only
   c->step_path = c->fused && !c->diag.fft_generic && (n == 8192 || (n >= 16384 && c->diag.step_long));
-  c->deep = c->step_path && n == 8192 && c->diag.deep && !(cfg->flags & SS_FLAG_SPECTROGRAM) && cfg->max_batch >= kHistRows;
+  if (cfg->flags & SS_FLAG_SPECTROGRAM) {
+    // output size rule of the Spectrogram block: min(SPECTROGRAM_MAX_FFT, getFft(fs, SPECTROGRAM_PREFERRED_MAX_STEP)),
+    // sources/radio/blocks/spectrogram.cpp:14, config.h:36-37
+    int out_n = get_fft(cfg->sample_rate, 1000);
+    if (out_n > 16384) out_n = 16384;
+    if (out_n > n) out_n = n;
+    c->spec_n = out_n;
+    c->spec_m = n / out_n;
+    // inside the detect kernel when that kernel runs and a tile's 256 bins hold whole groups of m: one partial row per
+    // frame tile (a batch that starts inside a tile touches one more)
+    c->spec_in_detect = c->fused && c->spec_m <= 256 && !c->diag.spec_standalone;
+  }
+  c->deep = c->step_path && n == 8192 && c->diag.deep && cfg->max_batch >= kHistRows && (!(cfg->flags & SS_FLAG_SPECTROGRAM) || c->spec_in_detect);
   c->lag = c->deep ? 2 : 1;
   c->ncnt = c->deep ? 6 : 3;
   c->nbuf = c->deep ? 4 : (c->step_path ? 2 : 1);
@@ -1447,19 +1550,18 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   }
   CREATE_HIP(hipMalloc(&c->d_counts, sizeof(int) * (size_t)cfg->max_batch));
   if (cfg->flags & SS_FLAG_SPECTROGRAM) {
-    // output size rule of the Spectrogram block: min(SPECTROGRAM_MAX_FFT, getFft(fs, SPECTROGRAM_PREFERRED_MAX_STEP)),
-    // sources/radio/blocks/spectrogram.cpp:14, config.h:36-37
-    int out_n = get_fft(cfg->sample_rate, 1000);
-    if (out_n > 16384) out_n = 16384;
-    if (out_n > n) out_n = n;
-    c->spec_n = out_n;
-    c->spec_m = n / out_n;
-    // inside the detect kernel when that kernel runs and a tile's 256 bins hold whole groups of m: one partial row per
-    // frame tile (a batch that starts inside a tile touches one more)
-    c->spec_in_detect = c->fused && c->spec_m <= 256 && !c->diag.spec_standalone;
+    const int out_n = c->spec_n;
     if (c->spec_in_detect) {
       const size_t tiles = (size_t)(cfg->max_batch + kFusedTF - 1) / kFusedTF + 1;
       for (int k = 0; k < 2; ++k) CREATE_HIP(hipMalloc(&c->d_spec_part2[k], sizeof(float) * (size_t)out_n * tiles));
+      if (c->deep) {  // one slot of partial sums per call in flight or not yet added to its container (ss_ctx::deep_folds)
+        c->spec_slot_floats = (size_t)out_n * tiles;
+        CREATE_HIP(hipMalloc(&c->d_spec_ring, sizeof(float) * c->spec_slot_floats * (size_t)kDeepSpecSlots));
+        CREATE_HIP(hipStreamCreateWithFlags(&c->s_fold, hipStreamNonBlocking));
+        for (auto& e : c->ev_fold_src) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : c->ev_fold_done) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& b : c->slot_batch) b = -1;
+      }
     } else {
       CREATE_HIP(hipMalloc(&c->d_spec_partial, sizeof(float) * (size_t)out_n * ((size_t)(cfg->max_batch + 31) / 32)));
     }

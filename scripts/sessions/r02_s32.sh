@@ -9,6 +9,7 @@ SS_TEST_DEEP_SEEDS=36 timeout 900 python -m pytest tests/test_gpu_step_pipeline.
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -2 $OUT/smoke.txt
 timeout 300 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cut -c1-260 $OUT/bench_default.json
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err; cut -c1-260 $OUT/bench_k20.json
+timeout 300 python bench.py --spectrogram --no-cpu-baseline > $OUT/bench_spectrogram.json 2> $OUT/bench_spectrogram.err; cut -c1-260 $OUT/bench_spectrogram.json
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_fetch -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --preheat-ms 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/pmc_fetch.log 2>&1

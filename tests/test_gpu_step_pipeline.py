@@ -103,10 +103,11 @@ def test_long_runs_of_overlapped_calls_equal_call_by_call(seed):
     fmt = [pkg.abi.SS_FMT_CF32, pkg.abi.SS_FMT_CS8][seed % 2]
     want_planes = seed % 3 == 1
     sets = [8, 8, 5, 3, 2, 8, 6, 4, 7][seed % 9]
+    flags = pkg.abi.SS_FLAG_SPECTROGRAM if seed % 4 == 3 else 0  # (the spectrogram branch rides in the detect stage: per-call partial sums, added at the next drain)
     nframes, learn, max_batch = 1400, 20, 128
     band = pkg.synth.SyntheticBand(N, seed=170 + seed, on_frame=60, off_frame=900, period=1000)
     iq = band.frames_cf32(nframes) if fmt == pkg.abi.SS_FMT_CF32 else band.frames_cs8(nframes)
-    kw = dict(fft_size=N, decim=1, in_format=fmt, learn_frames=learn, max_batch=max_batch)
+    kw = dict(fft_size=N, decim=1, in_format=fmt, learn_frames=learn, max_batch=max_batch, flags=flags)
     a, b = pkg.SpectrumEngine(FS, CENTER, **kw), pkg.SpectrumEngine(FS, CENTER, **kw)
     pub = torch.cuda.ExternalStream(b.stream_handle, device=dev)
     sizes, pos = [], 0
@@ -157,6 +158,11 @@ def test_long_runs_of_overlapped_calls_equal_call_by_call(seed):
         pending.append((k, j))
         pos += s_
     collect()
+    if flags:
+        ra, rb = a.spectrogram_read(), b.spectrogram_read()
+        assert ra[2] == rb[2] == nframes
+        np.testing.assert_array_equal(ra[0], rb[0])
+        np.testing.assert_array_equal(ra[1], rb[1])
     assert len(snap_b) >= len(sizes) // 2
     total = 0
     for k, ob in snap_b:
