@@ -210,7 +210,7 @@ struct ss_ctx {
   ss::EmitArgs pend_emit{};
   int buf_cur = 0;               // which of the rotating buffers the NEXT batch writes
   int psd_cur = 0;
-  // Deep pipelining (8192 points, no spectrogram branch; diag.deep). With the stages of three consecutive calls in one
+  // Deep pipelining (8192 points; diag.deep). With the stages of three consecutive calls in one
   // launch, launch k + 1 still depends on launch k (detect(k) needs FFT(k)), so every launch runs its ramp and its tail
   // alone — a quarter of a 1024-frame launch (scripts/ubench/launch_overlap_lab.hip). Independent launches on two
   // hardware queues fill each other's tails. Launch L therefore carries FFT(L), detect(L - 2) and emit(L - 4), and
