@@ -146,7 +146,8 @@ int ss_process(ss_ctx* ctx, const void* iq, int32_t nframes, const int64_t* t_ms
  * Handing a plane or candidate buffer to a later call again without ss_sync in between is safe — the library orders the
  * stages that touch it, draining its pipeline first where it has to — and costs nothing when the output sets rotate with
  * an even period of at least six calls (four for the PSD / rel planes alone); of course only the newest contents can be
- * read afterwards. Results are bit-identical to running the three stages back to back. The host-buffer entry points
+ * read afterwards. The call itself only enqueues; with SS_FLAG_SPECTROGRAM it waits once the host is 64 calls ahead of the
+ * device. Results are bit-identical to running the three stages back to back. The host-buffer entry points
  * (ss_process, ss_feed_*) and every call that reads or changes state (ss_set_frequency_range, ss_reset, ss_reset_noise,
  * ss_read_window, ss_read_noise, ss_spectrogram_read) drain the deferred stages themselves. */
 int ss_process_device(ss_ctx* ctx, const void* d_iq, int32_t nframes,
