@@ -395,7 +395,7 @@ def run(args):
     eng.sync()
     every = 0
     if not args.no_kernel_timing:
-        every = args.time_every or max(1, min(8, args.steps // 5))  # each timed launch costs ~4 us of GPU timeline: 5 samples in a 20-step run, 25 in a 200-step one
+        every = args.time_every or max(1, min(8, args.steps // 2))  # each timed launch costs ~5 us of queue time (its two event packets): 3 samples in a 20-step run, 25 in a 200-step one
         eng.kernel_timing(every)
     dist.barrier()
     torch.cuda.synchronize()
