@@ -1,6 +1,8 @@
 """BASELINE.json full sizes (config 2: 1024 frames x 8192 points on one MI355X) through
 size-independent properties: the oracle would need minutes here, the properties do not need it.
 Run with -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -110,7 +112,8 @@ def test_full_size_calls_in_flight_equal_call_by_call():
     for k in range(ncalls):
         o = outs[k]
         eng.process_device(d_iq[k], B, psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["cav"])
-    assert int(outs[ncalls - 1]["off"][-1]) == -1  # (nothing of the last call's candidate stage has run yet)
+    if os.environ.get("SS_PIPELINE") != "0":
+        assert int(outs[ncalls - 1]["off"][-1]) == -1  # (nothing of the last call's candidate stage has run yet)
     eng.sync()
     total = 0
     for k in range(ncalls):

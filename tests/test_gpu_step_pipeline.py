@@ -194,7 +194,8 @@ def test_flush_then_stream_sync_completes_the_results():
         torch.cuda.synchronize()
         _call(eng, d_iq, 64, o)
         outs.append(o)
-    assert int(outs[2]["off"][0]) == -1  # (the last call's candidate stage has not even been launched yet)
+    if os.environ.get("SS_PIPELINE") != "0":  # (the whole suite can be run on the diagnostics build without stage pipelining)
+        assert int(outs[2]["off"][0]) == -1  # (the last call's candidate stage has not even been launched yet)
     eng.flush()
     torch.cuda.synchronize()
     for k in range(3):
