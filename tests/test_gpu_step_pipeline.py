@@ -104,10 +104,11 @@ def test_long_runs_of_overlapped_calls_equal_call_by_call(seed):
     want_planes = seed % 3 == 1
     sets = [8, 8, 5, 3, 2, 8, 6, 4, 7][seed % 9]
     flags = pkg.abi.SS_FLAG_SPECTROGRAM if seed % 4 == 3 else 0  # (the spectrogram branch rides in the detect stage: per-call partial sums, added at the next drain)
-    nframes, learn, max_batch = 1400, 20, 128
-    band = pkg.synth.SyntheticBand(N, seed=170 + seed, on_frame=60, off_frame=900, period=1000)
+    decim = 3 if seed % 7 == 5 else 1  # (frame decimation: items of 3 x 8192 samples, the first 8192 scanned — also by the launch that transforms a call's last frames again)
+    nframes, learn, max_batch = (1400 if decim == 1 else 700), 20, 128
+    band = pkg.synth.SyntheticBand(N, decim=decim, seed=170 + seed, on_frame=60, off_frame=900 // decim, period=1000 // decim)
     iq = band.frames_cf32(nframes) if fmt == pkg.abi.SS_FMT_CF32 else band.frames_cs8(nframes)
-    kw = dict(fft_size=N, decim=1, in_format=fmt, learn_frames=learn, max_batch=max_batch, flags=flags)
+    kw = dict(fft_size=N, decim=decim, in_format=fmt, learn_frames=learn, max_batch=max_batch, flags=flags)
     a, b = pkg.SpectrumEngine(FS, CENTER, **kw), pkg.SpectrumEngine(FS, CENTER, **kw)
     pub = torch.cuda.ExternalStream(b.stream_handle, device=dev)
     sizes, pos = [], 0
@@ -174,7 +175,7 @@ def test_long_runs_of_overlapped_calls_equal_call_by_call(seed):
         s_ = sizes[k]
         cut = lambda o: {key: (v[:s_] if key in ("psd", "rel", "avg") and v is not None else (v[:s_ + 1] if key == "off" else v)) for key, v in o.items()}
         total += _same(cut(outs_a[k]), cut(ob), f"call {k} ({s_} frames)")
-    assert total > 2000
+    assert total > (2000 if decim == 1 else 500)
 
 
 def test_flush_then_stream_sync_completes_the_results():
