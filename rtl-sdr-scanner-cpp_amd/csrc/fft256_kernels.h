@@ -34,6 +34,7 @@ namespace ss {
 // belong to 4 FFTs, keeps 272 = 16 mod 32 so that consecutive FFTs use complementary bank halves
 constexpr int kFft256PitchCols = 273, kFft256PitchRows = 272;
 constexpr int kFft256LdsBytes = 32 * kFft256PitchCols * 4;  // one fp32 plane of 32 FFTs: 34 944 bytes
+constexpr int kFft256ColsLdsBytes = kFft256LdsBytes + 256 * 8;  // the column tiles keep W_256 behind the plane (below)
 constexpr int kFft256RowsLdsBytes = 256 * 33 * 4;           // rows kernel read-out plane [k2][rho], 33-word pitch: 33 792 bytes
 
 // the two register passes of 32 independent 256-point FFTs; `fft` = which of the 32, `j` = butterfly 0..15
@@ -74,6 +75,11 @@ struct ColsArgs {
 template <int FMT>
 __device__ __forceinline__ void fft_cols256_tile(const ColsArgs& g, int block, unsigned char* __restrict__ smem_raw, int t) {
   float* s = reinterpret_cast<float*>(smem_raw);
+  // W_256 (2 KiB) into LDS before anything else: read from global memory in the second pass it would wait behind the tile's
+  // own streaming loads and those of the CU's other workgroups (in-order vector memory: fft8192_v2.h). The barriers of the
+  // first exchange come before its first use.
+  float2* tw_lds = reinterpret_cast<float2*>(smem_raw + kFft256LdsBytes);
+  if (t < 256) tw_lds[t] = g.tw256[t];
   const int logn2 = g.logn2;
   const int q = t & 31, j = t >> 5;
   const int n2size = 1 << logn2;
@@ -94,7 +100,7 @@ __device__ __forceinline__ void fft_cols256_tile(const ColsArgs& g, int block, u
     a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
   }
   float2 c[16];
-  fft256_passes<kFft256PitchCols>(a, c, s, g.tw256, q, j);
+  fft256_passes<kFft256PitchCols>(a, c, s, tw_lds, q, j);
   // step-A twiddle W_N^(n2 k1), k1 = j + 16 k, as W_N^(n2 j) * W_N^(16 n2 k) from two tables laid out [j][n2] and [k][n2]:
   // the lanes of a wave (consecutive n2) read consecutive entries (a gather from the N-entry table W_N^m at m = n2 k1
   // costs as much as the whole transform). work[k1 * N2 + n2]: block-uniform base + one 32-bit offset per access.
@@ -126,6 +132,8 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s = reinterpret_cast<float*>(smem_raw);
   const int t = threadIdx.x;
+  float2* tw_lds = reinterpret_cast<float2*>(smem_raw + kFft256LdsBytes);  // W_256 in LDS, as in fft_cols256_tile
+  if (t < 256) tw_lds[t] = tw256[t];
   const int rho = t >> 4, j = t & 15;
   // blockIdx = ((f * nsub) + c) * 8 + k1 tile
   const int r0 = (blockIdx.x & 7) << 5;
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = row[j + 16 * r];
   float2 cc[16];
-  fft256_passes<kFft256PitchRows>(a, cc, s, tw256, rho, j);
+  fft256_passes<kFft256PitchRows>(a, cc, s, tw_lds, rho, j);
   __syncthreads();  // the exchange plane is reused for the read-out
   // dB values to LDS at [d][rho] (33-word pitch), then out along k1
 #pragma unroll
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
 // R-point DFT. Stores run along k'. For R = 16: three 16-point DFTs and two exchanges, the shape of the 8192-point kernel.
 // Compiled for 4 waves per SIMD: with 80 registers (6 waves) the 4096-point instance spills and is 10 % slower.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kFft256xRLdsBytes = 32 * 273 * 4;  // >= 32 sub-FFTs x 257 words for the second exchange
+constexpr int kFft256xRLdsBytes = 32 * 273 * 4 + 256 * 8;  // >= 32 sub-FFTs x 257 words for the second exchange, W_256 behind them
 
 // R-point DFT of a[B .. B+R-1] (compile-time base: the array must stay in registers)
 template <int R, int B>
@@ -213,6 +221,8 @@ __global__ __launch_bounds__(512, LOGR == 4 ? 4 : 6) void k_fft256xR_psd(const v
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s = reinterpret_cast<float*>(smem_raw);
   const int t = threadIdx.x;
+  float2* tw_lds = reinterpret_cast<float2*>(smem_raw + 32 * 273 * 4);  // W_256 in LDS, as in fft_cols256_tile
+  if (t < 256) tw_lds[t] = tw256[t];
   const int fl = t >> (4 + LOGR), tt = t & (16 * R - 1);
   const int q = tt & (R - 1), j = tt >> LOGR;
   // frames past the end (ragged last workgroup) recompute the last frame and do not store
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(512, LOGR == 4 ? 4 : 6) void k_fft256xR_psd(const v
   }
   float2 c[16];
   const int sub = (fl << LOGR) | q;  // which of the 32 sub-FFTs
-  fft256_passes<kFft256PitchCols>(a, c, s, tw256, sub, j);  // Z_q[j + 16 k] in c[slot16(k)]
+  fft256_passes<kFft256PitchCols>(a, c, s, tw_lds, sub, j);  // Z_q[j + 16 k] in c[slot16(k)]
   __syncthreads();
   // second exchange: Z_q[k'] to word sub * 257 + k'; pair p = t + 512 u = (frame p / 256, k' = p % 256) reads its R q's
   float* zp = s + sub * 257 + j;
@@ -274,11 +284,13 @@ __global__ __launch_bounds__(512, LOGR == 4 ? 4 : 6) void k_fft256xR_psd(const v
 // The same decomposition for the ROWS of a four-step with N2 = 256 R, R = 2, 4 (N = 131072, 262144): 32 / R rows k1 per
 // workgroup straight from the work buffer (the step-A twiddle is already in it), X_row[k' + 256 kap] -> bin
 // k1 + 256 (k' + 256 kap). The dB values go through LDS once more ([k2][row], pitch rows + 1) so that stores run along k1.
-// LDS of k_fft_rows256xR_psd: the Z planes (32 sub-sequences x 257) or the read-out tile (N2 k2 x (32 / R rows + 1)), whichever is larger
-constexpr int fft_rowsR_lds_bytes(int logr) {
+// LDS of k_fft_rows256xR_psd: the exchange plane of the register passes (32 sub-sequences x 273) or the read-out tile
+// (N2 k2 x (32 / R rows + 1)), whichever is larger, and W_256 behind it
+constexpr int fft_rowsR_plane_bytes(int logr) {
   const int n2 = 256 << logr, fpw = 32 >> logr;
-  return 4 * (n2 * (fpw + 1) > 32 * 257 ? n2 * (fpw + 1) : 32 * 257);
+  return 4 * (n2 * (fpw + 1) > 32 * kFft256PitchCols ? n2 * (fpw + 1) : 32 * kFft256PitchCols);
 }
+constexpr int fft_rowsR_lds_bytes(int logr) { return fft_rowsR_plane_bytes(logr) + 256 * 8; }
 
 template <int LOGR>
 __global__ __launch_bounds__(512, 4) void k_fft_rows256xR_psd(const float2* __restrict__ work, const float2* __restrict__ tw256,
@@ -288,6 +300,8 @@ __global__ __launch_bounds__(512, 4) void k_fft_rows256xR_psd(const float2* __re
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s = reinterpret_cast<float*>(smem_raw);
   const int t = threadIdx.x;
+  float2* tw_lds = reinterpret_cast<float2*>(smem_raw + fft_rowsR_plane_bytes(LOGR));  // W_256 in LDS, as in fft_cols256_tile
+  if (t < 256) tw_lds[t] = tw256[t];
   const int fl = t >> (4 + LOGR), tt = t & (16 * R - 1);
   const int q = tt & (R - 1), j = tt >> LOGR;
   constexpr int TILES = 256 / FPW;
@@ -311,7 +325,7 @@ __global__ __launch_bounds__(512, 4) void k_fft_rows256xR_psd(const float2* __re
   for (int r = 0; r < 16; ++r) a[r] = row[tt + 16 * R * r];
   float2 c[16];
   const int sub = (fl << LOGR) | q;
-  fft256_passes<kFft256PitchCols>(a, c, s, tw256, sub, j);
+  fft256_passes<kFft256PitchCols>(a, c, s, tw_lds, sub, j);
   __syncthreads();
   float* zp = s + sub * 257 + j;
 #pragma unroll

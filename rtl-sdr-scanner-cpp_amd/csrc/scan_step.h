@@ -80,7 +80,7 @@ constexpr int kStepThreads = 512;
 constexpr int kStepLdsBytes = kFft8192V2LdsBytes;
 static_assert(2 * (16 * DetectTile<21, 21, 16, 256>::P * 4 + 64) <= kFft8192V2LdsBytes, "two detect tiles per workgroup");
 static_assert((8 * kEmitList + 9) * 4 <= kFft8192V2LdsBytes, "eight emit lists per workgroup");
-static_assert(kFft256LdsBytes <= kFft8192V2LdsBytes, "a column tile");
+static_assert(kFft256ColsLdsBytes <= kFft8192V2LdsBytes, "a column tile");
 
 inline int step_fft_wgs(const StepArgs& a) { return a.n_fft ? (a.n_fft + a.fft_per_wg - 1) / a.fft_per_wg : 0; }
 inline int step_emit_wgs(const StepArgs& a) { return a.emit_per_wg == 1 ? a.n_emit : (a.n_emit + 7) / 8; }

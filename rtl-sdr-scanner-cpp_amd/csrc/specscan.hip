@@ -452,9 +452,9 @@ template <int LOGN2, int FMT>
 void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd, bool with_cols = true) {
   constexpr int N2 = 1 << LOGN2;
   if (with_cols)
-    hipLaunchKernelGGL((ss::k_fft_cols256<FMT>), dim3(nframes * (N2 / 32)), dim3(512), ss::kFft256LdsBytes, c->stream, cols256_args(c, d_iq, item_stride));
+    hipLaunchKernelGGL((ss::k_fft_cols256<FMT>), dim3(nframes * (N2 / 32)), dim3(512), ss::kFft256ColsLdsBytes, c->stream, cols256_args(c, d_iq, item_stride));
   if constexpr (LOGN2 == 8) {
-    hipLaunchKernelGGL(ss::k_fft_rows256_psd, dim3(nframes * 8), dim3(512), ss::kFft256LdsBytes, c->stream, (const float2*)c->d_work,
+    hipLaunchKernelGGL(ss::k_fft_rows256_psd, dim3(nframes * 8), dim3(512), ss::kFft256ColsLdsBytes, c->stream, (const float2*)c->d_work,
                        (const float2*)c->d_tw256, c->db_off, d_psd, 16, 0);
   } else {
     bool done = false;
@@ -472,7 +472,7 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
         // rows of 256 A points (A = 8, 16) as an in-place radix-A step over the stride-256 index, then 256-point rows
         constexpr int A = 1 << (LOGN2 - 8);
         hipLaunchKernelGGL((ss::k_fft_sub_dft<A>), dim3(nframes * 256), dim3(256), 0, c->stream, c->d_work, (const float2*)c->d_tw_sub);
-        hipLaunchKernelGGL(ss::k_fft_rows256_psd, dim3(nframes * A * 8), dim3(512), ss::kFft256LdsBytes, c->stream, (const float2*)c->d_work,
+        hipLaunchKernelGGL(ss::k_fft_rows256_psd, dim3(nframes * A * 8), dim3(512), ss::kFft256ColsLdsBytes, c->stream, (const float2*)c->d_work,
                            (const float2*)c->d_tw256, c->db_off, d_psd, 8 + LOGN2, LOGN2 - 8);
         done = true;
       }
