@@ -37,6 +37,10 @@ def main():
     print(f"  mean launch duration {busy / len(run) / 1e3:.2f} us, wall time per launch {(t1 - t0) / len(run) / 1e3:.2f} us, launches in flight {busy / (t1 - t0):.2f}")
     print("  share of the time with 0 / 1 / 2 / 3+ launches running: " + " / ".join(f"{100.0 * hist[k] / (t1 - t0):.1f} %" for k in range(4)))
     print("  launches per hardware queue: " + ", ".join(f"queue {q}: {n}" for q, n in sorted(queues.items())))
+    shapes = collections.defaultdict(list)
+    for r in rows:
+        shapes[int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print("  mean duration by launch shape (workgroups: launches, us): " + "; ".join(f"{k}: {len(v)}, {sum(v) / len(v):.1f}" for k, v in sorted(shapes.items())))
 
 
 if __name__ == "__main__":
