@@ -157,7 +157,7 @@ int ss_flush(ss_ctx* ctx); /* enqueue the deferred stages of earlier ss_process_
 int ss_sync(ss_ctx* ctx);  /* ss_flush + wait for the context's stream */
 void* ss_stream(ss_ctx* ctx); /* the hipStream_t ss_process_device enqueues on */
 
-/* Measurement aid (bench.py): when enabled (enable = 1: every launch, enable = k > 1: every k-th launch, to keep
+/* Measurement aid (bench.py): when enabled (enable = 1: every launch, enable = k > 1: every k-th launch from the k/2-th on, to keep
  * the ~4 us the two event packets cost out of most steps), a launch of the dominant kernel (fused load + window +
  * FFT + dB) carries its own start/stop events on the context's stream; ss_kernel_timing_read
  * synchronises the stream, returns the summed device time in ms and the number of timed launches,

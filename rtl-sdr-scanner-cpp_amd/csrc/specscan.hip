@@ -1714,7 +1714,7 @@ int ss_kernel_timing(ss_ctx* c, int enable) {
   std::lock_guard<std::mutex> lock(c->mtx);
   c->prof_on = enable != 0;
   c->prof_every = enable > 1 ? enable : 1;
-  c->prof_seen = 0;
+  c->prof_seen = (unsigned)c->prof_every / 2;  // (every k-th launch from the k/2-th on: not the first launches of a run, which fill the pipeline)
   c->prof_used = 0;
   return SS_OK;
 }
