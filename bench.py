@@ -263,6 +263,9 @@ def parse_args(argv):
     ap.add_argument("--preheat-ms", type=float, default=400.0, help="run untimed steps for this long before the W warm-up steps: the GPU's clocks take a few hundred steps to settle (a cold start reads ~10 %% slow)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--diag-lib", action="store_true", help="load libspecscan_diag.so (-DSS_DIAG: SS_* environment variables select alternative implementations; measurement runs only)")
+    ap.add_argument("--lib", default=None, help="path of an A/B build of the diagnostics library (build.build_variant; measurement runs only)")
+    ap.add_argument("--start-level", type=float, default=8.0, help="Device::m_startLevel in dB over the learned ceiling (reference default 8)")
+    ap.add_argument("--no-cull", action="store_true", help="SS_FLAG_NO_CULL: evaluate every averaging tile, also those whose segment maxima rule out a candidate (the data-independent cost of the chain)")
     ap.add_argument("--launch-check", action="store_true", help="exercise launcher, rendezvous, config broadcast and max-over-ranks timing only (no GPU work)")
     args = ap.parse_args(argv)
     preset = dict(CONFIGS.get(args.config or 2, {}))
@@ -298,7 +301,7 @@ def run(args):
     cfg0 = None
     if rank == 0:
         cfg0 = dict(fft_size=n, sample_rate=fs, decim=args.decim, in_format={"cf32": 0, "cs8": 1, "cu8": 2}[args.fmt], grouping_x=21, grouping_y=21,
-                    start_level_mdB=8000, learn_frames=min(100, nb), learn_ms=2000, max_batch=nb, band0_center=140_000_000,
+                    start_level_mdB=int(round(args.start_level * 1000)), learn_frames=min(100, nb), learn_ms=2000, max_batch=nb, band0_center=140_000_000,
                     band_spacing=max(2_000_000, fs), n_bands=world if args.shard == "bands" else 1, seed=0)
 
     if args.launch_check:
@@ -331,9 +334,10 @@ def run(args):
 
     eng_kw = dict(fft_size=int(cfg["fft_size"]), decim=int(cfg["decim"]), in_format=int(cfg["in_format"]), grouping_x=int(cfg["grouping_x"]),
                   grouping_y=int(cfg["grouping_y"]), start_level=cfg["start_level_mdB"] / 1000.0, learn_frames=int(cfg["learn_frames"]),
-                  max_batch=nb, device_id=device_index, flags=pkg.abi.SS_FLAG_SPECTROGRAM if args.spectrogram else 0)
-    if args.diag_lib:
-        pkg.engine.use_diag_library(True)
+                  max_batch=nb, device_id=device_index,
+                  flags=(pkg.abi.SS_FLAG_SPECTROGRAM if args.spectrogram else 0) | (pkg.abi.SS_FLAG_NO_CULL if args.no_cull else 0))
+    if args.diag_lib or args.lib:
+        pkg.engine.use_diag_library(args.lib or True)
     eng = pkg.SpectrumEngine(int(cfg["sample_rate"]), dist.band_center(cfg, band), **eng_kw)
 
     # ---- working set: `nsets` distinct input batches and output sets in rotation, well past the Infinity Cache ----
@@ -440,7 +444,8 @@ def run(args):
                                    + ("one band per GPU" if not shard_frames else "one band, a contiguous frame range per GPU (halo re-read, no exchange)"),
                        "baseline_config": args.config or 2, "fft_size": n, "frames_per_batch": nb, "bands": int(cfg["n_bands"]), "shard": args.shard if world > 1 else None,
                        "halo_frames": halo_frames, "candidates_per_batch": ncand,
-                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "sync_every_step": bool(args.sync_every_step), "diag_lib": bool(args.diag_lib),
+                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "sync_every_step": bool(args.sync_every_step), "diag_lib": bool(args.diag_lib or args.lib),
+                       "tile_culling": not args.no_cull,
                        "preheat_steps": preheat_steps, "input_sets": nsets, "output_sets": nout, "working_set_mib": round((nsets * in_bytes + nout * out_bytes) / 2**20, 1),
                        "dist_backend": backend if world > 1 else None, "ranks_share_devices": bool(world > ndev),
                        "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},

@@ -68,6 +68,10 @@ typedef enum ss_plane {
 /* Also run the Spectrogram side branch (sources/radio/blocks/spectrogram.cpp): accumulate the bin-decimated raw
  * PSD per centre frequency; read it back with ss_spectrogram_read. */
 #define SS_FLAG_SPECTROGRAM 2u
+/* 8192-point frames: evaluate every averaging tile, also those whose per-segment maxima show that no bin of the tile can
+ * reach start_level (csrc/detect_fused.h, tile culling). Results are identical either way; the flag exists so that the
+ * data-independent cost of the chain can be measured (bench.py reports both). */
+#define SS_FLAG_NO_CULL 4u
 
 #define SS_NO_DATA (-100.0f) /* setNoData sentinel, sources/utils/radio_utils.cpp:72-76 */
 

@@ -13,6 +13,7 @@ SS_FMT_CF32, SS_FMT_CS8, SS_FMT_CU8 = 0, 1, 2
 SS_PLANE_PSD, SS_PLANE_REL, SS_PLANE_AVG = 0, 1, 2
 SS_FLAG_KEEP_PLANES = 1
 SS_FLAG_SPECTROGRAM = 2
+SS_FLAG_NO_CULL = 4
 SS_NO_DATA = np.float32(-100.0)
 
 c_float_p = C.POINTER(C.c_float)

@@ -32,6 +32,20 @@ def needs_build(lib: str = LIB) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def build_variant(tag: str, defines, force: bool = False, verbose: bool = False) -> str:
+    """A/B builds for the measurement scripts: the diagnostics build with extra -D switches (cache-policy bits of the frame
+    loads and so on) -> scripts/ab/libspecscan_<tag>.so (git-ignored; travels to the GPU box). Never loaded by the product."""
+    out_dir = os.path.join(HERE, "..", "scripts", "ab")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.abspath(os.path.join(out_dir, f"libspecscan_{tag}.so"))
+    if force or needs_build(lib):
+        cmd = [_hipcc(), *FLAGS, "-DSS_DIAG", *[f"-D{d}" for d in defines], "-o", lib, *[os.path.join(CSRC, s) for s in SOURCES]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return lib
+
+
 def build_lib(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
     lib = LIB_DIAG if diag else LIB
     if force or needs_build(lib):

@@ -31,8 +31,46 @@
 #include <stdint.h>
 
 #include "detect_kernels.h"
+#include "fft8192_v2.h"
+
+// Cache policy of the detect tiles' row loads: 0 = default, 1 = non-temporal (A/B builds)
+#ifndef SS_DET_NT
+#define SS_DET_NT 0
+#endif
 
 namespace ss {
+
+__device__ __forceinline__ float load_row_value(const char* p) {
+#if SS_DET_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const float*>(p));
+#else
+  return *reinterpret_cast<const float*>(p);
+#endif
+}
+
+// Tile culling (8192-point frames): a tile whose every rel value is below start_level cannot hold a candidate — a mean of
+// values cannot exceed their maximum — so it need not read its 36 x 276 rel values at all. The bound: the FFT role leaves,
+// per frame and 256-bin tile column, the maximum dB value over the column's bins and 32 more on either side
+// (Fft8192Args::segsum); the tile takes the maximum M of its column over its 36 frames and the minimum m of the noise
+// ceiling over the same 320 bins (thr_tilemin, kept up to date by k_thr_tilemin); every rel = fl(psd - thr) <= fl(M - m)
+// because rounding is monotonic. The fp32 sums behind a mean of 441 such values (|rel| < 1000 dB: finite dB values lie in
+// [-450, 400]) are off by < 0.01 dB, so a tile with fl(M - m) < start_level - kCullMargin has no candidate whatever the
+// rounding. -inf and NaN rows need no care: they make no candidates either (a NaN never passes `start_level <= avg`), and
+// +inf is not below any level. The decision is exact — culled tiles produce what the full evaluation would have produced:
+// zero mask bits, no counts (tests/test_gpu_cull.py: identical candidate lists with SS_FLAG_NO_CULL and against oracle/_ref).
+// What a culled tile must not cost is a workgroup: inside the step kernel every detect workgroup holds one of a CU's four
+// slots for ~7 us whatever it does (its first loads queue behind the frames the CU streams), and with five tiles in six
+// culled that was a third of the step; a launch of their own behind the step costs two kernel boundaries
+// per queue instead (measured: worse). So the decision is taken for ALL tiles of a call by a handful of workgroups (the
+// plan role of k_scan_step, dispatched first: one lane per tile) which compact the tiles that must be evaluated into a
+// list and clear the mask words of the others; the FFT workgroups of the same launch — which live ~14 us before they
+// need to know — pick the lists up when their frame is done (scan_step.h). Plan workgroup s owns the tiles of 8 (or 4) tile
+// columns and a list of its own; consumer p serves list p mod S, entries 2 (p div S) and the next one, so all it has to
+// read is ONE header word, count | ready. The hand-over inside the launch follows MI355X_MICROARCH.md: write-through (sc1) stores
+// for the entries, drained (vmcnt 0 — not a release fence: that would write back an L2 full of dB rows being produced),
+// then the header word, sc1; consumers read header and entries with sc1 loads. Plan workgroups never wait for anybody
+// and are dispatched before every consumer: no deadlock.
+constexpr float kCullMargin = 0.0625f;
 
 // s / D for a compile-time integer D, correctly rounded like the reference's `sum / count`
 // (float / int -> IEEE division): q0 = s * RN(1/D), one Newton correction with exact residuals (FMA).
@@ -85,8 +123,17 @@ struct DetectArgs {
   float* spec_prev_sum;            // [spec_n] Container::m_sum they belong to
   int spec_prev_tiles;
   int spec_m, spec_n;              // m_decimatorFactor (a power of two <= 256), m_outputSize
+  // Tile culling (tile_is_culled, 8192 points): per-column maxima of this batch's PSD rows (Fft8192Args::segsum), or null
+  const float* segsum;             // [32][seg_pitch]
+  int seg_pitch;
+  const float* thr_tilemin;        // [32] min of thr over bins [256 c - 32, 256 c + 288)
+  // [s], s < 8: kLiveReady | number of tiles of plan workgroup s that must be evaluated; [8 + kLiveCap s ...] those tiles.
+  // Written by the plan role (plan_tiles), consumed by the workgroups of the same launch (list_pair), the header set back to
+  // zero by the call's emit stage.
+  int* live;
 #ifdef SS_DIAG
   long long* stamp_mid;  // measurement builds: wall clock after phase 1 (loads + time means) and after phase 2, per tile
+  unsigned* cull_stats;  // measurement builds: {tiles, tiles on the culling path, tiles culled}
 #endif
 };
 
@@ -190,6 +237,161 @@ __device__ __forceinline__ void spectrogram_fold(const DetectArgs& a, int tid, i
   a.spec_prev_sum[ob] = acc;
 }
 
+constexpr int kLiveHeader = 8;       // header words in front of DetectArgs::live's lists = the most plan workgroups a stage may have
+constexpr int kLiveCap = 640;        // capacity of a plan workgroup's list: its tile columns x the batch's frame tiles
+constexpr int kLiveReady = 1 << 30;  // header word: the list is complete
+constexpr int kPlanLdsFloats = 9600; // staging area of a plan workgroup (+ 64 ints of bookkeeping behind it)
+
+// Frame tiles of a batch, and how many tile columns one plan workgroup can take (0: the stage cannot be planned).
+__host__ __device__ inline int plan_frame_tiles(int nframes, int shift) { return (nframes + shift + 15) / 16; }
+__host__ __device__ inline int plan_cols_per_wg(int nframes, int shift) {
+  const int per_col = nframes + (nframes >> 4) + 1, nft = plan_frame_tiles(nframes, shift);
+  for (int cols = 8; cols >= 4; cols >>= 1)
+    if (cols * per_col <= kPlanLdsFloats && cols * nft <= kLiveCap && nft <= 192) return cols;
+  return 0;
+}
+
+// The plan role (8192-point frames: 32 tile columns). Workgroup `seg` takes `cols` tile columns, wave w the column
+// seg * cols + w, lane = frame tile (three rounds at most). Tiles on detect_tile's straight-line path whose sole products are
+// mask bits and counts are tested — no learning / warm-up / ring rows, no rel or avg plane wanted, not one of the tiles
+// that refresh the ring; all others are evaluated. The wave first copies its column of Fft8192Args::segsum (one float per
+// frame) into LDS with coalesced loads — a lane reading its own 36 frames straight from memory touches 36 cache lines
+// nobody shares with it: measured, a plan workgroup took 24 us that way and every consumer waited for it — then every lane
+// takes the maximum over its 36 frames from there (one pad word per 16 frames: lanes are 16 frames apart). Evaluated
+// tiles go to the workgroup's list in (column, frame tile) order, then the header word; the mask words of culled tiles
+// are cleared afterwards — all a culled tile ever writes, and nobody reads them before the next launch.
+// `lds` = kPlanLdsFloats floats + 64 ints.
+template <int G, int GX, int TF, int TB_ = 256>
+__device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int cols, int tid, float* __restrict__ lds) {
+  using T = DetectTile<G, GX, TF, TB_>;
+  constexpr int TB = T::TB, H = T::H, ROWS = T::ROWS;
+  static_assert(TF == 16, "one pad word per frame tile");
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = a.n, nframes = a.nframes;
+  const int tiles_per_row = n / TB;
+  const int nft = plan_frame_tiles(nframes, a.shift);
+  const int rounds = (nft + 63) >> 6;
+  int* book = reinterpret_cast<int*>(lds + kPlanLdsFloats);  // [w * 4 + round]: tiles wave w lists in that round
+  const int col = seg * cols + w;
+  const bool has_col = w < cols && col < tiles_per_row;
+  const bool plannable = a.segsum && !a.rel_out && !a.avg_out;
+  float* mine = lds + w * (nframes + (nframes >> 4) + 1);
+  float tm = 0.0f;
+  if (has_col && plannable) {
+    const float* src = a.segsum + (size_t)col * a.seg_pitch;
+    tm = a.thr_tilemin[col];
+    for (int f = lane; f < nframes; f += 64) mine[f + (f >> 4)] = src[f];
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's column is in LDS (nobody else reads it)
+  unsigned long long live_mask[3] = {0ull, 0ull, 0ull}, dead_mask[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    if (r < rounds) {
+      const int ft_seq = r * 64 + lane;
+      const bool exists = has_col && ft_seq < nft;
+      const int ft = (ft_seq + nft - 1) % nft;
+      const int f0 = ft * TF - a.shift;
+      const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes);
+      const bool writes_hist = f0 + TF > nframes - H;
+      bool culled = false;
+      if (exists && plannable && steady && !writes_hist) {
+        const int b = f0 - (G - 1);
+        float m = mine[b + (b >> 4)];
+#pragma unroll
+        for (int k = 1; k < ROWS; ++k) m = fmaxf(m, mine[b + k + ((b + k) >> 4)]);  // (NaNs are skipped)
+        culled = (m - tm) < a.start_level - kCullMargin;                          // (false for NaN)
+      }
+      live_mask[r] = __ballot(exists && !culled);
+      dead_mask[r] = __ballot(culled);
+      if (lane == 0) book[w * 4 + r] = __popcll(live_mask[r]);
+    } else if (lane == 0) {
+      book[w * 4 + r] = 0;
+    }
+  }
+  if (lane == 0) book[w * 4 + 3] = 0;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int k = 0; k < 32; ++k) {  // (wave, round) in order
+    const int c = book[k];
+    base += k < w * 4 ? c : 0;
+    total += c;
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    if (r < rounds) {
+      const int ft_seq = r * 64 + lane;
+      if ((live_mask[r] >> lane) & 1ull)
+        __hip_atomic_store(&a.live[kLiveHeader + seg * kLiveCap + base + __popcll(live_mask[r] & ((1ull << lane) - 1ull))], ft_seq * tiles_per_row + col,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+      base += __popcll(live_mask[r]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's entries are in memory
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(&a.live[seg], kLiveReady | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    unsigned long long dead = r < rounds ? dead_mask[r] : 0ull;
+    while (dead) {  // wave-uniform: the wave's culled tiles one after the other, TF frames x 8 mask words each
+      const int src = __ffsll((long long)dead) - 1;
+      dead &= dead - 1;
+      const int ft = (r * 64 + src + nft - 1) % nft;
+      const size_t w0 = ((size_t)(ft * TF - a.shift) * n + (size_t)col * TB) >> 5;
+#pragma unroll
+      for (int k = 0; k < TF * (TB / 32) / 64; ++k) {
+        const int e = k * 64 + lane;
+        a.maskbits[w0 + (size_t)(e >> 3) * (n >> 5) + (e & 7)] = 0u;
+      }
+    }
+  }
+#ifdef SS_DIAG
+  if (a.cull_stats && lane == 0 && has_col) {
+    int lv = 0, dd = 0;
+    for (int r = 0; r < 3; ++r) {
+      lv += __popcll(live_mask[r]);
+      dd += __popcll(dead_mask[r]);
+    }
+    atomicAdd(&a.cull_stats[0], (unsigned)(lv + dd));
+    atomicAdd(&a.cull_stats[2], (unsigned)dd);
+  }
+#endif
+}
+
+// Consumer side, called by every wave of a workgroup with the same arguments: the two tiles consumer `p` of `nseg` lists is
+// to evaluate (-1: none): list p mod nseg, entries 2 (p div nseg) and the next. `word` = that list's header word as read
+// earlier (the FFT role asks before it loads its frame, so the answer costs it nothing); if the list was not complete by
+// then, wait for it now. Every wave of the workgroup ends up with the same pair.
+__device__ __forceinline__ int2 list_pair(const DetectArgs& a, int p, int nseg, int word) {
+  const int seg = p % nseg, q = p / nseg;
+  word = __builtin_amdgcn_readfirstlane(word);
+  while (!(word & kLiveReady)) {
+    __builtin_amdgcn_s_sleep(8);
+    word = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.live[seg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  const int count = word & (kLiveReady - 1);
+  int2 t = make_int2(-1, -1);
+  if (2 * q < count) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.live + kLiveHeader + seg * kLiveCap + 2 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t.x = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    if (2 * q + 1 < count) t.y = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  }
+  return t;
+}
+
+// min of the noise ceiling over bins [256 c - 32, 256 c + 288), c = blockIdx.x (one wave each): DetectArgs::thr_tilemin,
+// refreshed whenever the ceiling changes (learning batches).
+__global__ __launch_bounds__(64) void k_thr_tilemin(const float* __restrict__ thr, int n, float* __restrict__ tilemin) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float m = __builtin_inff();
+  for (int i = lane; i < 320; i += 64) {
+    const int bin = 256 * c - 32 + i;
+    if (bin >= 0 && bin < n) m = fminf(m, thr[bin]);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fminf(m, __shfl_xor(m, d));
+  if (lane == 0) tilemin[c] = m;
+}
+
 // One tile of the fused back end. `block` = tile number (what blockIdx.x is for the stand-alone kernel), `tid` = 0..TB-1,
 // `tile` / `cnt` = this tile's LDS (TF * P floats, TF ints). `valid` = false: the caller has no tile for these threads (odd
 // tile count in a two-tile workgroup) — they only keep the workgroup's barriers company. Every __syncthreads() below is
@@ -241,7 +443,7 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
         const uint32_t coff = (uint32_t)colc * 4u;
         float x[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) x[r] = *reinterpret_cast<const float*>(p + (size_t)r * n * 4 + coff) - t;
+        for (int r = 0; r < ROWS; ++r) x[r] = load_row_value(p + (size_t)r * n * 4 + coff) - t;
         if (!interior) {
 #pragma unroll
           for (int r = 0; r < ROWS; ++r) x[r] = in_band ? x[r] : 0.0f;
@@ -434,6 +636,7 @@ struct EmitArgs {
   int clear_n;
   const float* avg;  // avg[f * n + bin] for every hit bin (the sparse plane, or the caller's full avg plane)
   int cap;
+  int* live_clear;   // DetectArgs::live of the call (or null): its header words go back to zero here
   int* off_int;      // [nframes + 1] the library's own copy of the offsets
   int* off_out;      // caller's cand_off or null
   int* cand_idx;     // null: offsets only
@@ -467,6 +670,9 @@ __device__ __forceinline__ int emit_frame_offset(const EmitArgs& a, int f, int l
       if (a.off_out) a.off_out[nframes] = begin + mine;
     }
     for (int g = f; g < a.clear_n; g += nframes) a.counts_clear[g] = 0;
+    if (f == 0 && a.live_clear) {
+      for (int k = 0; k < kLiveHeader; ++k) a.live_clear[k] = 0;
+    }
   }
   return begin;
 }

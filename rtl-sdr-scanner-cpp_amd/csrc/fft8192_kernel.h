@@ -126,15 +126,18 @@ __device__ __forceinline__ void dft32(float2 (&v)[32]) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* base, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);  // raw, 32-bit data format (gfx9)
 }
+// AUX: cache policy bits of the access (gfx94x/gfx950: 1 = sc0, 2 = nt, 16 = sc1); 0 = the default policy.
+template <int AUX = 0>
 __device__ __forceinline__ float2 buffer_load_f2(__amdgpu_buffer_rsrc_t r, int voffset_bytes, int soffset_bytes) {
-  const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voffset_bytes, soffset_bytes, 0);
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, voffset_bytes, soffset_bytes, AUX);
   return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
 }
 __device__ __forceinline__ float buffer_load_f1(__amdgpu_buffer_rsrc_t r, int voffset_bytes, int soffset_bytes) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voffset_bytes, soffset_bytes, 0));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buffer_store_f1(__amdgpu_buffer_rsrc_t r, int voffset_bytes, int soffset_bytes, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voffset_bytes, soffset_bytes, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voffset_bytes, soffset_bytes, AUX);
 }
 
 struct Fft8192Tables {

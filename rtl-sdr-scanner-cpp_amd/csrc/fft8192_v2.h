@@ -26,6 +26,15 @@
 
 #include "fft8192_kernel.h"
 
+// Cache policy of the frame loads (read once, never again) and of the dB row stores (read back by the detect stage two
+// launches later): measured in scripts/ubench and with bench.py, see DESIGN.md 4.1. Build-time so that variants can be A/B'd.
+#ifndef SS_AUX_IQ
+#define SS_AUX_IQ 0
+#endif
+#ifndef SS_AUX_PSD
+#define SS_AUX_PSD 0
+#endif
+
 namespace ss {
 
 struct Fft8192V2Tables {
@@ -64,7 +73,39 @@ struct Fft8192Args {
   Fft8192V2Tables tabs;
   float db_off, scale;
   float* psd;             // [frames][8192] dB rows, DC at bin 4096
+  // Optional summary for the detect stage (detect_fused.h, tile culling): for every 256-bin tile column c of every frame the
+  // maximum dB value over bins [256 c - 32, 256 c + 288) — the tile and one 32-bin segment either side, which covers the
+  // +-10 bins a tile's frequency means reach — at segsum[c * seg_pitch + frame]: tile-column major, so that the 36 frames a
+  // detect tile averages over are 36 consecutive floats (three scalar loads). Null: not wanted.
+  float* segsum;
+  int seg_pitch;
+  // Optional: the header word (DetectArgs::live, detect_fused.h) of the list this workgroup serves for the detect stage that
+  // rides on the launch (scan_step.h). It is asked for before the frame's own loads and handed back in `hdr` when they have
+  // landed: the answer costs the workgroup nothing.
+  const int* live_hint;
 };
+
+// max over the 32 lanes of a half-wave (lanes 0..31 / 32..63) of FOUR values at once, valid in each half's upper 16 lanes:
+// four butterfly steps inside each row of 16 (every lane of a row then holds the row's maximum), then lane 15 of rows 0 / 2
+// broadcast into rows 1 / 3. v_max_f32 returns the other operand for a (quiet) NaN, so NaN bins are ignored — they cannot
+// make a candidate. Written as v_max_f32_dpp by hand (the compiler emits v_mov_b32_dpp + canonicalising v_max triples, 3.5x
+// the instructions); four independent chains interleaved keep a DPP read three instructions behind the write it depends on
+// (the hardware wants two), the leading s_nop covers the values' producers.
+__device__ __forceinline__ void halfwave_max4_hi16(float& a, float& b, float& c, float& d) {
+#define SS_DPP4(ctrl)                                  \
+  "v_max_f32_dpp %0, %0, %0 " ctrl " bank_mask:0xf\n" \
+  "v_max_f32_dpp %1, %1, %1 " ctrl " bank_mask:0xf\n" \
+  "v_max_f32_dpp %2, %2, %2 " ctrl " bank_mask:0xf\n" \
+  "v_max_f32_dpp %3, %3, %3 " ctrl " bank_mask:0xf\n"
+  asm volatile("s_nop 1\n"
+               SS_DPP4("quad_perm:[1,0,3,2] row_mask:0xf")
+               SS_DPP4("quad_perm:[2,3,0,1] row_mask:0xf")
+               SS_DPP4("row_half_mirror row_mask:0xf")
+               SS_DPP4("row_mirror row_mask:0xf")
+               SS_DPP4("row_bcast:15 row_mask:0xa")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef SS_DPP4
+}
 
 // TW: 0 = every table from global memory (first generation), 1 = pass-2 table in LDS, 2 = all tables in LDS / SGPRs,
 //     3 = no tables at all (timing bound only: the output is meaningless).
@@ -72,7 +113,7 @@ struct Fft8192Args {
 //      stores into the 17-word pitch.
 // One frame by one workgroup of 512 threads; `smem_raw` = kFft8192V2LdsBytes of LDS, `t` = threadIdx.x.
 template <int FMT, int TW, bool SWZ = false, bool NOWIN = false>
-__device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t frame, unsigned char* __restrict__ smem_raw, int t) {
+__device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t frame, unsigned char* __restrict__ smem_raw, int t, int* hdr) {
   float* s = reinterpret_cast<float*>(smem_raw);
   float2* tw2_l = reinterpret_cast<float2*>(smem_raw + kFft8192V2PlaneBytes);
   float2* lane_l = tw2_l + 256;
@@ -81,8 +122,14 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
   const float* win = g.win;
   const float db_off = g.db_off, scale = g.scale;
   float* psd = g.psd;
+  float* segsum = g.segsum;
   const size_t in_base = frame * (size_t)g.item_stride;
 
+  // (a buffer load with the sc0 sc1 policy bits — it must see what other XCDs wrote during this launch — and not an atomic
+  // load: behind an atomic the compiler no longer trusts the twiddle tables to be unchanged and fetches the wave-uniform
+  // ones with vector loads)
+  unsigned hint = 0u;
+  if (g.live_hint) hint = __builtin_amdgcn_raw_buffer_load_b32(buffer_of(g.live_hint, 4), 0, 0, 17);
   // ---- tables first: these loads are ahead of the frame's own in the vector-memory queue ----
   float2 tf0 = make_float2(0.f, 0.f), tf1 = make_float2(0.f, 0.f);
   if constexpr (TW == 1) {
@@ -102,9 +149,9 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
     for (int r = 0; r < 16; ++r) {
       float2 x;
       if constexpr (FMT == FMT_CF32) {
-        x = buffer_load_f2(rin, t * 8, 4096 * r);
+        x = buffer_load_f2<SS_AUX_IQ>(rin, t * 8, 4096 * r);
       } else {
-        const unsigned short raw = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rin, t * 2, 1024 * r, 0);
+        const unsigned short raw = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rin, t * 2, 1024 * r, SS_AUX_IQ);
         if constexpr (FMT == FMT_CS8) x = make_float2((float)(signed char)(raw & 0xff) * scale, (float)(signed char)(raw >> 8) * scale);
         else x = make_float2(((float)(raw & 0xff) - 127.5f) * scale, ((float)(raw >> 8) - 127.5f) * scale);
       }
@@ -123,6 +170,8 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
     if (t < 128) lane_l[256 + t] = tf1;
   }
   dft16(a);
+  // the frame has landed, and with it everything asked for before it: into scalar registers, out of the way
+  *hdr = __builtin_amdgcn_readfirstlane((int)hint);
   float2 c[16];
   if constexpr (SWZ) {
     // exchange 1, unpadded: y[16 t + k] lives at word 16 t + 4 (((k >> 2) + (t >> 1)) & 3) + (k & 3). The 8 lanes of one
@@ -202,16 +251,21 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
   // twiddle of input r = 2q + h:  W_8192^(j r) = W_8192^(j (r & 3)) * W_2048^(j (r >> 2)),  r & 3 = 2 (q & 1) + h,  r >> 2 = q >> 1
   if constexpr (TW == 2) {
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const float2* __restrict__ sw = tabs.wave + w * 12;  // wave-uniform: scalar loads
-    const float2 sa0 = h ? sw[9] : sw[8];    // W_256^(w a), a = h
-    const float2 sa1 = h ? sw[11] : sw[10];  //              a = 2 + h
+    // wave-uniform and never written: the constant address space makes these scalar loads whatever else the kernel does
+    typedef const __attribute__((address_space(4))) float* const_fp;
+    const_fp swf = (const_fp)(uintptr_t)(tabs.wave + w * 12);
+    const auto sw = [swf](int i) { return make_float2(swf[2 * i], swf[2 * i + 1]); };
+    // (all four fetched, then selected per lane: a select between the two ADDRESSES would make them vector loads)
+    const float2 s8 = sw(8), s9 = sw(9), s10 = sw(10), s11 = sw(11);
+    const float2 sa0 = make_float2(h ? s9.x : s8.x, h ? s9.y : s8.y);      // W_256^(w a), a = h
+    const float2 sa1 = make_float2(h ? s11.x : s10.x, h ? s11.y : s10.y);  //              a = 2 + h
     const float2 wa0 = cmul(lane_l[256 + h * 32 + lam], sa0);
     const float2 wa1 = cmul(lane_l[256 + (2 + h) * 32 + lam], sa1);
     a[0] = cmul(a[0], wa0);
     a[1] = cmul(a[1], wa1);
 #pragma unroll
     for (int q2 = 1; q2 < 8; ++q2) {
-      const float2 wb = cmul(lane_l[q2 * 32 + lam], sw[q2]);
+      const float2 wb = cmul(lane_l[q2 * 32 + lam], sw(q2));
       a[2 * q2] = cmul(a[2 * q2], cmul(wa0, wb));
       a[2 * q2 + 1] = cmul(a[2 * q2 + 1], cmul(wa1, wb));
     }
@@ -257,19 +311,60 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
   float* out = psd + frame * 8192;
   const __amdgpu_buffer_rsrc_t rout = buffer_of(out, 8192 * 4);
   const int voff = (j + 2048 * h) * 4;
+  // Per-segment maxima for the detect stage's tile culling: the 32 lanes of a half-wave hold, for every (k, s), the 32
+  // consecutive bins of segment w + 8 k + 64 h + 128 s; lane 16 + i of each half keeps the maximum of value i = 2 k + s.
+  // The 256 segment maxima of the frame meet in LDS (the 512 floats behind the exchange plane, idle since exchange 1) and the
+  // first 32 threads turn them into the 32 tile-column maxima the detect stage reads.
+  const bool want_max = segsum != nullptr;  // (workgroup-uniform)
+  float mine;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    // v_permlane32_swap(vdst, src): lanes 32..63 of vdst <-> lanes 0..31 of src. With vdst = u[k], src = u[k+8]:
-    //   low half:  (e, o) = (own u[k] = A_even[k],          partner's u[k]   = W^k A_odd[k])
-    //   high half: (e, o) = (partner's u[k+8] = A_even[k+8], own u[k+8]      = W^(k+8) A_odd[k+8])
-    const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].x), __float_as_uint(u[k + 8].x), false, false);
-    const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].y), __float_as_uint(u[k + 8].y), false, false);
-    const float2 e = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
-    const float2 o = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
-    // this lane's output index kk = k + 8 h; bin0 = j + 256 kk < 4096: the half rotation (fft_v shift = true) sends
-    // X[kk] to bin0 + 4096 and X[kk + 16] to bin0
-    buffer_store_f1(rout, voff, 1024 * k + 16384, psd_db(cadd(e, o), db_off));
-    buffer_store_f1(rout, voff, 1024 * k, psd_db(csub(e, o), db_off));
+  for (int k2 = 0; k2 < 4; ++k2) {
+    float pv[4];  // pv[2 i + s]: the dB value of bin j + 2048 h + 256 (2 k2 + i) + 4096 s
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = 2 * k2 + i;
+      // v_permlane32_swap(vdst, src): lanes 32..63 of vdst <-> lanes 0..31 of src. With vdst = u[k], src = u[k+8]:
+      //   low half:  (e, o) = (own u[k] = A_even[k],          partner's u[k]   = W^k A_odd[k])
+      //   high half: (e, o) = (partner's u[k+8] = A_even[k+8], own u[k+8]      = W^(k+8) A_odd[k+8])
+      const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].x), __float_as_uint(u[k + 8].x), false, false);
+      const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[k].y), __float_as_uint(u[k + 8].y), false, false);
+      const float2 e = make_float2(__uint_as_float(sx[0]), __uint_as_float(sy[0]));
+      const float2 o = make_float2(__uint_as_float(sx[1]), __uint_as_float(sy[1]));
+      // this lane's output index kk = k + 8 h; bin0 = j + 256 kk < 4096: the half rotation (fft_v shift = true) sends
+      // X[kk] to bin0 + 4096 and X[kk + 16] to bin0
+      pv[2 * i + 1] = psd_db(cadd(e, o), db_off);
+      pv[2 * i] = psd_db(csub(e, o), db_off);
+      buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k + 16384, pv[2 * i + 1]);
+      buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k, pv[2 * i]);
+    }
+    if (want_max) {
+      halfwave_max4_hi16(pv[0], pv[1], pv[2], pv[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // value index 2 k + s = 4 k2 + q goes to lanes 16 + index and 48 + index (a constant lane mask: no compare)
+        const unsigned long long keep = (1ull << (16 + 4 * k2 + q)) | (1ull << (48 + 4 * k2 + q));
+        if (k2 == 0 && q == 0) mine = pv[0];  // (every lane: no initial value that would have to live through the frame loop)
+        else asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(mine) : "v"(pv[q]), "s"(keep));
+      }
+    }
+  }
+  if (want_max) {
+    // wave, half and lane come back out of the PSD stores' own offset (j + 2048 h) * 4, j = 32 w + lane mod 32 — the one
+    // per-thread value that is alive here anyway; anything else kept alive through pass 3 for this gets spilled (64 VGPRs)
+    int vv = voff;
+    asm volatile("" : "+v"(vv));
+    float* segs = s + 8192;
+    const int i = (vv >> 2) & 15;
+    if (vv & 64) segs[((vv >> 7) & 7) + 8 * (i >> 1) + 64 * (vv >> 13) + 128 * (i & 1)] = mine;
+    __syncthreads();
+    if (vv < 128) {  // wave 0, lower half: thread c = tile column
+      const int c = vv >> 2;
+      float m = segs[max(8 * c - 1, 0)];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) m = fmaxf(m, segs[min(8 * c + q, 255)]);
+      // block-uniform base and frame offset in scalar registers, one per-lane offset (no 64-bit address arithmetic in the vector pipe)
+      const __amdgpu_buffer_rsrc_t rseg = buffer_of(segsum, 32 * g.seg_pitch * 4);
+      buffer_store_f1(rseg, c * g.seg_pitch * 4, (int)frame * 4, m);
+    }
   }
 }
 
@@ -278,7 +373,8 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
 template <int FMT, int TW, bool SWZ = false, bool NOWIN = false>
 __global__ __launch_bounds__(512, 8) void k_fft8192_psd_v2(Fft8192Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  fft8192_v2_frame<FMT, TW, SWZ, NOWIN>(g, blockIdx.x, smem_raw, (int)threadIdx.x);
+  int hdr;
+  fft8192_v2_frame<FMT, TW, SWZ, NOWIN>(g, blockIdx.x, smem_raw, (int)threadIdx.x, &hdr);
 }
 
 }  // namespace ss

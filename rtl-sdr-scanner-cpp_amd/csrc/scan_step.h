@@ -53,8 +53,15 @@ struct StepArgs {
   DetectArgs det;
   EmitArgs emit;
   int n_fft;   // frames (KIND 0, n_halo included) or column tiles (KIND 1) of the FFT role (0: role absent)
-  int fft_per_wg;  // consecutive frames one FFT workgroup transforms, one after the other (see below; 1 for KIND 1)
   int n_det;   // detect TILES (two per workgroup)
+  // KIND 0, tile culling (detect_fused.h): the n_plan tiles of `det` are PLANNED by S = 32 / plan_cols plan workgroups,
+  // dispatched first, each listing those tiles of its plan_cols tile columns that must be evaluated; consumer p serves list
+  // p mod S, entries 2 (p div S) and the next. Consumers are the launch's FFT workgroups once their frame is done
+  // (plan_by_fft: the host makes sure there are enough of them) or, in a launch without an FFT role, detect workgroups of
+  // which those beyond their list leave at once.
+  int n_plan;
+  int plan_cols;
+  int plan_by_fft;
   int n_emit;  // frames of the emit role
   int emit_per_wg;  // 8: one wave per frame; 1 (KIND 2): rows of 2048 mask words and more, the eight waves share one frame
   // One workgroup per work item, dispatched in blockIdx order, four resident per CU. WHICH item a workgroup takes decides
@@ -68,28 +75,32 @@ struct StepArgs {
   long long* stamps;  // measurement builds only: {start, end (100 MHz wall clock), role << 32 | item, XCC_ID << 32 | HW_ID} per workgroup
 #endif
 };
-// Why an FFT workgroup takes SEVERAL frames. A CU holds four workgroups. Four FFT workgroups on a CU are four frames
-// waiting for HBM with the vector pipe idle and no slot left for anything else; but two FFT workgroups per CU already keep
-// the memory pipe as busy (1024 frames alone: 27.2 us with two per CU, 27.0 with three, 24.2 with four — fft8192_lab). So a
-// batch is cut into only as many FFT workgroups as fill TWO slots of every CU (2 x CUs), each transforming
-// fft_per_wg = nframes / (2 x CUs) frames in turn and living as long as the launch, and the order table hands the other two
-// slots of every CU to the short-lived detect and emit workgroups, which then run inside the FFT role's memory waits
-// instead of behind it.
+// (Tried in round 2 and dropped in round 3: FFT workgroups that take several frames each, so that the FFT role holds only
+// two of a CU's four slots. The step got no faster, and the frame loop cost the kernel registers.)
 
 constexpr int kStepThreads = 512;
 constexpr int kStepLdsBytes = kFft8192V2LdsBytes;
 static_assert(2 * (16 * DetectTile<21, 21, 16, 256>::P * 4 + 64) <= kFft8192V2LdsBytes, "two detect tiles per workgroup");
 static_assert((8 * kEmitList + 9) * 4 <= kFft8192V2LdsBytes, "eight emit lists per workgroup");
 static_assert(kFft256ColsLdsBytes <= kFft8192V2LdsBytes, "a column tile");
-
-inline int step_fft_wgs(const StepArgs& a) { return a.n_fft ? (a.n_fft + a.fft_per_wg - 1) / a.fft_per_wg : 0; }
+static_assert((kPlanLdsFloats + 64) * 4 <= kFft8192V2LdsBytes, "a plan workgroup's staging area");
+inline int step_fft_wgs(const StepArgs& a) { return a.n_fft; }
 inline int step_emit_wgs(const StepArgs& a) { return a.emit_per_wg == 1 ? a.n_emit : (a.n_emit + 7) / 8; }
-inline int step_items(const StepArgs& a) { return step_fft_wgs(a) + (a.n_det + 1) / 2 + step_emit_wgs(a); }
+__host__ __device__ inline int step_plan_wgs(const StepArgs& a) { return a.n_plan ? 32 / a.plan_cols : 0; }
+// consumers a planned stage needs: per list, a pair for every two tiles it may hold
+inline int step_plan_consumers(const StepArgs& a) { return step_plan_wgs(a) * ((a.plan_cols * (a.n_plan / 32) + 1) / 2); }
+inline int step_det_wgs(const StepArgs& a) { return (a.n_det + 1) / 2 + (a.plan_by_fft ? 0 : step_plan_consumers(a)); }
+inline int step_items(const StepArgs& a) { return step_fft_wgs(a) + step_det_wgs(a) + step_emit_wgs(a) + step_plan_wgs(a); }
 
-enum { ROLE_NONE = 0, ROLE_FFT = 1, ROLE_DET = 2, ROLE_EMIT = 3 };
+enum { ROLE_NONE = 0, ROLE_FFT = 1, ROLE_DET = 2, ROLE_EMIT = 3, ROLE_PLAN = 4 };
 
 template <int FMT, bool SPEC, int TW, bool SWZ, int KIND>
 __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int item, unsigned char* smem_raw, int tid) {
+  // Every big piece of code below has ONE call site (the compiler would otherwise carry several copies of a 3000-instruction
+  // tile evaluation and of the transform, and spill registers for them): the roles first decide WHICH tiles, if any, this
+  // workgroup evaluates — the detect role from its item number or from the planned stage's list, the FFT role from the list
+  // once its frame is done — and the evaluation follows at the bottom.
+  int tile_a = -1, tile_b = -1;  // the tiles of threads 0..255 / 256..511 (workgroup-uniform; -1: none)
   if (role == ROLE_EMIT) {
     if constexpr (KIND == 2) {
       // ---- emit role, long rows: the eight waves share one frame ----
@@ -101,35 +112,54 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       if (f < a.n_emit) cand_emit_frame(a.emit, f, tid & 63, reinterpret_cast<int*>(smem_raw) + w * kEmitList);
     }
   } else if (role == ROLE_DET) {
-    // ---- detect role: two tiles, threads 0..255 and 256..511 ----
-    using T = DetectTile<21, 21, 16, 256>;
-    const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
-    const int tile_no = 2 * item + half;
-    float* tile = reinterpret_cast<float*>(smem_raw) + half * (16 * T::P + 16);
-    int* cnt = reinterpret_cast<int*>(tile + 16 * T::P);
-    detect_tile<21, 21, 16, 256, SPEC>(a.det, min(tile_no, a.n_det - 1), tid & 255, tile, cnt, tile_no < a.n_det);
+    // ---- detect role: two tiles ----
+    if (KIND == 0 && a.n_plan) {  // the planned stage's lists (a launch without an FFT role)
+      const int2 pr = list_pair(a.det, item, step_plan_wgs(a), 0);
+      tile_a = pr.x;
+      tile_b = pr.y;
+    } else {
+      tile_a = 2 * item;
+      tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;
+    }
+  } else if (role == ROLE_PLAN) {
+    if constexpr (KIND == 0) plan_tiles<21, 21, 16, 256>(a.det, item, a.plan_cols, tid, reinterpret_cast<float*>(smem_raw));
   } else if constexpr (KIND >= 1) {
     // ---- FFT role, long transforms: one tile of 32 columns ----
     fft_cols256_tile<FMT>(a.cols, item, smem_raw, tid);
   } else {
-    // ---- FFT role: fft_per_wg consecutive frames, one after the other ----
-    const int f0 = item * a.fft_per_wg, f1 = min(f0 + a.fft_per_wg, a.n_fft);
-    for (int f = f0; f < f1; ++f) {
-      if (f > f0) __syncthreads();  // the previous frame's last LDS reads are done
-      int t = tid;
-      asm volatile("" : "+v"(t));  // the per-thread offsets are cheap to rebuild per frame and expensive to keep alive across the loop (64 VGPRs)
-      const int fu = __builtin_amdgcn_readfirstlane(f);  // (workgroup-uniform: keep the selects in scalar registers)
-      const bool halo = fu < a.n_halo;
-      Fft8192Args g = a.fft;
-      g.iq = halo ? a.halo_iq : a.fft.iq;
-      g.psd = halo ? a.halo_psd : a.fft.psd;
-      fft8192_v2_frame<FMT, TW, SWZ>(g, (size_t)(halo ? fu : fu - a.n_halo), smem_raw, t);
+    // ---- FFT role: one frame ----
+    int hdr;
+    const bool halo = item < a.n_halo;  // (workgroup-uniform)
+    Fft8192Args g = a.fft;
+    g.iq = halo ? a.halo_iq : a.fft.iq;
+    g.psd = halo ? a.halo_psd : a.fft.psd;
+    g.segsum = halo ? nullptr : a.fft.segsum;  // (the tiles that read halo rows are not culled)
+    g.live_hint = a.plan_by_fft ? a.det.live + item % step_plan_wgs(a) : nullptr;  // the list this workgroup serves for the detect stage that rides on the launch
+    fft8192_v2_frame<FMT, TW, SWZ>(g, (size_t)(halo ? item : item - a.n_halo), smem_raw, tid, &hdr);
+    if (a.plan_by_fft) {
+      const int2 pr = list_pair(a.det, item, step_plan_wgs(a), hdr);
+      tile_a = pr.x;
+      tile_b = pr.y;
+      if (tile_a >= 0) __syncthreads();  // the frame's last LDS reads are done
     }
+  }
+  if (tile_a >= 0) {
+    // ---- tile evaluation: threads 0..255 and 256..511 one tile each ----
+    using T = DetectTile<21, 21, 16, 256>;
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
+    float* tile = reinterpret_cast<float*>(smem_raw) + half * (16 * T::P + 16);
+    int* cnt = reinterpret_cast<int*>(tile + 16 * T::P);
+    const int mine = half ? tile_b : tile_a;
+    detect_tile<21, 21, 16, 256, SPEC>(a.det, mine < 0 ? tile_a : mine, tid & 255, tile, cnt, mine >= 0);
   }
 }
 
 template <int FMT, bool SPEC, int TW = 2, bool SWZ = true, bool PRIO = false, int KIND = 0>
-__global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a) {
+__global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a_by_value) {
+  // The arguments are read where they are used, straight from the kernel-argument segment (scalar loads from constant
+  // memory): taken from the by-value parameter they are all loaded at the top of the kernel and kept alive through every
+  // role — hundreds of scalar registers spilled into vector registers the 64-VGPR budget does not have.
+  const StepArgs& a = *(const StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   int role, item;
@@ -138,7 +168,7 @@ __global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a) {
     role = (int)(w >> 24);
     item = (int)(w & 0xffffffu);
   } else {  // a single role
-    role = a.n_fft ? ROLE_FFT : a.n_det ? ROLE_DET : ROLE_EMIT;  // (fft_per_wg frames per workgroup for the FFT role)
+    role = a.n_fft ? ROLE_FFT : a.n_det ? ROLE_DET : a.n_emit ? ROLE_EMIT : ROLE_PLAN;
     item = blockIdx.x;
   }
   if constexpr (PRIO) {  // (s_setprio takes an immediate)

@@ -91,10 +91,12 @@ struct ss_ctx {
     std::string stamp_path;        // SS_DIAG only: dump per-workgroup start / end stamps of the 40th full k_scan_step launch here
     long long* d_stamps = nullptr;
     int stamp_launches = 0;
+    unsigned* d_cull_stats = nullptr;  // SS_DIAG only (SS_CULL_STATS=1): tiles seen / on the culling path / culled, printed by ss_destroy
     bool emit_wide = true;         // long rows (n >= 16384): several waves per frame in the emit stage
+    int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
+    bool cull = true;              // 8192 points: detect tiles that cannot hold a candidate are not evaluated (detect_fused.h)
     bool deep = true;              // 8192 points: consecutive step launches independent of each other, alternating over two queues (see ss_ctx::deep)
     bool step_long = true;         // n >= 16384: the column half of the FFT as the FFT role of k_scan_step (false: one launch per stage)
-    int fft_per_wg = 0;            // frames per FFT workgroup of k_scan_step: 0 = one; -1 = as many as leave the FFT role two slots per CU (scan_step.h)
     // Dispatch order of k_scan_step's work items when all three roles ride one launch: "prefix|cycle", comma-separated
     // segments of a role letter (E emit, D detect, F FFT) and a workgroup count ('*' = all that are left); the cycle repeats
     // until every item is placed, a role that has run out is skipped.
@@ -128,10 +130,12 @@ struct ss_ctx {
       prio_fft = num("SS_STEP_PRIO_FFT", 0);
       prio_other = num("SS_STEP_PRIO_OTHER", 0);
       if (const char* v = getenv("SS_STEP_STAMPS")) stamp_path = v;
-      fft_per_wg = num("SS_FFT_PER_WG", fft_per_wg);
       emit_wide = tri("SS_EMIT_WIDE") != 0;
       step_long = tri("SS_STEP_LONG") != 0;
       deep = tri("SS_DEEP") != 0;
+      cull = tri("SS_CULL") != 0;
+      ablate_roles = num("SS_ABLATE_ROLES", 0);
+      if (tri("SS_CULL_STATS") == 1 && hipMalloc(&d_cull_stats, 3 * sizeof(unsigned)) == hipSuccess) (void)hipMemset(d_cull_stats, 0, 3 * sizeof(unsigned));
       if (const char* v = getenv("SS_STEP_ORDER")) step_order = step_order_long = v;
     }
 #else
@@ -275,7 +279,7 @@ struct ss_ctx {
   // k_scan_step's dispatch-order table for the current launch shape (rebuilt when the shape changes; two buffers so that a
   // launch still in flight keeps the table it was given)
   struct OrderTable {
-    int key[3];  // FFT / detect / emit workgroups of the launch shape
+    int key[4];  // FFT / detect / emit / plan workgroups of the launch shape
     uint32_t* d;
     unsigned long long used;
   };
@@ -287,6 +291,11 @@ struct ss_ctx {
   float* d_avg2[4] = {nullptr, nullptr, nullptr, nullptr};
   int* d_off4[4] = {nullptr, nullptr, nullptr, nullptr};  // the library's copy of the candidate offsets, per rotating set (d_off = the latest)
   float* d_psd2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // Tile culling (8192 points, detect_fused.h): the FFT role's per-column maxima of a call's PSD rows, [32][max_batch],
+  // rotating with the mask / avg / offset buffers (written by the call's FFT launch, read by its detect stage)
+  float* d_segsum[4] = {nullptr, nullptr, nullptr, nullptr};
+  int* d_live[4] = {nullptr, nullptr, nullptr, nullptr};  // DetectArgs::live: the tiles of a call that must be evaluated (plan role -> the launch's other workgroups)
+  bool cull = false;
   const float* last_avg = nullptr;  // the avg plane (sparse or kept) of the last batch
   const float* last_hist = nullptr;       // ring rows as they were before the last batch
   float* last_thr = nullptr;
@@ -490,13 +499,13 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
 // Dispatch order of a launch that carries more than one role, from the pattern in diag.step_order (see there): one word per
 // workgroup (role << 24 | item) in device memory, rebuilt only when the launch shape changes.
 void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
-  const int n_fft = ss::step_fft_wgs(a), wg_det = (a.n_det + 1) / 2, wg_emit = ss::step_emit_wgs(a);  // (FFT WORKGROUPS)
+  const int n_fft = ss::step_fft_wgs(a), wg_det = ss::step_det_wgs(a), wg_emit = ss::step_emit_wgs(a), wg_plan = ss::step_plan_wgs(a);  // (FFT WORKGROUPS)
   a.order = nullptr;
   a.prio_fft = c->diag.prio_fft;
   a.prio_other = c->diag.prio_other;
-  if ((n_fft > 0) + (wg_det > 0) + (wg_emit > 0) < 2) return;
+  if ((n_fft > 0) + (wg_det > 0) + (wg_emit > 0) + (wg_plan > 0) < 2) return;
   for (auto& t : c->order_tables)
-    if (t.key[0] == n_fft && t.key[1] == wg_det && t.key[2] == wg_emit) {
+    if (t.key[0] == n_fft && t.key[1] == wg_det && t.key[2] == wg_emit && t.key[3] == wg_plan) {
       t.used = ++c->order_clock;
       a.order = t.d;
       return;
@@ -528,15 +537,16 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
       while (i < sp.size() && sp[i] != '|' && !(sp[i] >= 'A' && sp[i] <= 'Z')) ++i;  // separators
     }
   }
-  const int total[4] = {0, n_fft, wg_det, wg_emit};
-  int next[4] = {0, 0, 0, 0};
+  const int total[5] = {0, n_fft, wg_det, wg_emit, wg_plan};
+  int next[5] = {0, 0, 0, 0, 0};
   std::vector<uint32_t> out;
   out.clear();
+  for (int k = 0; k < wg_plan; ++k) out.push_back((uint32_t)ss::ROLE_PLAN << 24 | (uint32_t)k);  // the few plan workgroups first: the launch's other workgroups wait for their list, never the other way round
   const auto place = [&](const Seg& sg) {
     for (int k = 0; k < sg.count && next[sg.role] < total[sg.role]; ++k) out.push_back((uint32_t)sg.role << 24 | (uint32_t)next[sg.role]++);
   };
   for (const Seg& sg : prefix) place(sg);
-  const size_t want = (size_t)n_fft + (size_t)wg_det + (size_t)wg_emit;
+  const size_t want = (size_t)n_fft + (size_t)wg_det + (size_t)wg_emit + (size_t)wg_plan;
   while (out.size() < want) {
     const size_t before = out.size();
     for (const Seg& sg : cycle) place(sg);
@@ -570,6 +580,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
   slot->key[0] = n_fft;
   slot->key[1] = wg_det;
   slot->key[2] = wg_emit;
+  slot->key[3] = wg_plan;
   slot->used = ++c->order_clock;
   a.order = slot->d;
 }
@@ -604,8 +615,11 @@ struct FftRole {
 // fft / det / emit: null = role absent. Start/stop events ride on launches that carry an FFT role (the dominant work).
 void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n_det_tiles, bool spec, const ss::EmitArgs* emit, hipStream_t stream = nullptr) {
   if (!stream) stream = c->stream;
+#ifdef SS_DIAG
+  if (c->diag.ablate_roles & 1) det = nullptr;
+  if (c->diag.ablate_roles & 2) emit = nullptr;
+#endif
   ss::StepArgs a{};
-  a.fft_per_wg = 1;
   a.emit_per_wg = (!c->use_fft8192 && c->diag.emit_wide && c->n / 32 >= 2048) ? 1 : 8;
   if (fft && fft->frames) {
     const int n_fft = fft->n + fft->n_halo;
@@ -614,16 +628,25 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
     a.halo_iq = fft->halo_iq;
     a.halo_psd = fft->halo_psd;
     a.n_halo = fft->n_halo;
-    // with other roles in the launch the FFT role keeps to two of every CU's four workgroup slots (scan_step.h)
-    if (c->diag.fft_per_wg > 0) a.fft_per_wg = c->diag.fft_per_wg;
-    else if (c->diag.fft_per_wg < 0 && (det || emit)) a.fft_per_wg = std::max(1, (n_fft + 2 * c->n_cus - 1) / (2 * c->n_cus));
   } else if (fft && fft->cols) {
     a.cols = *fft->cols;
     a.n_fft = fft->n;
   }
+  // Tile culling (detect_fused.h): a detect stage whose only products are mask bits and counts is PLANNED — a few plan
+  // workgroups list the tiles that may hold a candidate — and the list is evaluated by the launch's FFT workgroups after their
+  // frames, two entries each (there are always enough: nframes + 20 workgroups for nframes + 16 pairs at most), or by detect
+  // workgroups of its own in a launch without an FFT role.
+  const int plan_cols = (det && c->n == 8192) ? ss::plan_cols_per_wg(det->nframes, det->shift) : 0;
+  const bool planned = det && c->use_fft8192 && det->segsum && !det->rel_out && !det->avg_out && !spec && plan_cols > 0;
   if (det) {
     a.det = *det;
-    a.n_det = n_det_tiles;
+    if (planned) {
+      a.n_plan = n_det_tiles;
+      a.plan_cols = plan_cols;
+      a.plan_by_fft = a.n_fft >= ss::step_plan_consumers(a) ? 1 : 0;  // (consumer p serves list p mod S)
+    } else {
+      a.n_det = n_det_tiles;
+    }
   }
   if (emit) {
     a.emit = *emit;
@@ -631,6 +654,11 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   }
   if (ss::step_items(a) == 0) return;
   step_order(c, a, stream);
+  if (!a.order && planned) {  // no order table to be had (out of device memory): every tile evaluated by detect workgroups, no plan
+    a.n_det = a.n_plan;
+    a.n_plan = a.plan_by_fft = 0;
+    a.det.segsum = nullptr;
+  }
   if (!a.order && (fft != nullptr) + (det != nullptr) + (emit != nullptr) > 1) {
     // no order table to be had (out of device memory): the roles one launch after the other, oldest call first
     if (emit) launch_step(c, nullptr, nullptr, 0, false, emit, stream);
@@ -687,6 +715,8 @@ ss::Fft8192Args fft8192_args(ss_ctx* c, const void* d_iq, long long item_stride,
   g.db_off = c->db_off;
   g.scale = c->cfg.int_scale;
   g.psd = d_psd;
+  g.segsum = c->cull ? c->d_segsum[c->buf_cur] : nullptr;  // (run_backend_fused hands the same buffer to the call's detect stage)
+  g.seg_pitch = c->cfg.max_batch;
   return g;
 }
 
@@ -955,6 +985,13 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   da.rel_out = d_rel_out;
   da.avg_out = avg_full;
   da.avg_sparse = c->d_avg2[b];
+  da.segsum = (c->cull && !spec) ? c->d_segsum[b] : nullptr;
+  da.seg_pitch = c->cfg.max_batch;
+  da.thr_tilemin = z->d_thr + n;  // (kept behind the ceiling itself, get_noise)
+  da.live = c->d_live[b];
+#ifdef SS_DIAG
+  da.cull_stats = c->diag.d_cull_stats;
+#endif
   if (spec) {
     da.spec_partial = c->d_spec_part2[c->spec_cur];
     da.spec_m = c->spec_m;
@@ -979,6 +1016,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   ea.avg = avg_full ? avg_full : c->d_avg2[b];
   ea.cap = cand_cap;
   ea.off_int = c->d_off4[b];
+  ea.live_clear = da.live;
   c->d_off = c->d_off4[b];
   ea.off_out = d_cand_off;
   ea.cand_idx = (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr;
@@ -1144,7 +1182,10 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
     if (has_det) c->pe.push_back(ss_ctx::PendEmit{d.emit, L + 2});
     if (ring_reader) c->deep_barrier = L;
   }
-  if (n_learn > 0) hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
+  if (n_learn > 0) {
+    hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
+    if (c->cull) hipLaunchKernelGGL(ss::k_thr_tilemin, dim3(32), dim3(64), 0, c->stream, (const float*)z->d_thr, c->n, z->d_thr + c->n);
+  }
   ss_ctx::PendDet mine_det{};
   st = run_backend_fused(c, d_psd, nframes, n_learn, z, nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap, true,
                          &mine_det.a, &mine_det.tiles, &mine_det.emit);
@@ -1253,7 +1294,10 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       if (st != SS_OK) return st;
     }
     if (spec) spec->count += nframes;
-    if (n_learn > 0) hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
+    if (n_learn > 0) {
+      hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
+      if (c->cull) hipLaunchKernelGGL(ss::k_thr_tilemin, dim3(32), dim3(64), 0, c->stream, (const float*)z->d_thr, c->n, z->d_thr + c->n);
+    }
     st = run_backend_fused(c, d_psd, nframes, n_learn, z, c->spec_in_detect ? spec : nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg,
                            cand_cap, true, &c->pend_det, &c->pend_det_tiles, &c->pend_det_emit);
     if (st != SS_OK) return st;
@@ -1310,8 +1354,8 @@ int get_noise(ss_ctx* c, NoiseState** out) {
   if (!z) {
     NoiseState nz;
     nz.center = center;
-    SS_HIP(c, hipMalloc(&nz.d_thr, sizeof(float) * (size_t)c->n));
-    hipLaunchKernelGGL(ss::k_fill, dim3(grid_for((size_t)c->n, 256)), dim3(256), 0, c->stream, nz.d_thr, (size_t)c->n, -FLT_MAX);
+    SS_HIP(c, hipMalloc(&nz.d_thr, sizeof(float) * ((size_t)c->n + 32)));  // + the per-tile-column minima (tile culling, 8192 points)
+    hipLaunchKernelGGL(ss::k_fill, dim3(grid_for((size_t)c->n + 32, 256)), dim3(256), 0, c->stream, nz.d_thr, (size_t)c->n + 32, -FLT_MAX);
     c->noise.push_back(nz);
     z = &c->noise.back();
   }
@@ -1325,6 +1369,14 @@ void free_ctx(ss_ctx* c) {
   for (hipStream_t q : {c->s_ab[0], c->s_ab[1], c->s_fold})
     if (q) (void)hipStreamSynchronize(q);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+#ifdef SS_DIAG
+  if (c->diag.d_cull_stats) {
+    unsigned h[3] = {0, 0, 0};
+    if (hipMemcpy(h, c->diag.d_cull_stats, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "[specscan diag] detect tiles %u, on the culling path %u, culled %u\n", h[0], h[1], h[2]);
+    (void)hipFree(c->diag.d_cull_stats);
+  }
+#endif
   for (hipStream_t q : {c->s_ab[0], c->s_ab[1], c->s_fold})
     if (q) (void)hipStreamDestroy(q);
   for (hipEvent_t e : c->ev_fold_src)
@@ -1355,6 +1407,8 @@ void free_ctx(ss_ctx* c) {
   for (auto p : c->d_avg2) (void)hipFree(p);
   for (auto p : c->d_off4) (void)hipFree(p);
   for (auto p : c->d_psd2) (void)hipFree(p);
+  for (auto p : c->d_segsum) (void)hipFree(p);
+  for (auto p : c->d_live) (void)hipFree(p);
   for (auto p : c->d_halo) (void)hipFree(p);
   (void)hipFree(c->d_relplane);
   (void)hipFree(c->d_hist_tmp);
@@ -1533,6 +1587,14 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipMalloc(&c->d_off4[k], sizeof(int) * ((size_t)cfg->max_batch + 1)));
   }
   c->d_off = c->d_off4[0];
+  c->cull = c->fused && n == 8192 && !c->diag.fft_generic && !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
+  if (c->cull)
+    for (int k = 0; k < c->nbuf; ++k) {
+      CREATE_HIP(hipMalloc(&c->d_segsum[k], sizeof(float) * 32 * (size_t)cfg->max_batch));
+      const size_t live_ints = ss::kLiveHeader + (size_t)ss::kLiveHeader * ss::kLiveCap;
+      CREATE_HIP(hipMalloc(&c->d_live[k], sizeof(int) * live_ints));
+      CREATE_HIP(hipMemsetAsync(c->d_live[k], 0, sizeof(int) * live_ints, c->stream));
+    }
   if (c->deep) {
     c->deep_ring_safe = c->hist_rows / kHistRows >= kDeepSyncPhase + 8;
     for (auto& q : c->s_ab) CREATE_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
@@ -1545,7 +1607,8 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, cfg->device_id));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const size_t max_items = (size_t)(cfg->max_batch + kHistRows) * (size_t)(n / 8192) + ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256) / 2 + (size_t)cfg->max_batch + 4;
+    const size_t max_items = (size_t)(cfg->max_batch + kHistRows) * (size_t)(n / 8192) + ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256) / 2 + (size_t)cfg->max_batch + 4 +
+                             (size_t)ss::kLiveHeader * (ss::kLiveCap / 2 + 1);  // (a planned detect stage without an FFT role: 256 consumers per list, + the plan workgroups)
     c->order_capacity = max_items;
   }
   CREATE_HIP(hipMalloc(&c->d_counts, sizeof(int) * (size_t)cfg->max_batch));

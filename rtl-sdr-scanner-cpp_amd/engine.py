@@ -19,17 +19,18 @@ _libs = {}
 _use_diag = False  # tests / measurement scripts: route new engines to libspecscan_diag.so (use_diag_library)
 
 
-def use_diag_library(on: bool = True) -> None:
+def use_diag_library(on=True) -> None:
     """Engines created from now on load csrc/libspecscan_diag.so — the same sources built with -DSS_DIAG, the only build
-    that lets SS_* / SC_* environment variables pick one implementation of a step over another (A/B tests)."""
+    that lets SS_* / SC_* environment variables pick one implementation of a step over another (A/B tests). A string is the
+    path of an A/B build of the diagnostics library (build.build_variant) to load instead."""
     global _use_diag
-    _use_diag = bool(on)
+    _use_diag = on if isinstance(on, str) else bool(on)
 
 
 def load_library(diag: bool | None = None) -> C.CDLL:
     """dlopen csrc/libspecscan.so (built by build.build_lib / __graft_entry__.build). Raises if absent."""
     diag = _use_diag if diag is None else diag
-    path = LIB_DIAG if diag else LIB
+    path = diag if isinstance(diag, str) else (LIB_DIAG if diag else LIB)
     if path not in _libs:
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `python __graft_entry__.py build` (hipcc, gfx950). "

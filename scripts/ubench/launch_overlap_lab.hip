@@ -100,6 +100,12 @@ int main() {
     const ss::Fft8192Args g{d_iq[k % nsets], (long long)n, d_win, tabs, 63.1f, 1.0f, d_psd[k % nsets]};
     hipExtLaunchKernelGGL((ss::k_fft8192_psd_v2<ss::FMT_CF32, 2, true>), dim3(frames), dim3(512), ss::kFft8192V2LdsBytes, s, nullptr, nullptr, flags, g);
   };
+  std::vector<float*> d_seg(nsets);
+  for (int k = 0; k < nsets; ++k) CK(hipMalloc((void**)&d_seg[k], (size_t)(frames * 32 + 64) * 4));
+  auto fft_seg = [&](int k, hipStream_t s, int flags) {  // with the per-segment maxima for the detect stage's tile culling
+    const ss::Fft8192Args g{d_iq[k % nsets], (long long)n, d_win, tabs, 63.1f, 1.0f, d_psd[k % nsets], d_seg[k % nsets], frames};
+    hipExtLaunchKernelGGL((ss::k_fft8192_psd_v2<ss::FMT_CF32, 2, true>), dim3(frames), dim3(512), ss::kFft8192V2LdsBytes, s, nullptr, nullptr, flags, g);
+  };
   auto det = [&](int k, hipStream_t s, int flags) {
     hipExtLaunchKernelGGL((ss::k_detect_fused<21, 21, 16, 256, false>), dim3(tiles), dim3(256), 0, s, nullptr, nullptr, flags, det_args(k % nsets));
   };
@@ -119,6 +125,9 @@ int main() {
   timed("fft, one stream, any-order launches", [&](int k) { fft(k, st[0], hipExtAnyOrderLaunch); });
   timed("fft, two streams alternating", [&](int k) { fft(k, st[k & 1], 0); });
   timed("fft, three streams alternating", [&](int k) { fft(k, st[k % 3], 0); });
+  timed("fft + segment maxima, one stream", [&](int k) { fft_seg(k, st[0], 0); });
+  timed("fft + segment maxima, two streams alternating", [&](int k) { fft_seg(k, st[k & 1], 0); });
+  if (getenv("LAB_FFT_ONLY")) return 0;
   timed("detect, one stream", [&](int k) { det(k, st[0], 0); });
   timed("detect, one stream, any-order launches", [&](int k) { det(k, st[0], hipExtAnyOrderLaunch); });
   timed("fft + detect, one stream", [&](int k) { fft(k, st[0], 0); det(k, st[0], 0); });

@@ -1,0 +1,123 @@
+"""Tile culling (csrc/detect_fused.h): a 16-frame x 256-bin averaging tile whose per-segment PSD maxima (left by the FFT
+role) show that no bin can reach start_level is not evaluated. The decision must be EXACT: the candidate lists with
+culling equal those with SS_FLAG_NO_CULL bit for bit, and both equal the reference's own code (oracle/_ref) — on the
+host-buffer path, on the deep-pipelined device path, with ignored ranges, weak signals just around the threshold, degenerate
+frames, int8 input and calls that do not start on a tile boundary. Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+import rtl_sdr_scanner_cpp_amd as pkg
+from parity import BAND, cand_set, dont_care_limit
+
+pytestmark = pytest.mark.gpu
+
+N, FS, CENTER = 8192, 2_048_000, 145_000_000
+
+
+def _lists(o):
+    return [o["cand_idx"][o["cand_off"][f]:o["cand_off"][f + 1]] for f in range(len(o["cand_off"]) - 1)]
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for f, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), (f, x[:8], y[:8])
+
+
+def _engine(flags=0, **kw):
+    kw.setdefault("max_batch", 1024)
+    return pkg.SpectrumEngine(FS, CENTER, fft_size=N, decim=1, flags=flags, **kw)
+
+
+def _run_host(eng, iq, chunk, t=None, want=("psd",)):
+    outs = [eng.process(iq[a:a + chunk], t_ms=None if t is None else t[a:a + chunk], want=want) for a in range(0, len(iq), chunk)]
+    lists = []
+    for o in outs:
+        lists += _lists(o)
+    avgs = np.concatenate([o["cand_avg"] for o in outs])
+    return lists, avgs
+
+
+@pytest.mark.parametrize("chunk", [1024, 200, 77])
+def test_culled_lists_equal_unculled_lists_and_the_reference(ref_mod, chunk):
+    nframes = 1024
+    band = pkg.synth.SyntheticBand(N, seed=31, on_frame=150, off_frame=600, period=700)
+    iq = band.frames_cf32(nframes)
+    t = (10_000 + 20 * np.arange(nframes)).astype(np.int64)
+    a, a_avg = _run_host(_engine(), iq, chunk, t)
+    b, b_avg = _run_host(_engine(pkg.abi.SS_FLAG_NO_CULL), iq, chunk, t)
+    _same(a, b)
+    assert np.array_equal(a_avg, b_avg)
+    assert sum(len(x) for x in a) > 20_000
+    ref_mod.ref().orc_set_fft_backend(0)
+    r = ref_mod.RefChain(N, FS, CENTER - FS // 2, CENTER + FS // 2).process(iq, t)
+    got = {(f, int(i)) for f, x in enumerate(a) for i in x}
+    want = {(f, int(i)) for f, x in enumerate(r["cands"]) for i in x}
+    near = np.abs(r["avg"] - np.float32(8.0)) < BAND
+    outside = [(f, i) for (f, i) in got ^ want if not near[f, i]]
+    assert not outside, sorted(outside)[:10]
+    assert len(got ^ want) <= dont_care_limit(len(want))
+
+
+def test_signals_around_the_threshold_and_degenerate_frames():
+    """Combs from 4 dB below to 6 dB above start_level (tiles whose bound sits near the cut), an all-zero frame (-inf
+    rows), a NaN frame and a huge frame: culled == unculled, list by list."""
+    nframes = 640
+    rng = np.random.default_rng(5)
+    lists = {}
+    for rel_db in (16.0, 18.5, 20.0, 22.0, 26.0):
+        band = pkg.synth.SyntheticBand(N, seed=int(rel_db * 10), rel_db=rel_db, on_frame=130, off_frame=520, centres=(0.05, -0.11, 0.23, -0.31, 0.37, -0.45, 0.49))
+        iq = band.frames_cf32(nframes)
+        iq[300] = 0
+        iq[340, :100] = np.nan
+        iq[380] *= 1e15
+        iq[420, rng.integers(0, N, 50)] = np.inf
+        outs = {}
+        for name, flags in (("cull", 0), ("nocull", pkg.abi.SS_FLAG_NO_CULL)):
+            outs[name] = _run_host(_engine(flags, max_batch=320), iq, 320, want=())
+        _same(outs["cull"][0], outs["nocull"][0])
+        assert np.array_equal(outs["cull"][1], outs["nocull"][1], equal_nan=True)
+        lists[rel_db] = sum(len(x) for x in outs["cull"][0])
+    print("\ncandidates by comb level:", lists)
+    assert lists[26.0] > 10_000
+
+
+def test_ignored_ranges_int8_and_unaligned_calls():
+    nframes = 900
+    band = pkg.synth.SyntheticBand(N, seed=9, on_frame=120, off_frame=800)
+    iq8 = band.frames_cs8(nframes)
+    ignored = [CENTER + 300_000, CENTER + 420_000, CENTER - 600_000, CENTER - 500_000]
+    cuts = [0, 130, 131, 300, 563, 900]  # calls of 130, 1, 169, 263, 337 frames: most do not start on a 16-frame boundary
+    res = {}
+    for name, flags in (("cull", 0), ("nocull", pkg.abi.SS_FLAG_NO_CULL)):
+        eng = _engine(flags, in_format=pkg.abi.SS_FMT_CS8, ignored=ignored, max_batch=400)
+        lists = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            lists += _lists(eng.process(iq8[a:b], want=()))
+        res[name] = lists
+    _same(res["cull"], res["nocull"])
+    assert sum(len(x) for x in res["cull"]) > 20_000
+
+
+def test_deep_pipelined_device_calls_culled_equal_unculled():
+    import torch
+    nb, ncalls = 256, 9
+    band = pkg.synth.SyntheticBand(N, seed=4, on_frame=130, off_frame=1500, period=1900)
+    iq = band.frames_cf32(nb * ncalls)
+    dev = torch.device("cuda", 0)
+    res = {}
+    for name, flags in (("cull", 0), ("nocull", pkg.abi.SS_FLAG_NO_CULL)):
+        eng = _engine(flags, max_batch=nb)
+        d_iq = [torch.from_numpy(iq[k * nb:(k + 1) * nb].view(np.float32)).to(dev) for k in range(ncalls)]
+        outs = [dict(psd=torch.empty((nb, N), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
+                     idx=torch.empty(nb * 512, dtype=torch.int32, device=dev), avg=torch.empty(nb * 512, dtype=torch.float32, device=dev)) for _ in range(ncalls)]
+        for k in range(ncalls):  # no sync in between: five calls in flight on the library's two queues
+            eng.process_device(d_iq[k], nb, psd=outs[k]["psd"], cand_off=outs[k]["off"], cand_idx=outs[k]["idx"], cand_avg=outs[k]["avg"])
+        eng.sync()
+        lists = []
+        for o in outs:
+            off, idx = o["off"].cpu().numpy(), o["idx"].cpu().numpy()
+            lists += [idx[off[f]:off[f + 1]].copy() for f in range(nb)]
+        res[name] = lists
+    _same(res["cull"], res["nocull"])
+    assert sum(len(x) for x in res["cull"]) > 50_000

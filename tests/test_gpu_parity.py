@@ -98,8 +98,7 @@ ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurem
     ({"SS_FFT_TW": "0", "SS_FFT_SWZ": "0"}, 8192, 2_048_000, "cs8"),
     ({"SS_FFT_TW": "1"}, 8192, 2_048_000, "cu8"),
     ({"SS_PIPELINE": "0"}, 8192, 2_048_000, "cf32"),
-    ({"SS_FFT_PER_WG": "1"}, 8192, 2_048_000, "cf32"),
-    ({"SS_FFT_PER_WG": "3"}, 8192, 2_048_000, "cs8"),
+    ({"SS_CULL": "0"}, 8192, 2_048_000, "cf32"),
     ({"SS_STEP_ORDER": "|F5,D3,E1"}, 8192, 2_048_000, "cf32"),
     ({"SS_STEP_ORDER": "E*|D77,F99", "SS_STEP_PRIO_FFT": "2", "SS_STEP_PRIO_OTHER": "1"}, 8192, 2_048_000, "cf32"),
     ({"SS_FFT_IMPL": "generic"}, 2048, 512_000, "cf32"),
