@@ -26,10 +26,11 @@
 
 #include "fft8192_kernel.h"
 
-// Cache policy of the frame loads (read once, never again) and of the dB row stores (read back by the detect stage two
-// launches later): measured in scripts/ubench and with bench.py, see DESIGN.md 4.1. Build-time so that variants can be A/B'd.
+// Cache policy of the frame loads (read once, never again: nt = 2 measured 2.5 % faster per step than the default policy,
+// sc0 / sc1 variants the same as nt) and of the dB row stores (read back by the detect stage two launches later: nt slower).
+// Build-time so that variants can be A/B'd (scripts/build_ab.py), DESIGN.md 4.1.
 #ifndef SS_AUX_IQ
-#define SS_AUX_IQ 0
+#define SS_AUX_IQ 2
 #endif
 #ifndef SS_AUX_PSD
 #define SS_AUX_PSD 0
@@ -125,11 +126,6 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
   float* segsum = g.segsum;
   const size_t in_base = frame * (size_t)g.item_stride;
 
-  // (a buffer load with the sc0 sc1 policy bits — it must see what other XCDs wrote during this launch — and not an atomic
-  // load: behind an atomic the compiler no longer trusts the twiddle tables to be unchanged and fetches the wave-uniform
-  // ones with vector loads)
-  unsigned hint = 0u;
-  if (g.live_hint) hint = __builtin_amdgcn_raw_buffer_load_b32(buffer_of(g.live_hint, 4), 0, 0, 17);
   // ---- tables first: these loads are ahead of the frame's own in the vector-memory queue ----
   float2 tf0 = make_float2(0.f, 0.f), tf1 = make_float2(0.f, 0.f);
   if constexpr (TW == 1) {
@@ -170,8 +166,6 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
     if (t < 128) lane_l[256 + t] = tf1;
   }
   dft16(a);
-  // the frame has landed, and with it everything asked for before it: into scalar registers, out of the way
-  *hdr = __builtin_amdgcn_readfirstlane((int)hint);
   float2 c[16];
   if constexpr (SWZ) {
     // exchange 1, unpadded: y[16 t + k] lives at word 16 t + 4 (((k >> 2) + (t >> 1)) & 3) + (k & 3). The 8 lanes of one
@@ -228,6 +222,14 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
   }
   dft16(c);
   __syncthreads();  // every read of y is done before z overwrites the plane
+  // The list header word this workgroup will want when its frame is done (live_hint): asked for NOW — half a frame after
+  // the launch began, so the plan role has had time to finish, and with half a frame of work left to hide the round trip
+  // behind — by every wave for itself, straight into LDS (LDS-DMA: no register has to hold it through pass 3), with the
+  // sc0 sc1 policy bits: it must see what another XCD wrote during this launch. (Asked for before the frame's own loads it
+  // stood in front of them in the in-order return queue, and most workgroups were told "not ready yet" and had to ask again.)
+  float* hint_slot = s + 8192 + 256 + (t >> 6);  // (behind the segment maxima; the pad is idle since exchange 1)
+  if (g.live_hint && (t & 63) == 0)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(buffer_of(g.live_hint, 4), (__attribute__((address_space(3))) void*)hint_slot, 4, 0, 0, 0, 17);
   // exchange 2: z[(t/16)*256 + t%16 + 16 k]; pass 3 lane (w, l) reads z[j + 256 (2q + h)], j = 32 w + (l & 31), h = l >> 5
   const int zbase = ((t >> 4) << 8) + (t & 15);
   const int lane = t & 63;
@@ -315,6 +317,11 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
   // consecutive bins of segment w + 8 k + 64 h + 128 s; lane 16 + i of each half keeps the maximum of value i = 2 k + s.
   // The 256 segment maxima of the frame meet in LDS (the 512 floats behind the exchange plane, idle since exchange 1) and the
   // first 32 threads turn them into the 32 tile-column maxima the detect stage reads.
+  *hdr = 0;
+  if (g.live_hint) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing else of this wave is in flight here: the frame landed long ago, the dB stores come below)
+    *hdr = __builtin_amdgcn_readfirstlane(__float_as_int(*hint_slot));
+  }
   const bool want_max = segsum != nullptr;  // (workgroup-uniform)
   float mine;
 #pragma unroll

@@ -84,12 +84,12 @@ static_assert(2 * (16 * DetectTile<21, 21, 16, 256>::P * 4 + 64) <= kFft8192V2Ld
 static_assert((8 * kEmitList + 9) * 4 <= kFft8192V2LdsBytes, "eight emit lists per workgroup");
 static_assert(kFft256ColsLdsBytes <= kFft8192V2LdsBytes, "a column tile");
 static_assert((kPlanLdsFloats + 64) * 4 <= kFft8192V2LdsBytes, "a plan workgroup's staging area");
-inline int step_fft_wgs(const StepArgs& a) { return a.n_fft; }
-inline int step_emit_wgs(const StepArgs& a) { return a.emit_per_wg == 1 ? a.n_emit : (a.n_emit + 7) / 8; }
+__host__ __device__ inline int step_fft_wgs(const StepArgs& a) { return a.n_fft; }
+__host__ __device__ inline int step_emit_wgs(const StepArgs& a) { return a.emit_per_wg == 1 ? a.n_emit : (a.n_emit + 7) / 8; }
 __host__ __device__ inline int step_plan_wgs(const StepArgs& a) { return a.n_plan ? 32 / a.plan_cols : 0; }
 // consumers a planned stage needs: per list, a pair for every two tiles it may hold
-inline int step_plan_consumers(const StepArgs& a) { return step_plan_wgs(a) * ((a.plan_cols * (a.n_plan / 32) + 1) / 2); }
-inline int step_det_wgs(const StepArgs& a) { return (a.n_det + 1) / 2 + (a.plan_by_fft ? 0 : step_plan_consumers(a)); }
+__host__ __device__ inline int step_plan_consumers(const StepArgs& a) { return step_plan_wgs(a) * ((a.plan_cols * (a.n_plan / 32) + 1) / 2); }
+__host__ __device__ inline int step_det_wgs(const StepArgs& a) { return (a.n_det + 1) / 2 + (a.plan_by_fft ? 0 : step_plan_consumers(a)); }
 inline int step_items(const StepArgs& a) { return step_fft_wgs(a) + step_det_wgs(a) + step_emit_wgs(a) + step_plan_wgs(a); }
 
 enum { ROLE_NONE = 0, ROLE_FFT = 1, ROLE_DET = 2, ROLE_EMIT = 3, ROLE_PLAN = 4 };
@@ -167,9 +167,23 @@ __global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a_by_val
     const uint32_t w = a.order[blockIdx.x];
     role = (int)(w >> 24);
     item = (int)(w & 0xffffffu);
-  } else {  // a single role
-    role = a.n_fft ? ROLE_FFT : a.n_det ? ROLE_DET : a.n_emit ? ROLE_EMIT : ROLE_PLAN;
-    item = blockIdx.x;
+  } else {
+    // no table: the roles one after the other — plan, emit, detect, FFT. (The table's dependent scalar load stands between a
+    // workgroup's start and its first frame load; the steady-state launch, whose detect work rides on its FFT workgroups,
+    // has nothing to interleave and does without.)
+    int b = (int)blockIdx.x;
+    const int np = step_plan_wgs(a), ne = step_emit_wgs(a), nd = step_det_wgs(a);
+    if (b < np) {
+      role = ROLE_PLAN;
+    } else if ((b -= np) < ne) {
+      role = ROLE_EMIT;
+    } else if ((b -= ne) < nd) {
+      role = ROLE_DET;
+    } else {
+      role = ROLE_FFT;
+      b -= nd;
+    }
+    item = b;
   }
   if constexpr (PRIO) {  // (s_setprio takes an immediate)
     const int p = role == ROLE_FFT ? a.prio_fft : a.prio_other;

@@ -93,6 +93,7 @@ struct ss_ctx {
     int stamp_launches = 0;
     unsigned* d_cull_stats = nullptr;  // SS_DIAG only (SS_CULL_STATS=1): tiles seen / on the culling path / culled, printed by ss_destroy
     bool emit_wide = true;         // long rows (n >= 16384): several waves per frame in the emit stage
+    bool no_order_table = false;   // SS_DIAG: never use a dispatch-order table
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
     bool cull = true;              // 8192 points: detect tiles that cannot hold a candidate are not evaluated (detect_fused.h)
     bool deep = true;              // 8192 points: consecutive step launches independent of each other, alternating over two queues (see ss_ctx::deep)
@@ -135,6 +136,7 @@ struct ss_ctx {
       deep = tri("SS_DEEP") != 0;
       cull = tri("SS_CULL") != 0;
       ablate_roles = num("SS_ABLATE_ROLES", 0);
+      no_order_table = tri("SS_ORDER_TABLE") == 0;
       if (tri("SS_CULL_STATS") == 1 && hipMalloc(&d_cull_stats, 3 * sizeof(unsigned)) == hipSuccess) (void)hipMemset(d_cull_stats, 0, 3 * sizeof(unsigned));
       if (const char* v = getenv("SS_STEP_ORDER")) step_order = step_order_long = v;
     }
@@ -503,7 +505,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
   a.order = nullptr;
   a.prio_fft = c->diag.prio_fft;
   a.prio_other = c->diag.prio_other;
-  if ((n_fft > 0) + (wg_det > 0) + (wg_emit > 0) + (wg_plan > 0) < 2) return;
+  if (n_fft == 0 || wg_det == 0 || c->diag.no_order_table) return;  // nothing to interleave: the kernel takes the roles one after the other (plan, emit, detect, FFT)
   for (auto& t : c->order_tables)
     if (t.key[0] == n_fft && t.key[1] == wg_det && t.key[2] == wg_emit && t.key[3] == wg_plan) {
       t.used = ++c->order_clock;
@@ -654,18 +656,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   }
   if (ss::step_items(a) == 0) return;
   step_order(c, a, stream);
-  if (!a.order && planned) {  // no order table to be had (out of device memory): every tile evaluated by detect workgroups, no plan
-    a.n_det = a.n_plan;
-    a.n_plan = a.plan_by_fft = 0;
-    a.det.segsum = nullptr;
-  }
-  if (!a.order && (fft != nullptr) + (det != nullptr) + (emit != nullptr) > 1) {
-    // no order table to be had (out of device memory): the roles one launch after the other, oldest call first
-    if (emit) launch_step(c, nullptr, nullptr, 0, false, emit, stream);
-    if (det) launch_step(c, nullptr, det, n_det_tiles, spec, nullptr, stream);
-    if (fft) launch_step(c, fft, nullptr, 0, false, nullptr, stream);
-    return;
-  }
+  // (no order table — none wanted, or none to be had: out of device memory — means the roles in segments, which is always correct)
 #ifdef SS_DIAG
   bool dump_stamps = false;
   if (!c->diag.stamp_path.empty() && fft && det && emit && ss::step_items(a) <= 4096 && a.n_det <= 4096) {
