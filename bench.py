@@ -345,7 +345,7 @@ def run(args):
     out_bytes = nb * n * 4 * ((0 if args.no_psd_out else 1) + (2 if args.planes else 0))
     nsets = args.sets or max(6, -(-int(2.5 * L3_BYTES) // max(1, in_bytes + out_bytes)))
     nsets = min(nsets, 64)
-    nsets += nsets & 1  # an even number of sets: the library's two launch queues then order every buffer reuse by stream order alone (include/specscan.h)
+    nsets = -(-nsets // 12) * 12  # a multiple of the library's launch queues (2, 3 or 4): every buffer reuse is then ordered by stream order alone (include/specscan.h)
     gen = dist.synthetic_stream(cfg, band)  # one continuous frame stream of the band: noise + gated wide-band transmissions
     first = gen(nb)  # holds the learning frames; every rank of a frame-sharded band learns from these same frames
     to_dev = lambda a: torch.from_numpy(a.view(np.float32) if a.dtype == np.complex64 else a).to(dev)  # noqa: E731
@@ -409,7 +409,9 @@ def run(args):
     eng.flush()  # the deferred detect / emit stages of the last two steps belong to the timed work
     t_enq = time.perf_counter()
     eng.sync()
+    t_eng = time.perf_counter()
     torch.cuda.synchronize()
+    t_dev = time.perf_counter()
     dist.barrier()
     t1 = time.perf_counter()
     kern_ms, launches = (0.0, 0)
@@ -448,7 +450,9 @@ def run(args):
                        "tile_culling": not args.no_cull,
                        "preheat_steps": preheat_steps, "input_sets": nsets, "output_sets": nout, "working_set_mib": round((nsets * in_bytes + nout * out_bytes) / 2**20, 1),
                        "dist_backend": backend if world > 1 else None, "ranks_share_devices": bool(world > ndev),
-                       "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4)},
+                       "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4),
+                       # where the end of the timed region goes: the chain's own drain + wait, then the contract's device-wide synchronisation and barrier
+                       "tail_us": {"engine_sync": round((t_eng - t_enq) * 1e6, 1), "device_synchronize": round((t_dev - t_eng) * 1e6, 1), "barrier": round((t1 - t_dev) * 1e6, 1)}},
             "roofline": {"bound": "hbm", "kernel": kernel_name if n == 8192 else None,
                          "achieved": None if (achieved is None or n != 8192) else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if (achieved is None or n != 8192) else round(achieved / HBM_PEAK_GBS, 4),

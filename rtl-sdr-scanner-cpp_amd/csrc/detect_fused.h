@@ -127,7 +127,9 @@ struct DetectArgs {
   const float* segsum;             // [32][seg_pitch]
   int seg_pitch;
   const float* thr_tilemin;        // [32] min of thr over bins [256 c - 32, 256 c + 288)
-  // [s], s < 8: kLiveReady | number of tiles of plan workgroup s that must be evaluated; [8 + kLiveCap s ...] those tiles.
+  // [s], s < 8: nonzero once list s has been written through; [16 + kLiveCap s ...] the tiles of plan workgroup s that must be
+  // evaluated; [kLiveCounts + kLiveCopyStride k + s], k < kLiveCopies: kLiveReady | their number, published as soon as it is
+  // known (most consumers learn from it that there is nothing for them), in copies a page apart.
   // Written by the plan role (plan_tiles), consumed by the workgroups of the same launch (list_pair), the header set back to
   // zero by the call's emit stage.
   int* live;
@@ -237,7 +239,12 @@ __device__ __forceinline__ void spectrogram_fold(const DetectArgs& a, int tid, i
   a.spec_prev_sum[ob] = acc;
 }
 
-constexpr int kLiveHeader = 8;       // header words in front of DetectArgs::live's lists = the most plan workgroups a stage may have
+constexpr int kLiveLists = 8;        // the most plan workgroups (lists) a stage may have
+constexpr int kLiveCopies = 16;      // copies of the count words, kLiveCopyStride ints apart, behind the lists
+constexpr int kLiveCopyStride = 1024;
+constexpr int kLiveCounts = 8192;    // where the first copy starts
+constexpr int kLiveInts = kLiveCounts + kLiveCopies * kLiveCopyStride;  // ints of a DetectArgs::live buffer
+constexpr int kLiveHeader = 16;      // header words in front of DetectArgs::live's lists: the list-written flags
 constexpr int kLiveCap = 640;        // capacity of a plan workgroup's list: its tile columns x the batch's frame tiles
 constexpr int kLiveReady = 1 << 30;  // header word: the list is complete
 constexpr int kPlanLdsFloats = 9600; // staging area of a plan workgroup (+ 64 ints of bookkeeping behind it)
@@ -258,8 +265,9 @@ __host__ __device__ inline int plan_cols_per_wg(int nframes, int shift) {
 // frame) into LDS with coalesced loads — a lane reading its own 36 frames straight from memory touches 36 cache lines
 // nobody shares with it: measured, a plan workgroup took 24 us that way and every consumer waited for it — then every lane
 // takes the maximum over its 36 frames from there (one pad word per 16 frames: lanes are 16 frames apart). Evaluated
-// tiles go to the workgroup's list in (column, frame tile) order, then the header word; the mask words of culled tiles
-// are cleared afterwards — all a culled tile ever writes, and nobody reads them before the next launch.
+// tiles go to the workgroup's list in (column, frame tile) order, then the header word. A culled tile writes NOTHING: its
+// mask words are zero already — the emit stage of the buffer's previous user cleared every word it found set
+// (EmitArgs::clear_masks) — where clearing them here, a megabyte of 32-byte writes per call, cost 1.4 us per step.
 // `lds` = kPlanLdsFloats floats + 64 ints.
 template <int G, int GX, int TF, int TB_ = 256>
 __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int cols, int tid, float* __restrict__ lds) {
@@ -326,26 +334,14 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
       base += __popcll(live_mask[r]);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's entries are in memory
+  // the count at once, in kLiveCopies copies a page apart: a thousand consumers asking one address are a thousand requests to
+  // one memory channel (measured: 2 us per step) ...
+  if (tid < kLiveCopies) __hip_atomic_store(&a.live[kLiveCounts + tid * kLiveCopyStride + seg], kLiveReady | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... this wave's entries are in memory ...
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(&a.live[seg], kLiveReady | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    unsigned long long dead = r < rounds ? dead_mask[r] : 0ull;
-    while (dead) {  // wave-uniform: the wave's culled tiles one after the other, TF frames x 8 mask words each
-      const int src = __ffsll((long long)dead) - 1;
-      dead &= dead - 1;
-      const int ft = (r * 64 + src + nft - 1) % nft;
-      const size_t w0 = ((size_t)(ft * TF - a.shift) * n + (size_t)col * TB) >> 5;
-#pragma unroll
-      for (int k = 0; k < TF * (TB / 32) / 64; ++k) {
-        const int e = k * 64 + lane;
-        a.maskbits[w0 + (size_t)(e >> 3) * (n >> 5) + (e & 7)] = 0u;
-      }
-    }
-  }
+  if (tid == 0) __hip_atomic_store(&a.live[seg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ... every wave's: the list may be read
 #ifdef SS_DIAG
-  if (a.cull_stats && lane == 0 && has_col) {
+  if (a.cull_stats > reinterpret_cast<unsigned*>(1) && lane == 0 && has_col) {
     int lv = 0, dd = 0;
     for (int r = 0; r < 3; ++r) {
       lv += __popcll(live_mask[r]);
@@ -361,19 +357,24 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
 // to evaluate (-1: none): list p mod nseg, entries 2 (p div nseg) and the next. `word` = that list's header word as read
 // earlier (the FFT role asks before it loads its frame, so the answer costs it nothing); if the list was not complete by
 // then, wait for it now. Every wave of the workgroup ends up with the same pair.
+__host__ __device__ __forceinline__ int live_count_word(int p, int nseg) { return kLiveCounts + ((p / nseg) % kLiveCopies) * kLiveCopyStride + p % nseg; }
 __device__ __forceinline__ int2 list_pair(const DetectArgs& a, int p, int nseg, int word) {
   const int seg = p % nseg, q = p / nseg;
   word = __builtin_amdgcn_readfirstlane(word);
   while (!(word & kLiveReady)) {
     __builtin_amdgcn_s_sleep(8);
-    word = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.live[seg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    word = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.live[live_count_word(p, nseg)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   }
   const int count = word & (kLiveReady - 1);
   int2 t = make_int2(-1, -1);
   if (2 * q < count) {
+    while (!__builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.live[seg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) __builtin_amdgcn_s_sleep(8);
     const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.live + kLiveHeader + seg * kLiveCap + 2 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t.x = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
     if (2 * q + 1 < count) t.y = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    const int n_tiles = (a.n / 256) * plan_frame_tiles(a.nframes, a.shift);
+    if ((unsigned)t.x >= (unsigned)n_tiles) t.x = t.y = -1;  // (never: a tile number that is none must not become an address)
+    if ((unsigned)t.y >= (unsigned)n_tiles) t.y = -1;
   }
   return t;
 }
@@ -637,6 +638,8 @@ struct EmitArgs {
   const float* avg;  // avg[f * n + bin] for every hit bin (the sparse plane, or the caller's full avg plane)
   int cap;
   int* live_clear;   // DetectArgs::live of the call (or null): its header words go back to zero here
+  int clear_masks;   // set every mask word found set back to zero once it has been listed: the next user of the buffer may then
+                     // leave the words of tiles it does not evaluate alone (tile culling)
   int* off_int;      // [nframes + 1] the library's own copy of the offsets
   int* off_out;      // caller's cand_off or null
   int* cand_idx;     // null: offsets only
@@ -662,6 +665,14 @@ __device__ __forceinline__ int emit_frame_offset(const EmitArgs& a, int f, int l
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
   const int begin = part;
+  if (f == 0 && a.live_clear) {  // the call's lists are spent: list-written flags and every copy of the count words back to zero
+    if (lane < kLiveLists) a.live_clear[lane] = 0;
+#pragma unroll
+    for (int k = 0; k < kLiveCopies * kLiveLists / 64; ++k) {
+      const int e = k * 64 + lane;
+      a.live_clear[kLiveCounts + (e / kLiveLists) * kLiveCopyStride + e % kLiveLists] = 0;
+    }
+  }
   if (lane == 0) {
     a.off_int[f] = begin;
     if (a.off_out) a.off_out[f] = begin;
@@ -670,9 +681,6 @@ __device__ __forceinline__ int emit_frame_offset(const EmitArgs& a, int f, int l
       if (a.off_out) a.off_out[nframes] = begin + mine;
     }
     for (int g = f; g < a.clear_n; g += nframes) a.counts_clear[g] = 0;
-    if (f == 0 && a.live_clear) {
-      for (int k = 0; k < kLiveHeader; ++k) a.live_clear[k] = 0;
-    }
   }
   return begin;
 }
@@ -698,6 +706,11 @@ __device__ __forceinline__ void emit_span(const EmitArgs& a, int f, int lane, in
     }
     const uint32_t wv[4] = {w4.x, w4.y, w4.z, w4.w};
     const int c = __popc(wv[0]) + __popc(wv[1]) + __popc(wv[2]) + __popc(wv[3]);
+    if (a.clear_masks && c != 0) {  // listed below; the buffer's next user finds them zero (tile culling)
+      uint32_t* wrow = const_cast<uint32_t*>(row);
+      if (wide) *reinterpret_cast<uint4*>(wrow + base + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
+      else wrow[base + lane] = 0u;
+    }
     int incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -757,7 +770,7 @@ __device__ __forceinline__ void emit_span(const EmitArgs& a, int f, int lane, in
         for (int k = 0; k < 4; ++k) {
           const int p = p0 + k * 64 + lane;
           const int dst = carry + lo + p;
-          if (p < cnt && dst < a.cap) {
+          if (p < cnt && dst < a.cap && a.cand_idx) {
             a.cand_idx[dst] = idx[k];
             if (a.cand_avg) a.cand_avg[dst] = av[k];
           }
@@ -781,7 +794,7 @@ __device__ __forceinline__ void cand_emit_frame(const EmitArgs& a, int f, int la
   }
   const int mine = a.counts[f];
   const int begin = emit_frame_offset(a, f, lane, mine);
-  if (mine == 0 || !a.cand_idx) return;
+  if (mine == 0 || (!a.cand_idx && !a.clear_masks)) return;
   emit_span(a, f, lane, list, 0, words_per_row, begin, w4, true);
 }
 

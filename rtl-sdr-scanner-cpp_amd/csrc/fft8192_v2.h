@@ -27,13 +27,14 @@
 #include "fft8192_kernel.h"
 
 // Cache policy of the frame loads (read once, never again: nt = 2 measured 2.5 % faster per step than the default policy,
-// sc0 / sc1 variants the same as nt) and of the dB row stores (read back by the detect stage two launches later: nt slower).
+// sc0 / sc1 variants the same as nt) and of the dB row stores (sc1 = 16, write-through: 2.5 % faster per step in a long run, 5 % in a
+// 20-step run — the end of a launch no longer has an L2 full of dirty rows to write back before the queue's next launch may start).
 // Build-time so that variants can be A/B'd (scripts/build_ab.py), DESIGN.md 4.1.
 #ifndef SS_AUX_IQ
 #define SS_AUX_IQ 2
 #endif
 #ifndef SS_AUX_PSD
-#define SS_AUX_PSD 0
+#define SS_AUX_PSD 16
 #endif
 
 namespace ss {
@@ -84,6 +85,9 @@ struct Fft8192Args {
   // rides on the launch (scan_step.h). It is asked for before the frame's own loads and handed back in `hdr` when they have
   // landed: the answer costs the workgroup nothing.
   const int* live_hint;
+#ifdef SS_DIAG
+  int hint_nowait;  // timing ablation: do not wait for the header word (garbage result)
+#endif
 };
 
 // max over the 32 lanes of a half-wave (lanes 0..31 / 32..63) of FOUR values at once, valid in each half's upper 16 lanes:
@@ -222,14 +226,6 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
   }
   dft16(c);
   __syncthreads();  // every read of y is done before z overwrites the plane
-  // The list header word this workgroup will want when its frame is done (live_hint): asked for NOW — half a frame after
-  // the launch began, so the plan role has had time to finish, and with half a frame of work left to hide the round trip
-  // behind — by every wave for itself, straight into LDS (LDS-DMA: no register has to hold it through pass 3), with the
-  // sc0 sc1 policy bits: it must see what another XCD wrote during this launch. (Asked for before the frame's own loads it
-  // stood in front of them in the in-order return queue, and most workgroups were told "not ready yet" and had to ask again.)
-  float* hint_slot = s + 8192 + 256 + (t >> 6);  // (behind the segment maxima; the pad is idle since exchange 1)
-  if (g.live_hint && (t & 63) == 0)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(buffer_of(g.live_hint, 4), (__attribute__((address_space(3))) void*)hint_slot, 4, 0, 0, 0, 17);
   // exchange 2: z[(t/16)*256 + t%16 + 16 k]; pass 3 lane (w, l) reads z[j + 256 (2q + h)], j = 32 w + (l & 31), h = l >> 5
   const int zbase = ((t >> 4) << 8) + (t & 15);
   const int lane = t & 63;
@@ -249,6 +245,15 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
 #pragma unroll
   for (int q = 0; q < 16; ++q) a[q].y = s[rbase + 512 * q];
 
+  // The list header word this workgroup will want when its frame is done (live_hint): asked for NOW — two thirds of a
+  // frame after the workgroup began, so the plan role has had time to publish its counts, and with pass 3 left to hide the
+  // round trip behind — by the workgroup's first wave, straight into LDS (LDS-DMA: no register has to hold it through pass 3),
+  // with the sc0 sc1 policy bits: it must see what another XCD wrote during this launch. (Asked for before the frame's own
+  // loads it stood in front of them in the in-order return queue, and most workgroups were told "not ready yet" and had to
+  // ask again; asked for by all eight waves it was eight requests per workgroup to one memory channel.)
+  float* hint_slot = s + 8192 + 256;  // (behind the segment maxima; the pad is idle since exchange 1)
+  if (g.live_hint && t == 0)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(buffer_of(g.live_hint, 4), (__attribute__((address_space(3))) void*)hint_slot, 4, 0, 0, 0, 17);
   // ---------------- pass 3: radix 32, Ns = 256, butterfly j shared by lanes l and l + 32 ----------------
   // twiddle of input r = 2q + h:  W_8192^(j r) = W_8192^(j (r & 3)) * W_2048^(j (r >> 2)),  r & 3 = 2 (q & 1) + h,  r >> 2 = q >> 1
   if constexpr (TW == 2) {
@@ -318,10 +323,14 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
   // The 256 segment maxima of the frame meet in LDS (the 512 floats behind the exchange plane, idle since exchange 1) and the
   // first 32 threads turn them into the 32 tile-column maxima the detect stage reads.
   *hdr = 0;
-  if (g.live_hint) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (nothing else of this wave is in flight here: the frame landed long ago, the dB stores come below)
-    *hdr = __builtin_amdgcn_readfirstlane(__float_as_int(*hint_slot));
-  }
+#ifdef SS_DIAG
+  const bool hint_wait = !g.hint_nowait;
+#else
+  const bool hint_wait = true;
+#endif
+  // the first wave sees its header word land (nothing else of it is in flight here: the frame landed long ago, the dB stores
+  // come below); the others read it behind the barrier at the bottom
+  if (g.live_hint && hint_wait && t < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const bool want_max = segsum != nullptr;  // (workgroup-uniform)
   float mine;
 #pragma unroll
@@ -363,6 +372,7 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
     const int i = (vv >> 2) & 15;
     if (vv & 64) segs[((vv >> 7) & 7) + 8 * (i >> 1) + 64 * (vv >> 13) + 128 * (i & 1)] = mine;
     __syncthreads();
+    if (g.live_hint) *hdr = __builtin_amdgcn_readfirstlane(__float_as_int(*hint_slot));
     if (vv < 128) {  // wave 0, lower half: thread c = tile column
       const int c = vv >> 2;
       float m = segs[max(8 * c - 1, 0)];
@@ -372,6 +382,9 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
       const __amdgpu_buffer_rsrc_t rseg = buffer_of(segsum, 32 * g.seg_pitch * 4);
       buffer_store_f1(rseg, c * g.seg_pitch * 4, (int)frame * 4, m);
     }
+  } else if (g.live_hint) {  // (frames without a summary row — the re-transformed halo frames — still serve a list)
+    __syncthreads();
+    *hdr = __builtin_amdgcn_readfirstlane(__float_as_int(*hint_slot));
   }
 }
 

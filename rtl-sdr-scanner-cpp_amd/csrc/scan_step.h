@@ -72,6 +72,7 @@ struct StepArgs {
   const uint32_t* order;
   int prio_fft, prio_other;  // s_setprio of the roles' waves (0..3)
 #ifdef SS_DIAG
+  int hint_mode;      // timing ablations of the list hand-over (garbage results): 1 = FFT workgroups ignore the lists, 2 = they do not wait for their header word
   long long* stamps;  // measurement builds only: {start, end (100 MHz wall clock), role << 32 | item, XCC_ID << 32 | HW_ID} per workgroup
 #endif
 };
@@ -134,8 +135,15 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     g.iq = halo ? a.halo_iq : a.fft.iq;
     g.psd = halo ? a.halo_psd : a.fft.psd;
     g.segsum = halo ? nullptr : a.fft.segsum;  // (the tiles that read halo rows are not culled)
-    g.live_hint = a.plan_by_fft ? a.det.live + item % step_plan_wgs(a) : nullptr;  // the list this workgroup serves for the detect stage that rides on the launch
+    g.live_hint = a.plan_by_fft ? a.det.live + live_count_word(item, step_plan_wgs(a)) : nullptr;  // the list this workgroup serves for the detect stage that rides on the launch
+#ifdef SS_DIAG
+    if (a.hint_mode == 1) g.live_hint = nullptr;
+    g.hint_nowait = a.hint_mode == 2;
+#endif
     fft8192_v2_frame<FMT, TW, SWZ>(g, (size_t)(halo ? item : item - a.n_halo), smem_raw, tid, &hdr);
+#ifdef SS_DIAG
+    if (a.hint_mode) hdr = kLiveReady;  // "complete, empty"
+#endif
     if (a.plan_by_fft) {
       const int2 pr = list_pair(a.det, item, step_plan_wgs(a), hdr);
       tile_a = pr.x;

@@ -41,7 +41,8 @@ constexpr int kDeepSpecSlots = 64;  // calls whose spectrogram partial sums may 
 constexpr int kDeepFoldBatch = 8;   // ... added in batches of this many calls
 constexpr int kDeepSyncPeriod = 64;
 constexpr int kDeepSyncPhase = 32;
-constexpr int kDeepHorizon = 4 + kDeepSyncPeriod + 3 + 1;
+constexpr int kMaxQueues = 4;  // launch queues of the deep pipelining (ss_ctx::nq)
+constexpr int kDeepHorizon = 2 * kMaxQueues + kDeepSyncPeriod + 2 * kMaxQueues + 1;
 constexpr int kHistRows = ss::DetectTile<21, 21, kFusedTF, 256>::H;  // 35
 
 struct SpecState {  // Spectrogram::Container, sources/radio/blocks/spectrogram.h:10-16, one per centre frequency
@@ -94,6 +95,8 @@ struct ss_ctx {
     unsigned* d_cull_stats = nullptr;  // SS_DIAG only (SS_CULL_STATS=1): tiles seen / on the culling path / culled, printed by ss_destroy
     bool emit_wide = true;         // long rows (n >= 16384): several waves per frame in the emit stage
     bool no_order_table = false;   // SS_DIAG: never use a dispatch-order table
+    int hint_mode = 0;             // SS_DIAG timing ablations of the list hand-over (scan_step.h)
+    int queues = 2;                // 8192 points, deep pipelining: launch queues (2 .. 4)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
     bool cull = true;              // 8192 points: detect tiles that cannot hold a candidate are not evaluated (detect_fused.h)
     bool deep = true;              // 8192 points: consecutive step launches independent of each other, alternating over two queues (see ss_ctx::deep)
@@ -136,8 +139,11 @@ struct ss_ctx {
       deep = tri("SS_DEEP") != 0;
       cull = tri("SS_CULL") != 0;
       ablate_roles = num("SS_ABLATE_ROLES", 0);
+      queues = num("SS_QUEUES", queues);
+      hint_mode = num("SS_HINT_MODE", 0);
       no_order_table = tri("SS_ORDER_TABLE") == 0;
-      if (tri("SS_CULL_STATS") == 1 && hipMalloc(&d_cull_stats, 3 * sizeof(unsigned)) == hipSuccess) (void)hipMemset(d_cull_stats, 0, 3 * sizeof(unsigned));
+      if (tri("SS_PLAN_NOZERO") == 1) d_cull_stats = reinterpret_cast<unsigned*>(1);
+      else if (tri("SS_CULL_STATS") == 1 && hipMalloc(&d_cull_stats, 3 * sizeof(unsigned)) == hipSuccess) (void)hipMemset(d_cull_stats, 0, 3 * sizeof(unsigned));
       if (const char* v = getenv("SS_STEP_ORDER")) step_order = step_order_long = v;
     }
 #else
@@ -173,7 +179,7 @@ struct ss_ctx {
   // kDeepFoldBatch calls, behind one event from each queue, call by call in order. A slot is written again only after the
   // host has seen the event behind its additions complete.
   hipStream_t s_fold = nullptr;
-  hipEvent_t ev_fold_src[2] = {}, ev_fold_done[16] = {};
+  hipEvent_t ev_fold_src[kMaxQueues] = {}, ev_fold_done[16] = {};
   unsigned fold_batches = 0;
   int slot_batch[kDeepSpecSlots];  // the batch (index into ev_fold_done) that added the slot's sums, -1: nothing outstanding
   bool fold_dirty = false;         // s_fold holds work the public stream has not been made to wait for
@@ -198,9 +204,9 @@ struct ss_ctx {
   // run two launches later, next to the detect stage of batch k + 1 — reads them and zeroes [(k + 2) % 3] for batch k + 2
   // (deep pipelining, below: six buffers, the emit stage of batch k runs four launches after its FFT stage and zeroes
   // [(k + 4) % 6], whose last reader ran two launches earlier on the same queue)
-  int* d_cnt3[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int* d_cnt3[3 * kMaxQueues] = {};
   int cnt_cur = 0;
-  int cnt_frames[6] = {0, 0, 0, 0, 0, 0};  // how many entries of each buffer may be non-zero
+  int cnt_frames[3 * kMaxQueues] = {};  // how many entries of each buffer may be non-zero
   int ncnt = 3, nbuf = 1, npsd = 1, lag = 1;  // buffers in rotation: counters, mask / avg planes / offsets, internal PSD planes; launches between a call's stages
   float* d_relplane = nullptr;            // full rel plane, only when a caller asks for it (lazy)
   int last_n_learn = 0;
@@ -231,9 +237,14 @@ struct ss_ctx {
   // that cannot overlap (learning frames, fewer frames than the ring holds, a caller reusing a buffer too soon) drain
   // first and run their three stages in order on the public stream.
   bool deep = false;
-  hipStream_t s_ab[2] = {nullptr, nullptr};
-  hipEvent_t ev_launch[8] = {}, ev_in[4] = {}, ev_join[2] = {};
-  float* d_halo[4] = {nullptr, nullptr, nullptr, nullptr};  // [kHistRows][n] each: written by launch L, read by detect(L) in launch L + 2
+  // (Round 3: nq queues instead of two — launch L on queue L mod nq carries FFT(L), detect(L - nq), emit(L - 2 nq). With two,
+  // a queue's next launch cannot start before its previous one has wholly finished, and while that one's last workgroups
+  // drain, the OTHER queue's launch has long been dispatched in full: a third of the CU slots stand empty around every
+  // hand-over. Everything said about "even" distances below reads "multiples of nq".)
+  int nq = 2;
+  hipStream_t s_ab[kMaxQueues] = {};
+  hipEvent_t ev_launch[32] = {}, ev_in[4] = {}, ev_join[kMaxQueues] = {};
+  float* d_halo[2 * kMaxQueues] = {};  // [kHistRows][n] each: written by launch L, read by detect(L) in launch L + nq
   const void* deep_prev_iq = nullptr;  // the previous call's frames (caller's buffer: untouched until ss_sync by contract)
   long long deep_prev_stride = 0;
   long deep_L = 0;             // launches since the last drain
@@ -289,14 +300,14 @@ struct ss_ctx {
   size_t order_capacity = 0;
   unsigned long long order_clock = 0;
   int n_cus = 256;
-  uint32_t* d_mask2[4] = {nullptr, nullptr, nullptr, nullptr};
-  float* d_avg2[4] = {nullptr, nullptr, nullptr, nullptr};
-  int* d_off4[4] = {nullptr, nullptr, nullptr, nullptr};  // the library's copy of the candidate offsets, per rotating set (d_off = the latest)
-  float* d_psd2[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint32_t* d_mask2[2 * kMaxQueues] = {};
+  float* d_avg2[2 * kMaxQueues] = {};
+  int* d_off4[2 * kMaxQueues] = {};  // the library's copy of the candidate offsets, per rotating set (d_off = the latest)
+  float* d_psd2[2 * kMaxQueues + 1] = {};
   // Tile culling (8192 points, detect_fused.h): the FFT role's per-column maxima of a call's PSD rows, [32][max_batch],
   // rotating with the mask / avg / offset buffers (written by the call's FFT launch, read by its detect stage)
-  float* d_segsum[4] = {nullptr, nullptr, nullptr, nullptr};
-  int* d_live[4] = {nullptr, nullptr, nullptr, nullptr};  // DetectArgs::live: the tiles of a call that must be evaluated (plan role -> the launch's other workgroups)
+  float* d_segsum[2 * kMaxQueues] = {};
+  int* d_live[2 * kMaxQueues] = {};  // DetectArgs::live: the tiles of a call that must be evaluated (plan role -> the launch's other workgroups)
   bool cull = false;
   const float* last_avg = nullptr;  // the avg plane (sparse or kept) of the last batch
   const float* last_hist = nullptr;       // ring rows as they were before the last batch
@@ -569,8 +580,9 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
     c->order_tables.push_back(t);
     slot = &c->order_tables.back();
   } else {
-    for (hipStream_t q : {c->s_ab[0], c->s_ab[1], c->stream})
+    for (hipStream_t q : c->s_ab)
       if (q) (void)hipStreamSynchronize(q);
+    (void)hipStreamSynchronize(c->stream);
     slot = &c->order_tables[0];
     for (auto& t : c->order_tables)
       if (t.used < slot->used) slot = &t;
@@ -658,6 +670,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   step_order(c, a, stream);
   // (no order table — none wanted, or none to be had: out of device memory — means the roles in segments, which is always correct)
 #ifdef SS_DIAG
+  a.hint_mode = c->diag.hint_mode;
   bool dump_stamps = false;
   if (!c->diag.stamp_path.empty() && fft && det && emit && ss::step_items(a) <= 4096 && a.n_det <= 4096) {
     if (!c->diag.d_stamps) (void)hipMalloc(&c->diag.d_stamps, sizeof(long long) * 4 * 8192);
@@ -721,7 +734,7 @@ void fold_spectrogram_slots(ss_ctx* c, size_t count, bool behind_public) {
     (void)hipEventRecord(c->ev_fold_src[0], c->stream);
     (void)hipStreamWaitEvent(c->s_fold, c->ev_fold_src[0], 0);
   } else {
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < c->nq; ++q) {
       (void)hipEventRecord(c->ev_fold_src[q], c->s_ab[q]);
       (void)hipStreamWaitEvent(c->s_fold, c->ev_fold_src[q], 0);
     }
@@ -746,15 +759,15 @@ void drain_deep(ss_ctx* c) {
   bool in_order = c->deep_L == 0;
   for (const auto& d : c->pd) in_order = in_order || (d.a.halo_psd == nullptr && !c->deep_ring_safe);
   const auto join = [&]() {
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < c->nq; ++q) {
       (void)hipEventRecord(c->ev_join[q], c->s_ab[q]);
       (void)hipStreamWaitEvent(c->stream, c->ev_join[q], 0);
     }
   };
   if (in_order && c->deep_L > 0) join();
-  for (int parity = 0; parity < (in_order ? 1 : 2); ++parity) {
+  for (int parity = 0; parity < (in_order ? 1 : c->nq); ++parity) {
     hipStream_t q = in_order ? c->stream : c->s_ab[parity];
-    const auto mine = [&](long ready) { return in_order || (int)(ready & 1) == parity; };
+    const auto mine = [&](long ready) { return in_order || (int)(ready % c->nq) == parity; };
     for (;;) {
       auto d = c->pd.begin();
       while (d != c->pd.end() && !mine(d->ready)) ++d;
@@ -1008,6 +1021,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   ea.cap = cand_cap;
   ea.off_int = c->d_off4[b];
   ea.live_clear = da.live;
+  ea.clear_masks = c->cull ? 1 : 0;  // (every emit stage of a culling context: the mask buffers are all zero between uses)
   c->d_off = c->d_off4[b];
   ea.off_out = d_cand_off;
   ea.cand_idx = (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr;
@@ -1110,12 +1124,12 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
       for (int x = 0; x < 6 && !must_drain; ++x)
         for (int y = 0; y < 6 && !must_drain; ++y)
           if (clash(mine.p[x], mine.bytes[x], b.p[y], b.bytes[y])) {
-            const long last = b.launch + (y < 2 ? 2 : 4);  // the last launch that touches b.p[y]
-            if (last > L - 2) must_drain = true;                      // too close: not even stream order helps
-            else if (((L - last) & 1) == 0) continue;                 // same queue, earlier: stream order
-            else if (c->deep_events && L - 3 >= c->deep_events_from) wait_other_queue = true;  // (last <= L - 3: the other queue's launch L - 3 is at or behind it)
+            const long last = b.launch + (y < 2 ? c->nq : 2 * c->nq);  // the last launch that touches b.p[y]
+            if (last > L - c->nq) must_drain = true;                   // too close: not even stream order helps
+            else if ((L - last) % c->nq == 0) continue;                // same queue, earlier: stream order
+            else if (c->deep_events && L - 2 * c->nq + 1 >= c->deep_events_from) wait_other_queue = true;  // (last <= L - nq - 1: each other queue's latest launch but one is at or behind it)
             else must_drain = true;
-            if (((L - last) & 1) != 0) c->deep_events = true;         // a caller rotating an odd number of sets: keep events from now on
+            if ((L - last) % c->nq != 0) c->deep_events = true;        // a caller rotating a number of sets that is no multiple of nq: keep events from now on
           }
   }
   if (spec) {
@@ -1134,7 +1148,7 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   long L = -1;
   if (overlap) {
     L = c->deep_L++;
-    q = c->s_ab[L & 1];
+    q = c->s_ab[L % c->nq];
     // whatever the public stream holds (the caller's producers, a drain, a learning call) comes first
     if (hipStreamQuery(c->stream) != hipSuccess) {
       hipEvent_t ev = c->ev_in[c->deep_forks++ & 3];
@@ -1145,14 +1159,17 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
     // kDeepSyncPeriod launches each waits for the other's launch three back. Whatever a launch older than kDeepHorizon
     // touched is then finished for both queues, and the buffers of older calls need no tracking.
     const int phase = (int)(L % kDeepSyncPeriod);
-    if ((wait_other_queue && !must_drain) || phase == kDeepSyncPhase || phase == kDeepSyncPhase + 1) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 3) & 7], 0));
-    if (c->deep_barrier == L - 1) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[(L - 1) & 7], 0));  // a detect role that read the ring goes before the next one writes it (once per drain)
+    if ((wait_other_queue && !must_drain) || (phase >= kDeepSyncPhase && phase < kDeepSyncPhase + c->nq))
+      for (long other = L - c->nq - 1; other > L - 2 * c->nq; --other)  // one launch of every other queue, each at least nq + 1 back
+        if (other >= 0) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[other & 31], 0));
+    for (long prev = L - 1; prev > L - c->nq; --prev)
+      if (c->deep_barrier == prev) SS_HIP(c, hipStreamWaitEvent(q, c->ev_launch[prev & 31], 0));  // a detect role that read the ring goes before the next ones write it (once per drain)
     if (c->deep_prev_ok) {  // this call's detect stage will want the rows before the batch: the previous call's last frames, once more
       // (20 rows for the 21-frame mean, up to 15 more when the batch does not start on a tile boundary: two launch shapes)
       role.n_halo = c->abs_frames % kFusedTF == 0 ? c->cfg.grouping_y - 1 : kHistRows;
       role.halo_iq = static_cast<const char*>(c->deep_prev_iq) +
                      (size_t)(c->deep_prev_frames - role.n_halo) * (size_t)c->deep_prev_stride * in_bytes_per_sample(c->cfg.in_format);
-      role.halo_psd = c->d_halo[L & 3];
+      role.halo_psd = c->d_halo[L % (2 * c->nq)];
     }
     if (!c->pd.empty() && c->pd.front().ready <= L) {
       d = c->pd.front();
@@ -1169,8 +1186,8 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   if (overlap) {
     const bool ring_reader = has_det && !d.a.halo_psd && !c->deep_ring_safe;
     const int rec_phase = (int)(L % kDeepSyncPeriod);
-    if (c->deep_events || ring_reader || rec_phase == kDeepSyncPhase - 3 || rec_phase == kDeepSyncPhase - 2) SS_HIP(c, hipEventRecord(c->ev_launch[L & 7], q));
-    if (has_det) c->pe.push_back(ss_ctx::PendEmit{d.emit, L + 2});
+    if (c->deep_events || ring_reader || (rec_phase >= kDeepSyncPhase - 2 * c->nq && rec_phase < kDeepSyncPhase)) SS_HIP(c, hipEventRecord(c->ev_launch[L & 31], q));
+    if (has_det) c->pe.push_back(ss_ctx::PendEmit{d.emit, L + c->nq});
     if (ring_reader) c->deep_barrier = L;
   }
   if (n_learn > 0) {
@@ -1194,7 +1211,7 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
     mine_det.a.spec_m = c->spec_m;
     mine_det.a.spec_n = c->spec_n;
     mine_det.spec = true;
-    c->deep_folds.push_back(ss_ctx::PendFold{slot, (nframes + mine_det.a.shift + kFusedTF - 1) / kFusedTF, spec->d_sum, slot_no, L + 2});
+    c->deep_folds.push_back(ss_ctx::PendFold{slot, (nframes + mine_det.a.shift + kFusedTF - 1) / kFusedTF, spec->d_sum, slot_no, L + c->nq});
     spec->count += nframes;
     if (overlap) {  // calls whose detect stage is in a launch already enqueued: added in batches, beside the pipeline
       size_t ready = 0;
@@ -1202,7 +1219,7 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
       if (ready >= (size_t)kDeepFoldBatch) fold_spectrogram_slots(c, ready, false);
     }
   }
-  mine_det.ready = L + 2;
+  mine_det.ready = L + c->nq;
   c->pd.push_back(mine_det);
   if (overlap) {
     c->deep_prev_ok = true;
@@ -1357,19 +1374,21 @@ int get_noise(ss_ctx* c, NoiseState** out) {
 void free_ctx(ss_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->cfg.device_id);
-  for (hipStream_t q : {c->s_ab[0], c->s_ab[1], c->s_fold})
+  for (hipStream_t q : c->s_ab)
     if (q) (void)hipStreamSynchronize(q);
+  if (c->s_fold) (void)hipStreamSynchronize(c->s_fold);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
 #ifdef SS_DIAG
-  if (c->diag.d_cull_stats) {
+  if (c->diag.d_cull_stats > reinterpret_cast<unsigned*>(1)) {
     unsigned h[3] = {0, 0, 0};
     if (hipMemcpy(h, c->diag.d_cull_stats, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
       fprintf(stderr, "[specscan diag] detect tiles %u, on the culling path %u, culled %u\n", h[0], h[1], h[2]);
     (void)hipFree(c->diag.d_cull_stats);
   }
 #endif
-  for (hipStream_t q : {c->s_ab[0], c->s_ab[1], c->s_fold})
+  for (hipStream_t q : c->s_ab)
     if (q) (void)hipStreamDestroy(q);
+  if (c->s_fold) (void)hipStreamDestroy(c->s_fold);
   for (hipEvent_t e : c->ev_fold_src)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_fold_done)
@@ -1543,10 +1562,11 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     c->spec_in_detect = c->fused && c->spec_m <= 256 && !c->diag.spec_standalone;
   }
   c->deep = c->step_path && n == 8192 && c->diag.deep && cfg->max_batch >= kHistRows && (!(cfg->flags & SS_FLAG_SPECTROGRAM) || c->spec_in_detect);
-  c->lag = c->deep ? 2 : 1;
-  c->ncnt = c->deep ? 6 : 3;
-  c->nbuf = c->deep ? 4 : (c->step_path ? 2 : 1);
-  c->npsd = c->deep ? 4 : (c->step_path ? 2 : 1);  // (deep: written by launch L, read by launch L + 2, written again by launch L + 4 on the same queue)
+  c->nq = c->deep ? std::min(std::max(c->diag.queues, 2), kMaxQueues) : 1;
+  c->lag = c->deep ? c->nq : 1;
+  c->ncnt = c->deep ? 3 * c->nq : 3;
+  c->nbuf = c->deep ? 2 * c->nq : (c->step_path ? 2 : 1);
+  c->npsd = c->deep ? 2 * c->nq : (c->step_path ? 2 : 1);  // (deep: written by launch L, read by launch L + nq, written again by launch L + 2 nq on the same queue)
   if (c->fused) {
     {
       // ring capacity: at least three windows (a long batch needs a free one next to the one it reads), more when rows
@@ -1575,6 +1595,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   for (int k = 0; k < c->nbuf; ++k) {
     CREATE_HIP(hipMalloc(&c->d_avg2[k], plane));
     CREATE_HIP(hipMalloc(&c->d_mask2[k], sizeof(uint32_t) * (size_t)(n / 32) * (size_t)cfg->max_batch));
+    CREATE_HIP(hipMemsetAsync(c->d_mask2[k], 0, sizeof(uint32_t) * (size_t)(n / 32) * (size_t)cfg->max_batch, c->stream));  // (tile culling relies on it: EmitArgs::clear_masks)
     CREATE_HIP(hipMalloc(&c->d_off4[k], sizeof(int) * ((size_t)cfg->max_batch + 1)));
   }
   c->d_off = c->d_off4[0];
@@ -1582,14 +1603,15 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   if (c->cull)
     for (int k = 0; k < c->nbuf; ++k) {
       CREATE_HIP(hipMalloc(&c->d_segsum[k], sizeof(float) * 32 * (size_t)cfg->max_batch));
-      const size_t live_ints = ss::kLiveHeader + (size_t)ss::kLiveHeader * ss::kLiveCap;
+      static_assert(ss::kLiveHeader + ss::kLiveLists * ss::kLiveCap <= ss::kLiveCounts, "the lists end before the count copies");
+      const size_t live_ints = ss::kLiveInts;
       CREATE_HIP(hipMalloc(&c->d_live[k], sizeof(int) * live_ints));
       CREATE_HIP(hipMemsetAsync(c->d_live[k], 0, sizeof(int) * live_ints, c->stream));
     }
   if (c->deep) {
     c->deep_ring_safe = c->hist_rows / kHistRows >= kDeepSyncPhase + 8;
-    for (auto& q : c->s_ab) CREATE_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-    for (auto& h : c->d_halo) CREATE_HIP(hipMalloc(&h, sizeof(float) * (size_t)n * (size_t)kHistRows));
+    for (int k = 0; k < c->nq; ++k) CREATE_HIP(hipStreamCreateWithFlags(&c->s_ab[k], hipStreamNonBlocking));
+    for (int k = 0; k < 2 * c->nq; ++k) CREATE_HIP(hipMalloc(&c->d_halo[k], sizeof(float) * (size_t)n * (size_t)kHistRows));
     for (auto& e : c->ev_launch) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_in) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_join) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1599,7 +1621,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipGetDeviceProperties(&prop, cfg->device_id));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t max_items = (size_t)(cfg->max_batch + kHistRows) * (size_t)(n / 8192) + ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256) / 2 + (size_t)cfg->max_batch + 4 +
-                             (size_t)ss::kLiveHeader * (ss::kLiveCap / 2 + 1);  // (a planned detect stage without an FFT role: 256 consumers per list, + the plan workgroups)
+                             (size_t)ss::kLiveLists * (ss::kLiveCap / 2 + 1);  // (a planned detect stage without an FFT role: 256 consumers per list, + the plan workgroups)
     c->order_capacity = max_items;
   }
   CREATE_HIP(hipMalloc(&c->d_counts, sizeof(int) * (size_t)cfg->max_batch));

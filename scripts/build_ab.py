@@ -9,12 +9,12 @@ import rtl_sdr_scanner_cpp_amd as pkg
 
 VARIANTS = {
     "base": [],
-    "iqnt": ["SS_AUX_IQ=2"],
-    "iqnt_sc0": ["SS_AUX_IQ=3"],
-    "iqnt_sc1": ["SS_AUX_IQ=18"],
-    "iqnt_detnt": ["SS_AUX_IQ=2", "SS_DET_NT=1"],
-    "iqnt_psdnt": ["SS_AUX_IQ=2", "SS_AUX_PSD=2"],
+    "iqdef": ["SS_AUX_IQ=0"],
     "psdnt": ["SS_AUX_PSD=2"],
+    "psdsc1": ["SS_AUX_PSD=16"],
+    "psdsc0sc1": ["SS_AUX_PSD=17"],
+    "psdntsc1": ["SS_AUX_PSD=18"],
+    "detnt": ["SS_DET_NT=1"],
 }
 
 if __name__ == "__main__":

@@ -121,3 +121,23 @@ def test_deep_pipelined_device_calls_culled_equal_unculled():
         res[name] = lists
     _same(res["cull"], res["nocull"])
     assert sum(len(x) for x in res["cull"]) > 50_000
+
+
+def test_short_calls_between_long_ones():
+    """Calls of 1 .. 15 frames leave state behind for the next user of their buffers (list headers, mask words): the long
+    calls that follow must not see it. (Found by tests/test_gpu_fuzz.py: a 2-frame call's emit stage cleared only two of the
+    sixteen copies of its list counts.)"""
+    sizes = [300, 2, 7, 300, 15, 40, 1, 500, 3, 3, 260, 16, 90]
+    nframes = sum(sizes)
+    band = pkg.synth.SyntheticBand(N, seed=12, on_frame=110, off_frame=1400)
+    iq = band.frames_cf32(nframes)
+    res = {}
+    for name, flags in (("cull", 0), ("nocull", pkg.abi.SS_FLAG_NO_CULL)):
+        eng = _engine(flags, max_batch=512)
+        lists, pos = [], 0
+        for sz in sizes:
+            lists += _lists(eng.process(iq[pos:pos + sz], want=()))
+            pos += sz
+        res[name] = lists
+    _same(res["cull"], res["nocull"])
+    assert sum(len(x) for x in res["cull"]) > 50_000
