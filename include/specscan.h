@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 1
+#define SS_ABI_VERSION 2 /* 2: ss_flush, SS_FLAG_NO_CULL / SS_FLAG_STREAM_ORDERED, buffer lifetime of ss_process_device (round 2: ss_pipe_* removed) */
 
 typedef enum ss_status {
   SS_OK = 0,
@@ -72,6 +72,11 @@ typedef enum ss_plane {
  * reach start_level (csrc/detect_fused.h, tile culling). Results are identical either way; the flag exists so that the
  * data-independent cost of the chain can be measured (bench.py reports both). */
 #define SS_FLAG_NO_CULL 4u
+/* ss_process_device keeps to the context's stream: every stage of a call is enqueued on ss_stream, in order, and work the
+ * caller enqueues there afterwards (a producer refilling d_iq, a consumer of the planes) is ordered behind it — the
+ * classic stream contract, at about half the throughput of the default, in which consecutive calls overlap on queues of
+ * the library's own and every buffer of a call must stay untouched until ss_sync (see ss_process_device). */
+#define SS_FLAG_STREAM_ORDERED 8u
 
 #define SS_NO_DATA (-100.0f) /* setNoData sentinel, sources/utils/radio_utils.cpp:72-76 */
 
@@ -146,7 +151,10 @@ int ss_process(ss_ctx* ctx, const void* iq, int32_t nframes, const int64_t* t_ms
  * (csrc/scan_step.h); for 8192-point frames up to five calls are in flight, on two hardware queues of the library's own
  * (ss_ctx::deep in csrc/specscan.hip). The results of a call are therefore complete only after ss_sync, or after ss_flush
  * followed by any synchronisation of ss_stream; every buffer passed to a call (d_iq included) must stay valid and
- * untouched until then. Work the caller has enqueued on ss_stream before a call (a producer of d_iq) is waited for.
+ * untouched until then — d_iq in particular: the next call's launch reads the call's last frames once more. (A caller seen
+ * handing in frames where those of a call in flight lie is taken off the overlapped path for good: its calls then run
+ * their stages in order on ss_stream; SS_FLAG_STREAM_ORDERED asks for that from the start.) Work the caller has enqueued
+ * on ss_stream before a call (a producer of d_iq) is waited for.
  * Handing a plane or candidate buffer to a later call again without ss_sync in between is safe — the library orders the
  * stages that touch it, draining its pipeline first where it has to — and costs nothing when the output sets rotate with
  * an even period of at least six calls (four for the PSD / rel planes alone); of course only the newest contents can be

@@ -7,13 +7,14 @@ import ctypes as C
 
 import numpy as np
 
-SS_ABI_VERSION = 1
+SS_ABI_VERSION = 2
 SS_OK, SS_ERR_INVALID, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_BATCH, SS_ERR_CAND_OVERFLOW, SS_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 SS_FMT_CF32, SS_FMT_CS8, SS_FMT_CU8 = 0, 1, 2
 SS_PLANE_PSD, SS_PLANE_REL, SS_PLANE_AVG = 0, 1, 2
 SS_FLAG_KEEP_PLANES = 1
 SS_FLAG_SPECTROGRAM = 2
 SS_FLAG_NO_CULL = 4
+SS_FLAG_STREAM_ORDERED = 8
 SS_NO_DATA = np.float32(-100.0)
 
 c_float_p = C.POINTER(C.c_float)

@@ -254,15 +254,6 @@ __global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ d
   }
 }
 
-// rows of `row16` 16-byte words from a pitched source to a dense destination (ss_pipe: the tail of a call's input)
-__global__ void k_copy_pitched(const uint4* __restrict__ src, size_t src_pitch16, uint4* __restrict__ dst, int row16, int rows) {
-  const size_t total = (size_t)row16 * rows;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = e / row16, c = e % row16;
-    dst[e] = src[r * src_pitch16 + c];
-  }
-}
-
 __global__ void k_fill(float* __restrict__ dst, size_t count, float v) {
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) dst[e] = v;
 }

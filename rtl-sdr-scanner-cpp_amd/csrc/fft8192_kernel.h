@@ -174,7 +174,7 @@ __device__ __forceinline__ float2 mulw32_if(float2 x, bool on) {
 // bytes with 16-byte stores / 16-byte loads and stores (19.5 / 20.0 / 16.7 us per 1024 frames), 2 = transform
 // only (no global loads, stores never execute). Measured at 1024 / 4096 frames per launch: full 26.1 / 90.7 us,
 // memory only 19.2 / 72.3 us, transform only 16.7 / 48.6 us — see DESIGN.md.
-// TWO (ss_pipe): frames [0, split) come from `iq` / go to `psd` as usual, frames >= split from a second source to a second
+// TWO (round 1, lab only): frames [0, split) come from `iq` / go to `psd` as usual, frames >= split from a second source to a second
 // plane (a lane re-scans the halo it kept and scans the caller's batch in one launch).
 struct Fft8192Second {
   const void* iq;

@@ -278,8 +278,9 @@ struct ss_ctx {
   struct Buffers {
     const void* p[6];  // psd, rel | avg, cand_off, cand_idx, cand_avg
     size_t bytes[6];
-    long launch;       // the call's FFT launch; its detect stage runs in launch + 2 (last to touch psd / rel), its emit stage in launch + 4
+    long launch;       // the call's FFT launch; its detect stage runs in launch + nq (last to touch psd / rel), its emit stage in launch + 2 nq
     uintptr_t lo, hi;  // address range that holds all of them (a cheap first test)
+    uintptr_t iq_lo, iq_hi;  // the call's input frames: read by its FFT launch and, the last of them, once more by the next call's
   };
   std::deque<Buffers> deep_buffers;
   // A caller that waits after every call gains nothing from queues and deferred stages and pays for the fork and the join:
@@ -287,6 +288,7 @@ struct ss_ctx {
   // until two calls arrive without one in between.
   int deep_calls_since_sync = 0;
   bool deep_eager = false;
+  bool deep_iq_recycled = false;  // the caller was seen refilling an input buffer a call in flight still reads: no overlap for this context any more
   bool deep_events = false;   // record ev_launch after every launch
   long deep_events_from = 0;  // first launch of this run of launches that has its event
   // k_scan_step's dispatch-order table for the current launch shape (rebuilt when the shape changes; two buffers so that a
@@ -294,7 +296,9 @@ struct ss_ctx {
   struct OrderTable {
     int key[4];  // FFT / detect / emit / plan workgroups of the launch shape
     uint32_t* d;
-    unsigned long long used;
+    unsigned long long used;       // 0: free
+    std::vector<uint32_t> host;    // what was uploaded (kept alive: the copy is asynchronous)
+    hipStream_t stream;            // the stream it was uploaded on
   };
   std::vector<OrderTable> order_tables;  // one per launch shape met so far (a handful: steady state, pipeline fill, drain)
   size_t order_capacity = 0;
@@ -518,7 +522,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
   a.prio_other = c->diag.prio_other;
   if (n_fft == 0 || wg_det == 0 || c->diag.no_order_table) return;  // nothing to interleave: the kernel takes the roles one after the other (plan, emit, detect, FFT)
   for (auto& t : c->order_tables)
-    if (t.key[0] == n_fft && t.key[1] == wg_det && t.key[2] == wg_emit && t.key[3] == wg_plan) {
+    if (t.used && t.stream == stream && t.key[0] == n_fft && t.key[1] == wg_det && t.key[2] == wg_emit && t.key[3] == wg_plan) {  // (uploaded on this stream: complete for this launch by stream order)
       t.used = ++c->order_clock;
       a.order = t.d;
       return;
@@ -569,17 +573,19 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
       place(Seg{ss::ROLE_EMIT, 1 << 27});
     }
   }
-  // A new shape: a table of its own, copied synchronously — launches of other shapes, on any of the context's streams, keep
-  // theirs, and every later launch sees this one complete. Shapes are few (steady state, pipeline fill, drain); when the
-  // cache is full the least recently used table is recycled after everything in flight has finished.
-  if (out.size() > c->order_capacity) return;  // (capacity is sized from max_batch; launch_step then runs the roles one after the other)
+  // A new shape: one of the tables allocated at ss_create, filled by a copy on the launch's own stream (the table's host
+  // image stays alive with it), so that no launch ever waits for the host: launches of other shapes keep their tables, and
+  // this launch sees its own complete by stream order. Only when all sixteen tables are taken — a caller whose call sizes
+  // keep changing AND whose launches carry detect workgroups of their own — is the least recently used one recycled, after
+  // everything in flight has finished. (No table at all is always correct: the roles in segments.)
+  if (out.size() > c->order_capacity || c->order_tables.empty()) return;
   ss_ctx::OrderTable* slot = nullptr;
-  if (c->order_tables.size() < 8) {
-    ss_ctx::OrderTable t{};
-    if (hipMalloc(&t.d, sizeof(uint32_t) * c->order_capacity) != hipSuccess) return;
-    c->order_tables.push_back(t);
-    slot = &c->order_tables.back();
-  } else {
+  for (auto& t : c->order_tables)
+    if (t.used == 0) {
+      slot = &t;
+      break;
+    }
+  if (!slot) {
     for (hipStream_t q : c->s_ab)
       if (q) (void)hipStreamSynchronize(q);
     (void)hipStreamSynchronize(c->stream);
@@ -587,8 +593,11 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
     for (auto& t : c->order_tables)
       if (t.used < slot->used) slot = &t;
   }
-  if (hipMemcpy(slot->d, out.data(), sizeof(uint32_t) * out.size(), hipMemcpyHostToDevice) != hipSuccess) {
+  slot->host = out;
+  slot->stream = stream;
+  if (hipMemcpyAsync(slot->d, slot->host.data(), sizeof(uint32_t) * slot->host.size(), hipMemcpyHostToDevice, stream) != hipSuccess) {
     slot->key[0] = -1;
+    slot->used = 0;
     return;
   }
   slot->key[0] = n_fft;
@@ -1100,7 +1109,7 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   role.frames = &g;
   role.n = nframes;
   if (allow_overlap && ++c->deep_calls_since_sync >= 2) c->deep_eager = false;
-  const bool overlap = allow_overlap && !c->deep_eager && c->diag.pipeline && n_learn == 0 && nframes >= kHistRows;
+  const bool overlap = allow_overlap && !c->deep_eager && !c->deep_iq_recycled && c->diag.pipeline && n_learn == 0 && nframes >= kHistRows;
   const size_t plane_bytes = sizeof(float) * (size_t)nframes * (size_t)c->n;
   const auto clash = [](const void* a, size_t abytes, const void* b, size_t bbytes) {
     const char *pa = static_cast<const char*>(a), *pb = static_cast<const char*>(b);
@@ -1108,7 +1117,9 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   };
   ss_ctx::Buffers mine{{d_psd_out, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg},
                        {plane_bytes, plane_bytes, plane_bytes, sizeof(int32_t) * ((size_t)nframes + 1), sizeof(int32_t) * (size_t)cand_cap, sizeof(float) * (size_t)cand_cap},
-                       0, ~(uintptr_t)0, 0};
+                       0, ~(uintptr_t)0, 0, 0, 0};
+  mine.iq_lo = reinterpret_cast<uintptr_t>(d_iq);
+  mine.iq_hi = mine.iq_lo + (size_t)nframes * (size_t)item_stride * in_bytes_per_sample(c->cfg.in_format);
   for (int x = 0; x < 6; ++x)
     if (mine.p[x] && mine.bytes[x]) {
       const uintptr_t a0 = reinterpret_cast<uintptr_t>(mine.p[x]);
@@ -1119,6 +1130,16 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   bool must_drain = !overlap, wait_other_queue = false;
   if (overlap) {
     const long L = c->deep_L;
+    // A caller that hands in frames where the frames of a call still in flight lie — one input buffer filled again and again
+    // — has broken the contract (include/specscan.h: every buffer untouched until ss_sync), and the library cannot undo
+    // that: the producer that refilled the buffer ran on ss_stream, which overlapped launches do not hold up. What it can
+    // do is stop trusting this caller's input buffers: drain now, and from here on take the stages in order on the public
+    // stream, where a producer enqueued there is ordered against them (deep_eager, like a caller that waits after every call).
+    for (const auto& b : c->deep_buffers)
+      if (b.launch + 1 >= L - 2 * c->nq && b.iq_lo < mine.iq_hi && mine.iq_lo < b.iq_hi) {
+        must_drain = true;
+        c->deep_iq_recycled = true;
+      }
     for (const auto& b : c->deep_buffers)
       if (b.lo < mine.hi && mine.lo < b.hi)
       for (int x = 0; x < 6 && !must_drain; ++x)
@@ -1561,7 +1582,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     // frame tile (a batch that starts inside a tile touches one more)
     c->spec_in_detect = c->fused && c->spec_m <= 256 && !c->diag.spec_standalone;
   }
-  c->deep = c->step_path && n == 8192 && c->diag.deep && cfg->max_batch >= kHistRows && (!(cfg->flags & SS_FLAG_SPECTROGRAM) || c->spec_in_detect);
+  c->deep = c->step_path && n == 8192 && c->diag.deep && !(cfg->flags & SS_FLAG_STREAM_ORDERED) && cfg->max_batch >= kHistRows && (!(cfg->flags & SS_FLAG_SPECTROGRAM) || c->spec_in_detect);
   c->nq = c->deep ? std::min(std::max(c->diag.queues, 2), kMaxQueues) : 1;
   c->lag = c->deep ? c->nq : 1;
   c->ncnt = c->deep ? 3 * c->nq : 3;
@@ -1623,6 +1644,12 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     const size_t max_items = (size_t)(cfg->max_batch + kHistRows) * (size_t)(n / 8192) + ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256) / 2 + (size_t)cfg->max_batch + 4 +
                              (size_t)ss::kLiveLists * (ss::kLiveCap / 2 + 1);  // (a planned detect stage without an FFT role: 256 consumers per list, + the plan workgroups)
     c->order_capacity = max_items;
+    c->order_tables.resize(16);
+    for (auto& t : c->order_tables) {
+      t.used = 0;
+      t.d = nullptr;
+      CREATE_HIP(hipMalloc(&t.d, sizeof(uint32_t) * c->order_capacity));
+    }
   }
   CREATE_HIP(hipMalloc(&c->d_counts, sizeof(int) * (size_t)cfg->max_batch));
   if (cfg->flags & SS_FLAG_SPECTROGRAM) {
@@ -1777,11 +1804,21 @@ int ss_flush(ss_ctx* ctx) {
 
 int ss_sync(ss_ctx* ctx) {
   if (!ctx) return SS_ERR_INVALID;
-  std::lock_guard<std::mutex> lock(ctx->mtx);
-  SS_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
-  note_caller_sync(ctx);
-  flush_stages(ctx);
-  SS_HIP(ctx, stream_wait(ctx->stream));
+  hipStream_t stream = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mtx);
+    SS_HIP(ctx, hipSetDevice(ctx->cfg.device_id));
+    note_caller_sync(ctx);
+    flush_stages(ctx);
+    SS_HIP(ctx, hipGetLastError());
+    stream = ctx->stream;
+  }
+  // (the wait itself without the context's lock: a producer thread of ss_feed_*, or a control call, is not held up by it)
+  const hipError_t e = stream_wait(stream);
+  if (e != hipSuccess) {
+    std::lock_guard<std::mutex> lock(ctx->mtx);
+    return fail(ctx, SS_ERR_HIP, "stream_wait failed: %s", hipGetErrorString(e));
+  }
   return SS_OK;
 }
 
@@ -2038,6 +2075,7 @@ int ss_read_noise(ss_ctx* c, float* thr) {
   if (!c || !thr) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  flush_stages(c);  // (like every call that reads state; nothing deferred writes the ceiling today)
   NoiseState* z = noise_for(c, (c->range_lo + c->range_hi) / 2);
   if (!z) {
     for (int i = 0; i < c->n; ++i) thr[i] = -FLT_MAX;

@@ -110,8 +110,11 @@ class SpectrumEngine(abi.Chain):
         return int(self._lib.ss_stream(self._h) or 0)
 
     def process_device(self, iq, nframes: int, psd=None, rel=None, avg=None, cand_off=None, cand_idx=None, cand_avg=None):
-        """All arguments are torch tensors resident on this chain's device (or None). Asynchronous on the
-        chain's stream; call ``sync()`` before reading. iq must hold nframes items of N*D samples."""
+        """All arguments are torch tensors resident on this chain's device (or None). Asynchronous: consecutive calls
+        overlap on the library's own queues (include/specscan.h), so ``iq`` and every output must stay untouched — not
+        refilled, not read — until ``sync()``; the next call's launch reads this call's last frames once more.
+        ``flags=SS_FLAG_STREAM_ORDERED`` at construction gives the classic contract instead (all work on the chain's stream).
+        iq must hold nframes items of N*D samples."""
         cap = 0 if cand_idx is None else int(cand_idx.numel())
         st = self._lib.ss_process_device(self._h, _ptr(iq), int(nframes), _ptr(psd), _ptr(rel), _ptr(avg), _ptr(cand_off),
                                          _ptr(cand_idx), _ptr(cand_avg), cap)

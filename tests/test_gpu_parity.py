@@ -129,7 +129,7 @@ def test_alternative_implementations_meet_the_contract(oracle_mod, monkeypatch, 
                                    (65536, "cf32"), (131072, "cs8")])
 def test_psd_of_a_frame_does_not_depend_on_its_position_in_the_batch(n, fmt):
     """Kernels that take several frames per workgroup must round every frame the same way (the two unrolled halves of the
-    2048-point kernel once did not: the compiler chose the FMA operand per call site): frame-range sharding, ss_pipe and
+    2048-point kernel once did not: the compiler chose the FMA operand per call site): frame-range sharding and
     'any cut of the stream gives the same bits' all rest on it."""
     band = pkg.synth.SyntheticBand(n, seed=8, on_frame=5, off_frame=400)
     nf = 24 if n <= 16384 else 10

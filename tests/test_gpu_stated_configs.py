@@ -111,3 +111,71 @@ def test_headline_size_golden_made_by_the_reference():
     print(f"\n[golden N = 8192, int8] {len(b)} reference candidates, {len(a ^ b)} on the threshold; |err| dB: {format_quantiles(quant)}")
     assert len(b) > 1000 and len(a ^ b) <= 2
     check_plane("noise ceiling", eng.read_noise()[0][None], g["thr"][None], floor_tolerance(g["thr"][None]))
+
+
+def _device_calls(eng, iq_batches, n, planes=True):
+    """ss_process_device, one call per batch, NO synchronisation in between (what bench.py times: up to five calls in flight on
+    the library's two queues, a fresh output set per call, the PSD plane the only plane handed out)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    d_iq = [torch.from_numpy(b.view(np.float32) if b.dtype == np.complex64 else b).to(dev) for b in iq_batches]
+    outs = []
+    for b in iq_batches:
+        nb = b.shape[0]
+        outs.append(dict(psd=torch.empty((nb, n), dtype=torch.float32, device=dev) if planes else None,
+                         off=torch.zeros(nb + 1, dtype=torch.int32, device=dev), idx=torch.empty(nb * 1024, dtype=torch.int32, device=dev),
+                         avg=torch.empty(nb * 1024, dtype=torch.float32, device=dev)))
+    torch.cuda.synchronize()
+    for d, o in zip(d_iq, outs):
+        eng.process_device(d, d.shape[0], psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"], cand_avg=o["avg"])
+    eng.sync()
+    res = []
+    for o in outs:
+        off = o["off"].cpu().numpy()
+        res.append({"cand_off": off, "cand_idx": o["idx"].cpu().numpy()[:off[-1]], "cand_avg": o["avg"].cpu().numpy()[:off[-1]],
+                    **({"psd": o["psd"].cpu().numpy()} if planes else {})})
+    return res
+
+
+def test_config2_the_timed_path_against_the_reference(ref_mod):
+    """What bench.py times — consecutive 1024-frame ss_process_device calls with nothing in between: stages of five calls in
+    flight, halo frames re-transformed, tiles culled, lists handed from plan to FFT workgroups inside a launch — compared
+    DIRECTLY with the reference's own code, not with the engine's host path."""
+    n, fs, nb, ncalls = 8192, 2_048_000, 1024, 7
+    band = pkg.synth.SyntheticBand(n, seed=41, on_frame=150, off_frame=560, period=800)
+    iq = band.frames_cf32(nb * ncalls)
+    t = (10_000 + 20 * np.arange(nb * ncalls)).astype(np.int64)  # learning ends after 101 frames
+    ref_mod.ref().orc_set_fft_backend(0)
+    ref = _ref_result(ref_mod.RefChain(n, fs, CENTER - fs // 2, CENTER + fs // 2).process(iq, t))
+    eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, max_batch=nb, learn_frames=101)
+    outs = _device_calls(eng, [iq[k * nb:(k + 1) * nb] for k in range(ncalls)], n)
+    got = _cat(outs, ("psd", "cand_idx", "cand_avg"))
+    check_plane("psd", got["psd"], ref["psd"], floor_tolerance(ref["psd"]))
+    a, b = cand_set(got["cand_off"], got["cand_idx"]), cand_set(ref["cand_off"], ref["cand_idx"])
+    near = np.abs(ref["avg"] - np.float32(8.0)) < BAND
+    outside = [(f, i) for (f, i) in a ^ b if not near[f, i]]
+    assert not outside, sorted(outside)[:10]
+    frames = np.repeat(np.arange(nb * ncalls), np.diff(got["cand_off"]))
+    check_plane("cand_avg", got["cand_avg"][None], ref["avg"][frames, got["cand_idx"]][None], floor=np.full((1, len(frames)), 2e-3))
+    print(f"\n[config 2, timed path: {ncalls} x 1024 frames in flight] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band; "
+          f"|err| dB: {format_quantiles(error_quantiles({'psd': got['psd']}, {'psd': ref['psd']}, planes=('psd',)))}")
+    assert len(b) > 300_000 and len(a ^ b) <= dont_care_limit(len(b))
+
+
+def test_config3_device_calls_against_the_reference(ref_mod):
+    n, fs, chunk, ncalls = 65536, 20_000_000, 128, 3
+    band = pkg.synth.SyntheticBand(n, seed=42, on_frame=60, off_frame=330)
+    iq8 = band.frames_cs8(chunk * ncalls)
+    iq = (iq8[..., 0].astype(np.float32) / np.float32(128.0) + 1j * (iq8[..., 1].astype(np.float32) / np.float32(128.0))).astype(np.complex64)
+    t = (10_000 + 50 * np.arange(chunk * ncalls)).astype(np.int64)  # learning ends after 41 frames
+    ref_mod.ref().orc_set_fft_backend(0)
+    ref = _ref_result(ref_mod.RefChain(n, fs, CENTER - fs // 2, CENTER + fs // 2).process(iq, t))
+    eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, in_format=pkg.abi.SS_FMT_CS8, max_batch=chunk, learn_frames=41)
+    outs = _device_calls(eng, [iq8[k * chunk:(k + 1) * chunk] for k in range(ncalls)], n, planes=False)
+    got = _cat(outs, ("cand_idx", "cand_avg"))
+    a, b = cand_set(got["cand_off"], got["cand_idx"]), cand_set(ref["cand_off"], ref["cand_idx"])
+    near = np.abs(ref["avg"] - np.float32(8.0)) < BAND
+    outside = [(f, i) for (f, i) in a ^ b if not near[f, i]]
+    assert not outside, sorted(outside)[:10]
+    print(f"\n[config 3, device calls: {ncalls} x 128 frames of 65536 points, CS8] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band")
+    assert len(b) > 10_000 and len(a ^ b) <= dont_care_limit(len(b))
