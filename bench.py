@@ -165,7 +165,7 @@ def parity_sample(n: int, fs: int, fmt: str):
     import rtl_sdr_scanner_cpp_amd as pkg
     from oracle import oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from parity import check_all, dont_care_limit, error_quantiles
+    from parity import check_all, dont_care_limit, error_quantiles, excess_vs_fp64, strict_excess
     nframes = 96 if n <= 16384 else 48
     band = pkg.synth.SyntheticBand(n, seed=77, on_frame=nframes // 2, off_frame=nframes - 4)
     center = 145_000_000
@@ -192,29 +192,71 @@ def parity_sample(n: int, fs: int, fmt: str):
         ref["cand_off"] = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o["cand_off"]) for o in routs]))]).astype(np.int32)
         against = "C restatement (oracle/liboracle.so)"
     errs, ncand, ndc = check_all(got, ref)  # raises when the contract is broken
+    iq_c = iq if fmt == "cf32" else None  # (the fp64 comparison wants the frames as complex64)
+    vs64 = excess_vs_fp64(iq_c, got["psd"], ref["psd"], fs) if iq_c is not None else None
     return {"against": against, "frames": nframes, "reference_candidates": ncand, "inside_1e-3_dB_band": ndc, "band_limit": dont_care_limit(ncand),
-            "abs_err_dB": {k: {q: float(f"{v:.3g}") for q, v in d.items()} for k, d in error_quantiles(got, ref).items()}}
+            "abs_err_dB": {k: {q: float(f"{v:.3g}") for q, v in d.items()} for k, d in error_quantiles(got, ref).items()},
+            # bins the bare 1e-4 * max(1, |ref|) does not cover (held by the fp32-FFT floor allowance), and on those PSD bins the distance of
+            # the engine and of the reference's fp32 FFT to an fp64 FFT of the same windowed frame (engine <= 1.5 x reference asserted)
+            "outside_bare_1e-4": {k: {"n": v["n"], "frac": float(f"{v['frac']:.3g}"), "worst_dB": float(f"{v['worst']:.3g}")} for k, v in strict_excess(got, ref).items()},
+            "outside_bins_vs_fp64_fft_dB": None if vs64 is None else {k: (v if isinstance(v, int) else float(f"{v:.3g}")) for k, v in vs64.items()}}
 
 
 # ---------------------------------------------------------------------------------------------- launcher
-def traffic_from_profiles(threads_per_launch: int):
-    """Fabric bytes per launch of k_scan_step from the committed PMC passes of this command (profiles/r02/s32_pmc_*.csv:
-    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, --kernel-trace only), for launches of the given
-    grid size; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (round-1 calibration of gfx950's FETCH_SIZE).
+PMC_FILES = {"fetch": "pmc_fetch.csv", "write": "pmc_write.csv"}  # under profiles/<PMC_SET>/, one counter per rocprofv3 pass
+PMC_SET = {2: "r03/s30_cfg2", 3: "r03/s30_cfg3", 5: "r03/s30_cfg5"}  # the committed passes of each configuration's command line
+
+
+def traffic_from_profiles(config: int, kernel_match: str, threads_per_launch: int | None = None):
+    """Fabric bytes per launch of one kernel from the committed PMC passes of this configuration's command (`rocprofv3 --pmc
+    FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs, --kernel-trace only), optionally for launches of one grid size only;
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (round-1 calibration of gfx950's FETCH_SIZE).
     Counters cannot be collected from inside a run, so this is not a live figure: None when the files or the shape are absent."""
     import csv
+    base = PMC_SET.get(config)
+    if base is None:
+        return None
     out = {}
-    for kind in ("fetch", "write"):
-        path = os.path.join(ROOT, "profiles", "r02", f"s32_pmc_{kind}.csv")
+    for kind, name in PMC_FILES.items():
+        path = os.path.join(ROOT, "profiles", base + "_" + name)
         if not os.path.exists(path):
             return None
         vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                if "k_scan_step" in r["Kernel_Name"] and int(r["Grid_Size"]) == threads_per_launch]
+                if kernel_match in r["Kernel_Name"] and (threads_per_launch is None or int(r["Grid_Size"]) == threads_per_launch)]
         if not vals:
             return None
         out[kind] = sum(vals) / len(vals)
     return {"bytes_per_launch": round((2.0 * out["fetch"] + out["write"]) * 1024.0), "fetch_kib": round(out["fetch"], 1), "write_kib": round(out["write"], 1),
-            "source": "profiles/r02/s32_pmc_fetch.csv, s32_pmc_write.csv (rocprofv3 --pmc passes of `bench.py --steps 30`, not this run)"}
+            "source": f"profiles/{base}_pmc_fetch.csv, _pmc_write.csv (rocprofv3 --pmc passes of this configuration's command line, not this run)"}
+
+
+def is_preset(args) -> bool:
+    """The command line is the configuration's own (the committed PMC passes are of that one)."""
+    want = dict(fft=8192, frames=1024, fmt="cf32", sample_rate=None, no_psd_out=False)
+    want.update({k: v for k, v in CONFIGS.get(args.config or 2, {}).items() if k in want})
+    if want["sample_rate"] is None:
+        want["sample_rate"] = 2_048_000 * (want["fft"] // 8192 if want["fft"] >= 8192 else 1)
+    return (all(getattr(args, k) == v for k, v in want.items()) and not args.planes and not args.spectrogram and args.decim == 1 and not args.no_cull
+            and not args.sync_every_step and not (args.diag_lib or args.lib) and args.start_level == 8.0)
+
+
+def chain_kernels(n: int, fmt: str):
+    """The launches one call of the chain takes, as the library's timing slots name them (include/specscan.h SS_KSLOT_*), with
+    what each must move per sample given the decomposition (its inputs once + its outputs once)."""
+    in_b = 8.0 if fmt == "cf32" else 2.0
+    if n == 8192:
+        return [("step", "k_scan_step", "k_scan_step: load+window+FFT+dB of call k, carrying the 21x21 mean + threshold of call k-2 and the candidate lists "
+                 "of call k-4 as further roles of the same launch; consecutive launches alternate over two queues and overlap", in_b + 4.0)]
+    if n < 16384:
+        return [("step", "k_fft", "load+window+FFT+dB (one launch); detect and emit stages follow as launches of their own", in_b + 4.0)]
+    n2 = n // 256
+    ks = [("step", "k_scan_step", "k_scan_step: column half of the four-step FFT of call k (load, window, 256-point FFTs, twiddle -> work buffer), carrying the "
+           "21x21 mean + threshold of call k-1 (the tiles the plan listed) and the candidate lists of call k-2 as further roles", in_b + 8.0)]
+    if n2 >= 2048:
+        ks.append(("sub", "k_fft_sub_dft", f"k_fft_sub_dft: radix-{n2 // 256} step of the {n2}-point rows, in place in the work buffer", 16.0))
+    ks.append(("rows", "k_fft_rows", "row half: 256-point FFTs -> dB rows (+ run maxima and the averager ring rows for the tile culling)", 12.0))
+    ks.append(("plan", "k_plan_long", "k_plan_long: which averaging tiles of the call can hold a candidate (one thread per tile)", 0.0))
+    return ks
 
 
 def free_port() -> int:
@@ -267,6 +309,8 @@ def parse_args(argv):
     ap.add_argument("--start-level", type=float, default=8.0, help="Device::m_startLevel in dB over the learned ceiling (reference default 8)")
     ap.add_argument("--no-cull", action="store_true", help="SS_FLAG_NO_CULL: evaluate every averaging tile, also those whose segment maxima rule out a candidate (the data-independent cost of the chain)")
     ap.add_argument("--launch-check", action="store_true", help="exercise launcher, rendezvous, config broadcast and max-over-ranks timing only (no GPU work)")
+    ap.add_argument("--no-also", action="store_true", help="default line only: do not append the short runs of BASELINE configs 3 and 5 (`also`)")
+    ap.add_argument("--sub", action="store_true", help="(internal) this process is one of the `also` runs of another bench.py")
     args = ap.parse_args(argv)
     preset = dict(CONFIGS.get(args.config or 2, {}))
     args.cpu_only = bool(preset.pop("cpu_only", False))
@@ -282,6 +326,26 @@ def parse_args(argv):
     if args.sample_rate is None:
         args.sample_rate = 2_048_000 * (args.fft // 8192 if args.fft >= 8192 else 1)
     return args
+
+
+def also_lines():
+    """BASELINE configs 3 and 5 (one GPU each) as short runs of this script in processes of their own, appended to the default
+    line: ms_per_step, the chain's rate, and every kernel of the chain with its own duration and rate."""
+    res = []
+    for cfg_no, steps in ((3, 200), (5, 100)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg_no), "--gpus", "1", "--steps", str(steps), "--warmup", "5",
+               "--preheat-ms", "150", "--no-cpu-baseline", "--sub"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+            j = json.loads(line)
+            res.append({"baseline_config": cfg_no, "workload": j["config"]["workload"], "metric": j["metric"], "value": j["value"], "unit": j["unit"],
+                        "steps": j["steps"], "ms_per_step": j["ms_per_step"], "psd_plane_out": j["config"]["psd_plane_out"], "tile_culling": j["config"]["tile_culling"],
+                        "candidates_per_batch": j["config"]["candidates_per_batch"],
+                        "roofline_chain": j["roofline_chain"], "kernels": j["roofline"]["kernels"]})
+        except Exception as e:  # the default line must not depend on these
+            res.append({"baseline_config": cfg_no, "error": f"{type(e).__name__}: {str(e)[:200]}"})
+    return res
 
 
 # ---------------------------------------------------------------------------------------------- the measured job
@@ -414,9 +478,10 @@ def run(args):
     t_dev = time.perf_counter()
     dist.barrier()
     t1 = time.perf_counter()
-    kern_ms, launches = (0.0, 0)
+    kern_ms, launches, slots = 0.0, 0, {}
     if every:
-        kern_ms, launches = eng.kernel_timing_read()
+        slots = eng.kernel_timing_read_slots()
+        kern_ms, launches = slots["step"]
         eng.kernel_timing(0)
     elapsed = dist.max_over_ranks(t1 - t0, device=coll_dev)
     ncand = int(outs[(counter[0] - 1) % nout]["off"][-1].item())
@@ -425,21 +490,37 @@ def run(args):
         samples_per_step = nb * n * world
         value = samples_per_step * args.steps / elapsed / 1e6
         kern_avg_s = kern_ms / max(launches, 1) / 1e3
+        step_s = elapsed / args.steps
+        # every launch of the chain, kernel by kernel (start/stop events on the launches of the sampled calls)
+        kernels = []
+        for slot, match, what, bps in chain_kernels(n, args.fmt):
+            ms_k, cnt_k = slots.get(slot, (0.0, 0))
+            if not cnt_k:
+                continue
+            us = ms_k / cnt_k * 1e3
+            per_call = cnt_k / max(launches, 1)  # launches of this kernel per sampled call
+            kb = bps * nb * n / per_call if per_call else 0.0
+            tp = traffic_from_profiles(args.config or 2, match, (nb + 20 + nb // 8 + 4) * 512 if n == 8192 else None) if is_preset(args) else None
+            kernels.append({"slot": slot, "what": what, "us": round(us, 2), "launches_timed": cnt_k, "launches_per_call": round(per_call, 2),
+                            "bytes_per_launch_it_must_move": kb, "gbs": round(kb / us / 1e3, 1) if us else None,
+                            "frac_of_peak": round(kb / us / 1e3 / HBM_PEAK_GBS, 4) if us else None,
+                            "pmc_bytes_per_launch_from_profiles": tp["bytes_per_launch"] if tp else None})
+        dom = max(kernels, key=lambda k: k["us"] * k["launches_per_call"]) if kernels else None
         abps = algo_bytes_per_sample(args.fmt, True)  # the FFT kernel always writes its dB row
-        literal = abps * nb * n / kern_avg_s / 1e9 if launches else None  # bytes per launch / mean launch duration
+        literal = abps * nb * n / kern_avg_s / 1e9 if (launches and n == 8192) else (dom["gbs"] if dom else None)  # bytes per launch / mean launch duration
         # Consecutive launches of k_scan_step overlap on two hardware queues (deep pipelining): a launch lasts about
         # twice as long as the GPU spends per launch. in_flight = mean launch duration / wall time per launch; the kernel's
         # achieved rate is its bytes over duration / in_flight (= the literal figure when launches do not overlap).
-        in_flight = max(1.0, kern_avg_s / (elapsed / args.steps)) if launches else 1.0
-        achieved = literal * in_flight if launches else None
+        # (Other sizes: launches in order on one stream, nothing overlaps.)
+        in_flight = max(1.0, kern_avg_s / step_s) if (launches and n == 8192) else 1.0
+        achieved = literal * in_flight if literal is not None else None
         chain_bps = algo_bytes_per_sample(args.fmt, not args.no_psd_out) + (8.0 if args.planes else 0.0)
-        chain_gbs = chain_bps * nb * n / (elapsed / args.steps) / 1e9  # per GPU
-        kernel_name = ("k_scan_step: load+window+FFT+dB of call k, carrying the 21x21 mean + threshold of call k-2 and the candidate lists "
-                       "of call k-4 as further roles of the same launch; consecutive launches alternate over two queues and overlap") if n == 8192 else None
+        chain_gbs = chain_bps * nb * n / step_s / 1e9  # per GPU
+        pmc_chain = [k["pmc_bytes_per_launch_from_profiles"] * k["launches_per_call"] for k in kernels if k["pmc_bytes_per_launch_from_profiles"]]
         out = {
             "metric": "iq_msamples_per_sec_scanned_8192pt_fft" if n == 8192 else f"iq_msamples_per_sec_scanned_{n}pt_fft",
             "value": round(value, 1), "unit": "MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}-pt FFT, {fs / 1e6:.3f} MS/s, {nb}-frame batches, {args.fmt.upper()} IQ resident in HBM, full chain "
                                    "(window+FFT+dB -> noise-relative -> 21x21 mean -> threshold -> candidate lists), "
@@ -453,20 +534,24 @@ def run(args):
                        "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4),
                        # where the end of the timed region goes: the chain's own drain + wait, then the contract's device-wide synchronisation and barrier
                        "tail_us": {"engine_sync": round((t_eng - t_enq) * 1e6, 1), "device_synchronize": round((t_dev - t_eng) * 1e6, 1), "barrier": round((t1 - t_dev) * 1e6, 1)}},
-            "roofline": {"bound": "hbm", "kernel": kernel_name if n == 8192 else None,
-                         "achieved": None if (achieved is None or n != 8192) else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": None if (achieved is None or n != 8192) else round(achieved / HBM_PEAK_GBS, 4),
-                         "kernel_us": round(kern_avg_s * 1e6, 2) if launches and n == 8192 else None, "launches": launches if n == 8192 else 0,
-                         "launches_in_flight": round(in_flight, 2) if launches and n == 8192 else None,
-                         "achieved_if_launches_did_not_overlap": None if (literal is None or n != 8192) else round(literal, 1),
-                         "algorithmic_bytes_per_launch": abps * nb * n,
+            "roofline": {"bound": "hbm", "kernel": dom["what"] if dom else None,
+                         "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                         "kernel_us": dom["us"] if dom else None, "launches": dom["launches_timed"] if dom else 0,
+                         "launches_in_flight": round(in_flight, 2) if dom else None,
+                         "achieved_if_launches_did_not_overlap": None if literal is None else round(literal, 1),
+                         "algorithmic_bytes_per_launch": abps * nb * n if n == 8192 else (dom["bytes_per_launch_it_must_move"] if dom else None),
                          "traffic": None,  # PMC counters cannot be read from inside the run ...
-                         # ... the committed passes of the same command, for this launch shape (1024 + 20 FFT, 1024 detect and 128 emit workgroups of 512 threads):
-                         "traffic_from_profiles": traffic_from_profiles((nb + 20 + (nb // 16) * (n // 256) // 2 + nb // 8) * 512) if (n == 8192 and args.fmt == "cf32" and not args.no_psd_out and not args.planes) else None},
+                         # ... the committed passes of the same command line (for 8192 points: launches of the steady-state shape, 1024 + 20 FFT, 128 emit and 4 plan workgroups of 512 threads)
+                         "traffic_from_profiles": ({"bytes_per_launch": dom["pmc_bytes_per_launch_from_profiles"]} if dom and dom["pmc_bytes_per_launch_from_profiles"] else None),
+                         "kernels": kernels},
             "roofline_chain": {"bound": "hbm", "what": "whole step (every kernel of the chain + launch gaps), per GPU",
                                "algorithmic_bytes_per_sample": chain_bps, "achieved": round(chain_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(chain_gbs / HBM_PEAK_GBS, 4)},
+                               "frac": round(chain_gbs / HBM_PEAK_GBS, 4),
+                               "pmc_bytes_per_sample_from_profiles": round(sum(pmc_chain) / (nb * n), 2) if pmc_chain else None},
         }
+        if world == 1 and not args.sub and not args.no_also and (args.config or 2) == 2 and n == 8192 and not (args.diag_lib or args.lib):
+            out["also"] = also_lines()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, fs, args.cpu_seconds)
             try:

@@ -177,6 +177,12 @@ void* ss_stream(ss_ctx* ctx); /* the hipStream_t ss_process_device enqueues on *
  * called from PSD::work, psd.cpp:15-17). */
 int ss_kernel_timing(ss_ctx* ctx, int enable);
 int ss_kernel_timing_read(ss_ctx* ctx, double* total_ms, int32_t* launches);
+/* The same tally kernel by kernel, for the chains that take several launches per call (16384 points and more: the column half of
+ * the transform with the deferred detect / emit stages riding on it, the radix-A step of 2^19 / 2^20-point rows, the row half +
+ * dB, the tile-culling plan): a sampled call attaches events to every one of its launches. ms_by_slot and launches_by_slot
+ * hold SS_KSLOT_COUNT entries each; ss_kernel_timing_read is entry SS_KSLOT_STEP of this. Either call clears the tally. */
+enum { SS_KSLOT_STEP = 0, SS_KSLOT_ROWS = 1, SS_KSLOT_SUB = 2, SS_KSLOT_PLAN = 3, SS_KSLOT_COUNT = 4 };
+int ss_kernel_timing_read_slots(ss_ctx* ctx, double* ms_by_slot, int32_t* launches_by_slot);
 
 /* Device self-test of arithmetic shortcuts used by the kernels (which = 0: the 3-instruction division by
  * 21 equals the IEEE division for every float). Returns the number of mismatches (0 = pass) or < 0. */

@@ -48,14 +48,13 @@ __device__ __forceinline__ float load_row_value(const char* p) {
 #endif
 }
 
-// Tile culling (8192-point frames): a tile whose every rel value is below start_level cannot hold a candidate — a mean of
-// values cannot exceed their maximum — so it need not read its 36 x 276 rel values at all. The bound: the FFT role leaves,
-// per frame and 256-bin tile column, the maximum dB value over the column's bins and 32 more on either side
-// (Fft8192Args::segsum); the tile takes the maximum M of its column over its 36 frames and the minimum m of the noise
-// ceiling over the same 320 bins (thr_tilemin, kept up to date by k_thr_tilemin); every rel = fl(psd - thr) <= fl(M - m)
-// because rounding is monotonic. The fp32 sums behind a mean of 441 such values (|rel| < 1000 dB: finite dB values lie in
-// [-450, 400]) are off by < 0.01 dB, so a tile with fl(M - m) < start_level - kCullMargin has no candidate whatever the
-// rounding. -inf and NaN rows need no care: they make no candidates either (a NaN never passes `start_level <= avg`), and
+// Tile culling (8192-point frames): a tile that provably holds no candidate need not read its 36 x 276 rel values at all. The
+// bound: the FFT role leaves, per frame and 256-bin tile column, the maximum dB value M_g over the column's bins and 32 more on
+// either side (Fft8192Args::segsum); with m the minimum of the noise ceiling over the same 320 bins (thr_tilemin, kept up to date
+// by k_thr_tilemin) every rel = fl(psd - thr) of frame g is <= fl(M_g - m) because rounding is monotonic, so the 21-bin mean of
+// any frame is, and the 21 x 21 mean ending at frame f is at most mean(M_{f-20} .. M_f) - m. The fp32 sums behind a mean of 441
+// such values (|rel| < 1000 dB: finite dB values lie in [-450, 400]) and behind the bound are off by < 0.01 dB, so a tile whose
+// bound stays below start_level - kCullMargin for each of its 16 frames has no candidate whatever the rounding. -inf and NaN rows need no care: they make no candidates either (a NaN never passes `start_level <= avg`), and
 // +inf is not below any level. The decision is exact — culled tiles produce what the full evaluation would have produced:
 // zero mask bits, no counts (tests/test_gpu_cull.py: identical candidate lists with SS_FLAG_NO_CULL and against oracle/_ref).
 // What a culled tile must not cost is a workgroup: inside the step kernel every detect workgroup holds one of a CU's four
@@ -133,6 +132,13 @@ struct DetectArgs {
   // Written by the plan role (plan_tiles), consumed by the workgroups of the same launch (list_pair), the header set back to
   // zero by the call's emit stage.
   int* live;
+  // Tile culling, long transforms (N = 256 x N2; k_plan_long below): lists of the tiles that must be evaluated — per plan
+  // workgroup a count and that many tile numbers — written by a launch of its own between the call's FFT and detect stages;
+  // null = every tile. hist_by_fft: the FFT stage has written the ring rows of this batch itself (fft256_kernels.h, RowsExtra),
+  // no tile does.
+  const int* tile_list;
+  int list_cap;  // entries per list (C nft); list s starts at tile_list + s (1 + list_cap)
+  int hist_by_fft;
 #ifdef SS_DIAG
   long long* stamp_mid;  // measurement builds: wall clock after phase 1 (loads + time means) and after phase 2, per tile
   unsigned* cull_stats;  // measurement builds: {tiles, tiles on the culling path, tiles culled}
@@ -272,7 +278,7 @@ __host__ __device__ inline int plan_cols_per_wg(int nframes, int shift) {
 template <int G, int GX, int TF, int TB_ = 256>
 __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int cols, int tid, float* __restrict__ lds) {
   using T = DetectTile<G, GX, TF, TB_>;
-  constexpr int TB = T::TB, H = T::H, ROWS = T::ROWS;
+  constexpr int TB = T::TB, H = T::H;
   static_assert(TF == 16, "one pad word per frame tile");
   const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = a.n, nframes = a.nframes;
@@ -303,11 +309,24 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
       const bool writes_hist = f0 + TF > nframes - H;
       bool culled = false;
       if (exists && plannable && steady && !writes_hist) {
+        // the 21 x 21 mean that ends at frame f is at most mean(M_{f-20} .. M_f) - tm, M_g = the column's maximum in frame g
+        // (round 3; until then max(M) - tm over all 36 frames, which noise alone brings within 1.5 dB of an 8 dB threshold).
+        // The sum slides over the tile's 16 frames; a sum that is not a number (a frame of NaNs, -inf leaving the window)
+        // decides nothing: evaluated.
         const int b = f0 - (G - 1);
-        float m = mine[b + (b >> 4)];
+        float sum = 0.0f;
 #pragma unroll
-        for (int k = 1; k < ROWS; ++k) m = fmaxf(m, mine[b + k + ((b + k) >> 4)]);  // (NaNs are skipped)
-        culled = (m - tm) < a.start_level - kCullMargin;                          // (false for NaN)
+        for (int k = 0; k < G; ++k) sum += mine[b + k + ((b + k) >> 4)];
+        float best = sum;
+        bool unsure = sum != sum;
+#pragma unroll
+        for (int j = 1; j < TF; ++j) {
+          sum -= mine[b + j - 1 + ((b + j - 1) >> 4)];
+          sum += mine[b + j + G - 1 + ((b + j + G - 1) >> 4)];
+          unsure = unsure || (sum != sum);
+          best = fmaxf(best, sum);
+        }
+        culled = !unsure && (best * (1.0f / (float)G) - tm) < a.start_level - kCullMargin;  // (false for NaN)
       }
       live_mask[r] = __ballot(exists && !culled);
       dead_mask[r] = __ballot(culled);
@@ -393,6 +412,118 @@ __global__ __launch_bounds__(64) void k_thr_tilemin(const float* __restrict__ th
   if (lane == 0) tilemin[c] = m;
 }
 
+// Tile culling for long transforms (N = 256 x N2: 65536 points and up, 256 and more tile columns). Same idea as plan_tiles — a
+// tile that provably holds no candidate is not evaluated — from what the rows kernel of the FFT stage left per frame and 32-bin
+// run (RowsExtra::smax, a ring over the frames since the last reset, so that the tile's rows from BEFORE the batch are covered
+// too: a 16-frame call of 2^20-point rows has no others). The bound: with M_g the largest dB value of frame g over the tile's 256
+// bins and one run on either side, and m the minimum of the noise ceiling over the same bins (thr_tilemin), every rel value of
+// frame g in reach of the tile is <= M_g - m, so the 21 x 21 mean that ends at frame f is <= mean(M_{f-20} .. M_f) - m: the tile
+// is dropped when that stays below start_level - kCullMargin for each of its frames (the margin covers the fp32 sums on either
+// side: < 0.01 dB). A frame of zeros (M = -inf) makes the bound -inf for every window that holds it — those produce no candidate
+// either — and a NaN anywhere makes the tile "cannot tell": evaluated. A tile is only tested when all its rows are frames since
+// `clean_rel` (batch-relative, <= 0): no learning frame among them, one noise ceiling for all of them, the averager past its
+// warm-up. The ring rows such a tile would have written are written by the rows kernel itself (RowsExtra::hist_out), its mask
+// words are zero already (EmitArgs::clear_masks). The launch is a stage of its own between the call's rows kernel and the launch
+// that carries its detect stage: kernel boundaries order everything, the lists need no hand-over protocol.
+// Workgroup s takes tile columns [s C, s C + C) with all their frame tiles: every thread first reduces (column, frame) pairs to M
+// (ten ring values each) into LDS, then thread (column, frame tile) slides the 21-frame sum over its 16 frames; the tiles to be
+// evaluated go to the workgroup's own list — list + s (1 + C nft): count, then tile numbers in detect_tile's numbering — in
+// thread order: no atomics, the same list whatever the scheduling.
+struct PlanLongArgs {
+  const float* smax;
+  int smax_mask;
+  int abs0;       // frames since the last reset before this batch
+  int clean_rel;  // first batch-relative frame (<= 0 in a call without learning frames) from which every row qualifies
+  int cols;       // C: tile columns per workgroup
+  int* list;
+};
+constexpr int kPlanLongFloats = 8192;  // LDS of a plan workgroup: C x (16 nft + 20) values of M
+__host__ __device__ inline int plan_long_cols(int nframes, int shift, int tile_cols) {  // 0: the stage cannot be planned
+  const int nft = (nframes + shift + 15) / 16, rows = 16 * nft + 20;
+  int c = tile_cols / 256 > 1 ? tile_cols / 256 : 1;  // at least 256 workgroups where there are that many columns
+  if (c > 8) c = 8;
+  if (c > kPlanLongFloats / rows) c = kPlanLongFloats / rows;
+  if (nft > 0 && c > 256 / nft) c = 256 / nft;
+  return c;
+}
+
+template <int G, int GX, int TF, int TB_ = 256>
+__global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p) {
+  using T = DetectTile<G, GX, TF, TB_>;
+  constexpr int TB = T::TB;
+  static_assert(TB == 256 && T::A <= 32 && TF == 16 && G == 21, "eight 32-bin runs per tile column, one more on either side");
+  __shared__ float mrow[kPlanLongFloats];
+  __shared__ int wave_cnt[4];
+  const int n = a.n, nframes = a.nframes, tid = threadIdx.x;
+  const int tiles_per_row = n / TB, groups = n >> 5;
+  const int nft = (nframes + a.shift + TF - 1) / TF;
+  const int rows = TF * nft + (G - 1);  // frames [-shift - 20, 16 nft - shift) of the batch's frame numbering
+  const int C = p.cols, col0 = (int)blockIdx.x * C;
+  for (int e = tid; e < C * rows; e += 256) {
+    const int col = col0 + e / rows, r = e % rows;
+    float m = -__builtin_inff();
+    if (col < tiles_per_row) {
+      const int frame = r - a.shift - (G - 1);
+      const float* row = p.smax + ((size_t)((p.abs0 + frame) & p.smax_mask) * groups);
+      const int g_lo = max(8 * col - 1, 0), g_hi = min(8 * col + 8, groups - 1);
+      float v[10];
+#pragma unroll
+      for (int g = 0; g < 10; ++g) v[g] = row[min(g_lo + g, g_hi)];
+      bool bad = false;
+#pragma unroll
+      for (int g = 0; g < 10; ++g) {
+        bad = bad || (v[g] != v[g]);
+        m = fmaxf(m, v[g]);
+      }
+      if (bad) m = __builtin_nanf("");
+    }
+    mrow[e] = m;
+  }
+  __syncthreads();
+  bool live = false;
+  int block = 0;
+  if (tid < C * nft && col0 + tid / nft < tiles_per_row) {
+    const int cl = tid / nft, ft_seq = tid % nft;
+    const int ft = (ft_seq + nft - 1) % nft;
+    const int f0 = ft * TF - a.shift;
+    block = ft_seq * tiles_per_row + col0 + cl;
+    live = true;
+    if (a.n_learn == 0 && f0 - (G - 1) >= p.clean_rel && !a.rel_out && !a.avg_out) {
+      const float* mr = mrow + cl * rows + ft * TF;  // mr[k] = M of frame f0 - 20 + k
+      float best = -__builtin_inff();
+      bool unsure = false;
+#pragma unroll
+      for (int j = 0; j < TF; ++j) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < G; ++k) sum += mr[j + k];
+        if (f0 + j >= 0 && f0 + j < nframes) {  // the frames of this batch the tile answers for
+          unsure = unsure || (sum != sum);
+          best = fmaxf(best, sum);
+        }
+      }
+      const float bound = best * (1.0f / (float)G) - a.thr_tilemin[col0 + cl];
+      live = unsure || !(bound < a.start_level - kCullMargin);  // (a NaN difference: live)
+    }
+  }
+  // this workgroup's list, in thread order
+  const int lane = tid & 63, w = tid >> 6;
+  const unsigned long long mask = __ballot(live);
+  if (lane == 0) wave_cnt[w] = __popcll(mask);
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    base += k < w ? wave_cnt[k] : 0;
+    total += wave_cnt[k];
+  }
+  int* seg = p.list + (size_t)blockIdx.x * (size_t)(1 + C * nft);
+  if (live) seg[1 + base + __popcll(mask & ((1ull << lane) - 1ull))] = block;
+  if (tid == 0) seg[0] = total;
+}
+
+// min of the noise ceiling over bins [256 c - 32, 256 c + 288) is k_thr_tilemin above, one wave per tile column.
+
 // One tile of the fused back end. `block` = tile number (what blockIdx.x is for the stand-alone kernel), `tid` = 0..TB-1,
 // `tile` / `cnt` = this tile's LDS (TF * P floats, TF ints). `valid` = false: the caller has no tile for these threads (odd
 // tile count in a two-tile workgroup) — they only keep the workgroup's barriers company. Every __syncthreads() below is
@@ -420,7 +551,7 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
   // block-uniform classification
   const bool interior = (b0 - A >= 0) && (b0 + TB + A <= n);
   const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes);
-  const int first_hist = nframes - H;  // batch frames >= first_hist become the ring rows [frame - first_hist]
+  const int first_hist = a.hist_by_fft ? (1 << 30) : nframes - H;  // batch frames >= first_hist become the ring rows [frame - first_hist]
   const float* before_base = a.halo_psd ? a.halo_psd : a.hist_in;  // rows before the batch: the previous call's last frames, or the ring
   const int before_rows = a.halo_psd ? a.halo_rows : H;
   const bool writes_hist = f0 + TF > first_hist;
@@ -816,7 +947,8 @@ __device__ __forceinline__ void cand_emit_frame_wide(const EmitArgs& a, int f, i
   int begin = 0;
   if (w == 0) begin = emit_frame_offset(a, f, lane, mine);
   int cnt = 0;
-  if (mine != 0 && a.cand_idx) {
+  const bool walk = mine != 0 && (a.cand_idx || a.clear_masks);  // (offsets only: the words still have to go back to zero)
+  if (walk) {
     for (int base = lo; base < hi; base += 256) {
       const uint4 q = *reinterpret_cast<const uint4*>(row + base + 4 * lane);
       cnt += __popc(q.x) + __popc(q.y) + __popc(q.z) + __popc(q.w);
@@ -827,7 +959,7 @@ __device__ __forceinline__ void cand_emit_frame_wide(const EmitArgs& a, int f, i
   if (lane == 0) slice_cnt[w] = cnt;
   if (w == 0 && lane == 0) *frame_begin = begin;
   __syncthreads();
-  if (mine == 0 || !a.cand_idx) return;
+  if (!walk) return;
   int carry = *frame_begin;
   for (int k = 0; k < w; ++k) carry += slice_cnt[k];
   if (cnt == 0) return;  // wave-uniform

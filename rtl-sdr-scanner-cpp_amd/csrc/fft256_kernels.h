@@ -124,16 +124,37 @@ __global__ __launch_bounds__(512, 8) void k_fft_cols256(ColsArgs g) {
   fft_cols256_tile<FMT>(g, (int)blockIdx.x, smem_raw, (int)threadIdx.x);
 }
 
+// What the rows kernel leaves for the detect stage of a long transform besides the dB rows (tile culling for N = 256 x N2,
+// detect_fused.h: k_plan_long). Every workgroup owns one 32-bin run of each of 256 tile columns:
+//   smax      the largest dB value of each run -> smax[(abs0 + frame) & smax_mask][first bin / 32], a ring over the frames since
+//             the last reset. Taken in the power domain (the largest re^2 + im^2 of the run through the same dB formula as the
+//             bins themselves: the hardware log2 is monotonic to within an ulp, the culling margin is 0.06 dB), by LDS atomics on
+//             the bit patterns of the non-negative powers; a NaN wins and is taken for "cannot be bounded" by the plan.
+//   hist_out  the averager ring (rel = dB - thr, what detect_tile stores for the newest H frames of a batch): written here when
+//             the call has no learning frames — thr is then what the call's detect stage will subtract, the same fp32
+//             subtraction on the same values — so that a detect tile that cannot hold a candidate has nothing left to do.
+struct RowsExtra {
+  float* smax;       // null: no maxima
+  int smax_mask;     // ring rows - 1 (a power of two)
+  int abs0;          // frames since the last reset before this batch
+  const float* thr;  // the noise ceiling (hist_out != null)
+  float* hist_out;   // null: the detect stage writes the ring
+  int first_hist;    // batch frames >= first_hist become ring rows [frame - first_hist]
+};
+constexpr int kFft256RowsPsdLdsBytes = kFft256ColsLdsBytes + 256 * 4;  // + one word per tile column for the run maxima
+
 // Rows of 256 points spaced row_stride apart: N2 = 256 (row_stride 256, nsub 1) directly after the columns pass, or
 // N2 = 256 A after k_fft_sub_dft (row_stride N2, nsub = A sub-rows c per row). Output bin of X_row[d] is
 // k1 + 256 c + 256 nsub d; a workgroup takes 32 consecutive k1 of one c so that stores run along k1.
 __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __restrict__ work, const float2* __restrict__ tw256, float db_off,
-                                                            float* __restrict__ psd, int logn, int lognsub) {
+                                                            float* __restrict__ psd, int logn, int lognsub, RowsExtra x) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* s = reinterpret_cast<float*>(smem_raw);
   const int t = threadIdx.x;
   float2* tw_lds = reinterpret_cast<float2*>(smem_raw + kFft256LdsBytes);  // W_256 in LDS, as in fft_cols256_tile
+  unsigned* pmax = reinterpret_cast<unsigned*>(smem_raw + kFft256ColsLdsBytes);
   if (t < 256) tw_lds[t] = tw256[t];
+  if (x.smax && t < 256) pmax[t] = 0u;  // (the barriers of the register passes come before the first atomic)
   const int rho = t >> 4, j = t & 15;
   // blockIdx = ((f * nsub) + c) * 8 + k1 tile
   const int r0 = (blockIdx.x & 7) << 5;
@@ -146,6 +167,16 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
   for (int r = 0; r < 16; ++r) a[r] = row[j + 16 * r];
   float2 cc[16];
   fft256_passes<kFft256PitchRows>(a, cc, s, tw_lds, rho, j);
+#ifndef SS_ROWS_ABL  // (A/B builds, scripts/build_ab.py: 1 = no maxima, 2 = no ring rows — garbage results, the kernel's time without them)
+#define SS_ROWS_ABL 0
+#endif
+  if (x.smax && SS_ROWS_ABL != 1) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float2 v = cc[slot16(k)];
+      atomicMax(&pmax[j + 16 * k], __float_as_uint(fmaf(v.x, v.x, v.y * v.y)));  // psd_db's own power, >= +0 or NaN
+    }
+  }
   __syncthreads();  // the exchange plane is reused for the read-out
   // dB values to LDS at [d][rho] (33-word pitch), then out along k1
 #pragma unroll
@@ -154,11 +185,20 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
   float* out = psd + ((size_t)f << logn);
   const int rr = t & 31, kb = t >> 5;
   const int half = 1 << (logn - 1);
+  if (x.smax && t < 256) {  // tile column d = t: its 32-bin run starts at bin (r0 + 256 c + (t << log_row)) ^ half, a multiple of 32
+    const float bound = fmaf(__log2f(__uint_as_float(pmax[t])), 3.01029995663981195f, -db_off);
+    const int first = (r0 + (c << 8) + (t << log_row)) ^ half;
+    x.smax[((size_t)((x.abs0 + f) & x.smax_mask) << (logn - 5)) + (first >> 5)] = bound;
+  }
+  float* hrow = (x.hist_out && f >= x.first_hist && SS_ROWS_ABL != 2) ? x.hist_out + ((size_t)(f - x.first_hist) << logn) : nullptr;  // (workgroup-uniform)
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int d = kb + 16 * i;
     // fft_v shift=true: X[k] lands at k ^ (N/2)
-    out[((r0 + rr) + (c << 8) + (d << log_row)) ^ half] = s[d * 33 + rr];
+    const int bin = ((r0 + rr) + (c << 8) + (d << log_row)) ^ half;
+    const float v = s[d * 33 + rr];
+    out[bin] = v;
+    if (hrow) hrow[bin] = v - x.thr[bin];  // noise_learner.cpp:55, as detect_tile forms it
   }
 }
 

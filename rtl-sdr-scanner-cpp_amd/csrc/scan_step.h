@@ -118,6 +118,15 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       const int2 pr = list_pair(a.det, item, step_plan_wgs(a), 0);
       tile_a = pr.x;
       tile_b = pr.y;
+    } else if (KIND >= 1 && a.det.tile_list) {  // long transforms: the tiles k_plan_long listed; workgroups beyond a list's end leave at once
+      const int pairs = (a.det.list_cap + 1) >> 1;  // workgroups per list
+      const int* seg = a.det.tile_list + (size_t)(item / pairs) * (size_t)(1 + a.det.list_cap);
+      const int q = item % pairs, cnt = min(seg[0], a.det.list_cap);
+      const int n_tiles = (a.det.n / 256) * plan_frame_tiles(a.det.nframes, a.det.shift);
+      tile_a = 2 * q < cnt ? seg[1 + 2 * q] : -1;
+      tile_b = 2 * q + 1 < cnt ? seg[2 + 2 * q] : -1;
+      if ((unsigned)tile_a >= (unsigned)n_tiles) tile_a = tile_b = -1;  // (never: a tile number that is none must not become an address)
+      if ((unsigned)tile_b >= (unsigned)n_tiles) tile_b = -1;
     } else {
       tile_a = 2 * item;
       tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;

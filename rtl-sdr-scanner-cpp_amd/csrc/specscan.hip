@@ -313,6 +313,17 @@ struct ss_ctx {
   float* d_segsum[2 * kMaxQueues] = {};
   int* d_live[2 * kMaxQueues] = {};  // DetectArgs::live: the tiles of a call that must be evaluated (plan role -> the launch's other workgroups)
   bool cull = false;
+  // Tile culling, long transforms (65536 points and 2^19 / 2^20: the sizes whose rows go through k_fft_rows256_psd): the rows
+  // kernel leaves the maximum of every 32-bin run per frame in d_smax, a ring of smax_rows frames (>= max_batch + 35) indexed by
+  // the frame count since the last reset, and writes the averager ring itself in calls without learning frames; k_plan_long
+  // lists the tiles that must be evaluated in d_tlist (rotating with the mask buffers). clean_abs: the first frame (counted
+  // since the last reset) from which every frame is a non-learning frame under the current noise ceiling — a tile is only
+  // tested when all 36 of its rows are at or behind it.
+  bool cull_long = false;
+  float* d_smax = nullptr;
+  int smax_rows = 0;
+  int* d_tlist[2] = {};
+  long long clean_abs = 0;
   const float* last_avg = nullptr;  // the avg plane (sparse or kept) of the last batch
   const float* last_hist = nullptr;       // ring rows as they were before the last batch
   float* last_thr = nullptr;
@@ -342,7 +353,9 @@ struct ss_ctx {
   int prof_every = 1;       // attach events to every prof_every-th launch only (the event packets cost ~4 us of GPU timeline each)
   unsigned prof_seen = 0;
   std::vector<hipEvent_t> prof_events;  // pairs
+  std::vector<int> prof_slots;          // which kernel of the chain each pair timed (SS_KSLOT_*)
   size_t prof_used = 0;
+  bool prof_call = false;   // the current call is a sampled one: its other kernels (rows, radix-A step, plan) carry events too
   std::mutex mtx;
   char err[512] = "";
 };
@@ -414,21 +427,38 @@ NoiseState* noise_for(ss_ctx* c, int32_t center) {
 }
 
 // next start/stop event pair for a timed launch, or false when timing is off / the pool is exhausted
-bool prof_pair(ss_ctx* c, hipEvent_t* a, hipEvent_t* b) {
-  if (!c->prof_on) return false;
-  if ((c->prof_seen++ % (unsigned)c->prof_every) != 0) return false;
+// A start/stop event pair for the launch of kernel `slot` (SS_KSLOT_*). The FFT launch of a call (slot 0) decides whether the call
+// is a sampled one (every prof_every-th); the call's other kernels follow it (prof_call).
+bool prof_take(ss_ctx* c, int slot, hipEvent_t* a, hipEvent_t* b) {
   if (c->prof_used + 2 > c->prof_events.size()) {
     if (c->prof_events.size() >= 2 * 8192) return false;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return false;
     c->prof_events.push_back(e0);
     c->prof_events.push_back(e1);
+    c->prof_slots.push_back(0);
   }
   *a = c->prof_events[c->prof_used];
   *b = c->prof_events[c->prof_used + 1];
+  c->prof_slots[c->prof_used / 2] = slot;
   c->prof_used += 2;
   return true;
 }
+bool prof_pair(ss_ctx* c, hipEvent_t* a, hipEvent_t* b) {
+  c->prof_call = false;
+  if (!c->prof_on) return false;
+  if ((c->prof_seen++ % (unsigned)c->prof_every) != 0) return false;
+  c->prof_call = prof_take(c, SS_KSLOT_STEP, a, b);
+  return c->prof_call;
+}
+bool prof_slot(ss_ctx* c, int slot, hipEvent_t* a, hipEvent_t* b) { return c->prof_on && c->prof_call && prof_take(c, slot, a, b); }
+// a launch on the context's stream that carries events when the call is a sampled one
+#define SS_LAUNCH_SLOT(c, slot, kernel, grid, block, lds, ...)                                                        \
+  do {                                                                                                                \
+    hipEvent_t pe0_, pe1_;                                                                                            \
+    if (prof_slot((c), (slot), &pe0_, &pe1_)) hipExtLaunchKernelGGL(kernel, grid, block, lds, (c)->stream, pe0_, pe1_, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, (c)->stream, __VA_ARGS__);                                      \
+  } while (0)
 
 // ---- FFT + PSD dispatch ---------------------------------------------------------------------------
 template <int LOGN, int FMT>
@@ -475,21 +505,21 @@ ss::ColsArgs cols256_args(ss_ctx* c, const void* d_iq, long long item_stride) {
 
 // with_cols = false: the column half ran as a role of k_scan_step (run_batch), only the row half is launched here
 template <int LOGN2, int FMT>
-void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd, bool with_cols = true) {
+void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, float* d_psd, bool with_cols = true, const ss::RowsExtra& rx = ss::RowsExtra{}) {
   constexpr int N2 = 1 << LOGN2;
   if (with_cols)
     hipLaunchKernelGGL((ss::k_fft_cols256<FMT>), dim3(nframes * (N2 / 32)), dim3(512), ss::kFft256ColsLdsBytes, c->stream, cols256_args(c, d_iq, item_stride));
   if constexpr (LOGN2 == 8) {
-    hipLaunchKernelGGL(ss::k_fft_rows256_psd, dim3(nframes * 8), dim3(512), ss::kFft256ColsLdsBytes, c->stream, (const float2*)c->d_work,
-                       (const float2*)c->d_tw256, c->db_off, d_psd, 16, 0);
+    SS_LAUNCH_SLOT(c, SS_KSLOT_ROWS, ss::k_fft_rows256_psd, dim3(nframes * 8), dim3(512), ss::kFft256RowsPsdLdsBytes, (const float2*)c->d_work,
+                   (const float2*)c->d_tw256, c->db_off, d_psd, 16, 0, rx);
   } else {
     bool done = false;
     if constexpr (LOGN2 >= 9 && LOGN2 <= 12) {
       if (c->d_tw_rowsR) {  // rows of 256 R points: R sub-sequences through the register passes, an R-point DFT across them
         constexpr int LOGR = LOGN2 - 8;
-        hipLaunchKernelGGL((ss::k_fft_rows256xR_psd<LOGR>), dim3(nframes * (256 / (32 >> LOGR))), dim3(512), ss::fft_rowsR_lds_bytes(LOGR),
-                           c->stream, (const float2*)c->d_work, (const float2*)c->d_tw256, (const float2*)c->d_tw_rowsR, c->db_off, d_psd,
-                           c->diag.fft_xcd_map ? 1 : 0);
+        SS_LAUNCH_SLOT(c, SS_KSLOT_ROWS, (ss::k_fft_rows256xR_psd<LOGR>), dim3(nframes * (256 / (32 >> LOGR))), dim3(512), ss::fft_rowsR_lds_bytes(LOGR),
+                       (const float2*)c->d_work, (const float2*)c->d_tw256, (const float2*)c->d_tw_rowsR, c->db_off, d_psd,
+                       c->diag.fft_xcd_map ? 1 : 0);
         done = true;
       }
     }
@@ -497,17 +527,17 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
       if (!done && c->d_tw_sub) {
         // rows of 256 A points (A = 8, 16) as an in-place radix-A step over the stride-256 index, then 256-point rows
         constexpr int A = 1 << (LOGN2 - 8);
-        hipLaunchKernelGGL((ss::k_fft_sub_dft<A>), dim3(nframes * 256), dim3(256), 0, c->stream, c->d_work, (const float2*)c->d_tw_sub);
-        hipLaunchKernelGGL(ss::k_fft_rows256_psd, dim3(nframes * A * 8), dim3(512), ss::kFft256ColsLdsBytes, c->stream, (const float2*)c->d_work,
-                           (const float2*)c->d_tw256, c->db_off, d_psd, 8 + LOGN2, LOGN2 - 8);
+        SS_LAUNCH_SLOT(c, SS_KSLOT_SUB, (ss::k_fft_sub_dft<A>), dim3(nframes * 256), dim3(256), 0, c->d_work, (const float2*)c->d_tw_sub);
+        SS_LAUNCH_SLOT(c, SS_KSLOT_ROWS, ss::k_fft_rows256_psd, dim3(nframes * A * 8), dim3(512), ss::kFft256RowsPsdLdsBytes, (const float2*)c->d_work,
+                       (const float2*)c->d_tw256, c->db_off, d_psd, 8 + LOGN2, LOGN2 - 8, rx);
         done = true;
       }
     }
     if (!done) {
       const size_t lds = sizeof(float2) * ((1 << 13) + 128);
       const int row_tiles = 256 >> (13 - LOGN2);
-      hipLaunchKernelGGL((ss::k_fft_rows_psd<8, LOGN2>), dim3(nframes * row_tiles), dim3(ss::kFftThreads), lds, c->stream, c->d_work, c->d_tw,
-                         c->db_off, d_psd);
+      SS_LAUNCH_SLOT(c, SS_KSLOT_ROWS, (ss::k_fft_rows_psd<8, LOGN2>), dim3(nframes * row_tiles), dim3(ss::kFftThreads), lds, c->d_work, c->d_tw,
+                     c->db_off, d_psd);
     }
   }
 }
@@ -883,16 +913,16 @@ int launch_fft(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, 
 }
 
 // Row half of the four-step transform whose column half ran as a role of k_scan_step.
-int launch_fft_rows(ss_ctx* c, int nframes, float* d_psd) {
+int launch_fft_rows(ss_ctx* c, int nframes, float* d_psd, const ss::RowsExtra& rx) {
   constexpr int F = ss::FMT_CF32;  // (the rows read the work buffer, whatever the input format was)
   switch (c->logn) {
-    case 14: launch_four_step256<6, F>(c, nullptr, 0, nframes, d_psd, false); break;
-    case 15: launch_four_step256<7, F>(c, nullptr, 0, nframes, d_psd, false); break;
-    case 16: launch_four_step256<8, F>(c, nullptr, 0, nframes, d_psd, false); break;
-    case 17: launch_four_step256<9, F>(c, nullptr, 0, nframes, d_psd, false); break;
-    case 18: launch_four_step256<10, F>(c, nullptr, 0, nframes, d_psd, false); break;
-    case 19: launch_four_step256<11, F>(c, nullptr, 0, nframes, d_psd, false); break;
-    case 20: launch_four_step256<12, F>(c, nullptr, 0, nframes, d_psd, false); break;
+    case 14: launch_four_step256<6, F>(c, nullptr, 0, nframes, d_psd, false, rx); break;
+    case 15: launch_four_step256<7, F>(c, nullptr, 0, nframes, d_psd, false, rx); break;
+    case 16: launch_four_step256<8, F>(c, nullptr, 0, nframes, d_psd, false, rx); break;
+    case 17: launch_four_step256<9, F>(c, nullptr, 0, nframes, d_psd, false, rx); break;
+    case 18: launch_four_step256<10, F>(c, nullptr, 0, nframes, d_psd, false, rx); break;
+    case 19: launch_four_step256<11, F>(c, nullptr, 0, nframes, d_psd, false, rx); break;
+    case 20: launch_four_step256<12, F>(c, nullptr, 0, nframes, d_psd, false, rx); break;
     default: return fail(c, SS_ERR_INVALID, "fft_size 2^%d has no column / row split", c->logn);
   }
   return SS_OK;
@@ -953,13 +983,17 @@ int run_backend_unfused(ss_ctx* c, const float* d_psd, int nframes, int n_learn,
 // Builds the two stages' arguments and advances the host-side state (ring window, counter rotation, buffer rotation);
 // launches them at once (deferred = false: FFT sizes other than 8192) or leaves them in *det_out / *emit_out for the
 // caller to schedule (k_scan_step).
-int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, NoiseState* z, SpecState* spec, float* d_rel_out,
-                      float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap, bool deferred,
-                      ss::DetectArgs* det_out, int* det_tiles_out, ss::EmitArgs* emit_out) {
+// Where a batch of nframes reads the averager ring and where its newest rows go. Called by run_backend_fused, and before it by
+// run_batch when the rows kernel of a long transform writes the ring rows itself: the second call finds the window where the
+// first left it and gives the same answer.
+struct RingPlace {
+  const float* in;
+  float* out;
+  int next_start;
+};
+RingPlace place_ring(ss_ctx* c, int nframes) {
   const int n = c->n;
-  constexpr int G = 21, GX = 21, TF = kFusedTF, TB = 256;  // measured against 32-frame and 128-bin tiles: 16 x 256 is fastest
   constexpr int H = kHistRows;
-  static_assert(H == ss::DetectTile<G, GX, TF, TB>::H, "ring depth");
   // The detect stage writes the batch's newest min(nframes, H) rel rows to the LAST rows of hist_out[0..H).
   if (nframes < H && c->hist_start + H + nframes > c->hist_rows) {
     // end of the buffer: move the window to the front once (rare: every (hist_rows - H) / nframes batches).
@@ -969,11 +1003,25 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
                        (const float*)(c->d_hist + (size_t)c->hist_start * n), c->d_hist, n, H, 0);
     c->hist_start = 0;
   }
-  const float* hist_in = c->d_hist + (size_t)c->hist_start * n;
-  int next_start;
-  if (nframes < H) next_start = c->hist_start + nframes;  // old rows [nframes, H) stay where they are, new ones land behind them
-  else next_start = c->hist_start + 2 * H <= c->hist_rows ? c->hist_start + H : 0;  // a whole new window, clear of the one being read (the ring holds at least three)
-  float* hist_out = c->d_hist + (size_t)next_start * n;
+  RingPlace r{};
+  r.in = c->d_hist + (size_t)c->hist_start * n;
+  if (nframes < H) r.next_start = c->hist_start + nframes;  // old rows [nframes, H) stay where they are, new ones land behind them
+  else r.next_start = c->hist_start + 2 * H <= c->hist_rows ? c->hist_start + H : 0;  // a whole new window, clear of the one being read (the ring holds at least three)
+  r.out = c->d_hist + (size_t)r.next_start * n;
+  return r;
+}
+
+int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, NoiseState* z, SpecState* spec, float* d_rel_out,
+                      float* d_avg_out, int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int cand_cap, bool deferred,
+                      ss::DetectArgs* det_out, int* det_tiles_out, ss::EmitArgs* emit_out) {
+  const int n = c->n;
+  constexpr int G = 21, GX = 21, TF = kFusedTF, TB = 256;  // measured against 32-frame and 128-bin tiles: 16 x 256 is fastest
+  constexpr int H = kHistRows;
+  static_assert(H == ss::DetectTile<G, GX, TF, TB>::H, "ring depth");
+  const RingPlace ring = place_ring(c, nframes);
+  const float* hist_in = ring.in;
+  const int next_start = ring.next_start;
+  float* hist_out = ring.out;
   const int cur = c->cnt_cur, clr = (c->cnt_cur + c->ncnt - c->lag) % c->ncnt;
   int* counts = c->d_cnt3[cur];
   const int b = c->buf_cur;
@@ -1030,7 +1078,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   ea.cap = cand_cap;
   ea.off_int = c->d_off4[b];
   ea.live_clear = da.live;
-  ea.clear_masks = c->cull ? 1 : 0;  // (every emit stage of a culling context: the mask buffers are all zero between uses)
+  ea.clear_masks = (c->cull || c->cull_long) ? 1 : 0;  // (every emit stage of a culling context: the mask buffers are all zero between uses)
   c->d_off = c->d_off4[b];
   ea.off_out = d_cand_off;
   ea.cand_idx = (d_cand_idx && cand_cap > 0) ? d_cand_idx : nullptr;
@@ -1213,7 +1261,7 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   }
   if (n_learn > 0) {
     hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
-    if (c->cull) hipLaunchKernelGGL(ss::k_thr_tilemin, dim3(32), dim3(64), 0, c->stream, (const float*)z->d_thr, c->n, z->d_thr + c->n);
+    if (c->cull || c->cull_long) hipLaunchKernelGGL(ss::k_thr_tilemin, dim3(c->n / 256), dim3(64), 0, c->stream, (const float*)z->d_thr, c->n, z->d_thr + c->n);
   }
   ss_ctx::PendDet mine_det{};
   st = run_backend_fused(c, d_psd, nframes, n_learn, z, nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg, cand_cap, true,
@@ -1275,6 +1323,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
   }
   float* d_psd = d_psd_out ? d_psd_out : c->d_psd2[c->psd_cur];
   if (!d_psd_out) c->psd_cur = (c->psd_cur + 1) % c->npsd;
+  c->prof_call = false;
   int st = SS_OK;
   SpecState* spec = nullptr;
   if (c->spec_n > 0) {
@@ -1298,6 +1347,22 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       role.cols = &gc;
       role.n = nframes * (c->n >> 13);
     }
+    // Tile culling for long transforms: the rows kernel leaves the run maxima of every frame and, in a call without learning
+    // frames, writes the ring rows of the batch itself (placed now: moving the ring window drains the deferred stages).
+    ss::RowsExtra rx{};
+    bool ring_by_rows = false;
+    if (c->cull_long) {
+      rx.smax = c->d_smax;
+      rx.smax_mask = c->smax_rows - 1;
+      rx.abs0 = (int)(c->abs_frames & 0x3fffffff);
+      if (n_learn == 0) {
+        const RingPlace rp = place_ring(c, nframes);
+        rx.thr = z->d_thr;
+        rx.hist_out = rp.out;
+        rx.first_hist = nframes - kHistRows;
+        ring_by_rows = true;
+      }
+    }
     const bool overlap = c->diag.pipeline && n_learn == 0;
     // A caller that hands the same PSD or avg plane to consecutive calls would have this call's stages write what a
     // deferred stage of the previous call still has to read in the same launch: drain first (no overlap for such callers).
@@ -1315,7 +1380,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     c->pend_emit = c->pend_det_emit;
     c->have_det = false;
     if (!c->use_fft8192) {
-      st = launch_fft_rows(c, nframes, d_psd);
+      st = launch_fft_rows(c, nframes, d_psd, rx);
       if (st != SS_OK) return st;
     }
     if (spec && !c->spec_in_detect) {
@@ -1325,13 +1390,35 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     if (spec) spec->count += nframes;
     if (n_learn > 0) {
       hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
-      if (c->cull) hipLaunchKernelGGL(ss::k_thr_tilemin, dim3(32), dim3(64), 0, c->stream, (const float*)z->d_thr, c->n, z->d_thr + c->n);
+      if (c->cull || c->cull_long) hipLaunchKernelGGL(ss::k_thr_tilemin, dim3(c->n / 256), dim3(64), 0, c->stream, (const float*)z->d_thr, c->n, z->d_thr + c->n);
     }
     st = run_backend_fused(c, d_psd, nframes, n_learn, z, c->spec_in_detect ? spec : nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg,
                            cand_cap, true, &c->pend_det, &c->pend_det_tiles, &c->pend_det_emit);
     if (st != SS_OK) return st;
     c->have_det = true;
     c->pend_det_spec = c->spec_in_detect && spec != nullptr;
+    if (c->cull_long) {
+      c->pend_det.hist_by_fft = ring_by_rows ? 1 : 0;
+      c->pend_det.tile_list = nullptr;
+      // the plan: which tiles of this call can hold a candidate at all (k_plan_long) — behind the rows kernel, ahead of the
+      // launch that carries the detect stage. Only a stage whose sole products are mask bits and counts is planned.
+      const int plan_cols = ss::plan_long_cols(nframes, c->pend_det.shift, c->n / 256);
+      if (ring_by_rows && !spec && !c->pend_det.rel_out && !c->pend_det.avg_out && plan_cols > 0) {
+        int* list = c->d_tlist[(c->buf_cur + c->nbuf - 1) % c->nbuf];  // (run_backend_fused has moved buf_cur on: the set this call's mask bits go to)
+        const int nft = ss::plan_frame_tiles(nframes, c->pend_det.shift), segs = (c->n / 256 + plan_cols - 1) / plan_cols;
+        ss::PlanLongArgs pl{};
+        pl.smax = c->d_smax;
+        pl.smax_mask = c->smax_rows - 1;
+        pl.abs0 = rx.abs0;
+        pl.clean_rel = (int)std::max<long long>(c->clean_abs - c->abs_frames, -(1ll << 29));
+        pl.cols = plan_cols;
+        pl.list = list;
+        SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(segs), dim3(256), 0, c->pend_det, pl);
+        c->pend_det.tile_list = list;
+        c->pend_det.list_cap = plan_cols * nft;
+        c->pend_det_tiles = 2 * segs * ((plan_cols * nft + 1) / 2);  // detect workgroups: a pair of entries each, per list
+      }
+    }
     if (!overlap) flush_stages(c);
   } else {
     st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
@@ -1355,6 +1442,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
   ++c->batch_no;
   SS_HIP(c, hipGetLastError());
   c->frames_pushed = c->frames_pushed + nframes < G ? c->frames_pushed + nframes : G;
+  if (n_learn > 0) c->clean_abs = c->abs_frames + n_learn;  // (tile culling, long transforms: rows before this one hold learning frames)
   c->abs_frames += nframes;
   c->last_psd = d_psd;
   c->last_n = nframes;
@@ -1383,8 +1471,9 @@ int get_noise(ss_ctx* c, NoiseState** out) {
   if (!z) {
     NoiseState nz;
     nz.center = center;
-    SS_HIP(c, hipMalloc(&nz.d_thr, sizeof(float) * ((size_t)c->n + 32)));  // + the per-tile-column minima (tile culling, 8192 points)
-    hipLaunchKernelGGL(ss::k_fill, dim3(grid_for((size_t)c->n + 32, 256)), dim3(256), 0, c->stream, nz.d_thr, (size_t)c->n + 32, -FLT_MAX);
+    const size_t extra = (size_t)std::max(32, c->n / 256);  // + the per-tile-column minima (tile culling)
+    SS_HIP(c, hipMalloc(&nz.d_thr, sizeof(float) * ((size_t)c->n + extra)));
+    hipLaunchKernelGGL(ss::k_fill, dim3(grid_for((size_t)c->n + extra, 256)), dim3(256), 0, c->stream, nz.d_thr, (size_t)c->n + extra, -FLT_MAX);
     c->noise.push_back(nz);
     z = &c->noise.back();
   }
@@ -1440,6 +1529,8 @@ void free_ctx(ss_ctx* c) {
   for (auto p : c->d_psd2) (void)hipFree(p);
   for (auto p : c->d_segsum) (void)hipFree(p);
   for (auto p : c->d_live) (void)hipFree(p);
+  for (auto p : c->d_tlist) (void)hipFree(p);
+  (void)hipFree(c->d_smax);
   for (auto p : c->d_halo) (void)hipFree(p);
   (void)hipFree(c->d_relplane);
   (void)hipFree(c->d_hist_tmp);
@@ -1772,6 +1863,16 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipMemcpy(c->d_win, win.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
   }
+  // Tile culling for long transforms: the sizes whose rows go through k_fft_rows256_psd (N2 = 256, or the radix-A step in front)
+  c->cull_long = c->step_path && c->use_fft256 && n >= 65536 && (n == 65536 || (c->d_tw_sub && !c->d_tw_rowsR)) && !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
+  if (c->cull_long) {
+    int rows = 64;
+    while (rows < cfg->max_batch + kHistRows + 1) rows <<= 1;
+    c->smax_rows = rows;
+    CREATE_HIP(hipMalloc(&c->d_smax, sizeof(float) * (size_t)rows * (size_t)(n / 32)));
+    const size_t max_tiles = ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256);
+    for (int k = 0; k < 2; ++k) CREATE_HIP(hipMalloc(&c->d_tlist[k], sizeof(int) * (2 * max_tiles + (size_t)(n / 256) + 1)));  // (per plan workgroup a count and up to C nft entries, C nft rounded up per list)
+  }
   // 64 KiB of dynamic LDS needs no opt-in on gfx950 (160 KiB/CU), but say so explicitly for clarity
   CREATE_HIP(hipStreamSynchronize(c->stream));
 #undef CREATE_HIP
@@ -1832,21 +1933,36 @@ int ss_kernel_timing(ss_ctx* c, int enable) {
   return SS_OK;
 }
 
-int ss_kernel_timing_read(ss_ctx* c, double* total_ms, int32_t* launches) {
-  if (!c || !total_ms || !launches) return SS_ERR_INVALID;
+int ss_kernel_timing_read_slots(ss_ctx* c, double* ms_by_slot, int32_t* launches_by_slot) {
+  if (!c || !ms_by_slot || !launches_by_slot) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
   flush_stages(c);  // (timed launches may sit on the side streams of the deep pipelining)
   SS_HIP(c, hipStreamSynchronize(c->stream));
-  double sum = 0.0;
+  for (int k = 0; k < SS_KSLOT_COUNT; ++k) {
+    ms_by_slot[k] = 0.0;
+    launches_by_slot[k] = 0;
+  }
   for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
     float ms = 0.f;
     SS_HIP(c, hipEventElapsedTime(&ms, c->prof_events[i], c->prof_events[i + 1]));
-    sum += ms;
+    const int slot = c->prof_slots[i / 2];
+    ms_by_slot[slot] += ms;
+    ++launches_by_slot[slot];
   }
-  *total_ms = sum;
-  *launches = (int32_t)(c->prof_used / 2);
   c->prof_used = 0;
+  c->prof_call = false;
+  return SS_OK;
+}
+
+int ss_kernel_timing_read(ss_ctx* c, double* total_ms, int32_t* launches) {
+  if (!total_ms || !launches) return SS_ERR_INVALID;
+  double ms[SS_KSLOT_COUNT];
+  int32_t cnt[SS_KSLOT_COUNT];
+  const int st = ss_kernel_timing_read_slots(c, ms, cnt);
+  if (st != SS_OK) return st;
+  *total_ms = ms[SS_KSLOT_STEP];
+  *launches = cnt[SS_KSLOT_STEP];
   return SS_OK;
 }
 
@@ -1944,6 +2060,7 @@ int ss_set_frequency_range(ss_ctx* c, int32_t lo_hz, int32_t hi_hz) {
   c->range_lo = lo_hz;
   c->range_hi = hi_hz;
   c->pass_dirty = true;
+  c->clean_abs = c->abs_frames;  // another centre frequency, another noise ceiling: the ring rows so far were formed with the old one
   return SS_OK;
 }
 
@@ -1961,6 +2078,7 @@ int ss_reset(ss_ctx* c) {  // Transmission::resetBuffers -> Averager::reset: row
   }
   c->frames_pushed = 0;
   c->abs_frames = 0;
+  c->clean_abs = 0;
   c->rot_frames = 0;
   c->last_n = 0;
   return SS_OK;
@@ -1974,6 +2092,7 @@ int ss_reset_noise(ss_ctx* c) {
   SS_HIP(c, hipStreamSynchronize(c->stream));
   for (auto& z : c->noise) (void)hipFree(z.d_thr);
   c->noise.clear();
+  c->clean_abs = c->abs_frames;
   c->last_thr = nullptr;  // ss_read_window(SS_PLANE_REL) of the last batch has nothing to subtract any more
   c->last_n = 0;
   return SS_OK;

@@ -15,6 +15,8 @@ VARIANTS = {
     "psdsc0sc1": ["SS_AUX_PSD=17"],
     "psdntsc1": ["SS_AUX_PSD=18"],
     "detnt": ["SS_DET_NT=1"],
+    "rowsnomax": ["SS_ROWS_ABL=1"],   # rows kernel of the long transforms without the run maxima (garbage culling: timing only)
+    "rowsnoring": ["SS_ROWS_ABL=2"],  # ... without the ring rows
 }
 
 if __name__ == "__main__":

@@ -120,6 +120,66 @@ def format_quantiles(q):
     return "; ".join(f"{k} p50 {v['p50']:.1e} p99.9 {v['p99.9']:.1e} max {v['max']:.1e}" for k, v in q.items())
 
 
+def strict_excess(got, ref, planes=("psd", "rel", "avg")):
+    """How much of each plane the contract's BARE tolerance 1e-4 * max(1, |ref|) does not cover — the bins held by the fp32-FFT
+    floor / drift allowances instead: count, fraction of the ordinary bins, and the worst error among them."""
+    out = {}
+    for k in planes:
+        if k in got and k in ref:
+            fin = np.isfinite(ref[k]) & (ref[k] != -100.0) & np.isfinite(got[k])
+            err = np.abs(got[k].astype(np.float64) - ref[k].astype(np.float64))
+            over = fin & (err > TOL * np.maximum(1.0, np.abs(ref[k])))
+            out[k] = {"n": int(over.sum()), "frac": float(over.sum() / max(int(fin.sum()), 1)), "worst": float(err[over].max()) if over.any() else 0.0}
+    return out
+
+
+def hamming_f32(n):
+    """gr::fft::window::hamming(N) as fft_v gets it (sdr_device.cpp:164): 0.54 - 0.46 cos(2 pi k / (N - 1)) in double, stored as float."""
+    return (0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(n) / (n - 1))).astype(np.float32)
+
+
+def fp64_psd_rows(iq_rows, fs):
+    """dB rows of the SAME windowed frames (the fp32 product sample x tap both chains form) through an fp64 FFT: the truth two
+    fp32 FFTs are measured against."""
+    n = iq_rows.shape[1]
+    w = hamming_f32(n)
+    x = (iq_rows.real.astype(np.float32) * w).astype(np.float64) + 1j * (iq_rows.imag.astype(np.float32) * w).astype(np.float64)
+    spec = np.fft.fftshift(np.fft.fft(x, axis=1), axes=1)
+    with np.errstate(divide="ignore"):
+        return 10.0 * np.log10((spec.real ** 2 + spec.imag ** 2) / float(fs))
+
+
+def excess_vs_fp64(iq, got_psd, ref_psd, fs, max_rows=256):
+    """On the PSD bins outside the bare 1e-4 tolerance (deep nulls, where two correct fp32 FFTs part): how far the engine and the
+    reference's fp32 FFT each are from an fp64 FFT of the same windowed frame. The engine is held to being no worse than 1.5 x the
+    reference there (rms), i.e. the allowance covers fp32 rounding, not a defect. iq: complex64 frames [nframes, N] (decimated).
+    Returns None when no bin is outside."""
+    fin = np.isfinite(ref_psd) & np.isfinite(got_psd)
+    err = np.abs(got_psd.astype(np.float64) - ref_psd.astype(np.float64))
+    over = fin & (err > TOL * np.maximum(1.0, np.abs(ref_psd)))
+    rows = np.flatnonzero(over.any(axis=1))
+    if rows.size == 0:
+        return None
+    if rows.size > max_rows:
+        rows = rows[np.linspace(0, rows.size - 1, max_rows).astype(int)]
+    truth = fp64_psd_rows(iq[rows], fs)
+    m = over[rows]
+    de = np.abs(got_psd[rows].astype(np.float64) - truth)[m]
+    dr = np.abs(ref_psd[rows].astype(np.float64) - truth)[m]
+    res = {"bins": int(m.sum()), "frames": int(rows.size), "engine_rms": float(np.sqrt(np.mean(de ** 2))), "reference_rms": float(np.sqrt(np.mean(dr ** 2))),
+           "engine_max": float(de.max()), "reference_max": float(dr.max())}
+    assert res["engine_rms"] <= 1.5 * res["reference_rms"] + 1e-6, res
+    return res
+
+
+def format_excess(ex, vs64=None):
+    s = "; ".join(f"{k} {v['n']} bins ({100.0 * v['frac']:.3f} %) worst {v['worst']:.1e}" for k, v in ex.items())
+    if vs64:
+        s += (f"; on those PSD bins, distance to an fp64 FFT of the same windowed frame: engine rms {vs64['engine_rms']:.1e} max {vs64['engine_max']:.1e}, "
+              f"reference's fp32 FFT rms {vs64['reference_rms']:.1e} max {vs64['reference_max']:.1e} dB")
+    return s
+
+
 def dont_care_limit(ncand):
     """How many candidates may sit inside the +-1e-3 dB band around start_level (decided by fp32 rounding, counted, not
     compared): 2, or one per 2000 reference candidates for the very long vectors."""
@@ -139,7 +199,8 @@ def check_all(got, ref, start_level=8.0, gy=21, gx=21):
                     extra = extra + propagated_floor(floor, gy, gx)
             errs[k] = check_plane(k, got[k], ref[k], extra)
     if floor is not None:  # the allowance must stay an exception: almost every bin is held to ~1e-4 x |ref|
-        assert (floor > 1e-3).mean() < 0.10 and (floor > 1e-2).mean() < 0.005
+        # (achieved on the suite's signals, every frame carrying its four combs: <= 6.0 % / 0.071 % at N = 2048, less at every other size)
+        assert (floor > 1e-3).mean() < 0.08 and (floor > 1e-2).mean() < 0.0015
     ncand, ndc = check_candidates(got["cand_off"], got["cand_idx"], ref["cand_off"], ref["cand_idx"], ref["avg"], start_level)
     # cand_avg = avg plane at the candidates
     frames = np.repeat(np.arange(len(got["cand_off"]) - 1), np.diff(got["cand_off"]))

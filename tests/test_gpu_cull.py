@@ -141,3 +141,104 @@ def test_short_calls_between_long_ones():
         res[name] = lists
     _same(res["cull"], res["nocull"])
     assert sum(len(x) for x in res["cull"]) > 50_000
+
+
+# ---- long transforms (N = 256 x N2: csrc/detect_fused.h, k_plan_long): the rows kernel leaves the maximum of every 32-bin run
+# per frame and writes the averager ring itself; tiles whose 36 rows cannot reach start_level are not evaluated — rows from
+# BEFORE the batch included, so short calls cull too. Same bar: culled == unculled, list by list, key by key.
+def _long_engine(n, fs, flags=0, **kw):
+    return pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, flags=flags, **kw)
+
+
+def _long_session(n, fs, iq, cuts, flags, in_format, retune_at=(), reset_at=(), learn_frames=24, t=None):
+    eng = _long_engine(n, fs, flags, in_format=in_format, max_batch=max(b - a for a, b in zip(cuts[:-1], cuts[1:])), learn_frames=learn_frames)
+    lists, avgs = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if a in retune_at:  # away and back: another centre frequency has another noise ceiling (learnt from scratch), the averager keeps its rows
+            eng.set_frequency_range(CENTER + fs - fs // 2, CENTER + fs + fs // 2)
+            o = eng.process(iq[a:a + 30], want=())
+            lists += _lists(o)
+            avgs.append(o["cand_avg"])
+            eng.set_frequency_range(CENTER - fs // 2, CENTER + fs // 2)
+        if a in reset_at:
+            eng.reset()
+        o = eng.process(iq[a:b], t_ms=None if t is None else t[a:b], want=())
+        lists += _lists(o)
+        avgs.append(o["cand_avg"])
+    return lists, np.concatenate(avgs)
+
+
+def test_long_rows_65536_culled_equal_unculled_and_the_reference(ref_mod):
+    n, fs, nframes = 65536, 20_000_000, 300
+    band = pkg.synth.SyntheticBand(n, seed=41, on_frame=70, off_frame=230)
+    iq8 = band.frames_cs8(nframes)
+    cuts = [0, 40, 168, 184, 191, 192, 300]  # the last learning frame opens the second call; calls of 128, 16, 7, 1 and 108 frames
+    t = (10_000 + 50 * np.arange(nframes)).astype(np.int64)
+    a = _long_session(n, fs, iq8, cuts, 0, pkg.abi.SS_FMT_CS8, t=t)
+    b = _long_session(n, fs, iq8, cuts, pkg.abi.SS_FLAG_NO_CULL, pkg.abi.SS_FMT_CS8, t=t)
+    _same(a[0], b[0])
+    assert np.array_equal(a[1], b[1])
+    assert sum(len(x) for x in a[0]) > 10_000
+    iq = (iq8[..., 0].astype(np.float32) / np.float32(128.0) + 1j * (iq8[..., 1].astype(np.float32) / np.float32(128.0))).astype(np.complex64)
+    ref_mod.ref().orc_set_fft_backend(0)
+    r = ref_mod.RefChain(n, fs, CENTER - fs // 2, CENTER + fs // 2).process(iq, t)
+    got = {(f, int(i)) for f, x in enumerate(a[0]) for i in x}
+    want = {(f, int(i)) for f, x in enumerate(r["cands"]) for i in x}
+    near = np.abs(r["avg"] - np.float32(8.0)) < BAND
+    outside = [(f, i) for (f, i) in got ^ want if not near[f, i]]
+    assert not outside, sorted(outside)[:10]
+    assert len(got ^ want) <= dont_care_limit(len(want))
+
+
+def test_long_rows_retune_reset_and_degenerate_frames():
+    n, fs, nframes = 65536, 20_000_000, 260
+    band = pkg.synth.SyntheticBand(n, seed=43, on_frame=50, off_frame=240, rel_db=19.0, centres=(0.05, -0.11, 0.23, -0.31, 0.37, -0.45, 0.49))
+    iq = band.frames_cf32(nframes)
+    iq[100] = 0           # -inf rows
+    iq[140, :100] = np.nan
+    iq[150] *= 1e15
+    cuts = [0, 64, 96, 128, 160, 192, 224, 260]
+    res = {}
+    for name, flags in (("cull", 0), ("nocull", pkg.abi.SS_FLAG_NO_CULL)):
+        res[name] = _long_session(n, fs, iq, cuts, flags, pkg.abi.SS_FMT_CF32, retune_at=(160,), reset_at=(224,))
+    _same(res["cull"][0], res["nocull"][0])
+    assert np.array_equal(res["cull"][1], res["nocull"][1], equal_nan=True)
+    assert sum(len(x) for x in res["cull"][0]) > 3_000
+
+
+def test_long_rows_one_million_points_short_calls():
+    n, fs, nframes = 1 << 20, 61_440_000, 80
+    band = pkg.synth.SyntheticBand(n, seed=47, on_frame=30, off_frame=70)
+    iq8 = band.frames_cs8(nframes)
+    cuts = [0, 16, 32, 48, 59, 64, 80]  # 16-frame calls (every row a tile reads lies before the batch or in it), one of 11, one of 5
+    res = {}
+    for name, flags in (("cull", 0), ("nocull", pkg.abi.SS_FLAG_NO_CULL)):
+        res[name] = _long_session(n, fs, iq8, cuts, flags, pkg.abi.SS_FMT_CS8, learn_frames=6)
+    _same(res["cull"][0], res["nocull"][0])
+    assert np.array_equal(res["cull"][1], res["nocull"][1])
+    assert sum(len(x) for x in res["cull"][0]) > 1_000
+
+
+def test_long_rows_device_calls_without_sync_culled_equal_unculled():
+    import torch
+    n, fs, nb, ncalls = 65536, 20_000_000, 64, 6
+    band = pkg.synth.SyntheticBand(n, seed=49, on_frame=70, off_frame=300)
+    iq8 = band.frames_cs8(nb * ncalls)
+    dev = torch.device("cuda", 0)
+    res = {}
+    for name, flags in (("cull", 0), ("nocull", pkg.abi.SS_FLAG_NO_CULL)):
+        eng = _long_engine(n, fs, flags, in_format=pkg.abi.SS_FMT_CS8, max_batch=nb, learn_frames=24)
+        d_iq = [torch.from_numpy(iq8[k * nb:(k + 1) * nb]).to(dev) for k in range(ncalls)]
+        outs = [dict(off=torch.zeros(nb + 1, dtype=torch.int32, device=dev), idx=torch.empty(nb * 4096, dtype=torch.int32, device=dev),
+                     avg=torch.empty(nb * 4096, dtype=torch.float32, device=dev)) for _ in range(ncalls)]
+        for k in range(ncalls):  # stages deferred from call to call, nothing waited for in between; offsets only for the last call but one
+            eng.process_device(d_iq[k], nb, cand_off=outs[k]["off"], cand_idx=None if k == ncalls - 2 else outs[k]["idx"],
+                               cand_avg=None if k == ncalls - 2 else outs[k]["avg"])
+        eng.sync()
+        lists = []
+        for k, o in enumerate(outs):
+            off, idx = o["off"].cpu().numpy(), o["idx"].cpu().numpy()
+            lists += [off.copy()] if k == ncalls - 2 else [idx[off[f]:off[f + 1]].copy() for f in range(nb)]
+        res[name] = lists
+    _same(res["cull"], res["nocull"])
+    assert sum(len(x) for x in res["cull"]) > 5_000
