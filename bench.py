@@ -365,7 +365,7 @@ def run(args):
     cfg0 = None
     if rank == 0:
         cfg0 = dict(fft_size=n, sample_rate=fs, decim=args.decim, in_format={"cf32": 0, "cs8": 1, "cu8": 2}[args.fmt], grouping_x=21, grouping_y=21,
-                    start_level_mdB=int(round(args.start_level * 1000)), learn_frames=min(100, nb), learn_ms=2000, max_batch=nb, band0_center=140_000_000,
+                    start_level_mdB=int(round(args.start_level * 1000)), learn_frames=100, learn_ms=2000, max_batch=nb, band0_center=140_000_000,
                     band_spacing=max(2_000_000, fs), n_bands=world if args.shard == "bands" else 1, seed=0)
 
     if args.launch_check:
@@ -411,14 +411,16 @@ def run(args):
     nsets = min(nsets, 64)
     nsets = -(-nsets // 12) * 12  # a multiple of the library's launch queues (2, 3 or 4): every buffer reuse is then ordered by stream order alone (include/specscan.h)
     gen = dist.synthetic_stream(cfg, band)  # one continuous frame stream of the band: noise + gated wide-band transmissions
-    first = gen(nb)  # holds the learning frames; every rank of a frame-sharded band learns from these same frames
+    # the learning frames (the reference's default: 100 frames — NOISE_LEARNING_TIME = 2000 ms at 50 frames per second — whatever the
+    # batch size: calls of fewer frames learn over several calls); every rank of a frame-sharded band learns from these same frames
+    n_first = -(-int(cfg["learn_frames"]) // nb)
     to_dev = lambda a: torch.from_numpy(a.view(np.float32) if a.dtype == np.complex64 else a).to(dev)  # noqa: E731
-    d_first = to_dev(first)
+    d_first = [to_dev(gen(nb)) for _ in range(n_first)]
     halo_frames = 0
     if shard_frames:
         # rank r owns frames [lo, lo + (warmup + steps) * nb) of the stream; it re-reads the halo in front of its range after
         # an averager reset (dist.scan_frame_range: the tile boundary at or below lo - 20, so 32-47 frames), nothing is exchanged
-        lo = nb + rank * (args.warmup + args.steps) * nb
+        lo = n_first * nb + rank * (args.warmup + args.steps) * nb
         start = ((lo // 16) * 16 - 20) // 16 * 16
         halo_frames = lo - start
         gen = dist.synthetic_stream(cfg, band, start_frame=start, stream_seed=1000 + rank)
@@ -445,7 +447,8 @@ def run(args):
         if args.sync_every_step:
             eng.sync()
 
-    step(d_first)  # noise learning (identical on every rank of a frame-sharded band)
+    for d in d_first:  # noise learning (identical on every rank of a frame-sharded band)
+        step(d)
     if shard_frames and rank > 0:
         eng.sync()
         eng.reset()
@@ -463,7 +466,10 @@ def run(args):
     eng.sync()
     every = 0
     if not args.no_kernel_timing:
-        every = args.time_every or max(1, min(8, args.steps // 2))  # each timed launch costs ~5 us of queue time (its two event packets): 3 samples in a 20-step run, 25 in a 200-step one
+        # each timed launch costs its queue ~13 us (the start packet ~7 us before it, the stop packet ~6 us before the queue's next
+        # launch: profiles/r03/s37_timeline_k20.txt): every 8th launch in a long run (25 samples in 200 steps), ONE launch — the
+        # (steps / 2)-th — in a run of up to 32 steps, where two of them were 5 % of the time measured
+        every = args.time_every or (8 if args.steps > 32 else max(1, args.steps))
         eng.kernel_timing(every)
     dist.barrier()
     torch.cuda.synchronize()

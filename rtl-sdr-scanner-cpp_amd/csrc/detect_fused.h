@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include "detect_kernels.h"
+#include "fft256_kernels.h"
 #include "fft8192_v2.h"
 
 // Cache policy of the detect tiles' row loads: 0 = default, 1 = non-temporal (A/B builds)
@@ -132,12 +133,10 @@ struct DetectArgs {
   // Written by the plan role (plan_tiles), consumed by the workgroups of the same launch (list_pair), the header set back to
   // zero by the call's emit stage.
   int* live;
-  // Tile culling, long transforms (N = 256 x N2; k_plan_long below): lists of the tiles that must be evaluated — per plan
-  // workgroup a count and that many tile numbers — written by a launch of its own between the call's FFT and detect stages;
-  // null = every tile. hist_by_fft: the FFT stage has written the ring rows of this batch itself (fft256_kernels.h, RowsExtra),
-  // no tile does.
+  // Tile culling, long transforms (N = 256 x N2; k_plan_long below): [0] = how many tiles must be evaluated, [1 ...] = their
+  // numbers, written by a launch of its own between the call's FFT and detect stages; null = every tile. hist_by_fft: the
+  // FFT stage has written the ring rows of this batch itself (fft256_kernels.h, RowsExtra), no tile does.
   const int* tile_list;
-  int list_cap;  // entries per list (C nft); list s starts at tile_list + s (1 + list_cap)
   int hist_by_fft;
 #ifdef SS_DIAG
   long long* stamp_mid;  // measurement builds: wall clock after phase 1 (loads + time means) and after phase 2, per tile
@@ -425,16 +424,20 @@ __global__ __launch_bounds__(64) void k_thr_tilemin(const float* __restrict__ th
 // warm-up. The ring rows such a tile would have written are written by the rows kernel itself (RowsExtra::hist_out), its mask
 // words are zero already (EmitArgs::clear_masks). The launch is a stage of its own between the call's rows kernel and the launch
 // that carries its detect stage: kernel boundaries order everything, the lists need no hand-over protocol.
-// Workgroup s takes tile columns [s C, s C + C) with all their frame tiles: every thread first reduces (column, frame) pairs to M
+// A workgroup takes C tile columns with all their frame tiles: every thread first reduces (column, frame) pairs to M
 // (ten ring values each) into LDS, then thread (column, frame tile) slides the 21-frame sum over its 16 frames; the tiles to be
-// evaluated go to the workgroup's own list — list + s (1 + C nft): count, then tile numbers in detect_tile's numbering — in
-// thread order: no atomics, the same list whatever the scheduling.
+// evaluated — numbers in detect_tile's numbering — are appended to ONE list (list[0] = count, zeroed before the launch; one
+// atomic per workgroup), so that the detect role can spread whatever there is evenly over a fixed number of workgroups: a
+// workgroup per tile pair, leaving at once when the pair is culled, cost the launch 11 us in DISPATCH alone (1024 workgroups
+// of eight waves take the hardware that long to start). The order of the list depends on the scheduling, the
+// results do not: tiles touch disjoint mask words, and the per-frame counts are integer sums.
 struct PlanLongArgs {
   const float* smax;
   int smax_mask;
   int abs0;       // frames since the last reset before this batch
   int clean_rel;  // first batch-relative frame (<= 0 in a call without learning frames) from which every row qualifies
   int cols;       // C: tile columns per workgroup
+  int logn;
   int* list;
 };
 constexpr int kPlanLongFloats = 8192;  // LDS of a plan workgroup: C x (16 nft + 20) values of M
@@ -458,17 +461,23 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
   const int tiles_per_row = n / TB, groups = n >> 5;
   const int nft = (nframes + a.shift + TF - 1) / TF;
   const int rows = TF * nft + (G - 1);  // frames [-shift - 20, 16 nft - shift) of the batch's frame numbering
-  const int C = p.cols, col0 = (int)blockIdx.x * C;
+  // this workgroup's C tile columns: the ones whose run maxima lie side by side in a frame's row of smax (rows_smax_index: the
+  // same c, consecutive d) — any C columns would do, these are read with 32-byte requests instead of 4-byte ones
+  const int C = p.cols, lognsub = p.logn - 16;
+  const int wc = (int)blockIdx.x & ((1 << lognsub) - 1), d0 = ((int)blockIdx.x >> lognsub) * C;
+  const auto column = [&](int i) { return d0 + i < 256 ? (wc + ((d0 + i) << lognsub)) ^ (tiles_per_row >> 1) : tiles_per_row; };
   for (int e = tid; e < C * rows; e += 256) {
-    const int col = col0 + e / rows, r = e % rows;
+    const int i = e % C, r = e / C, col = column(i);
     float m = -__builtin_inff();
     if (col < tiles_per_row) {
       const int frame = r - a.shift - (G - 1);
       const float* row = p.smax + ((size_t)((p.abs0 + frame) & p.smax_mask) * groups);
-      const int g_lo = max(8 * col - 1, 0), g_hi = min(8 * col + 8, groups - 1);
+      // the column's eight runs, the last run of the column below and the first of the one above (the band's edges: its own once more)
       float v[10];
 #pragma unroll
-      for (int g = 0; g < 10; ++g) v[g] = row[min(g_lo + g, g_hi)];
+      for (int g = 0; g < 8; ++g) v[g] = row[rows_smax_index(col, g, p.logn)];
+      v[8] = row[col > 0 ? rows_smax_index(col - 1, 7, p.logn) : rows_smax_index(col, 0, p.logn)];
+      v[9] = row[col + 1 < tiles_per_row ? rows_smax_index(col + 1, 0, p.logn) : rows_smax_index(col, 7, p.logn)];
       bool bad = false;
 #pragma unroll
       for (int g = 0; g < 10; ++g) {
@@ -477,16 +486,16 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
       }
       if (bad) m = __builtin_nanf("");
     }
-    mrow[e] = m;
+    mrow[i * rows + r] = m;
   }
   __syncthreads();
   bool live = false;
   int block = 0;
-  if (tid < C * nft && col0 + tid / nft < tiles_per_row) {
+  if (tid < C * nft && column(tid / nft) < tiles_per_row) {
     const int cl = tid / nft, ft_seq = tid % nft;
     const int ft = (ft_seq + nft - 1) % nft;
     const int f0 = ft * TF - a.shift;
-    block = ft_seq * tiles_per_row + col0 + cl;
+    block = ft_seq * tiles_per_row + column(cl);
     live = true;
     if (a.n_learn == 0 && f0 - (G - 1) >= p.clean_rel && !a.rel_out && !a.avg_out) {
       const float* mr = mrow + cl * rows + ft * TF;  // mr[k] = M of frame f0 - 20 + k
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
           best = fmaxf(best, sum);
         }
       }
-      const float bound = best * (1.0f / (float)G) - a.thr_tilemin[col0 + cl];
+      const float bound = best * (1.0f / (float)G) - a.thr_tilemin[column(cl)];
       live = unsure || !(bound < a.start_level - kCullMargin);  // (a NaN difference: live)
     }
   }
@@ -517,9 +526,10 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
     base += k < w ? wave_cnt[k] : 0;
     total += wave_cnt[k];
   }
-  int* seg = p.list + (size_t)blockIdx.x * (size_t)(1 + C * nft);
-  if (live) seg[1 + base + __popcll(mask & ((1ull << lane) - 1ull))] = block;
-  if (tid == 0) seg[0] = total;
+  __shared__ int list_base;
+  if (tid == 0) list_base = total ? atomicAdd(&p.list[0], total) : 0;
+  __syncthreads();
+  if (live) p.list[1 + list_base + base + __popcll(mask & ((1ull << lane) - 1ull))] = block;
 }
 
 // min of the noise ceiling over bins [256 c - 32, 256 c + 288) is k_thr_tilemin above, one wave per tile column.

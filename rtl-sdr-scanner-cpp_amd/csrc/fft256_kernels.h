@@ -126,8 +126,10 @@ __global__ __launch_bounds__(512, 8) void k_fft_cols256(ColsArgs g) {
 
 // What the rows kernel leaves for the detect stage of a long transform besides the dB rows (tile culling for N = 256 x N2,
 // detect_fused.h: k_plan_long). Every workgroup owns one 32-bin run of each of 256 tile columns:
-//   smax      the largest dB value of each run -> smax[(abs0 + frame) & smax_mask][first bin / 32], a ring over the frames since
-//             the last reset. Taken in the power domain (the largest re^2 + im^2 of the run through the same dB formula as the
+//   smax      the largest dB value of each run -> smax[(abs0 + frame) & smax_mask][rows_smax_index(...)], a ring over the frames
+//             since the last reset; within a frame the runs lie in the order the workgroups produce them (256 consecutive floats
+//             per workgroup: as 4-byte stores scattered over the row in bin order they cost a 32-byte write each, 1 B per
+//             sample). Taken in the power domain (the largest re^2 + im^2 of the run through the same dB formula as the
 //             bins themselves: the hardware log2 is monotonic to within an ulp, the culling margin is 0.06 dB), by LDS atomics on
 //             the bit patterns of the non-negative powers; a NaN wins and is taken for "cannot be bounded" by the plan.
 //   hist_out  the averager ring (rel = dB - thr, what detect_tile stores for the newest H frames of a batch): written here when
@@ -140,8 +142,17 @@ struct RowsExtra {
   const float* thr;  // the noise ceiling (hist_out != null)
   float* hist_out;   // null: the detect stage writes the ring
   int first_hist;    // batch frames >= first_hist become ring rows [frame - first_hist]
+  int* zero_word;    // set to zero by the first workgroup: the count of the list k_plan_long appends to right behind this launch (or null)
 };
 constexpr int kFft256RowsPsdLdsBytes = kFft256ColsLdsBytes + 256 * 4;  // + one word per tile column for the run maxima
+// Where the maximum of run `run` (0..7) of tile column `col` (256 bins, in output order: DC in the middle) lies in a frame's row
+// of RowsExtra::smax: the workgroup (c, r0 = 32 run) of k_fft_rows256_psd holds, for d = 0..255, the run of the column whose
+// unshifted number is c + nsub d — [run][c][d], d fastest.
+__host__ __device__ inline int rows_smax_index(int col, int run, int logn) {
+  const int cols = 1 << (logn - 8), lognsub = logn - 16;
+  const int cx = col ^ (cols >> 1);
+  return run * cols + ((cx & ((1 << lognsub) - 1)) << 8) + (cx >> lognsub);
+}
 
 // Rows of 256 points spaced row_stride apart: N2 = 256 (row_stride 256, nsub 1) directly after the columns pass, or
 // N2 = 256 A after k_fft_sub_dft (row_stride N2, nsub = A sub-rows c per row). Output bin of X_row[d] is
@@ -155,6 +166,7 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
   unsigned* pmax = reinterpret_cast<unsigned*>(smem_raw + kFft256ColsLdsBytes);
   if (t < 256) tw_lds[t] = tw256[t];
   if (x.smax && t < 256) pmax[t] = 0u;  // (the barriers of the register passes come before the first atomic)
+  if (x.zero_word && blockIdx.x == 0 && t == 0) *x.zero_word = 0;
   const int rho = t >> 4, j = t & 15;
   // blockIdx = ((f * nsub) + c) * 8 + k1 tile
   const int r0 = (blockIdx.x & 7) << 5;
@@ -185,10 +197,9 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
   float* out = psd + ((size_t)f << logn);
   const int rr = t & 31, kb = t >> 5;
   const int half = 1 << (logn - 1);
-  if (x.smax && t < 256) {  // tile column d = t: its 32-bin run starts at bin (r0 + 256 c + (t << log_row)) ^ half, a multiple of 32
+  if (x.smax && t < 256) {  // d = t: the run of 32 bins from (r0 + 256 c + (t << log_row)) ^ half on, run r0 / 32 of its tile column
     const float bound = fmaf(__log2f(__uint_as_float(pmax[t])), 3.01029995663981195f, -db_off);
-    const int first = (r0 + (c << 8) + (t << log_row)) ^ half;
-    x.smax[((size_t)((x.abs0 + f) & x.smax_mask) << (logn - 5)) + (first >> 5)] = bound;
+    x.smax[((size_t)((x.abs0 + f) & x.smax_mask) << (logn - 5)) + ((r0 >> 5) << (logn - 8)) + (c << 8) + t] = bound;  // rows_smax_index
   }
   float* hrow = (x.hist_out && f >= x.first_hist && SS_ROWS_ABL != 2) ? x.hist_out + ((size_t)(f - x.first_hist) << logn) : nullptr;  // (workgroup-uniform)
 #pragma unroll

@@ -62,6 +62,10 @@ struct StepArgs {
   int n_plan;
   int plan_cols;
   int plan_by_fft;
+  // KIND 1, 2, tile culling (k_plan_long): the launch's column workgroups take the pairs of the detect stage's list once their
+  // tile is done, pair p to column workgroup p; detect workgroups of their own only for the pairs beyond (n_det counts those).
+  // (Evaluated BEFORE the column tile the same pairs cost the launch 5 us more: the workgroups that find one finish last.)
+  int list_by_fft;
   int n_emit;  // frames of the emit role
   int emit_per_wg;  // 8: one wave per frame; 1 (KIND 2): rows of 2048 mask words and more, the eight waves share one frame
   // One workgroup per work item, dispatched in blockIdx order, four resident per CU. WHICH item a workgroup takes decides
@@ -90,6 +94,9 @@ __host__ __device__ inline int step_emit_wgs(const StepArgs& a) { return a.emit_
 __host__ __device__ inline int step_plan_wgs(const StepArgs& a) { return a.n_plan ? 32 / a.plan_cols : 0; }
 // consumers a planned stage needs: per list, a pair for every two tiles it may hold
 __host__ __device__ inline int step_plan_consumers(const StepArgs& a) { return step_plan_wgs(a) * ((a.plan_cols * (a.n_plan / 32) + 1) / 2); }
+// (Tried for the launches without an FFT role — the drain at the end of a run of calls: 32 detect workgroups per list, each taking
+// every 32nd pair of it, instead of one per possible pair of which most leave at once. The tiles that must be evaluated sit in
+// the lists of a few tile columns, a hundred pairs and more each: the launch went from 24 to 40 us, profiles/r03/s38_timeline_k20.txt.)
 __host__ __device__ inline int step_det_wgs(const StepArgs& a) { return (a.n_det + 1) / 2 + (a.plan_by_fft ? 0 : step_plan_consumers(a)); }
 inline int step_items(const StepArgs& a) { return step_fft_wgs(a) + step_det_wgs(a) + step_emit_wgs(a) + step_plan_wgs(a); }
 
@@ -102,6 +109,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
   // workgroup evaluates — the detect role from its item number or from the planned stage's list, the FFT role from the list
   // once its frame is done — and the evaluation follows at the bottom.
   int tile_a = -1, tile_b = -1;  // the tiles of threads 0..255 / 256..511 (workgroup-uniform; -1: none)
+  int list_pair_no = -1;  // long transforms: the pair of k_plan_long's list this workgroup evaluates (-1: it does not read the list)
   if (role == ROLE_EMIT) {
     if constexpr (KIND == 2) {
       // ---- emit role, long rows: the eight waves share one frame ----
@@ -118,15 +126,11 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       const int2 pr = list_pair(a.det, item, step_plan_wgs(a), 0);
       tile_a = pr.x;
       tile_b = pr.y;
-    } else if (KIND >= 1 && a.det.tile_list) {  // long transforms: the tiles k_plan_long listed; workgroups beyond a list's end leave at once
-      const int pairs = (a.det.list_cap + 1) >> 1;  // workgroups per list
-      const int* seg = a.det.tile_list + (size_t)(item / pairs) * (size_t)(1 + a.det.list_cap);
-      const int q = item % pairs, cnt = min(seg[0], a.det.list_cap);
-      const int n_tiles = (a.det.n / 256) * plan_frame_tiles(a.det.nframes, a.det.shift);
-      tile_a = 2 * q < cnt ? seg[1 + 2 * q] : -1;
-      tile_b = 2 * q + 1 < cnt ? seg[2 + 2 * q] : -1;
-      if ((unsigned)tile_a >= (unsigned)n_tiles) tile_a = tile_b = -1;  // (never: a tile number that is none must not become an address)
-      if ((unsigned)tile_b >= (unsigned)n_tiles) tile_b = -1;
+    } else if (KIND >= 1 && a.det.tile_list) {
+      // long transforms: the tiles k_plan_long listed. With an FFT role in the launch its workgroups take pairs 0 .. n_fft - 1
+      // (below) and the detect workgroups the pairs beyond (calls that are no multiple of 16 frames have a few); without one,
+      // a workgroup per possible pair. Workgroups beyond the list's end leave at once.
+      list_pair_no = item + (a.list_by_fft ? a.n_fft : 0);
     } else {
       tile_a = 2 * item;
       tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;
@@ -136,6 +140,10 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
   } else if constexpr (KIND >= 1) {
     // ---- FFT role, long transforms: one tile of 32 columns ----
     fft_cols256_tile<FMT>(a.cols, item, smem_raw, tid);
+    // ... then this workgroup's share of the tiles k_plan_long listed for the detect stage that rides on the launch. (The other
+    // way round — the pairs first, while the memory system is still idle, then the column tile — was 5 us slower per launch at
+    // 65536 points x 128 frames: the two dozen workgroups that find a pair then finish their column tile last.)
+    if (a.list_by_fft) list_pair_no = item;
   } else {
     // ---- FFT role: one frame ----
     int hdr;
@@ -158,6 +166,20 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       tile_a = pr.x;
       tile_b = pr.y;
       if (tile_a >= 0) __syncthreads();  // the frame's last LDS reads are done
+    }
+  }
+  if constexpr (KIND >= 1) {
+    if (list_pair_no >= 0) {
+      // (a tile number that is none must not become an address; the slot behind an odd count is not an entry)
+      const int n_tiles = (a.det.n / 256) * plan_frame_tiles(a.det.nframes, a.det.shift);
+      const int cnt = min(a.det.tile_list[0], n_tiles);
+      if (2 * list_pair_no < cnt) {
+        tile_a = a.det.tile_list[1 + 2 * list_pair_no];
+        tile_b = 2 * list_pair_no + 1 < cnt ? a.det.tile_list[2 + 2 * list_pair_no] : -1;
+        if ((unsigned)tile_a >= (unsigned)n_tiles) tile_a = tile_b = -1;
+        if ((unsigned)tile_b >= (unsigned)n_tiles) tile_b = -1;
+        if (tile_a >= 0 && role == ROLE_FFT) __syncthreads();  // the column tile's last LDS reads are done
+      }
     }
   }
   if (tile_a >= 0) {

@@ -697,6 +697,9 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
       a.n_plan = n_det_tiles;
       a.plan_cols = plan_cols;
       a.plan_by_fft = a.n_fft >= ss::step_plan_consumers(a) ? 1 : 0;  // (consumer p serves list p mod S)
+    } else if (det->tile_list && fft && fft->cols) {
+      a.list_by_fft = 1;  // long transforms, planned stage: column workgroup p takes pair p of the list after its own tile (scan_step.h)
+      a.n_det = 2 * std::max(0, (n_det_tiles + 1) / 2 - fft->n);  // detect workgroups for the pairs beyond
     } else {
       a.n_det = n_det_tiles;
     }
@@ -1360,6 +1363,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         rx.thr = z->d_thr;
         rx.hist_out = rp.out;
         rx.first_hist = nframes - kHistRows;
+        rx.zero_word = c->d_tlist[c->buf_cur];  // (the list this call's plan appends to; its last reader was the detect stage of the call before last)
         ring_by_rows = true;
       }
     }
@@ -1405,18 +1409,16 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       const int plan_cols = ss::plan_long_cols(nframes, c->pend_det.shift, c->n / 256);
       if (ring_by_rows && !spec && !c->pend_det.rel_out && !c->pend_det.avg_out && plan_cols > 0) {
         int* list = c->d_tlist[(c->buf_cur + c->nbuf - 1) % c->nbuf];  // (run_backend_fused has moved buf_cur on: the set this call's mask bits go to)
-        const int nft = ss::plan_frame_tiles(nframes, c->pend_det.shift), segs = (c->n / 256 + plan_cols - 1) / plan_cols;
         ss::PlanLongArgs pl{};
         pl.smax = c->d_smax;
         pl.smax_mask = c->smax_rows - 1;
         pl.abs0 = rx.abs0;
         pl.clean_rel = (int)std::max<long long>(c->clean_abs - c->abs_frames, -(1ll << 29));
         pl.cols = plan_cols;
+        pl.logn = c->logn;
         pl.list = list;
-        SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(segs), dim3(256), 0, c->pend_det, pl);
+        SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3((c->n >> 16) * ((256 + plan_cols - 1) / plan_cols)), dim3(256), 0, c->pend_det, pl);
         c->pend_det.tile_list = list;
-        c->pend_det.list_cap = plan_cols * nft;
-        c->pend_det_tiles = 2 * segs * ((plan_cols * nft + 1) / 2);  // detect workgroups: a pair of entries each, per list
       }
     }
     if (!overlap) flush_stages(c);
@@ -1871,7 +1873,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     c->smax_rows = rows;
     CREATE_HIP(hipMalloc(&c->d_smax, sizeof(float) * (size_t)rows * (size_t)(n / 32)));
     const size_t max_tiles = ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256);
-    for (int k = 0; k < 2; ++k) CREATE_HIP(hipMalloc(&c->d_tlist[k], sizeof(int) * (2 * max_tiles + (size_t)(n / 256) + 1)));  // (per plan workgroup a count and up to C nft entries, C nft rounded up per list)
+    for (int k = 0; k < 2; ++k) CREATE_HIP(hipMalloc(&c->d_tlist[k], sizeof(int) * (max_tiles + 2)));  // (count, entries, one slot behind an odd count)
   }
   // 64 KiB of dynamic LDS needs no opt-in on gfx950 (160 KiB/CU), but say so explicitly for clarity
   CREATE_HIP(hipStreamSynchronize(c->stream));
