@@ -64,7 +64,10 @@ struct StepArgs {
   int plan_by_fft;
   // KIND 1, 2, tile culling (k_plan_long): the launch's column workgroups take the pairs of the detect stage's list once their
   // tile is done, pair p to column workgroup p; detect workgroups of their own only for the pairs beyond (n_det counts those).
-  // (Evaluated BEFORE the column tile the same pairs cost the launch 5 us more: the workgroups that find one finish last.)
+  // (Evaluated BEFORE the column tile the same pairs cost the launch 5 us more: the workgroups that find one finish last. And
+  // without k_plan_long — every workgroup testing its own pair from the run maxima after its column tile: 360 values, five
+  // barriers — the launch grew by the 7 us the plan launch takes: 65536 x 128: 66.0 against 65.3 us per call, 2^20 x 16: 178
+  // against 174, profiles/r03/s41.)
   int list_by_fft;
   int n_emit;  // frames of the emit role
   int emit_per_wg;  // 8: one wave per frame; 1 (KIND 2): rows of 2048 mask words and more, the eight waves share one frame
