@@ -93,6 +93,18 @@ struct ss_ctx {
     long long* d_stamps = nullptr;
     int stamp_launches = 0;
     unsigned* d_cull_stats = nullptr;  // SS_DIAG only (SS_CULL_STATS=1): tiles seen / on the culling path / culled, printed by ss_destroy
+    // SS_DIAG only, deep pipelining: the input canary. The launch of call L + 1 reads the last frames of call L's input once
+    // more (the halo, run_call_deep); include/specscan.h tells callers to leave every input alone until ss_sync. A checksum of
+    // those frames is taken right behind launch L (the public stream waits for it: whatever the caller enqueues there after the
+    // call comes later) and again right before launch L + 1; ss_sync compares the two and fails loudly when a caller has
+    // refilled the buffer in between — a case the address check of run_call_deep cannot see (the same bytes under another pointer).
+    // Opt-in (SS_CANARY=1): the wait puts the public stream behind every launch, which is not what one wants to time.
+    bool canary = false;
+    unsigned long long* d_canary = nullptr;  // [64][2]
+    hipEvent_t ev_canary = nullptr;
+    std::vector<int> canary_pairs;           // slots whose two sums have both been enqueued
+    unsigned canary_seq = 0;
+    int canary_prev_slot = -1;               // the slot that holds the first sum of the previous call's frames (-1: none taken)
     bool emit_wide = true;         // long rows (n >= 16384): several waves per frame in the emit stage
     bool no_order_table = false;   // SS_DIAG: never use a dispatch-order table
     int hint_mode = 0;             // SS_DIAG timing ablations of the list hand-over (scan_step.h)
@@ -139,6 +151,7 @@ struct ss_ctx {
       deep = tri("SS_DEEP") != 0;
       cull = tri("SS_CULL") != 0;
       ablate_roles = num("SS_ABLATE_ROLES", 0);
+      canary = tri("SS_CANARY") == 1;
       queues = num("SS_QUEUES", queues);
       hint_mode = num("SS_HINT_MODE", 0);
       no_order_table = tri("SS_ORDER_TABLE") == 0;
@@ -1149,6 +1162,31 @@ int spectrogram_accumulate(ss_ctx* c, SpecState* g, const float* d_psd, int nfra
   return SS_OK;
 }
 
+#ifdef SS_DIAG
+// (input canary, Diag::d_canary) position-weighted sum of `nwords` 32-bit words: one workgroup, result in *out
+__global__ __launch_bounds__(1024) void k_iq_checksum(const uint32_t* __restrict__ words, size_t nwords, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long part[16];
+  unsigned long long acc = 0;
+  for (size_t i = threadIdx.x; i < nwords; i += 1024) acc += (unsigned long long)words[i] * (unsigned long long)(2 * (i & 0xffff) + 1);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int k = 0; k < 16; ++k) t += part[k];
+    *out = t;
+  }
+}
+// the last kHistRows frames of a call's input, as the words the checksum runs over
+static void canary_sum(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, hipStream_t q, unsigned long long* out) {
+  const size_t bps = in_bytes_per_sample(c->cfg.in_format);
+  const size_t off = (size_t)(nframes - kHistRows) * (size_t)item_stride * bps;
+  const size_t bytes = ((size_t)(kHistRows - 1) * (size_t)item_stride + (size_t)c->n) * bps;  // (up to the end of the last frame's N samples)
+  hipLaunchKernelGGL(k_iq_checksum, dim3(1), dim3(1024), 0, q, reinterpret_cast<const uint32_t*>(static_cast<const char*>(d_iq) + off), bytes / 4, out);
+}
+#endif
+
 // One call on a context with deep pipelining (ss_ctx::deep): launch L = FFT(L) + detect(L - 2) + emit(L - 4) on queue L & 1, or
 // — learning frames, short calls, callers that wait after every call — the three stages in order on the public stream.
 int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int n_learn, NoiseState* z, SpecState* spec, float* d_psd,
@@ -1242,6 +1280,12 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
       role.halo_iq = static_cast<const char*>(c->deep_prev_iq) +
                      (size_t)(c->deep_prev_frames - role.n_halo) * (size_t)c->deep_prev_stride * in_bytes_per_sample(c->cfg.in_format);
       role.halo_psd = c->d_halo[L % (2 * c->nq)];
+#ifdef SS_DIAG
+      if (c->diag.d_canary && c->diag.canary_prev_slot >= 0) {  // the frames this launch reads once more: are they what the launch before saw?
+        canary_sum(c, c->deep_prev_iq, c->deep_prev_stride, c->deep_prev_frames, q, c->diag.d_canary + 2 * c->diag.canary_prev_slot + 1);
+        c->diag.canary_pairs.push_back(c->diag.canary_prev_slot);
+      }
+#endif
     }
     if (!c->pd.empty() && c->pd.front().ready <= L) {
       d = c->pd.front();
@@ -1255,6 +1299,15 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
     }
   }
   launch_step(c, &role, has_det ? &d.a : nullptr, d.tiles, d.spec, has_emit ? &e.a : nullptr, q);
+#ifdef SS_DIAG
+  c->diag.canary_prev_slot = -1;
+  if (overlap && c->diag.d_canary && nframes >= kHistRows && c->diag.canary_pairs.size() < 60) {
+    c->diag.canary_prev_slot = (int)(c->diag.canary_seq++ & 63);
+    canary_sum(c, d_iq, item_stride, nframes, q, c->diag.d_canary + 2 * c->diag.canary_prev_slot);
+    SS_HIP(c, hipEventRecord(c->diag.ev_canary, q));
+    SS_HIP(c, hipStreamWaitEvent(c->stream, c->diag.ev_canary, 0));
+  }
+#endif
   if (overlap) {
     const bool ring_reader = has_det && !d.a.halo_psd && !c->deep_ring_safe;
     const int rec_phase = (int)(L % kDeepSyncPeriod);
@@ -1532,6 +1585,8 @@ void free_ctx(ss_ctx* c) {
   for (auto p : c->d_segsum) (void)hipFree(p);
   for (auto p : c->d_live) (void)hipFree(p);
   for (auto p : c->d_tlist) (void)hipFree(p);
+  (void)hipFree(c->diag.d_canary);
+  if (c->diag.ev_canary) (void)hipEventDestroy(c->diag.ev_canary);
   (void)hipFree(c->d_smax);
   for (auto p : c->d_halo) (void)hipFree(p);
   (void)hipFree(c->d_relplane);
@@ -1723,6 +1778,13 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       CREATE_HIP(hipMemsetAsync(c->d_live[k], 0, sizeof(int) * live_ints, c->stream));
     }
   if (c->deep) {
+#ifdef SS_DIAG
+    if (c->diag.canary) {
+      CREATE_HIP(hipMalloc(&c->diag.d_canary, sizeof(unsigned long long) * 128));
+      CREATE_HIP(hipMemset(c->diag.d_canary, 0, sizeof(unsigned long long) * 128));
+      CREATE_HIP(hipEventCreateWithFlags(&c->diag.ev_canary, hipEventDisableTiming));
+    }
+#endif
     c->deep_ring_safe = c->hist_rows / kHistRows >= kDeepSyncPhase + 8;
     for (int k = 0; k < c->nq; ++k) CREATE_HIP(hipStreamCreateWithFlags(&c->s_ab[k], hipStreamNonBlocking));
     for (int k = 0; k < 2 * c->nq; ++k) CREATE_HIP(hipMalloc(&c->d_halo[k], sizeof(float) * (size_t)n * (size_t)kHistRows));
@@ -1922,6 +1984,22 @@ int ss_sync(ss_ctx* ctx) {
     std::lock_guard<std::mutex> lock(ctx->mtx);
     return fail(ctx, SS_ERR_HIP, "stream_wait failed: %s", hipGetErrorString(e));
   }
+#ifdef SS_DIAG
+  {
+    std::lock_guard<std::mutex> lock(ctx->mtx);
+    if (ctx->diag.d_canary && !ctx->diag.canary_pairs.empty()) {
+      unsigned long long h[128];
+      SS_HIP(ctx, hipMemcpy(h, ctx->diag.d_canary, sizeof(h), hipMemcpyDeviceToHost));
+      int bad = -1;
+      for (int slot : ctx->diag.canary_pairs)
+        if (h[2 * slot] != h[2 * slot + 1]) bad = slot;
+      ctx->diag.canary_pairs.clear();
+      if (bad >= 0)
+        return fail(ctx, SS_ERR_INVALID, "input canary: the last frames of a call's d_iq changed before the next call's launch had read them again "
+                                         "(every buffer of ss_process_device must stay untouched until ss_sync; SS_FLAG_STREAM_ORDERED lifts that)");
+    }
+  }
+#endif
   return SS_OK;
 }
 

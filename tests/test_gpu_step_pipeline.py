@@ -301,3 +301,36 @@ def test_other_sizes_asynchronous_calls_equal_call_by_call(n, fs, max_batch, fmt
     b.sync()
     total = sum(_same(oa, ob, f"call {k}") for k, (oa, ob) in enumerate(zip(outs_a, outs_b)))
     assert total > 200
+
+
+def test_diag_canary_catches_an_input_buffer_refilled_in_flight(monkeypatch, diag_lib):
+    """The launch of call k + 1 reads the last frames of call k's input once more; include/specscan.h asks callers to leave
+    every buffer alone until ss_sync. The diagnostics build can check that (SS_CANARY=1): a checksum of those frames right
+    behind launch k and again right before launch k + 1, compared by ss_sync. A clean run passes; a producer on the context's
+    stream that refills the previous call's buffer between two calls is reported."""
+    import torch
+    monkeypatch.setenv("SS_CANARY", "1")
+    dev = torch.device("cuda", 0)
+    nb = 64
+    band = pkg.synth.SyntheticBand(N, seed=91, on_frame=40, off_frame=10_000)
+    iq = band.frames_cf32(nb * 5)
+    eng = pkg.SpectrumEngine(FS, CENTER, fft_size=N, decim=1, max_batch=nb, learn_frames=8)
+    bufs = [torch.from_numpy(iq[k * nb:(k + 1) * nb].view(np.float32)).to(dev) for k in range(5)]
+    outs = [dict(off=torch.zeros(nb + 1, dtype=torch.int32, device=dev), idx=torch.empty(nb * 512, dtype=torch.int32, device=dev)) for _ in range(5)]
+
+    def call(k):
+        eng.process_device(bufs[k], nb, cand_off=outs[k]["off"], cand_idx=outs[k]["idx"])
+
+    call(0)  # the learning frames: not overlapped
+    eng.sync()
+    for k in range(1, 5):  # (the first call after a single-call sync still runs in order; from the second on launches overlap)
+        call(k)
+    eng.sync()  # nothing was touched: passes
+    ss_stream = torch.cuda.ExternalStream(eng.stream_handle)
+    for k in range(1, 4):
+        call(k)
+    with torch.cuda.stream(ss_stream):  # a producer on the context's stream, behind call 3: refills ITS buffer while call 4's launch still has to read its tail
+        bufs[3][-1].add_(1.0)
+    call(4)
+    with pytest.raises(pkg.abi.SpecscanError, match="input canary"):
+        eng.sync()
