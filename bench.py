@@ -204,7 +204,7 @@ def parity_sample(n: int, fs: int, fmt: str):
 
 # ---------------------------------------------------------------------------------------------- launcher
 PMC_FILES = {"fetch": "pmc_fetch.csv", "write": "pmc_write.csv"}  # under profiles/<PMC_SET>/, one counter per rocprofv3 pass
-PMC_SET = {2: "r03/s30_cfg2", 3: "r03/s30_cfg3", 5: "r03/s30_cfg5"}  # the committed passes of each configuration's command line
+PMC_SET = {2: "r03/s42_cfg2", 3: "r03/s42_cfg3", 5: "r03/s42_cfg5"}  # the committed passes of each configuration's command line
 
 
 def traffic_from_profiles(config: int, kernel_match: str, threads_per_launch: int | None = None):
@@ -255,7 +255,7 @@ def chain_kernels(n: int, fmt: str):
     if n2 >= 2048:
         ks.append(("sub", "k_fft_sub_dft", f"k_fft_sub_dft: radix-{n2 // 256} step of the {n2}-point rows, in place in the work buffer", 16.0))
     ks.append(("rows", "k_fft_rows", "row half: 256-point FFTs -> dB rows (+ run maxima and the averager ring rows for the tile culling)", 12.0))
-    ks.append(("plan", "k_plan_long", "k_plan_long: which averaging tiles of the call can hold a candidate (one thread per tile)", 0.0))
+    ks.append(("plan", "k_plan_long", "k_plan_long: which averaging tiles of the call can hold a candidate, from the run maxima the rows kernel left (one list per call)", 0.0))
     return ks
 
 
@@ -506,7 +506,10 @@ def run(args):
             us = ms_k / cnt_k * 1e3
             per_call = cnt_k / max(launches, 1)  # launches of this kernel per sampled call
             kb = bps * nb * n / per_call if per_call else 0.0
-            tp = traffic_from_profiles(args.config or 2, match, (nb + 20 + nb // 8 + 4) * 512 if n == 8192 else None) if is_preset(args) else None
+            # launches of the steady-state shape only. 8192 points: 1024 + 20 FFT, 128 emit and 4 plan workgroups of 512 threads; long
+            # transforms: the column tiles + one emit workgroup per frame (the listed tiles ride on the column workgroups)
+            shape = (nb + 20 + nb // 8 + 4) * 512 if n == 8192 else ((nb * (n // 8192) + (nb if n >= 65536 else -(-nb // 8))) * 512 if slot == "step" and n >= 16384 else None)
+            tp = traffic_from_profiles(args.config or 2, match, shape) if is_preset(args) else None
             kernels.append({"slot": slot, "what": what, "us": round(us, 2), "launches_timed": cnt_k, "launches_per_call": round(per_call, 2),
                             "bytes_per_launch_it_must_move": kb, "gbs": round(kb / us / 1e3, 1) if us else None,
                             "frac_of_peak": round(kb / us / 1e3 / HBM_PEAK_GBS, 4) if us else None,
