@@ -242,3 +242,69 @@ def test_long_rows_device_calls_without_sync_culled_equal_unculled():
         res[name] = lists
     _same(res["cull"], res["nocull"])
     assert sum(len(x) for x in res["cull"]) > 5_000
+
+
+# ---- random detect-mode sessions: what test_gpu_fuzz.py does not reach (it asks for every plane, and a stage that hands out rel /
+# avg planes is never culled). Random size, format, call sizes from one frame up, learning inside or across calls, retunes with and
+# without a reset, ignored ranges, zero-frame calls, host and device entry points mixed — culled == unculled, list by list.
+def _cull_scenario(seed):
+    rng = np.random.default_rng(7000 + seed)
+    n = [8192, 65536, 8192, 65536, 1 << 20][seed % 5] if seed % 10 != 9 else 16384  # (16384: a long transform without culling support)
+    fs = {8192: 2_048_000, 16384: 4_096_000, 65536: 20_000_000, 1 << 20: 61_440_000}[n]
+    nframes = {8192: int(rng.integers(300, 700)), 16384: 200, 65536: int(rng.integers(120, 260)), 1 << 20: 72}[n]
+    max_batch = {8192: int(rng.choice([64, 200, 512])), 16384: 64, 65536: int(rng.choice([16, 48, 128])), 1 << 20: 16}[n]
+    fmt = str(rng.choice(["cf32", "cs8"])) if n < (1 << 20) else "cs8"
+    learn = int(rng.integers(5, 50)) if n < (1 << 20) else 6
+    return rng, n, fs, nframes, max_batch, fmt, learn
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SS_FUZZ_CULL_SEEDS", "10"))))
+def test_random_detect_mode_sessions_culled_equal_unculled(seed):
+    import torch
+    rng, n, fs, nframes, max_batch, fmt, learn = _cull_scenario(seed)
+    on_frame, off_frame = learn + int(rng.integers(3, 40)), nframes - int(rng.integers(4, 20))
+    band = pkg.synth.SyntheticBand(n, seed=300 + seed, on_frame=on_frame, off_frame=off_frame, rel_db=float(rng.choice([18.0, 20.0, 25.0])))
+    iq = band.frames_cf32(nframes) if fmt == "cf32" else band.frames_cs8(nframes)
+    in_format = pkg.abi.SS_FMT_CF32 if fmt == "cf32" else pkg.abi.SS_FMT_CS8
+    ign = []
+    if rng.random() < 0.5:
+        lo = CENTER + int(rng.integers(-fs // 3, fs // 4))
+        ign = [lo, lo + fs // 20]
+    # the session's script, drawn once and played to both engines
+    script, pos = [], 0
+    while pos < nframes:
+        size = int(min(nframes - pos, rng.integers(1, max_batch + 1)))
+        ev = rng.random()
+        script.append(("retune_reset" if ev < 0.04 else "retune" if ev < 0.08 else "reset" if ev < 0.11 else "zero" if ev < 0.14 else "", pos, size,
+                       bool(rng.random() < 0.5)))
+        pos += size
+    dev = torch.device("cuda", 0)
+    res = {}
+    for name, flags in (("cull", 0), ("nocull", pkg.abi.SS_FLAG_NO_CULL)):
+        eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, in_format=in_format, learn_frames=learn, max_batch=max_batch, ignored=ign, flags=flags)
+        lists, pending, away = [], [], False
+        for what, a, size, on_device in script:
+            if what in ("retune", "retune_reset"):
+                away = not away
+                off = fs if away else 0
+                eng.set_frequency_range(CENTER + off - fs // 2, CENTER + off + fs // 2)
+            if what in ("reset", "retune_reset"):
+                eng.reset()
+            if what == "zero":
+                eng.process(iq[:0], want=())
+            if on_device:  # asynchronous entry point: stages deferred from call to call, results fetched at the end
+                d = torch.from_numpy(iq[a:a + size].view(np.float32) if fmt == "cf32" else iq[a:a + size]).to(dev)
+                o = dict(off=torch.zeros(size + 1, dtype=torch.int32, device=dev), idx=torch.empty(size * 2048, dtype=torch.int32, device=dev), iq=d)
+                eng.process_device(d, size, cand_off=o["off"], cand_idx=o["idx"])
+                pending.append((len(lists), size, o))
+                lists += [None] * size
+            else:
+                lists += _lists(eng.process(iq[a:a + size], want=()))
+        eng.sync()
+        for at, size, o in pending:
+            off, idx = o["off"].cpu().numpy(), o["idx"].cpu().numpy()
+            lists[at:at + size] = [idx[off[f]:off[f + 1]].copy() for f in range(size)]
+        res[name] = lists
+    _same(res["cull"], res["nocull"])
+    if off_frame - on_frame >= 40 and not any(w for w, *_ in script):  # a transmission well inside an undisturbed session: there is something to find
+        assert sum(len(x) for x in res["cull"]) > 0
