@@ -134,8 +134,10 @@ struct DetectArgs {
   // zero by the call's emit stage.
   int* live;
   // Tile culling, long transforms (N = 256 x N2; k_plan_long below): [0] = how many tiles must be evaluated, [1 ...] = their
-  // numbers, written by a launch of its own between the call's FFT and detect stages; null = every tile. hist_by_fft: the
-  // FFT stage has written the ring rows of this batch itself (fft256_kernels.h, RowsExtra), no tile does.
+  // numbers, written by a launch of its own between the call's FFT and detect stages; null = every tile. hist_by_fft: no tile
+  // writes ring rows — the FFT stage has written those of this batch itself (long transforms: fft256_kernels.h, RowsExtra), or
+  // nobody needs them before the pipeline is drained, which then writes them from the call's PSD plane (8192 points, deep
+  // pipelining: k_ring_fill, specscan.hip).
   const int* tile_list;
   int hist_by_fft;
 #ifdef SS_DIAG
@@ -305,7 +307,7 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
       const int ft = (ft_seq + nft - 1) % nft;
       const int f0 = ft * TF - a.shift;
       const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes);
-      const bool writes_hist = f0 + TF > nframes - H;
+      const bool writes_hist = !a.hist_by_fft && f0 + TF > nframes - H;
       bool culled = false;
       if (exists && plannable && steady && !writes_hist) {
         // the 21 x 21 mean that ends at frame f is at most mean(M_{f-20} .. M_f) - tm, M_g = the column's maximum in frame g
@@ -760,6 +762,23 @@ __global__ void k_hist_shift(const float* __restrict__ hist_in, float* __restric
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     hist_out[e] = hist_in[e + (size_t)nframes * n];
   }
+}
+
+// Deep pipelining (8192 points): the ring rows a call's detect tiles would have written — rel = dB - thr of its newest `rows`
+// frames, the same subtraction on the same values — written when the pipeline is drained instead of by every call: between
+// drains nobody reads them (a call's rows from before its batch come from the previous call's frames, transformed once more),
+// and the tiles that wrote them, three frame tiles of every call, could not be culled: a third of all evaluated tiles.
+struct RingFillArgs {  // up to two calls' rows in one launch (blockIdx.y)
+  const float* psd_tail[2];
+  const float* thr[2];
+  float* hist_out[2];
+};
+__global__ void k_ring_fill(RingFillArgs a, int n, int rows) {
+  const float* __restrict__ src = a.psd_tail[blockIdx.y];
+  const float* __restrict__ thr = a.thr[blockIdx.y];
+  float* __restrict__ dst = a.hist_out[blockIdx.y];
+  const size_t total = (size_t)rows * n;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) dst[e] = src[e] - thr[e % n];
 }
 
 // Candidate lists (CSR) from the mask bits: one wave per frame. The frame's offset is the sum of the

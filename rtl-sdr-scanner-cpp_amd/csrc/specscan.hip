@@ -281,6 +281,17 @@ struct ss_ctx {
   };
   std::deque<PendDet> pd;
   std::deque<PendEmit> pe;
+  // Ring rows owed: overlapped calls do not write the averager ring (DetectArgs::hist_by_fft) — the drain does, for the last two
+  // of them (the newest call's rows are what the next call starts from, the one before's are "the rows before the last batch"
+  // ss_read_window hands out), from their PSD planes, which stay valid until then (the caller's by contract, the library's own
+  // rotate over four).
+  struct RingOwed {
+    const float* psd = nullptr;
+    int nframes = 0;
+    float* hist_out = nullptr;
+    const float* thr = nullptr;
+  };
+  RingOwed ring_owed[2];
   bool deep_prev_ok = false;   // the previous call overlapped: its PSD plane serves as this call's halo
   int deep_prev_frames = 0;
   // The caller's buffers of the last calls, which stages still in flight may read or write. A buffer handed to a later call
@@ -851,6 +862,20 @@ void drain_deep(ss_ctx* c) {
     (void)hipStreamWaitEvent(c->stream, c->ev_fold_done[c->fold_last], 0);
     c->fold_dirty = false;
   }
+  {  // the ring rows the overlapped calls left to the drain (on the public stream, which by now waits for everything the two queues held)
+    ss::RingFillArgs rf{};
+    unsigned owed = 0;
+    for (auto& o : c->ring_owed) {
+      if (o.psd) {
+        rf.psd_tail[owed] = o.psd + (size_t)(o.nframes - kHistRows) * c->n;
+        rf.thr[owed] = o.thr;
+        rf.hist_out[owed] = o.hist_out;
+        ++owed;
+      }
+      o = ss_ctx::RingOwed{};
+    }
+    if (owed) hipLaunchKernelGGL(ss::k_ring_fill, dim3((unsigned)((size_t)kHistRows * c->n / 1024), owed), dim3(256), 0, c->stream, rf, c->n, kHistRows);
+  }
   c->deep_L = 0;
   c->deep_barrier = -10;
   c->deep_prev_ok = false;  // after a drain the caller may reuse its planes: the next call takes its rows from the ring
@@ -1326,6 +1351,17 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   if (role.n_halo) {
     mine_det.a.halo_psd = role.halo_psd;
     mine_det.a.halo_rows = role.n_halo;
+  }
+#ifndef SS_RING_AT_DRAIN  // (A/B builds, scripts/build_ab.py: 0 = the ring rows by the tiles of every call, as until round 3)
+#define SS_RING_AT_DRAIN 1
+#endif
+  if (overlap && SS_RING_AT_DRAIN) {  // this call's ring rows: at the next drain (nframes >= kHistRows here: all of them come from this call's plane)
+    mine_det.a.hist_by_fft = 1;
+    c->ring_owed[0] = c->ring_owed[1];
+    c->ring_owed[1].psd = d_psd;
+    c->ring_owed[1].nframes = nframes;
+    c->ring_owed[1].hist_out = mine_det.a.hist_out;
+    c->ring_owed[1].thr = z->d_thr;
   }
   if (spec) {  // Spectrogram::work (spectrogram.cpp:45-60): this call's frames, bin-decimated, summed per frame tile into a slot of their own
     const int slot_no = c->spec_ring_next;

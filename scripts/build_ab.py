@@ -17,6 +17,7 @@ VARIANTS = {
     "detnt": ["SS_DET_NT=1"],
     "rowsnomax": ["SS_ROWS_ABL=1"],   # rows kernel of the long transforms without the run maxima (garbage culling: timing only)
     "rowsnoring": ["SS_ROWS_ABL=2"],  # ... without the ring rows
+    "ringlegacy": ["SS_RING_AT_DRAIN=0"],  # 8192 points, deep pipelining: ring rows written by three frame tiles of every call
 }
 
 if __name__ == "__main__":
