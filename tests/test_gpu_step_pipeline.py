@@ -309,6 +309,8 @@ def test_diag_canary_catches_an_input_buffer_refilled_in_flight(monkeypatch, dia
     behind launch k and again right before launch k + 1, compared by ss_sync. A clean run passes; a producer on the context's
     stream that refills the previous call's buffer between two calls is reported."""
     import torch
+    if os.environ.get("SS_DEEP") == "0" or os.environ.get("SS_PIPELINE") == "0":
+        pytest.skip("launches in order: no call reads another call's input")
     monkeypatch.setenv("SS_CANARY", "1")
     dev = torch.device("cuda", 0)
     nb = 64
