@@ -204,7 +204,7 @@ def parity_sample(n: int, fs: int, fmt: str):
 
 # ---------------------------------------------------------------------------------------------- launcher
 PMC_FILES = {"fetch": "pmc_fetch.csv", "write": "pmc_write.csv"}  # under profiles/<PMC_SET>/, one counter per rocprofv3 pass
-PMC_SET = {2: "r03/s42_cfg2", 3: "r03/s42_cfg3", 5: "r03/s42_cfg5"}  # the committed passes of each configuration's command line
+PMC_SET = {2: "r03/s47_cfg2", 3: "r03/s47_cfg3", 5: "r03/s47_cfg5"}  # the committed passes of each configuration's command line
 
 
 def traffic_from_profiles(config: int, kernel_match: str, threads_per_launch: int | None = None):
@@ -332,14 +332,14 @@ def also_lines():
     """BASELINE configs 3 and 5 (one GPU each) as short runs of this script in processes of their own, appended to the default
     line: ms_per_step, the chain's rate, and every kernel of the chain with its own duration and rate."""
     res = []
-    for cfg_no, steps in ((3, 200), (5, 100)):
+    for cfg_no, steps, extra in ((3, 200, []), (5, 100, []), (5, 40, ["--frames", "64"])):  # (config 5 also in 64-frame calls: 35 of 64 rows are ring rows instead of all)
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg_no), "--gpus", "1", "--steps", str(steps), "--warmup", "5",
-               "--preheat-ms", "150", "--no-cpu-baseline", "--sub"]
+               "--preheat-ms", "150", "--no-cpu-baseline", "--sub", *extra]
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
             j = json.loads(line)
-            res.append({"baseline_config": cfg_no, "workload": j["config"]["workload"], "metric": j["metric"], "value": j["value"], "unit": j["unit"],
+            res.append({"baseline_config": cfg_no, "frames_per_batch": j["config"]["frames_per_batch"], "workload": j["config"]["workload"], "metric": j["metric"], "value": j["value"], "unit": j["unit"],
                         "steps": j["steps"], "ms_per_step": j["ms_per_step"], "psd_plane_out": j["config"]["psd_plane_out"], "tile_culling": j["config"]["tile_culling"],
                         "candidates_per_batch": j["config"]["candidates_per_batch"],
                         "roofline_chain": j["roofline_chain"], "kernels": j["roofline"]["kernels"]})
