@@ -1,0 +1,56 @@
+"""bench.py's bookkeeping, on the CPU: which command lines count as a configuration's own (the committed PMC passes belong to those),
+the kernels a chain's `roofline.kernels` lists with what each must move, and the fabric bytes per launch read back from the
+committed passes under profiles/ (steady-state launch shapes)."""
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_presets_and_what_counts_as_one():
+    b = _bench()
+    a = b.parse_args([])
+    assert (a.fft, a.frames, a.fmt, a.no_psd_out, a.gpus) == (8192, 1024, "cf32", False, 1) and b.is_preset(a)
+    a = b.parse_args(["--config", "3", "--gpus", "1"])
+    assert (a.fft, a.frames, a.fmt, a.no_psd_out, a.sample_rate) == (65536, 128, "cs8", True, 20_000_000) and b.is_preset(a)
+    a = b.parse_args(["--config", "5", "--gpus", "1"])
+    assert (a.fft, a.frames, a.fmt, a.shard, a.sample_rate) == (1 << 20, 16, "cf32", "frames", 61_440_000) and b.is_preset(a)
+    assert b.parse_args(["--config", "5"]).gpus == 8 and b.parse_args(["--config", "4"]).gpus == 8
+    for extra in (["--no-cull"], ["--no-psd-out"], ["--fmt", "cs8"], ["--frames", "512"], ["--spectrogram"], ["--start-level", "3"]):
+        assert not b.is_preset(b.parse_args(extra)), extra
+    assert not b.is_preset(b.parse_args(["--config", "5", "--gpus", "1", "--frames", "64"]))
+
+
+def test_chain_kernels_and_their_bytes():
+    b = _bench()
+    assert [k[0] for k in b.chain_kernels(8192, "cf32")] == ["step"] and b.chain_kernels(8192, "cf32")[0][3] == 12.0
+    assert b.chain_kernels(8192, "cs8")[0][3] == 6.0
+    k3 = {k[0]: k[3] for k in b.chain_kernels(65536, "cs8")}
+    assert k3 == {"step": 10.0, "rows": 12.0, "plan": 0.0}  # columns: int8 in + work buffer out; rows: work in + dB out
+    k5 = {k[0]: k[3] for k in b.chain_kernels(1 << 20, "cf32")}
+    assert k5 == {"step": 16.0, "sub": 16.0, "rows": 12.0, "plan": 0.0}
+    assert b.algo_bytes_per_sample("cf32", True) == 12.0 and b.algo_bytes_per_sample("cs8", False) == 2.0
+
+
+def test_traffic_from_the_committed_pmc_passes():
+    b = _bench()
+    step = b.traffic_from_profiles(2, "k_scan_step", (1024 + 20 + 128 + 4) * 512)
+    assert step and 100.66e6 < step["bytes_per_launch"] < 1.35 * 100.66e6, step  # the review's mark: <= 1.35 x the algorithmic 100.66 MB
+    assert b.traffic_from_profiles(2, "k_scan_step", 12345) is None  # no launch of that shape
+    c3 = sum(b.traffic_from_profiles(3, m, s)["bytes_per_launch"] for m, s in (("k_scan_step", (128 * 8 + 128) * 512), ("k_fft_rows", None), ("k_plan_long", None)))
+    c5 = sum(b.traffic_from_profiles(5, m, s)["bytes_per_launch"]
+             for m, s in (("k_scan_step", (16 * 128 + 16) * 512), ("k_fft_sub_dft", None), ("k_fft_rows", None), ("k_plan_long", None)))
+    assert 20.0 < c3 / (128 * 65536) < 31.0 and 40.0 < c5 / (16 * (1 << 20)) < 64.0, (c3, c5)  # below round 2's 31 and 64 B per sample
+    assert b.traffic_from_profiles(4, "k_scan_step") is None
