@@ -309,6 +309,7 @@ def parse_args(argv):
     ap.add_argument("--start-level", type=float, default=8.0, help="Device::m_startLevel in dB over the learned ceiling (reference default 8)")
     ap.add_argument("--no-cull", action="store_true", help="SS_FLAG_NO_CULL: evaluate every averaging tile, also those whose segment maxima rule out a candidate (the data-independent cost of the chain)")
     ap.add_argument("--launch-check", action="store_true", help="exercise launcher, rendezvous, config broadcast and max-over-ranks timing only (no GPU work)")
+    ap.add_argument("--sync-engine-first", action="store_true", help="end of the timed region as in round 2: ss_sync, then torch.cuda.synchronize() (A/B; the default lets the device-wide synchronisation do the waiting)")
     ap.add_argument("--no-also", action="store_true", help="default line only: do not append the short runs of BASELINE configs 3 and 5 (`also`)")
     ap.add_argument("--sub", action="store_true", help="(internal) this process is one of the `also` runs of another bench.py")
     args = ap.parse_args(argv)
@@ -478,12 +479,14 @@ def run(args):
         step()
     eng.flush()  # the deferred detect / emit stages of the last two steps belong to the timed work
     t_enq = time.perf_counter()
-    eng.sync()
+    if args.sync_engine_first:  # (round 2's order: the library's own wait first, then the contract's device-wide one on an idle device — two wake-ups)
+        eng.sync()
     t_eng = time.perf_counter()
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()  # the contract's synchronisation IS the wait: hipDeviceSynchronize covers every stream of the device, the library's queues included
     t_dev = time.perf_counter()
     dist.barrier()
     t1 = time.perf_counter()
+    eng.sync()  # (settles the library's own bookkeeping; nothing left to wait for)
     kern_ms, launches, slots = 0.0, 0, {}
     if every:
         slots = eng.kernel_timing_read_slots()
@@ -542,7 +545,7 @@ def run(args):
                        "dist_backend": backend if world > 1 else None, "ranks_share_devices": bool(world > ndev),
                        "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4),
                        # where the end of the timed region goes: the chain's own drain + wait, then the contract's device-wide synchronisation and barrier
-                       "tail_us": {"engine_sync": round((t_eng - t_enq) * 1e6, 1), "device_synchronize": round((t_dev - t_eng) * 1e6, 1), "barrier": round((t1 - t_dev) * 1e6, 1)}},
+                       "tail_us": {"engine_sync": round((t_eng - t_enq) * 1e6, 1) if args.sync_engine_first else None, "device_synchronize": round((t_dev - t_eng) * 1e6, 1), "barrier": round((t1 - t_dev) * 1e6, 1)}},
             "roofline": {"bound": "hbm", "kernel": dom["what"] if dom else None,
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
