@@ -96,7 +96,10 @@ __device__ __forceinline__ void fft_cols256_tile(const ColsArgs& g, int block, u
   for (int r = 0; r < 16; ++r) {
     const size_t un = (size_t)(16 * r) << logn2;
     const float2 x = load_iq<FMT>(in_frame + un * kInBytes + tn * kInBytes, 0, g.scale);
-    const float w = *reinterpret_cast<const float*>(win_b + un * 4 + tn * 4u);
+#ifndef SS_COLS_ABL  // (A/B builds, scripts/build_ab.py — garbage results, the column tiles' time without: 1 = the step-A twiddle table loads, 2 = the window loads, 3 = both)
+#define SS_COLS_ABL 0
+#endif
+    const float w = (SS_COLS_ABL & 2) ? 1.0f : *reinterpret_cast<const float*>(win_b + un * 4 + tn * 4u);
     a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
   }
   float2 c[16];
@@ -108,13 +111,36 @@ __device__ __forceinline__ void fft_cols256_tile(const ColsArgs& g, int block, u
   const char* t1 = reinterpret_cast<const char*>(g.twc);
   const char* t2 = reinterpret_cast<const char*>(g.twc + ((size_t)16 << logn2));
   const float2 tj = *reinterpret_cast<const float2*>(t1 + 8u * (((uint32_t)j << logn2) + (uint32_t)n2));
+#ifndef SS_COLS_TW6  // (A/B builds: 0 = one table entry per k, fifteen loads per thread, as until the end of round 3)
+#define SS_COLS_TW6 1
+#endif
+#if SS_COLS_TW6
+  // W_N^(16 n2 k) = w^k, w = W_N^(16 n2), from SIX entries of the [k][n2] table — w, w^2, w^3 and w^4, w^8, w^12 — as
+  // w^(4 a + b) = w^(4 a) w^b (one more rounding than the table's own entry: inside the fp32 FFT's floor, §5 of DESIGN.md). The
+  // fifteen loads per thread stood, like every table read of a streaming workgroup, behind the tile's and its neighbours' frame
+  // loads: without them the column launch ran 5 us (65536 x 128) and 14 us (2^20 x 16) shorter (profiles/r03/s50_summary.txt).
+  const auto tw_at = [&](int k) { return *reinterpret_cast<const float2*>(t2 + 8u * (((uint32_t)k << logn2) + (uint32_t)n2)); };
+  const float2 wb1 = tw_at(1), wb2 = tw_at(2), wb3 = tw_at(3), wa1 = tw_at(4), wa2 = tw_at(8), wa3 = tw_at(12);
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const uint32_t k1 = (uint32_t)(j + 16 * k);
     float2 y = cmul(c[slot16(k)], tj);
-    if (k > 0) y = cmul(y, *reinterpret_cast<const float2*>(t2 + 8u * (((uint32_t)k << logn2) + (uint32_t)n2)));
+    if (k > 0) {
+      const int a = k >> 2, b = k & 3;
+      const float2 wa = a == 1 ? wa1 : a == 2 ? wa2 : wa3, wb = b == 1 ? wb1 : b == 2 ? wb2 : wb3;
+      y = cmul(y, a == 0 ? wb : b == 0 ? wa : cmul(wa, wb));
+    }
     *reinterpret_cast<float2*>(wf + 8u * ((k1 << logn2) + (uint32_t)n2)) = y;
   }
+#else
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t k1 = (uint32_t)(j + 16 * k);
+    float2 y = cmul(c[slot16(k)], tj);
+    if (k > 0 && !(SS_COLS_ABL & 1)) y = cmul(y, *reinterpret_cast<const float2*>(t2 + 8u * (((uint32_t)k << logn2) + (uint32_t)n2)));
+    *reinterpret_cast<float2*>(wf + 8u * ((k1 << logn2) + (uint32_t)n2)) = y;
+  }
+#endif
 }
 
 // Stand-alone launch (learning batches are launched this way too; otherwise the tiles run as a role of k_scan_step).

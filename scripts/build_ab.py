@@ -17,7 +17,11 @@ VARIANTS = {
     "detnt": ["SS_DET_NT=1"],
     "rowsnomax": ["SS_ROWS_ABL=1"],   # rows kernel of the long transforms without the run maxima (garbage culling: timing only)
     "rowsnoring": ["SS_ROWS_ABL=2"],  # ... without the ring rows
-    "ringlegacy": ["SS_RING_AT_DRAIN=0"],  # 8192 points, deep pipelining: ring rows written by three frame tiles of every call
+    "ringlegacy": ["SS_RING_AT_DRAIN=0"],
+    "colstw15": ["SS_COLS_TW6=0"],   # column tiles: one step-A twiddle table entry per k (fifteen loads per thread) instead of six
+    "colsnotw": ["SS_COLS_TW6=0", "SS_COLS_ABL=1"],   # column tiles of the long transforms without the step-A twiddle table loads (garbage results: timing only)
+    "colsnowin": ["SS_COLS_ABL=2"],  # ... without the window loads
+    "colsnone": ["SS_COLS_TW6=0", "SS_COLS_ABL=3"],   # ... without either  # 8192 points, deep pipelining: ring rows written by three frame tiles of every call
 }
 
 if __name__ == "__main__":
