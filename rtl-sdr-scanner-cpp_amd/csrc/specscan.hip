@@ -109,6 +109,7 @@ struct ss_ctx {
     bool no_order_table = false;   // SS_DIAG: never use a dispatch-order table
     int hint_mode = 0;             // SS_DIAG timing ablations of the list hand-over (scan_step.h)
     int queues = 2;                // 8192 points, deep pipelining: launch queues (2 .. 4)
+    bool cull_65536 = false;       // SS_DIAG (SS_CULL_65536=1): tile culling also at 65536 points (see ss_create)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
     bool cull = true;              // 8192 points: detect tiles that cannot hold a candidate are not evaluated (detect_fused.h)
     bool deep = true;              // 8192 points: consecutive step launches independent of each other, alternating over two queues (see ss_ctx::deep)
@@ -151,6 +152,7 @@ struct ss_ctx {
       deep = tri("SS_DEEP") != 0;
       cull = tri("SS_CULL") != 0;
       ablate_roles = num("SS_ABLATE_ROLES", 0);
+      cull_65536 = tri("SS_CULL_65536") == 1;
       canary = tri("SS_CANARY") == 1;
       queues = num("SS_QUEUES", queues);
       hint_mode = num("SS_HINT_MODE", 0);
@@ -1963,8 +1965,13 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipMemcpy(c->d_win, win.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
     CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
   }
-  // Tile culling for long transforms: the sizes whose rows go through k_fft_rows256_psd (N2 = 256, or the radix-A step in front)
-  c->cull_long = c->step_path && c->use_fft256 && n >= 65536 && (n == 65536 || (c->d_tw_sub && !c->d_tw_rowsR)) && !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
+  // Tile culling for long transforms: the sizes whose rows go through k_fft_rows256_psd (N2 = 256, or the radix-A step in front).
+  // On by default where it pays — 2^20 points: 163 against 197 us per 16-frame call. At 65536 points it takes 5 B/sample off the
+  // fabric but loses time since the column tiles got faster (the plan launch and the ring rows cost more than the evaluation
+  // they save: 57.1 against 53.4 us per 128-frame call, 37 against 26 for 16 frames, profiles/r03/s53_summary.txt): there only the
+  // diagnostics build switches it on (SS_CULL_65536=1; tests/test_gpu_cull.py keeps it honest).
+  c->cull_long = c->step_path && c->use_fft256 && ((n == 65536 && c->diag.cull_65536) || (n > 65536 && c->d_tw_sub && !c->d_tw_rowsR)) &&
+                 !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
   if (c->cull_long) {
     int rows = 64;
     while (rows < cfg->max_batch + kHistRows + 1) rows <<= 1;

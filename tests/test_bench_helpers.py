@@ -49,7 +49,10 @@ def test_traffic_from_the_committed_pmc_passes():
     step = b.traffic_from_profiles(2, "k_scan_step", (1024 + 20 + 128 + 4) * 512)
     assert step and 100.66e6 < step["bytes_per_launch"] < 1.35 * 100.66e6, step  # the review's mark: <= 1.35 x the algorithmic 100.66 MB
     assert b.traffic_from_profiles(2, "k_scan_step", 12345) is None  # no launch of that shape
+    b.PMC_SET[3] = "r03/s47_cfg3"  # (the culled form of config 3: committed, quoted in DESIGN.md 4.4, not the default any more)
     c3 = sum(b.traffic_from_profiles(3, m, s)["bytes_per_launch"] for m, s in (("k_scan_step", (128 * 8 + 128) * 512), ("k_fft_rows", None), ("k_plan_long", None)))
+    del b.PMC_SET[3]
+    assert b.traffic_from_profiles(3, "k_scan_step") is None
     c5 = sum(b.traffic_from_profiles(5, m, s)["bytes_per_launch"]
              for m, s in (("k_scan_step", (16 * 128 + 16) * 512), ("k_fft_sub_dft", None), ("k_fft_rows", None), ("k_plan_long", None)))
     assert 20.0 < c3 / (128 * 65536) < 31.0 and 40.0 < c5 / (16 * (1 << 20)) < 64.0, (c3, c5)  # below round 2's 31 and 64 B per sample

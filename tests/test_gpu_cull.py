@@ -146,6 +146,11 @@ def test_short_calls_between_long_ones():
 # ---- long transforms (N = 256 x N2: csrc/detect_fused.h, k_plan_long): the rows kernel leaves the maximum of every 32-bin run
 # per frame and writes the averager ring itself; tiles whose 36 rows cannot reach start_level are not evaluated — rows from
 # BEFORE the batch included, so short calls cull too. Same bar: culled == unculled, list by list, key by key.
+# The product library culls at 2^20 points only (at 65536 points the plan launch costs more than it saves); the
+# 65536-point cases below run on the diagnostics build with SS_CULL_65536=1, so the path stays tested.
+@pytest.fixture
+def cull_65536(monkeypatch, diag_lib):
+    monkeypatch.setenv("SS_CULL_65536", "1")
 def _long_engine(n, fs, flags=0, **kw):
     return pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, flags=flags, **kw)
 
@@ -168,7 +173,7 @@ def _long_session(n, fs, iq, cuts, flags, in_format, retune_at=(), reset_at=(), 
     return lists, np.concatenate(avgs)
 
 
-def test_long_rows_65536_culled_equal_unculled_and_the_reference(ref_mod):
+def test_long_rows_65536_culled_equal_unculled_and_the_reference(ref_mod, cull_65536):
     n, fs, nframes = 65536, 20_000_000, 300
     band = pkg.synth.SyntheticBand(n, seed=41, on_frame=70, off_frame=230)
     iq8 = band.frames_cs8(nframes)
@@ -190,7 +195,7 @@ def test_long_rows_65536_culled_equal_unculled_and_the_reference(ref_mod):
     assert len(got ^ want) <= dont_care_limit(len(want))
 
 
-def test_long_rows_retune_reset_and_degenerate_frames():
+def test_long_rows_retune_reset_and_degenerate_frames(cull_65536):
     n, fs, nframes = 65536, 20_000_000, 260
     band = pkg.synth.SyntheticBand(n, seed=43, on_frame=50, off_frame=240, rel_db=19.0, centres=(0.05, -0.11, 0.23, -0.31, 0.37, -0.45, 0.49))
     iq = band.frames_cf32(nframes)
@@ -219,7 +224,7 @@ def test_long_rows_one_million_points_short_calls():
     assert sum(len(x) for x in res["cull"][0]) > 1_000
 
 
-def test_long_rows_device_calls_without_sync_culled_equal_unculled():
+def test_long_rows_device_calls_without_sync_culled_equal_unculled(cull_65536):
     import torch
     n, fs, nb, ncalls = 65536, 20_000_000, 64, 6
     band = pkg.synth.SyntheticBand(n, seed=49, on_frame=70, off_frame=300)
@@ -259,7 +264,7 @@ def _cull_scenario(seed):
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SS_FUZZ_CULL_SEEDS", "10"))))
-def test_random_detect_mode_sessions_culled_equal_unculled(seed):
+def test_random_detect_mode_sessions_culled_equal_unculled(seed, cull_65536):
     import torch
     rng, n, fs, nframes, max_batch, fmt, learn = _cull_scenario(seed)
     on_frame, off_frame = learn + int(rng.integers(3, 40)), nframes - int(rng.integers(4, 20))
