@@ -19,7 +19,12 @@ Prints ONE JSON line on rank 0:
                         overlap on two queues, so a launch lasts ~2x the time the GPU spends per launch: kernel_us is the
                         measured mean duration (what rocprofv3 --stats reports), launches_in_flight = kernel_us / wall time
                         per launch, achieved = bytes / (kernel_us / launches_in_flight)
+  roofline.kernels      every launch of the chain with its own event-timed duration, what it must move per sample given the
+                        decomposition, and the fabric bytes of the committed PMC passes (one entry at 8192 points; column half,
+                        radix-A step, row half and plan launch for the long transforms)
   roofline_chain        the same algorithmic bytes / the whole step's time (every kernel of the chain, launch gaps included)
+  also                  (default line, one GPU) BASELINE configs 3 and 5 as short runs in processes of their own: 65536 x 128 CS8,
+                        2^20 x 16 and 2^20 x 64, each with ms_per_step, its chain figure and its kernels
   cpu_baseline          the reference's own compiled sources (oracle/_ref; the C restatement where that is absent) on the
                         host cores over a bounded sample of the same workload, one thread and all threads
 """
