@@ -1,0 +1,7 @@
+// The headline kernel alone, compiled for the device only by tests/test_kernel_resources.py: its register budget is part of the
+// design (512 threads x 64 VGPRs = four workgroups per CU whatever their roles) and easy to lose — a loop around
+// the tile evaluation, even one never taken, cost eleven more spilled registers and 12 % of the step (round 3).
+#include "../../rtl-sdr-scanner-cpp_amd/csrc/scan_step.h"
+
+template __global__ void ss::k_scan_step<ss::FMT_CF32, false, 2, true, false, 0>(ss::StepArgs);  // 8192 points, CF32, no spectrogram branch: what bench.py times
+template __global__ void ss::k_scan_step<ss::FMT_CS8, false, 2, true, false, 2>(ss::StepArgs);   // long transforms, int8: config 3's column launch
