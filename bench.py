@@ -547,7 +547,7 @@ def run(args):
                        "baseline_config": args.config or 2, "fft_size": n, "frames_per_batch": nb, "bands": int(cfg["n_bands"]), "shard": args.shard if world > 1 else None,
                        "halo_frames": halo_frames, "candidates_per_batch": ncand,
                        "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "sync_every_step": bool(args.sync_every_step), "diag_lib": bool(args.diag_lib or args.lib),
-                       "tile_culling": not args.no_cull,
+                       "tile_culling": (not args.no_cull) and (n == 8192 or n >= (1 << 20)),  # (what the product library does: 8192 points and 2^20)
                        "preheat_steps": preheat_steps, "input_sets": nsets, "output_sets": nout, "working_set_mib": round((nsets * in_bytes + nout * out_bytes) / 2**20, 1),
                        "dist_backend": backend if world > 1 else None, "ranks_share_devices": bool(world > ndev),
                        "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4),
