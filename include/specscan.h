@@ -68,9 +68,9 @@ typedef enum ss_plane {
 /* Also run the Spectrogram side branch (sources/radio/blocks/spectrogram.cpp): accumulate the bin-decimated raw
  * PSD per centre frequency; read it back with ss_spectrogram_read. */
 #define SS_FLAG_SPECTROGRAM 2u
-/* 8192-point frames: evaluate every averaging tile, also those whose per-segment maxima show that no bin of the tile can
- * reach start_level (csrc/detect_fused.h, tile culling). Results are identical either way; the flag exists so that the
- * data-independent cost of the chain can be measured (bench.py reports both). */
+/* 8192-point and 2^20-point frames: evaluate every averaging tile, also those whose per-frame maxima show that no window
+ * mean of the tile can reach start_level (csrc/detect_fused.h, tile culling). Results are identical either way; the flag
+ * exists so that the data-independent cost of the chain can be measured (bench.py reports both). */
 #define SS_FLAG_NO_CULL 4u
 /* ss_process_device keeps to the context's stream: every stage of a call is enqueued on ss_stream, in order, and work the
  * caller enqueues there afterwards (a producer refilling d_iq, a consumer of the planes) is ordered behind it — the
