@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 2 /* 2: ss_flush, SS_FLAG_NO_CULL / SS_FLAG_STREAM_ORDERED, buffer lifetime of ss_process_device (round 2: ss_pipe_* removed) */
+#define SS_ABI_VERSION 3 /* 3: ss_get_stats, ss_input_wait, SS_FLAG_REFERENCE_NAN; 2: ss_flush, SS_FLAG_NO_CULL / SS_FLAG_STREAM_ORDERED, buffer lifetime of ss_process_device */
 
 typedef enum ss_status {
   SS_OK = 0,
@@ -72,11 +72,22 @@ typedef enum ss_plane {
  * mean of the tile can reach start_level (csrc/detect_fused.h, tile culling). Results are identical either way; the flag
  * exists so that the data-independent cost of the chain can be measured (bench.py reports both). */
 #define SS_FLAG_NO_CULL 4u
-/* ss_process_device keeps to the context's stream: every stage of a call is enqueued on ss_stream, in order, and work the
- * caller enqueues there afterwards (a producer refilling d_iq, a consumer of the planes) is ordered behind it — the
- * classic stream contract, at about half the throughput of the default, in which consecutive calls overlap on queues of
- * the library's own and every buffer of a call must stay untouched until ss_sync (see ss_process_device). */
+/* ss_process_device keeps to the context's stream: every stage of a call — FFT + dB, averaging / threshold, candidate lists — is
+ * enqueued on ss_stream, in order, before the call returns, and work the caller enqueues there afterwards (a producer refilling
+ * d_iq, a consumer of the planes or the lists) is ordered behind it: the classic stream contract, no ss_flush needed, at about
+ * half the throughput of the default, in which consecutive calls overlap on queues of the library's own and every buffer of a
+ * call must stay untouched until ss_sync (see ss_process_device). tests/test_gpu_stream_ordered.py. */
 #define SS_FLAG_STREAM_ORDERED 8u
+/* Reproduce what the reference does after a degenerate frame instead of recovering from it. A dB value that is not finite
+ * (-inf: a bin of exact zeros, psd.cpp:19; NaN: a NaN sample) poisons the reference's running sums for good: the Averager's per-bin
+ * sum turns NaN when the row leaves its 21-frame window (inf - inf, averager.cpp:40-50) — at once for a NaN — and average()'s one
+ * running sum per row carries the first such bin along the rest of the row (utils.cpp:39-48), so from then on every bin from ten
+ * below the first poisoned one upwards is NaN and detects nothing until Transmission::resetBuffers (transmission.cpp:42-55, here
+ * ss_reset). With this flag the library does the same: identical candidate lists and the same NaN / -inf pattern in the avg plane
+ * to the end of the stream (tests/test_gpu_degenerate_input.py). Without it (the default) the library is blind exactly while the
+ * degenerate row is inside the window and detects again at most 15 frames later. Needs the 21 x 21 grouping; calls run their
+ * stages in order on ss_stream (as with SS_FLAG_STREAM_ORDERED). */
+#define SS_FLAG_REFERENCE_NAN 16u
 
 #define SS_NO_DATA (-100.0f) /* setNoData sentinel, sources/utils/radio_utils.cpp:72-76 */
 
@@ -151,10 +162,12 @@ int ss_process(ss_ctx* ctx, const void* iq, int32_t nframes, const int64_t* t_ms
  * (csrc/scan_step.h); for 8192-point frames up to five calls are in flight, on two hardware queues of the library's own
  * (ss_ctx::deep in csrc/specscan.hip). The results of a call are therefore complete only after ss_sync, or after ss_flush
  * followed by any synchronisation of ss_stream; every buffer passed to a call (d_iq included) must stay valid and
- * untouched until then — d_iq in particular: the next call's launch reads the call's last frames once more. (A caller seen
- * handing in frames where those of a call in flight lie is taken off the overlapped path for good: its calls then run
- * their stages in order on ss_stream; SS_FLAG_STREAM_ORDERED asks for that from the start.) Work the caller has enqueued
- * on ss_stream before a call (a producer of d_iq) is waited for.
+ * untouched until then — d_iq in particular: the next call's launch reads the call's last frames once more. A streaming
+ * producer that cannot afford ss_sync learns when an input buffer is dead from ss_input_wait (below). (As a courtesy, a caller
+ * seen handing in frames where those of one of the last five calls lie is taken off the overlapped path until ss_reset: its
+ * calls then run their stages in order on ss_stream, ss_get_stats says so; SS_FLAG_STREAM_ORDERED asks for that from the
+ * start. The check sees addresses, not contents, and only the latest calls: it is no substitute for ss_input_wait.) Work the
+ * caller has enqueued on ss_stream before a call (a producer of d_iq) is waited for.
  * Handing a plane or candidate buffer to a later call again without ss_sync in between is safe — the library orders the
  * stages that touch it, draining its pipeline first where it has to — and costs nothing when the output sets rotate with
  * an even period of at least six calls (four for the PSD / rel planes alone); of course only the newest contents can be
@@ -166,8 +179,39 @@ int ss_process_device(ss_ctx* ctx, const void* d_iq, int32_t nframes,
                       float* d_psd_db, float* d_rel_db, float* d_avg_db,
                       int32_t* d_cand_off, int32_t* d_cand_idx, float* d_cand_avg, int32_t cand_cap);
 int ss_flush(ss_ctx* ctx); /* enqueue the deferred stages of earlier ss_process_device calls (asynchronous) */
+/* Input lifetime without ss_sync, for a streaming producer that rotates m >= 2 input buffers: makes `stream` (a hipStream_t; NULL =
+ * ss_stream) wait until the input frames of every ss_process_device call up to and including the one `calls_back` calls before the
+ * latest are dead — read for the last time. calls_back >= 1: the LATEST call's last frames are read once more by the launch of the
+ * call that follows it, so they cannot be released before that call exists. A producer refilling buffer k mod m for call k calls
+ * ss_input_wait(ctx, its_stream, m - 1) first, then enqueues the refill on its_stream, then (its_stream == ss_stream, or after
+ * making ss_stream wait for the refill) calls ss_process_device. From the first use on the library records one event per launch
+ * (about 1 us per call). On contexts whose calls run in order on ss_stream (SS_FLAG_STREAM_ORDERED, transforms other than 8192
+ * points) the wait is on ss_stream's latest work. */
+int ss_input_wait(ss_ctx* ctx, void* stream, int32_t calls_back);
 int ss_sync(ss_ctx* ctx);  /* ss_flush + wait for the context's stream */
 void* ss_stream(ss_ctx* ctx); /* the hipStream_t ss_process_device enqueues on */
+
+/* What the library did, for callers and benchmarks that want to say so: every counter runs from ss_create. The device-side counters
+ * (tiles_*, wait_fallbacks) cover the stages that have finished on the device; call ss_sync first for exact figures. `size` must
+ * hold sizeof(ss_stats) as the caller knows it (fields are only ever appended). */
+typedef struct ss_stats {
+  uint32_t size;
+  uint32_t state;             /* SS_STATE_* bits, as of now */
+  uint64_t calls;             /* batches processed (ss_process, ss_process_device, ss_feed_submit) */
+  uint64_t calls_overlapped;  /* ... whose launch went to the library's own queues, overlapping its neighbours (8192 points) */
+  uint64_t calls_in_order;    /* ... whose stages ran in order on ss_stream */
+  uint64_t drains;            /* times the deferred stages were drained (ss_sync, ss_flush, reads, retunes, resets, buffer clashes) */
+  uint64_t demotions;         /* times a caller refilling an input buffer in flight took the context off the overlapped path */
+  uint64_t tiles_total;       /* 16-frame x 256-bin averaging tiles of the batches processed (21 x 21 grouping) */
+  uint64_t tiles_tested;      /* ... that went through the culling test (tile culling: 8192 and 2^20 points, not with SS_FLAG_NO_CULL) */
+  uint64_t tiles_culled;      /* ... that the test proved empty and nobody evaluated (tiles evaluated = tiles_total - tiles_culled) */
+  uint64_t wait_fallbacks;    /* workgroups that stopped waiting for a launch's tile plan and made it themselves (csrc/detect_fused.h) */
+} ss_stats;
+#define SS_STATE_CULLING 1u        /* tile culling is on for this context */
+#define SS_STATE_OVERLAP 2u        /* consecutive ss_process_device calls may overlap on the library's queues */
+#define SS_STATE_DEMOTED 4u        /* ... but this caller was seen refilling an input buffer in flight: in order until ss_reset */
+#define SS_STATE_EAGER 8u          /* ... but this caller waits after every call: in order until it stops doing so */
+int ss_get_stats(ss_ctx* ctx, ss_stats* out);
 
 /* Measurement aid (bench.py): when enabled (enable = 1: every launch, enable = k > 1: every k-th launch from the k/2-th on, to keep
  * the ~4 us the two event packets cost out of most steps), a launch of the dominant kernel (fused load + window +

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-SS_ABI_VERSION = 2
+SS_ABI_VERSION = 3
 SS_OK, SS_ERR_INVALID, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_BATCH, SS_ERR_CAND_OVERFLOW, SS_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 SS_FMT_CF32, SS_FMT_CS8, SS_FMT_CU8 = 0, 1, 2
 SS_PLANE_PSD, SS_PLANE_REL, SS_PLANE_AVG = 0, 1, 2
@@ -15,6 +15,8 @@ SS_FLAG_KEEP_PLANES = 1
 SS_FLAG_SPECTROGRAM = 2
 SS_FLAG_NO_CULL = 4
 SS_FLAG_STREAM_ORDERED = 8
+SS_FLAG_REFERENCE_NAN = 16
+SS_STATE_CULLING, SS_STATE_OVERLAP, SS_STATE_DEMOTED, SS_STATE_EAGER = 1, 2, 4, 8
 SS_NO_DATA = np.float32(-100.0)
 
 c_float_p = C.POINTER(C.c_float)
@@ -32,6 +34,12 @@ class SsConfig(C.Structure):
         ("learn_frames", C.c_int32), ("learn_ms", C.c_int32), ("max_batch", C.c_int32), ("device_id", C.c_int32),
         ("flags", C.c_uint32),
     ]
+
+
+class SsStats(C.Structure):
+    """struct ss_stats (include/specscan.h)."""
+    _fields_ = [("size", C.c_uint32), ("state", C.c_uint32)] + [(k, C.c_uint64) for k in (
+        "calls", "calls_overlapped", "calls_in_order", "drains", "demotions", "tiles_total", "tiles_tested", "tiles_culled", "wait_fallbacks")]
 
 
 class SsFeedResult(C.Structure):  # ss_feed_result, include/specscan.h

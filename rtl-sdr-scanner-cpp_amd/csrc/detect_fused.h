@@ -69,8 +69,14 @@ __device__ __forceinline__ float load_row_value(const char* p) {
 // read is ONE header word, count | ready. The hand-over inside the launch follows MI355X_MICROARCH.md: write-through (sc1) stores
 // for the entries, drained (vmcnt 0 — not a release fence: that would write back an L2 full of dB rows being produced),
 // then the header word, sc1; consumers read header and entries with sc1 loads. Plan workgroups never wait for anybody
-// and are dispatched before every consumer: no deadlock.
+// and are dispatched before every consumer in practice — but HIP promises nothing about dispatch order, so no consumer
+// relies on it: a consumer polls its list's header a bounded number of times (StepArgs::wait_limit) and then makes the plan
+// of its list ITSELF (plan_tiles again, with the same inputs: the same list, the same count, written to the same words — two
+// writers of identical values are harmless) and goes on from there; ss_get_stats counts those workgroups. Nothing in a launch
+// waits without bound (scan_step.h; tests/test_gpu_wait_bound.py runs the chain with plan workgroups that never publish,
+// and under HSA_CU_MASK with a handful of CUs).
 constexpr float kCullMargin = 0.0625f;
+enum { kStatTested = 0, kStatCulled = 1, kStatWaitFallbacks = 2, kStatWords = 4 };
 
 // s / D for a compile-time integer D, correctly rounded like the reference's `sum / count`
 // (float / int -> IEEE division): q0 = s * RN(1/D), one Newton correction with exact residuals (FMA).
@@ -140,6 +146,9 @@ struct DetectArgs {
   // pipelining: k_ring_fill, specscan.hip).
   const int* tile_list;
   int hist_by_fft;
+  // What the library did (ss_get_stats): [0] tiles that went through a culling test, [1] tiles the test proved empty,
+  // [2] workgroups that stopped waiting for a launch's plan and made it themselves (kStat*). Null: not counted.
+  unsigned long long* stats;
 #ifdef SS_DIAG
   long long* stamp_mid;  // measurement builds: wall clock after phase 1 (loads + time means) and after phase 2, per tile
   unsigned* cull_stats;  // measurement builds: {tiles, tiles on the culling path, tiles culled}
@@ -276,8 +285,10 @@ __host__ __device__ inline int plan_cols_per_wg(int nframes, int shift) {
 // mask words are zero already — the emit stage of the buffer's previous user cleared every word it found set
 // (EmitArgs::clear_masks) — where clearing them here, a megabyte of 32-byte writes per call, cost 1.4 us per step.
 // `lds` = kPlanLdsFloats floats + 64 ints.
+// `first` = false: the call is a consumer's fallback (the plan role's own workgroup has not been heard of): everything is
+// written as the plan role writes it, nothing is counted twice.
 template <int G, int GX, int TF, int TB_ = 256>
-__device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int cols, int tid, float* __restrict__ lds) {
+__device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int cols, int tid, float* __restrict__ lds, bool first) {
   using T = DetectTile<G, GX, TF, TB_>;
   constexpr int TB = T::TB, H = T::H;
   static_assert(TF == 16, "one pad word per frame tile");
@@ -331,6 +342,13 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
       }
       live_mask[r] = __ballot(exists && !culled);
       dead_mask[r] = __ballot(culled);
+      if (a.stats && first) {  // (wave-uniform)
+        const int tested = __popcll(__ballot(exists && plannable && steady && !writes_hist));
+        if (lane == 0 && tested) {
+          atomicAdd(&a.stats[kStatTested], (unsigned long long)tested);
+          atomicAdd(&a.stats[kStatCulled], (unsigned long long)__popcll(dead_mask[r]));
+        }
+      }
       if (lane == 0) book[w * 4 + r] = __popcll(live_mask[r]);
     } else if (lane == 0) {
       book[w * 4 + r] = 0;
@@ -373,22 +391,35 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
 #endif
 }
 
-// Consumer side, called by every wave of a workgroup with the same arguments: the two tiles consumer `p` of `nseg` lists is
-// to evaluate (-1: none): list p mod nseg, entries 2 (p div nseg) and the next. `word` = that list's header word as read
-// earlier (the FFT role asks before it loads its frame, so the answer costs it nothing); if the list was not complete by
-// then, wait for it now. Every wave of the workgroup ends up with the same pair.
+// Consumer side (scan_step.h), called by every wave of a workgroup with the same arguments. Consumer `p` of `nseg` lists serves
+// list p mod nseg, entries 2 (p div nseg) and the next one. All it has to read first is ONE header word, kLiveReady | count:
+//   live_wait_count  `word` = the header word as read earlier (the FFT role asks before its pass 3, so the answer usually costs it
+//                    nothing); if the list's count was not known by then, poll for it — at most `limit` times. Returns the word
+//                    as last seen (kLiveReady missing: gave up);
+//   live_wait_list   polls the list-written flag the same way (only consumers that have entries to fetch ask);
+//   live_pair        the two tiles (-1: none), once count and entries are known to be there.
+// A consumer that gives up makes the plan itself (see the top of this file): nothing waits without bound.
 __host__ __device__ __forceinline__ int live_count_word(int p, int nseg) { return kLiveCounts + ((p / nseg) % kLiveCopies) * kLiveCopyStride + p % nseg; }
-__device__ __forceinline__ int2 list_pair(const DetectArgs& a, int p, int nseg, int word) {
-  const int seg = p % nseg, q = p / nseg;
+__device__ __forceinline__ int live_wait_count(const DetectArgs& a, int p, int nseg, int word, int limit) {
   word = __builtin_amdgcn_readfirstlane(word);
-  while (!(word & kLiveReady)) {
+  for (int i = 0; i < limit && !(word & kLiveReady); ++i) {
     __builtin_amdgcn_s_sleep(8);
     word = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.live[live_count_word(p, nseg)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   }
-  const int count = word & (kLiveReady - 1);
+  return word;
+}
+__device__ __forceinline__ bool live_wait_list(const DetectArgs& a, int seg, int limit) {
+  int flag = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.live[seg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  for (int i = 0; i < limit && !flag; ++i) {
+    __builtin_amdgcn_s_sleep(8);
+    flag = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.live[seg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  return flag != 0;
+}
+__device__ __forceinline__ int2 live_pair(const DetectArgs& a, int p, int nseg, int count) {
+  const int seg = p % nseg, q = p / nseg;
   int2 t = make_int2(-1, -1);
   if (2 * q < count) {
-    while (!__builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.live[seg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) __builtin_amdgcn_s_sleep(8);
     const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.live + kLiveHeader + seg * kLiveCap + 2 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t.x = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
     if (2 * q + 1 < count) t.y = __builtin_amdgcn_readfirstlane((int)(v >> 32));
@@ -491,7 +522,7 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
     mrow[i * rows + r] = m;
   }
   __syncthreads();
-  bool live = false;
+  bool live = false, tested = false;
   int block = 0;
   if (tid < C * nft && column(tid / nft) < tiles_per_row) {
     const int cl = tid / nft, ft_seq = tid % nft;
@@ -500,6 +531,7 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
     block = ft_seq * tiles_per_row + column(cl);
     live = true;
     if (a.n_learn == 0 && f0 - (G - 1) >= p.clean_rel && !a.rel_out && !a.avg_out) {
+      tested = true;
       const float* mr = mrow + cl * rows + ft * TF;  // mr[k] = M of frame f0 - 20 + k
       float best = -__builtin_inff();
       bool unsure = false;
@@ -521,6 +553,13 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
   const int lane = tid & 63, w = tid >> 6;
   const unsigned long long mask = __ballot(live);
   if (lane == 0) wave_cnt[w] = __popcll(mask);
+  if (a.stats) {  // ss_get_stats
+    const int n_tested = __popcll(__ballot(tested)), n_culled = __popcll(__ballot(tested && !live));
+    if (lane == 0 && n_tested) {
+      atomicAdd(&a.stats[kStatTested], (unsigned long long)n_tested);
+      atomicAdd(&a.stats[kStatCulled], (unsigned long long)n_culled);
+    }
+  }
   __syncthreads();
   int base = 0, total = 0;
 #pragma unroll

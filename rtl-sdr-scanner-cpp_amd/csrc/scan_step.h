@@ -13,8 +13,11 @@
 // so FFT+dB(k), detect(k-1) and emit(k-2) are independent of each other. k_scan_step carries all three as ROLES of one
 // launch: every workgroup takes one work item — one frame through the FFT, two 16-frame x 256-bin detect tiles of an earlier
 // call, or the candidate lists of eight frames of a still earlier one — and whatever one role leaves idle (the FFT role's
-// wait for HBM, the detect role's dependence on L2 latency) the others use. No workgroup ever waits for another: all
-// dependencies are launch boundaries, so there is nothing to spin on and nothing to deadlock. The host side (specscan.hip)
+// wait for HBM, the detect role's dependence on L2 latency) the others use. Between STAGES every dependency is a launch
+// boundary. Inside a launch there is one hand-over since round 3 — the tile-culling plan of the detect stage that rides on the
+// launch, from a few plan workgroups to the workgroups that evaluate the listed tiles — and it is bounded: a consumer that has
+// polled StepArgs::wait_limit times makes the plan of its list itself (detect_fused.h), so no workgroup waits for another
+// without bound and nothing can deadlock whatever the dispatch order. The host side (specscan.hip)
 // keeps the deferred stages' arguments and drains them — launches with the finished roles empty — whenever a result is
 // asked for (ss_sync, ss_flush, the host-buffer entry points, retunes and resets): results are exactly those of the
 // three-launch chain, bit for bit, because every role runs the same code on the same data.
@@ -77,9 +80,12 @@ struct StepArgs {
   // a run-length list in the kernel arguments, decoded with scalar instructions — ~800 of them per wave: 40 against 35 us
   // per step.)
   const uint32_t* order;
+  // how many times a consumer of a planned stage's lists polls for its list before it makes the plan itself (detect_fused.h):
+  // a poll is a sleep of ~0.25 us and a load, the plan role publishes within a few microseconds of the launch's start
+  int wait_limit;
   int prio_fft, prio_other;  // s_setprio of the roles' waves (0..3)
 #ifdef SS_DIAG
-  int hint_mode;      // timing ablations of the list hand-over (garbage results): 1 = FFT workgroups ignore the lists, 2 = they do not wait for their header word
+  int hint_mode;      // timing ablations of the list hand-over (garbage results): 1 = FFT workgroups ignore the lists, 2 = they do not wait for their header word; 3 (a test, correct results) = the plan workgroups never publish
   long long* stamps;  // measurement builds only: {start, end (100 MHz wall clock), role << 32 | item, XCC_ID << 32 | HW_ID} per workgroup
 #endif
 };
@@ -113,6 +119,10 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
   // once its frame is done — and the evaluation follows at the bottom.
   int tile_a = -1, tile_b = -1;  // the tiles of threads 0..255 / 256..511 (workgroup-uniform; -1: none)
   int list_pair_no = -1;  // long transforms: the pair of k_plan_long's list this workgroup evaluates (-1: it does not read the list)
+  // 8192 points, planned stage: which consumer of the plan's lists this workgroup is (-1: none) and its list's header word as far
+  // as it is known; the plan this workgroup makes (-1: none) — its own as a plan workgroup, or its list's when it has waited for
+  // the plan workgroup in vain (detect_fused.h: nothing in a launch waits without bound)
+  int consumer = -1, word = 0, plan_seg = -1;
   if (role == ROLE_EMIT) {
     if constexpr (KIND == 2) {
       // ---- emit role, long rows: the eight waves share one frame ----
@@ -126,9 +136,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
   } else if (role == ROLE_DET) {
     // ---- detect role: two tiles ----
     if (KIND == 0 && a.n_plan) {  // the planned stage's lists (a launch without an FFT role)
-      const int2 pr = list_pair(a.det, item, step_plan_wgs(a), 0);
-      tile_a = pr.x;
-      tile_b = pr.y;
+      consumer = item;
     } else if (KIND >= 1 && a.det.tile_list) {
       // long transforms: the tiles k_plan_long listed. With an FFT role in the launch its workgroups take pairs 0 .. n_fft - 1
       // (below) and the detect workgroups the pairs beyond (calls that are no multiple of 16 frames have a few); without one,
@@ -139,7 +147,10 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;
     }
   } else if (role == ROLE_PLAN) {
-    if constexpr (KIND == 0) plan_tiles<21, 21, 16, 256>(a.det, item, a.plan_cols, tid, reinterpret_cast<float*>(smem_raw));
+    if constexpr (KIND == 0) plan_seg = item;
+#ifdef SS_DIAG
+    if (a.hint_mode == 3) plan_seg = -1;  // test switch: the plan workgroups never publish anything — every consumer has to help itself
+#endif
   } else if constexpr (KIND >= 1) {
     // ---- FFT role, long transforms: one tile of 32 columns ----
     fft_cols256_tile<FMT>(a.cols, item, smem_raw, tid);
@@ -162,13 +173,61 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
 #endif
     fft8192_v2_frame<FMT, TW, SWZ>(g, (size_t)(halo ? item : item - a.n_halo), smem_raw, tid, &hdr);
 #ifdef SS_DIAG
-    if (a.hint_mode) hdr = kLiveReady;  // "complete, empty"
+    if (a.hint_mode == 1 || a.hint_mode == 2) hdr = kLiveReady;  // "complete, empty"
 #endif
     if (a.plan_by_fft) {
-      const int2 pr = list_pair(a.det, item, step_plan_wgs(a), hdr);
+      consumer = item;
+      word = hdr;
+    }
+  }
+  if constexpr (KIND == 0) {
+    // ---- the planned stage's lists: consumer `consumer` serves list consumer mod nseg, entries 2 (consumer div nseg) and the next ----
+    // Everything that decides a branch here is workgroup-uniform: the header word came out of LDS (or is still unknown for the
+    // whole workgroup), and where somebody has to wait the first wave waits — a bounded number of polls — and tells the others
+    // through LDS (the role's own use of it is over). The common case — the count was there when the FFT role asked, and this
+    // consumer's share of the list is empty — touches no barrier at all.
+    int* note = reinterpret_cast<int*>(smem_raw);
+    const int nseg = step_plan_wgs(a);
+    bool helped_itself = false;
+    if (consumer >= 0) {
+      bool ok = true;
+      if (!(word & kLiveReady)) {
+        __syncthreads();
+        if (tid < 64) {
+          const int w = live_wait_count(a.det, consumer, nseg, word, a.wait_limit);
+          if (tid == 0) note[0] = w;
+        }
+        __syncthreads();
+        word = __builtin_amdgcn_readfirstlane(note[0]);
+        ok = (word & kLiveReady) != 0;
+      }
+      if (ok && 2 * (consumer / nseg) < (word & (kLiveReady - 1))) {  // there are entries to fetch: is the list written?
+        __syncthreads();
+        if (tid < 64) {
+          const bool f = live_wait_list(a.det, consumer % nseg, a.wait_limit);
+          if (tid == 0) note[1] = f ? 1 : 0;
+        }
+        __syncthreads();
+        ok = __builtin_amdgcn_readfirstlane(note[1]) != 0;
+      }
+      if (!ok) {  // the plan workgroup of this list has not been heard of: make its plan here
+        plan_seg = consumer % nseg;
+        helped_itself = true;
+        __syncthreads();
+        if (tid == 0 && a.det.stats) atomicAdd(&a.det.stats[kStatWaitFallbacks], 1ull);
+      }
+    }
+    if (plan_seg >= 0) plan_tiles<21, 21, 16, 256>(a.det, plan_seg, a.plan_cols, tid, reinterpret_cast<float*>(smem_raw), !helped_itself);
+    if (consumer >= 0) {
+      if (helped_itself) {
+        // (plan_tiles has drained its stores and passed a barrier: count and entries are where a write-through load finds them)
+        __syncthreads();
+        word = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&a.det.live[live_count_word(consumer, nseg)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+      const int2 pr = live_pair(a.det, consumer, nseg, word & (kLiveReady - 1));
       tile_a = pr.x;
       tile_b = pr.y;
-      if (tile_a >= 0) __syncthreads();  // the frame's last LDS reads are done
+      if (tile_a >= 0) __syncthreads();  // the frame's (or the plan's) last LDS reads are done
     }
   }
   if constexpr (KIND >= 1) {

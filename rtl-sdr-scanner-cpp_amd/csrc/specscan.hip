@@ -25,6 +25,7 @@
 #include "detect_fused.h"
 #include "detect_kernels.h"
 #include "fft256_kernels.h"
+#include "reference_nan.h"
 #include "fft_kernels.h"
 #include "scan_step.h"
 
@@ -58,6 +59,15 @@ struct NoiseState {  // NoiseLearner::Noise, sources/radio/blocks/noise_learner.
   bool ready = false;
   int64_t start_ms = 0;
   bool have_start = false;
+};
+
+// SS_FLAG_REFERENCE_NAN (reference_nan.h): what the poison stage between a call's detect and emit stages works on
+struct NanStage {
+  const float* psd = nullptr;
+  int nframes = 0, n_learn = 0, pushed_before = 0;
+  uint32_t* maskbits = nullptr;
+  int* counts = nullptr;
+  float* avg_full = nullptr;
 };
 
 }  // namespace
@@ -107,7 +117,8 @@ struct ss_ctx {
     int canary_prev_slot = -1;               // the slot that holds the first sum of the previous call's frames (-1: none taken)
     bool emit_wide = true;         // long rows (n >= 16384): several waves per frame in the emit stage
     bool no_order_table = false;   // SS_DIAG: never use a dispatch-order table
-    int hint_mode = 0;             // SS_DIAG timing ablations of the list hand-over (scan_step.h)
+    int hint_mode = 0;             // SS_DIAG timing ablations of the list hand-over (scan_step.h); 3: plan workgroups never publish (tests/test_gpu_wait_bound.py)
+    int wait_limit = 0;            // SS_DIAG (SS_WAIT_LIMIT): StepArgs::wait_limit, 0 = the product's
     int queues = 2;                // 8192 points, deep pipelining: launch queues (2 .. 4)
     bool cull_65536 = false;       // SS_DIAG (SS_CULL_65536=1): tile culling also at 65536 points (see ss_create)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
@@ -156,6 +167,7 @@ struct ss_ctx {
       canary = tri("SS_CANARY") == 1;
       queues = num("SS_QUEUES", queues);
       hint_mode = num("SS_HINT_MODE", 0);
+      wait_limit = num("SS_WAIT_LIMIT", 0);
       no_order_table = tri("SS_ORDER_TABLE") == 0;
       if (tri("SS_PLAN_NOZERO") == 1) d_cull_stats = reinterpret_cast<unsigned*>(1);
       else if (tri("SS_CULL_STATS") == 1 && hipMalloc(&d_cull_stats, 3 * sizeof(unsigned)) == hipSuccess) (void)hipMemset(d_cull_stats, 0, 3 * sizeof(unsigned));
@@ -382,6 +394,21 @@ struct ss_ctx {
   std::vector<int> prof_slots;          // which kernel of the chain each pair timed (SS_KSLOT_*)
   size_t prof_used = 0;
   bool prof_call = false;   // the current call is a sampled one: its other kernels (rows, radix-A step, plan) carry events too
+  // ss_get_stats: host-side counters, and the device-side ones (detect_fused.h kStat*: tiles tested / culled, wait fallbacks)
+  ss_stats stats{};
+  unsigned long long* d_stats = nullptr;
+  int wait_limit = 1 << 14;  // StepArgs::wait_limit (a poll is a ~0.25 us sleep and a load: tens of milliseconds before a consumer plans for itself)
+  // ss_input_wait: the launches (or, in order on the public stream, the calls) whose events a producer may wait on
+  hipEvent_t ev_call[32] = {};   // in-order contexts: recorded on the public stream behind every call once ss_input_wait has been used
+  bool input_events = false;
+  long input_events_from = 0;    // deep pipelining: first launch of the current run of launches that has its event (ev_launch)
+  unsigned long long call_seq = 0;  // device calls so far (ss_process_device)
+  // SS_FLAG_REFERENCE_NAN (reference_nan.h): per-frame first non-finite bins of the batch, the state carried between batches, per-frame poison limits
+  bool ref_nan = false;
+  int* d_nf = nullptr;        // [max_batch][4]: first NaN / -inf / +inf bin of every frame of the batch (n: none)
+  int* d_nan_state = nullptr; // ss::NanState
+  int* d_bad_from = nullptr;  // [max_batch]: bins >= this are NaN in the reference's avg row (n: none)
+  NanStage nan_pending{};     // of the call whose detect stage is still deferred
   std::mutex mtx;
   char err[512] = "";
 };
@@ -735,6 +762,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
     a.n_emit = emit->nframes;
   }
   if (ss::step_items(a) == 0) return;
+  a.wait_limit = c->wait_limit;
   step_order(c, a, stream);
   // (no order table — none wanted, or none to be had: out of device memory — means the roles in segments, which is always correct)
 #ifdef SS_DIAG
@@ -883,13 +911,30 @@ void drain_deep(ss_ctx* c) {
   c->deep_prev_ok = false;  // after a drain the caller may reuse its planes: the next call takes its rows from the ring
   c->deep_buffers.clear();
   c->deep_events_from = 0;
+  c->input_events_from = 0;
+}
+
+// SS_FLAG_REFERENCE_NAN (reference_nan.h): the poison between a call's detect and emit stages, on the public stream.
+void launch_nan_stage(ss_ctx* c, const NanStage& g) {
+  if (!g.psd || g.nframes <= 0) return;
+  hipLaunchKernelGGL(ss::k_nonfinite_scan, dim3(g.nframes), dim3(256), 0, c->stream, g.psd, c->n, g.n_learn, c->d_nf);
+  hipLaunchKernelGGL(ss::k_nan_plan, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<ss::NanState*>(c->d_nan_state), (const int*)c->d_nf, g.nframes, c->n, g.pushed_before, c->d_bad_from);
+  hipLaunchKernelGGL(ss::k_nan_apply, dim3(g.nframes), dim3(256), 0, c->stream, (const int*)c->d_bad_from, c->n, g.maskbits, g.counts, g.avg_full);
 }
 
 // Drain the deferred stages: detect (+ the emit stage before it), then the last emit. Nothing is synchronised.
 void flush_stages(ss_ctx* c) {
-  if (c->deep) return drain_deep(c);
+  if (c->deep) {
+    if (c->deep_L > 0 || !c->pd.empty() || !c->pe.empty()) ++c->stats.drains;
+    return drain_deep(c);
+  }
+  if (c->have_det || c->have_emit) ++c->stats.drains;
   while (c->have_det || c->have_emit) {
     launch_step(c, nullptr, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
+    if (c->have_det && c->ref_nan) {  // (such contexts never defer a stage across calls: no emit stage rode on that launch)
+      launch_nan_stage(c, c->nan_pending);
+      c->nan_pending = NanStage{};
+    }
     c->have_emit = c->have_det;
     c->pend_emit = c->pend_det_emit;
     c->have_det = false;
@@ -1093,6 +1138,8 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   da.seg_pitch = c->cfg.max_batch;
   da.thr_tilemin = z->d_thr + n;  // (kept behind the ceiling itself, get_noise)
   da.live = c->d_live[b];
+  da.stats = c->d_stats;
+  c->stats.tiles_total += (unsigned long long)tiles;
 #ifdef SS_DIAG
   da.cull_stats = c->diag.d_cull_stats;
 #endif
@@ -1135,14 +1182,26 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   c->hist_start = next_start;
   c->last_n_learn = n_learn;
   c->last_thr = z->d_thr;
+  NanStage ns;
+  if (c->ref_nan) {
+    ns.psd = d_psd;
+    ns.nframes = nframes;
+    ns.n_learn = n_learn;
+    ns.pushed_before = da.pushed_before;
+    ns.maskbits = da.maskbits;
+    ns.counts = counts;
+    ns.avg_full = avg_full;
+  }
   if (deferred) {
     *det_out = da;
     *det_tiles_out = tiles;
     *emit_out = ea;
+    c->nan_pending = ns;  // (flush_stages puts it between the two)
     return SS_OK;
   }
   if (spec) hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, true>), dim3(tiles), dim3(TB), 0, c->stream, da);
   else hipLaunchKernelGGL((ss::k_detect_fused<G, GX, TF, TB, false>), dim3(tiles), dim3(TB), 0, c->stream, da);
+  if (c->ref_nan) launch_nan_stage(c, ns);
   // long rows: several waves per frame (slices of at least 256 mask words)
   const int words = n / 32;
   if (c->diag.emit_wide && words >= 2048) hipLaunchKernelGGL(ss::k_cand_emit_wide<8>, dim3(nframes), dim3(512), 0, c->stream, ea);
@@ -1251,9 +1310,12 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
     // that: the producer that refilled the buffer ran on ss_stream, which overlapped launches do not hold up. What it can
     // do is stop trusting this caller's input buffers: drain now, and from here on take the stages in order on the public
     // stream, where a producer enqueued there is ordered against them (deep_eager, like a caller that waits after every call).
+    // (A caller that uses ss_input_wait has taken the matter into its own hands: its refills are ordered behind the launches
+    // that read the buffer, and rotating a few buffers is exactly what it is there for.)
     for (const auto& b : c->deep_buffers)
-      if (b.launch + 1 >= L - 2 * c->nq && b.iq_lo < mine.iq_hi && mine.iq_lo < b.iq_hi) {
+      if (!c->input_events && b.launch + 1 >= L - 2 * c->nq && b.iq_lo < mine.iq_hi && mine.iq_lo < b.iq_hi) {
         must_drain = true;
+        if (!c->deep_iq_recycled) ++c->stats.demotions;
         c->deep_iq_recycled = true;
       }
     for (const auto& b : c->deep_buffers)
@@ -1283,6 +1345,7 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   ss_ctx::PendEmit e{};
   bool has_det = false, has_emit = false;
   long L = -1;
+  ++(overlap ? c->stats.calls_overlapped : c->stats.calls_in_order);
   if (overlap) {
     L = c->deep_L++;
     q = c->s_ab[L % c->nq];
@@ -1338,7 +1401,7 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   if (overlap) {
     const bool ring_reader = has_det && !d.a.halo_psd && !c->deep_ring_safe;
     const int rec_phase = (int)(L % kDeepSyncPeriod);
-    if (c->deep_events || ring_reader || (rec_phase >= kDeepSyncPhase - 2 * c->nq && rec_phase < kDeepSyncPhase)) SS_HIP(c, hipEventRecord(c->ev_launch[L & 31], q));
+    if (c->deep_events || c->input_events || ring_reader || (rec_phase >= kDeepSyncPhase - 2 * c->nq && rec_phase < kDeepSyncPhase)) SS_HIP(c, hipEventRecord(c->ev_launch[L & 31], q));
     if (has_det) c->pe.push_back(ss_ctx::PendEmit{d.emit, L + c->nq});
     if (ring_reader) c->deep_barrier = L;
   }
@@ -1458,7 +1521,9 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         ring_by_rows = true;
       }
     }
-    const bool overlap = c->diag.pipeline && n_learn == 0;
+    // (SS_FLAG_STREAM_ORDERED / SS_FLAG_REFERENCE_NAN: every stage of the call before the call returns, in order on the public stream)
+    const bool overlap = c->diag.pipeline && n_learn == 0 && !(c->cfg.flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN));
+    ++c->stats.calls_in_order;
     // A caller that hands the same PSD or avg plane to consecutive calls would have this call's stages write what a
     // deferred stage of the previous call still has to read in the same launch: drain first (no overlap for such callers).
     const size_t plane_bytes = sizeof(float) * (size_t)nframes * (size_t)c->n;
@@ -1514,6 +1579,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     }
     if (!overlap) flush_stages(c);
   } else {
+    ++c->stats.calls_in_order;
     st = launch_fft(c, d_iq, item_stride, nframes, d_psd);
     if (st != SS_OK) return st;
     if (spec) {
@@ -1533,6 +1599,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     if (st != SS_OK) return st;
   }
   ++c->batch_no;
+  ++c->stats.calls;
   SS_HIP(c, hipGetLastError());
   c->frames_pushed = c->frames_pushed + nframes < G ? c->frames_pushed + nframes : G;
   if (n_learn > 0) c->clean_abs = c->abs_frames + n_learn;  // (tile culling, long transforms: rows before this one hold learning frames)
@@ -1640,6 +1707,12 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_spec_part2[0]);
   (void)hipFree(c->d_spec_part2[1]);
   (void)hipFree(c->d_counts);
+  (void)hipFree(c->d_stats);
+  (void)hipFree(c->d_nf);
+  (void)hipFree(c->d_bad_from);
+  (void)hipFree(c->d_nan_state);
+  for (hipEvent_t e : c->ev_call)
+    if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->d_in);
   (void)hipFree(c->d_cand_idx);
   (void)hipFree(c->d_cand_avg);
@@ -1768,7 +1841,22 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     // frame tile (a batch that starts inside a tile touches one more)
     c->spec_in_detect = c->fused && c->spec_m <= 256 && !c->diag.spec_standalone;
   }
-  c->deep = c->step_path && n == 8192 && c->diag.deep && !(cfg->flags & SS_FLAG_STREAM_ORDERED) && cfg->max_batch >= kHistRows && (!(cfg->flags & SS_FLAG_SPECTROGRAM) || c->spec_in_detect);
+  c->ref_nan = (cfg->flags & SS_FLAG_REFERENCE_NAN) != 0;
+  if (c->ref_nan && !c->fused) {
+    fail(nullptr, SS_ERR_INVALID, "SS_FLAG_REFERENCE_NAN needs the 21 x 21 grouping (and max_batch <= 65536)");
+    free_ctx(c);
+    return SS_ERR_INVALID;
+  }
+  c->deep = c->step_path && n == 8192 && c->diag.deep && !(cfg->flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN)) && cfg->max_batch >= kHistRows && (!(cfg->flags & SS_FLAG_SPECTROGRAM) || c->spec_in_detect);
+  if (c->diag.wait_limit > 0) c->wait_limit = c->diag.wait_limit;
+  CREATE_HIP(hipMalloc(&c->d_stats, sizeof(unsigned long long) * ss::kStatWords));
+  CREATE_HIP(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * ss::kStatWords, c->stream));
+  if (c->ref_nan) {
+    CREATE_HIP(hipMalloc(&c->d_nf, sizeof(int) * 4 * (size_t)cfg->max_batch));
+    CREATE_HIP(hipMalloc(&c->d_bad_from, sizeof(int) * (size_t)cfg->max_batch));
+    CREATE_HIP(hipMalloc(&c->d_nan_state, sizeof(ss::NanState)));
+    hipLaunchKernelGGL(ss::k_nan_state_reset, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<ss::NanState*>(c->d_nan_state), n);
+  }
   c->nq = c->deep ? std::min(std::max(c->diag.queues, 2), kMaxQueues) : 1;
   c->lag = c->deep ? c->nq : 1;
   c->ncnt = c->deep ? 3 * c->nq : 3;
@@ -2046,6 +2134,67 @@ int ss_sync(ss_ctx* ctx) {
   return SS_OK;
 }
 
+// ss_get_stats: the host-side counters as they stand, the device-side ones as far as the device has got (a blocking 32-byte
+// copy that synchronises with none of the context's streams: they are all non-blocking streams).
+int ss_get_stats(ss_ctx* c, ss_stats* out) {
+  if (!c || !out || out->size < sizeof(uint32_t) * 2) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  unsigned long long dev[ss::kStatWords] = {};
+  SS_HIP(c, hipMemcpy(dev, c->d_stats, sizeof(dev), hipMemcpyDeviceToHost));
+  ss_stats st = c->stats;
+  st.tiles_tested = dev[ss::kStatTested];
+  st.tiles_culled = dev[ss::kStatCulled];
+  st.wait_fallbacks = dev[ss::kStatWaitFallbacks];
+  st.state = (c->cull || c->cull_long ? SS_STATE_CULLING : 0u) | (c->deep ? SS_STATE_OVERLAP : 0u) | (c->deep && c->deep_iq_recycled ? SS_STATE_DEMOTED : 0u) |
+             (c->deep && c->deep_eager ? SS_STATE_EAGER : 0u);
+  const uint32_t want = out->size < sizeof(ss_stats) ? out->size : (uint32_t)sizeof(ss_stats);
+  st.size = want;
+  memcpy(out, &st, want);
+  return SS_OK;
+}
+
+// ss_input_wait (include/specscan.h): `stream` waits until the input frames of every call up to the one `calls_back` before the
+// latest have been read for the last time — by their own launch and, their last frames, by the launch of the call after it.
+int ss_input_wait(ss_ctx* c, void* stream_v, int32_t calls_back) {
+  if (!c) return SS_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(c->mtx);
+  if (calls_back < 1) return fail(c, SS_ERR_INVALID, "ss_input_wait: calls_back %d < 1 (the latest call's last frames are read again by the call after it)", calls_back);
+  SS_HIP(c, hipSetDevice(c->cfg.device_id));
+  hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : c->stream;
+  const auto behind_public = [&]() -> int {  // whatever the public stream holds now
+    if (stream == c->stream) return SS_OK;
+    hipEvent_t& ev = c->ev_call[c->call_seq & 31];
+    if (!ev) SS_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    SS_HIP(c, hipEventRecord(ev, c->stream));
+    SS_HIP(c, hipStreamWaitEvent(stream, ev, 0));
+    ++c->call_seq;
+    return SS_OK;
+  };
+  if (!c->deep || c->deep_L == 0) return behind_public();  // every stage so far is on (or joined into) the public stream
+  const long target = c->deep_L - 1 - calls_back;  // the launch of the newest call whose input is to be dead
+  const bool first_use = !c->input_events;
+  c->input_events = true;
+  if (target < 0) {
+    // (calls from before this run of overlapped launches: in order on the public stream, and the run's first launch takes its
+    // rows from before the batch from the ring, not from their frames)
+    return behind_public();
+  }
+  const long hi = target + 1, lo = std::max(0l, hi - (c->nq - 1));  // one launch per queue, the newest at or below target + 1
+  const bool recorded = !first_use && lo >= c->input_events_from && (32 % c->nq) == 0;
+  if (recorded) {
+    for (long L = hi; L >= lo; --L) SS_HIP(c, hipStreamWaitEvent(stream, c->ev_launch[L & 31], 0));  // (a slot recorded again since then belongs to a later launch of the same queue: waits longer, never shorter)
+  } else {
+    // no per-launch events yet (first use, or launches from before it): behind everything the queues hold now
+    for (int q = 0; q < c->nq; ++q) {
+      SS_HIP(c, hipEventRecord(c->ev_join[q], c->s_ab[q]));
+      SS_HIP(c, hipStreamWaitEvent(stream, c->ev_join[q], 0));
+    }
+    if (first_use) c->input_events_from = c->deep_L;
+  }
+  return SS_OK;
+}
+
 int ss_kernel_timing(ss_ctx* c, int enable) {
   if (!c) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
@@ -2204,6 +2353,8 @@ int ss_reset(ss_ctx* c) {  // Transmission::resetBuffers -> Averager::reset: row
   c->clean_abs = 0;
   c->rot_frames = 0;
   c->last_n = 0;
+  c->deep_iq_recycled = false;  // (a retune is a fresh start for the caller's buffers too; ss_get_stats keeps the count)
+  if (c->ref_nan) hipLaunchKernelGGL(ss::k_nan_state_reset, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<ss::NanState*>(c->d_nan_state), c->n);  // Averager::reset zeroes the sums: the poison goes with them
   return SS_OK;
 }
 

@@ -47,6 +47,10 @@ def load_library(diag: bool | None = None) -> C.CDLL:
         lib.ss_flush.restype = C.c_int
         lib.ss_stream.argtypes = [C.c_void_p]
         lib.ss_stream.restype = C.c_void_p
+        lib.ss_get_stats.argtypes = [C.c_void_p, C.POINTER(abi.SsStats)]
+        lib.ss_get_stats.restype = C.c_int
+        lib.ss_input_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        lib.ss_input_wait.restype = C.c_int
         lib.ss_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         lib.ss_kernel_timing.restype = C.c_int
         lib.ss_kernel_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
@@ -78,7 +82,7 @@ def load_library(diag: bool | None = None) -> C.CDLL:
 
 
 EXPORTS = ("ss_default_config", "ss_device_count", "ss_create", "ss_destroy", "ss_last_error", "ss_process",
-           "ss_process_device", "ss_flush", "ss_sync", "ss_stream", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
+           "ss_process_device", "ss_flush", "ss_sync", "ss_stream", "ss_input_wait", "ss_get_stats", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
            "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read", "ss_kernel_timing_read_slots", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read",
            "ss_spectrogram_payload", "ss_feed_create", "ss_feed_destroy", "ss_feed_acquire", "ss_feed_submit", "ss_feed_collect", "ss_feed_pending")
 
@@ -129,6 +133,22 @@ class SpectrumEngine(abi.Chain):
     def flush(self):
         """Enqueue the deferred stages of earlier process_device calls without waiting."""
         self._check(self._lib.ss_flush(self._h))
+
+    def stats(self) -> dict:
+        """ss_get_stats: what the library did so far (counters from creation; the device-side ones — tiles_tested, tiles_culled,
+        wait_fallbacks — as far as the device has got: sync() first for exact figures). `state` is decoded into booleans."""
+        st = abi.SsStats()
+        st.size = C.sizeof(abi.SsStats)
+        self._check(self._lib.ss_get_stats(self._h, C.byref(st)))
+        out = {k: int(getattr(st, k)) for k, _ in abi.SsStats._fields_ if k not in ("size", "state")}
+        out.update(culling=bool(st.state & abi.SS_STATE_CULLING), overlap=bool(st.state & abi.SS_STATE_OVERLAP),
+                   demoted=bool(st.state & abi.SS_STATE_DEMOTED), eager=bool(st.state & abi.SS_STATE_EAGER))
+        return out
+
+    def input_wait(self, stream_handle: int | None, calls_back: int):
+        """ss_input_wait: `stream_handle` (a hipStream_t as an integer; None = the chain's own stream) waits until the input frames of
+        every process_device call up to the one `calls_back` (>= 1) before the latest have been read for the last time."""
+        self._check(self._lib.ss_input_wait(self._h, C.c_void_p(stream_handle) if stream_handle else None, int(calls_back)))
 
     def spectrogram_read(self):
         """(int8 spectrogram row, float means, frames accumulated) for the current centre; clears the accumulator."""

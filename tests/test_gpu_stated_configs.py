@@ -186,3 +186,31 @@ def test_config3_device_calls_against_the_reference(ref_mod):
     assert not outside, sorted(outside)[:10]
     print(f"\n[config 3, device calls: {ncalls} x 128 frames of 65536 points, CS8] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band")
     assert len(b) > 10_000 and len(a ^ b) <= dont_care_limit(len(b))
+
+
+def test_config5_device_calls_against_the_reference(ref_mod):
+    """Config 5 as it ships and as bench.py times it: 2^20-point CF32 frames in 16-frame ss_process_device calls, detect mode (no
+    plane handed out), tile culling on, six calls enqueued back to back with no synchronisation — compared DIRECTLY with the
+    reference's own code. ss_get_stats shows that tiles really were culled."""
+    n, fs, chunk, ncalls, learn = 1 << 20, 61_440_000, 16, 8, 32
+    band = pkg.synth.SyntheticBand(n, seed=43, on_frame=70, off_frame=118)
+    iq = band.frames_cf32(chunk * ncalls)
+    t = (10_000 + 30 * np.arange(chunk * ncalls)).astype(np.int64)
+    t[learn - 1:] += 2_000  # the reference's wall clock (noise_learner.cpp:23) ends learning with frame learn - 1: `learn` frames, as ss_process_device counts them
+    ref_mod.ref().orc_set_fft_backend(0)
+    ref = _ref_result(ref_mod.RefChain(n, fs, CENTER - fs // 2, CENTER + fs // 2).process(iq, t))
+    del ref["psd"], ref["rel"]
+    eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, max_batch=chunk, learn_frames=learn)
+    outs = _device_calls(eng, [iq[k * chunk:(k + 1) * chunk] for k in range(ncalls)], n, planes=False)
+    st = eng.stats()
+    got = _cat(outs, ("cand_idx", "cand_avg"))
+    a, b = cand_set(got["cand_off"], got["cand_idx"]), cand_set(ref["cand_off"], ref["cand_idx"])
+    near = np.abs(ref["avg"] - np.float32(8.0)) < BAND
+    outside = [(f, i) for (f, i) in a ^ b if not near[f, i]]
+    assert not outside, sorted(outside)[:10]
+    frames = np.repeat(np.arange(chunk * ncalls), np.diff(got["cand_off"]))
+    check_plane("cand_avg", got["cand_avg"][None], ref["avg"][frames, got["cand_idx"]][None], floor=np.full((1, len(frames)), 2e-3))
+    print(f"\n[config 5, device calls: {ncalls} x 16 frames of 2^20 points, detect mode, culled] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band; "
+          f"tiles {st['tiles_total']}, tested {st['tiles_tested']}, culled {st['tiles_culled']}")
+    assert st["culling"] and st["tiles_culled"] > 0 and st["tiles_culled"] <= st["tiles_tested"] <= st["tiles_total"], st
+    assert len(b) > 2000 and len(a ^ b) <= dont_care_limit(len(b))
