@@ -23,8 +23,9 @@ Prints ONE JSON line on rank 0:
                         decomposition, and the fabric bytes of the committed PMC passes (one entry at 8192 points; column half,
                         radix-A step, row half and plan launch for the long transforms)
   roofline_chain        the same algorithmic bytes / the whole step's time (every kernel of the chain, launch gaps included)
-  also                  (default line, one GPU) BASELINE configs 3 and 5 as short runs in processes of their own: 65536 x 128 CS8,
-                        2^20 x 16 and 2^20 x 64, each with ms_per_step, its chain figure and its kernels
+  also                  (default line, one GPU) short runs in processes of their own: the default configuration with every averaging tile
+                        evaluated (variant no_cull: the data-independent cost), BASELINE configs 3 and 5 (65536 x 128 CS8, 2^20 x 16 and
+                        2^20 x 64), each with ms_per_step, its chain figure, its kernels, the tiles the library culled and a parity sample
   cpu_baseline          the reference's own compiled sources (oracle/_ref; the C restatement where that is absent) on the
                         host cores over a bounded sample of the same workload, one thread and all threads
 """
@@ -80,14 +81,23 @@ def _cpu_worker(args):
     else:
         O.lib().orc_set_fft_backend(backend)
         chain = O.oracle_chain(fs, center, fft_size=n, decim=1, max_batch=chunk)
-    t0 = time.perf_counter()
-    while True:
+    def one_chunk():
+        nonlocal t_ms
         if use_ref and not stages:
             chain.process(iq, t_ms + 20 * np.arange(chunk))
             t_ms += 20 * chunk
         else:
             chain.process(iq, want=(), cand_cap=chunk * n)
+
+    if not (use_ref and not stages):
+        t_ms = 0
+    one_chunk()  # untimed: the first call of a freshly forked worker pays for MKL's start-up (seconds, once)
+    chunks = 0
+    t0 = time.perf_counter()
+    while True:
+        one_chunk()
         frames += chunk
+        chunks += 1
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
@@ -99,7 +109,7 @@ def _cpu_worker(args):
         tot = sum(buf) or 1.0
         names = ("window+fft+shift", "psd_db", "noise_relative", "averager_21_frames", "average_21_bins", "threshold")
         split = {k: round(v / tot, 3) for k, v in zip(names, buf)}
-    return frames, el, split
+    return frames, el, split, chunks
 
 
 def usable_cores() -> int:
@@ -150,7 +160,8 @@ def cpu_baseline(n: int, fs: int, budget_s: float = 12.0, stages: bool = False):
     out = {
         "value": round(frames * n / wall / 1e6, 3), "unit": "MS/s", "cores": cores,
         "kind": "reference" if use_ref else "port",
-        "one_thread": round(one[0] * n / one[1] / 1e6, 3), "nproc": os.cpu_count(), "cpu_model": cpu_model(),
+        # (fewer than ten chunks inside the budget is not a rate: null)
+        "one_thread": round(one[0] * n / one[1] / 1e6, 3) if one[3] >= 10 else None, "nproc": os.cpu_count(), "cpu_model": cpu_model(),
         "sample": (f"{frames} frames of {n} CF32 samples ({frames * n / 1e6:.0f} MS) in {wall:.1f} s on {cores} threads "
                    f"(one independent band per thread), {one[0]} frames in {one[1]:.1f} s on one thread; "
                    f"full chain window+FFT+dB+noise+21x21 mean+threshold, "
@@ -162,29 +173,42 @@ def cpu_baseline(n: int, fs: int, budget_s: float = 12.0, stages: bool = False):
     return out
 
 
-def parity_sample(n: int, fs: int, fmt: str):
-    """A small parity check beside the numbers (the checker leg, like cpu_baseline): 96 frames through the engine and through
-    the reference's own code (oracle/_ref; the C restatement where that is absent), same contract as tests/parity.py;
-    reports the achieved error quantiles per plane and the candidate counts."""
+def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False):
+    """A small parity check beside the numbers (the checker leg, like cpu_baseline), against the reference's own code (oracle/_ref;
+    the C restatement where that is absent), same contract as tests/parity.py:
+      host path    frames through ss_process with every plane handed out: achieved error quantiles per plane (dB and relative on
+                   linear power), the bins outside the bare tolerance measured against an fp64 chain, candidate lists
+      timed path   the same frames once more the way the timed region runs them — ss_process_device calls without a synchronisation
+                   in between, the planes this configuration hands out and no others (detect mode: none), tile culling as the
+                   library does it at this size — candidate lists against the reference, and what ss_get_stats says was culled."""
     import numpy as np
     import rtl_sdr_scanner_cpp_amd as pkg
     from oracle import oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from parity import check_all, dont_care_limit, error_quantiles, excess_vs_fp64, strict_excess
-    nframes = 96 if n <= 16384 else 48
+    from parity import BAND, cand_set, check_all, dont_care_limit, error_quantiles, excess_vs_fp64, excess_vs_fp64_rel, linear_power_error, strict_excess
+    chunk = 48 if n <= 16384 else (32 if n <= 65536 else 16)
+    nframes = 2 * chunk if n <= 65536 else 5 * chunk  # (2^20 points: 80 frames, so that whole 16-frame tiles lie behind learning + warm-up and can be culled)
+    n_learn = 21
     band = pkg.synth.SyntheticBand(n, seed=77, on_frame=nframes // 2, off_frame=nframes - 4)
     center = 145_000_000
     in_format = {"cf32": 0, "cs8": 1, "cu8": 2}[fmt]
-    iq = band.frames_cf32(nframes) if fmt == "cf32" else (band.frames_cs8(nframes) if fmt == "cs8" else band.frames_cu8(nframes))
+    raw = band.frames_cf32(nframes) if fmt == "cf32" else (band.frames_cs8(nframes) if fmt == "cs8" else band.frames_cu8(nframes))
+    if fmt == "cf32":
+        iq_c = raw
+    elif fmt == "cs8":  # what the engine's load stage makes of the bytes (include/specscan.h: int8 * 1 / 128)
+        iq_c = (raw[..., 0].astype(np.float32) / np.float32(128.0) + 1j * (raw[..., 1].astype(np.float32) / np.float32(128.0))).astype(np.complex64)
+    else:
+        iq_c = ((raw[..., 0].astype(np.float32) - np.float32(127.5)) / np.float32(127.5) + 1j * ((raw[..., 1].astype(np.float32) - np.float32(127.5)) / np.float32(127.5))).astype(np.complex64)
     t = (1_000 + 100 * np.arange(nframes)).astype(np.int64)  # learning: the first 21 frames
-    chunk = min(nframes, 48)
-    eng = pkg.SpectrumEngine(fs, center, fft_size=n, decim=1, in_format=in_format, max_batch=chunk)
-    outs = [eng.process(iq[a:a + chunk], t_ms=t[a:a + chunk]) for a in range(0, nframes, chunk)]
+    flags = pkg.abi.SS_FLAG_NO_CULL if no_cull else 0
+    eng = pkg.SpectrumEngine(fs, center, fft_size=n, decim=1, in_format=in_format, max_batch=chunk, flags=flags)
+    outs = [eng.process(raw[a:a + chunk], t_ms=t[a:a + chunk]) for a in range(0, nframes, chunk)]
+    eng.close()
     got = {k: np.concatenate([o[k] for o in outs]) for k in ("psd", "rel", "avg", "cand_idx", "cand_avg")}
     got["cand_off"] = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o["cand_off"]) for o in outs]))]).astype(np.int32)
-    if O.have_ref() and fmt == "cf32":
+    if O.have_ref() and fmt != "cu8":
         O.ref().orc_set_fft_backend(0)
-        r = O.RefChain(n, fs, center - fs // 2, center + fs // 2).process(iq, t)
+        r = O.RefChain(n, fs, center - fs // 2, center + fs // 2).process(iq_c, t)
         off = np.zeros(nframes + 1, np.int32)
         off[1:] = np.cumsum([len(c) for c in r["cands"]])
         ref = {"psd": r["psd"], "rel": r["rel"], "avg": r["avg"], "cand_off": off, "cand_idx": np.concatenate(r["cands"]).astype(np.int32)}
@@ -192,19 +216,50 @@ def parity_sample(n: int, fs: int, fmt: str):
     else:
         O.lib().orc_set_fft_backend(0)
         ch = O.oracle_chain(fs, center, fft_size=n, decim=1, in_format=in_format, max_batch=chunk)
-        routs = [ch.process(iq[a:a + chunk], t_ms=t[a:a + chunk]) for a in range(0, nframes, chunk)]
+        routs = [ch.process(raw[a:a + chunk], t_ms=t[a:a + chunk]) for a in range(0, nframes, chunk)]
         ref = {k: np.concatenate([o[k] for o in routs]) for k in ("psd", "rel", "avg", "cand_idx")}
         ref["cand_off"] = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o["cand_off"]) for o in routs]))]).astype(np.int32)
         against = "C restatement (oracle/liboracle.so)"
     errs, ncand, ndc = check_all(got, ref)  # raises when the contract is broken
-    iq_c = iq if fmt == "cf32" else None  # (the fp64 comparison wants the frames as complex64)
-    vs64 = excess_vs_fp64(iq_c, got["psd"], ref["psd"], fs) if iq_c is not None else None
-    return {"against": against, "frames": nframes, "reference_candidates": ncand, "inside_1e-3_dB_band": ndc, "band_limit": dont_care_limit(ncand),
-            "abs_err_dB": {k: {q: float(f"{v:.3g}") for q, v in d.items()} for k, d in error_quantiles(got, ref).items()},
-            # bins the bare 1e-4 * max(1, |ref|) does not cover (held by the fp32-FFT floor allowance), and on those PSD bins the distance of
-            # the engine and of the reference's fp32 FFT to an fp64 FFT of the same windowed frame (engine <= 1.5 x reference asserted)
-            "outside_bare_1e-4": {k: {"n": v["n"], "frac": float(f"{v['frac']:.3g}"), "worst_dB": float(f"{v['worst']:.3g}")} for k, v in strict_excess(got, ref).items()},
-            "outside_bins_vs_fp64_fft_dB": None if vs64 is None else {k: (v if isinstance(v, int) else float(f"{v:.3g}")) for k, v in vs64.items()}}
+    vs64 = excess_vs_fp64(iq_c, got["psd"], ref["psd"], fs)
+    vs64_rel = excess_vs_fp64_rel(iq_c, got["rel"], ref["rel"], fs, n_learn)
+    fmt3 = lambda d: None if d is None else {k: (v if isinstance(v, int) else float(f"{v:.3g}")) for k, v in d.items()}  # noqa: E731
+    res = {"against": against, "frames": nframes, "reference_candidates": ncand, "inside_1e-3_dB_band": ndc, "band_limit": dont_care_limit(ncand),
+           "abs_err_dB": {k: {q: float(f"{v:.3g}") for q, v in d.items()} for k, d in error_quantiles(got, ref).items()},
+           # north_star's wording, on linear power |X|^2 / fs: |got / ref - 1| per bin of the PSD plane
+           "rel_linear": {"psd": fmt3(linear_power_error(got["psd"], ref["psd"]))},
+           # bins the bare 1e-4 * max(1, |ref|) does not cover (held by the fp32-FFT floor allowance), and on those bins the distance of
+           # the engine and of the reference to an fp64 chain on the same windowed frames (engine <= 1.5 x reference asserted)
+           "outside_bare_1e-4": {k: {"n": v["n"], "frac": float(f"{v['frac']:.3g}"), "worst_dB": float(f"{v['worst']:.3g}")} for k, v in strict_excess(got, ref).items()},
+           "outside_bins_vs_fp64_fft_dB": {"psd": fmt3(vs64), "rel": fmt3(vs64_rel)}}
+    # ---- the timed path: device calls, nothing synchronised in between ----
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    eng = pkg.SpectrumEngine(fs, center, fft_size=n, decim=1, in_format=in_format, max_batch=max(chunk, n_learn), learn_frames=n_learn, flags=flags, device_id=dev.index)
+    d_iq, d_out = [], []
+    cuts = [(0, n_learn)] + [(a, min(a + chunk, nframes)) for a in range(n_learn, nframes, chunk)]  # (the learning frames as a call of their own: the calls behind it overlap)
+    for a, b in cuts:
+        x = raw[a:b]
+        d_iq.append(torch.from_numpy(x.view(np.float32) if x.dtype == np.complex64 else x).to(dev))
+        d_out.append(dict(off=torch.zeros(b - a + 1, dtype=torch.int32, device=dev), idx=torch.empty((b - a) * 1024, dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    for d, o in zip(d_iq, d_out):
+        eng.process_device(d, d.shape[0], cand_off=o["off"], cand_idx=o["idx"])
+    eng.sync()
+    st = eng.stats()
+    offs = [o["off"].cpu().numpy() for o in d_out]
+    doff = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(x) for x in offs]))]).astype(np.int32)
+    didx = np.concatenate([o["idx"].cpu().numpy()[:x[-1]] for o, x in zip(d_out, offs)])
+    eng.close()
+    a_, b_ = cand_set(doff, didx), cand_set(ref["cand_off"], ref["cand_idx"])
+    near = np.abs(ref["avg"] - np.float32(8.0)) < BAND
+    outside = [(f, i) for (f, i) in a_ ^ b_ if not near[f, i]]
+    if outside:
+        raise AssertionError(f"timed path: candidate lists differ from the reference outside the {BAND} dB band: {sorted(outside)[:6]}")
+    res["timed_path"] = {"what": f"{len(cuts)} ss_process_device calls of <= {chunk} frames, candidates only, no synchronisation in between", "reference_candidates": len(b_),
+                         "inside_1e-3_dB_band": len(a_ ^ b_), "calls_overlapped": st["calls_overlapped"], "tiles_total": st["tiles_total"],
+                         "tiles_tested": st["tiles_tested"], "tiles_culled": st["tiles_culled"], "wait_fallbacks": st["wait_fallbacks"]}
+    return res
 
 
 # ---------------------------------------------------------------------------------------------- launcher
@@ -319,6 +374,7 @@ def parse_args(argv):
     ap.add_argument("--sync-engine-first", action="store_true", help="end of the timed region as in round 2: ss_sync, then torch.cuda.synchronize() (A/B; the default lets the device-wide synchronisation do the waiting)")
     ap.add_argument("--no-also", action="store_true", help="default line only: do not append the short runs of BASELINE configs 3 and 5 (`also`)")
     ap.add_argument("--sub", action="store_true", help="(internal) this process is one of the `also` runs of another bench.py")
+    ap.add_argument("--no-parity", action="store_true", help="no parity sample beside the numbers (the `also` runs carry one each unless told otherwise)")
     args = ap.parse_args(argv)
     preset = dict(CONFIGS.get(args.config or 2, {}))
     args.cpu_only = bool(preset.pop("cpu_only", False))
@@ -337,22 +393,29 @@ def parse_args(argv):
 
 
 def also_lines():
-    """BASELINE configs 3 and 5 (one GPU each) as short runs of this script in processes of their own, appended to the default
-    line: ms_per_step, the chain's rate, and every kernel of the chain with its own duration and rate."""
+    """Beside the default line, as short runs of this script in processes of their own: the default configuration once more with
+    every averaging tile evaluated (`--no-cull`: the data-independent cost of the chain — the reference evaluates every bin of every
+    frame, transmission.cpp:88-96), and BASELINE configs 3 and 5 (one GPU each). Every entry has ms_per_step, the chain's rate, every
+    kernel of the chain with its own duration and rate, what the library says it culled (ss_get_stats), and — except the last — a
+    parity sample of its own against the reference (host path with every plane, and the timed device path in the entry's own mode)."""
     res = []
-    for cfg_no, steps, extra in ((3, 200, []), (5, 100, []), (5, 40, ["--frames", "64"])):  # (config 5 also in 64-frame calls: 35 of 64 rows are ring rows instead of all)
+    runs = ((2, 40, ["--no-cull"], "no_cull"), (3, 200, [], None), (5, 100, [], None), (5, 40, ["--frames", "64", "--no-parity"], None))  # (config 5 also in 64-frame calls: 35 of 64 rows are ring rows instead of all)
+    for cfg_no, steps, extra, variant in runs:
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg_no), "--gpus", "1", "--steps", str(steps), "--warmup", "5",
                "--preheat-ms", "150", "--no-cpu-baseline", "--sub", *extra]
         try:
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
             j = json.loads(line)
-            res.append({"baseline_config": cfg_no, "frames_per_batch": j["config"]["frames_per_batch"], "workload": j["config"]["workload"], "metric": j["metric"], "value": j["value"], "unit": j["unit"],
-                        "steps": j["steps"], "ms_per_step": j["ms_per_step"], "psd_plane_out": j["config"]["psd_plane_out"], "tile_culling": j["config"]["tile_culling"],
-                        "candidates_per_batch": j["config"]["candidates_per_batch"],
-                        "roofline_chain": j["roofline_chain"], "kernels": j["roofline"]["kernels"]})
+            entry = {"baseline_config": cfg_no, "frames_per_batch": j["config"]["frames_per_batch"], "workload": j["config"]["workload"], "metric": j["metric"], "value": j["value"], "unit": j["unit"],
+                     "steps": j["steps"], "ms_per_step": j["ms_per_step"], "psd_plane_out": j["config"]["psd_plane_out"], "tile_culling": j["config"]["tile_culling"],
+                     "tiles": j["config"].get("tiles"), "candidates_per_batch": j["config"]["candidates_per_batch"],
+                     "roofline_chain": j["roofline_chain"], "kernels": j["roofline"]["kernels"], "parity": j.get("parity")}
+            if variant:
+                entry = {"variant": variant, **entry}
+            res.append(entry)
         except Exception as e:  # the default line must not depend on these
-            res.append({"baseline_config": cfg_no, "error": f"{type(e).__name__}: {str(e)[:200]}"})
+            res.append({"baseline_config": cfg_no, **({"variant": variant} if variant else {}), "error": f"{type(e).__name__}: {str(e)[:200]}"})
     return res
 
 
@@ -501,6 +564,7 @@ def run(args):
         eng.kernel_timing(0)
     elapsed = dist.max_over_ranks(t1 - t0, device=coll_dev)
     ncand = int(outs[(counter[0] - 1) % nout]["off"][-1].item())
+    lib_stats = eng.stats()  # what the library says it did (counters from creation: learning, preheat, warm-up and the timed steps)
 
     if rank == 0:
         samples_per_step = nb * n * world
@@ -547,7 +611,12 @@ def run(args):
                        "baseline_config": args.config or 2, "fft_size": n, "frames_per_batch": nb, "bands": int(cfg["n_bands"]), "shard": args.shard if world > 1 else None,
                        "halo_frames": halo_frames, "candidates_per_batch": ncand,
                        "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "sync_every_step": bool(args.sync_every_step), "diag_lib": bool(args.diag_lib or args.lib),
-                       "tile_culling": (not args.no_cull) and (n == 8192 or n >= (1 << 20)),  # (what the product library does: 8192 points and 2^20)
+                       # read back from the library (ss_get_stats), not mirrored from its policy: is tile culling on for this context, and of the
+                       # averaging tiles of every batch so far how many went through the test and how many were proven empty and never evaluated
+                       "tile_culling": bool(lib_stats["culling"]),
+                       "tiles": {"total": lib_stats["tiles_total"], "tested": lib_stats["tiles_tested"], "culled": lib_stats["tiles_culled"],
+                                 "evaluated_frac": round(1.0 - lib_stats["tiles_culled"] / max(lib_stats["tiles_total"], 1), 4), "wait_fallbacks": lib_stats["wait_fallbacks"]},
+                       "calls": {"overlapped": lib_stats["calls_overlapped"], "in_order": lib_stats["calls_in_order"], "drains": lib_stats["drains"], "demotions": lib_stats["demotions"]},
                        "preheat_steps": preheat_steps, "input_sets": nsets, "output_sets": nout, "working_set_mib": round((nsets * in_bytes + nout * out_bytes) / 2**20, 1),
                        "dist_backend": backend if world > 1 else None, "ranks_share_devices": bool(world > ndev),
                        "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4),
@@ -573,12 +642,13 @@ def run(args):
             out["also"] = also_lines()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, fs, args.cpu_seconds)
-            try:
-                out["parity"] = parity_sample(n, fs, args.fmt)
-            except AssertionError as e:
-                out["parity"] = {"failed": str(e)[:300]}
         elif world == 1:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_parity and (not args.no_cpu_baseline or args.sub):  # (the `also` runs drop the CPU timing, not the parity sample)
+            try:
+                out["parity"] = parity_sample(n, fs, args.fmt, args.no_cull)
+            except AssertionError as e:
+                out["parity"] = {"failed": str(e)[:300]}
         print(json.dumps(out), flush=True)
 
     if world > 1:

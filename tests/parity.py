@@ -172,6 +172,40 @@ def excess_vs_fp64(iq, got_psd, ref_psd, fs, max_rows=256):
     return res
 
 
+def excess_vs_fp64_rel(iq, got_rel, ref_rel, fs, n_learn, max_rows=256):
+    """The same arbitration for the noise-relative plane (rel = dB - learned ceiling, noise_learner.cpp:55): on its bins outside the
+    bare 1e-4 tolerance, the distance of the engine and of the reference to an fp64 chain — fp64 FFT of the same windowed frames,
+    ceiling = the maximum over the first n_learn frames, subtraction in fp64. None when no bin is outside."""
+    fin = np.isfinite(ref_rel) & np.isfinite(got_rel) & (ref_rel != -100.0)
+    err = np.abs(got_rel.astype(np.float64) - ref_rel.astype(np.float64))
+    over = fin & (err > TOL * np.maximum(1.0, np.abs(ref_rel)))
+    rows = np.flatnonzero(over.any(axis=1))
+    if rows.size == 0 or n_learn <= 0:
+        return None
+    if rows.size > max_rows:
+        rows = rows[np.linspace(0, rows.size - 1, max_rows).astype(int)]
+    thr = fp64_psd_rows(iq[:n_learn], fs).max(axis=0)
+    truth = fp64_psd_rows(iq[rows], fs) - thr[None, :]
+    m = over[rows]
+    de = np.abs(got_rel[rows].astype(np.float64) - truth)[m]
+    dr = np.abs(ref_rel[rows].astype(np.float64) - truth)[m]
+    res = {"bins": int(m.sum()), "frames": int(rows.size), "engine_rms": float(np.sqrt(np.mean(de ** 2))), "reference_rms": float(np.sqrt(np.mean(dr ** 2))),
+           "engine_max": float(de.max()), "reference_max": float(dr.max())}
+    assert res["engine_rms"] <= 1.5 * res["reference_rms"] + 1e-6, res
+    return res
+
+
+def linear_power_error(got_psd, ref_psd):
+    """north_star's own wording — "per-bin power within 1e-4 relative" — on LINEAR power |X|^2 / fs: |10^((got - ref) / 10) - 1| over the
+    ordinary bins, p50 / p99.9 / max, and the share of bins above 1e-4 (the deep nulls two correct fp32 FFTs disagree on)."""
+    fin = np.isfinite(ref_psd) & np.isfinite(got_psd)
+    d = got_psd[fin].astype(np.float64) - ref_psd[fin].astype(np.float64)
+    r = np.abs(np.expm1(d * (np.log(10.0) / 10.0)))
+    if r.size == 0:
+        return None
+    return {"p50": float(np.quantile(r, 0.5)), "p99.9": float(np.quantile(r, 0.999)), "max": float(r.max()), "frac_above_1e-4": float((r > 1e-4).mean())}
+
+
 def format_excess(ex, vs64=None):
     s = "; ".join(f"{k} {v['n']} bins ({100.0 * v['frac']:.3f} %) worst {v['worst']:.1e}" for k, v in ex.items())
     if vs64:
