@@ -1,6 +1,6 @@
 // fft8192_v2.h — second generation of the N = 8192 front end (BASELINE.json configs 1/2/4).
 //
-// Same contract and the same three register passes as k_fft8192_psd_w8 in fft8192_kernel.h (Decimator + fft_v(Hamming,
+// Same contract and the same three register passes as the round-1 kernel (scripts/ubench/fft8192_round1.h) (Decimator + fft_v(Hamming,
 // forward, shift) + PSD::work; reference sources/radio/blocks/decimator.h:15-22, sources/radio/sdr_device.cpp:164,
 // sources/radio/blocks/psd.cpp:18-20). What changes is WHERE the twiddle factors come from.
 //
@@ -386,15 +386,6 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
     __syncthreads();
     *hdr = __builtin_amdgcn_readfirstlane(__float_as_int(*hint_slot));
   }
-}
-
-// Stand-alone launch, one frame per workgroup (scripts/ubench/fft8192_lab; the product runs fft8192_v2_frame as a role of
-// k_scan_step, scan_step.h).
-template <int FMT, int TW, bool SWZ = false, bool NOWIN = false>
-__global__ __launch_bounds__(512, 8) void k_fft8192_psd_v2(Fft8192Args g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  int hdr;
-  fft8192_v2_frame<FMT, TW, SWZ, NOWIN>(g, blockIdx.x, smem_raw, (int)threadIdx.x, &hdr);
 }
 
 }  // namespace ss

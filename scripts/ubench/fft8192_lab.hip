@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "../../rtl-sdr-scanner-cpp_amd/csrc/fft8192_v2.h"
+#include "fft8192_round1.h"
 
 #define CK(x)                                                                         \
   do {                                                                                \
