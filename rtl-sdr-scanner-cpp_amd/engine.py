@@ -47,10 +47,11 @@ def load_library(diag: bool | None = None) -> C.CDLL:
         lib.ss_flush.restype = C.c_int
         lib.ss_stream.argtypes = [C.c_void_p]
         lib.ss_stream.restype = C.c_void_p
-        lib.ss_get_stats.argtypes = [C.c_void_p, C.POINTER(abi.SsStats)]
-        lib.ss_get_stats.restype = C.c_int
-        lib.ss_input_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
-        lib.ss_input_wait.restype = C.c_int
+        if hasattr(lib, "ss_get_stats"):  # (A/B builds of older trees, scripts/ab: measurement runs only)
+            lib.ss_get_stats.argtypes = [C.c_void_p, C.POINTER(abi.SsStats)]
+            lib.ss_get_stats.restype = C.c_int
+            lib.ss_input_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+            lib.ss_input_wait.restype = C.c_int
         lib.ss_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         lib.ss_kernel_timing.restype = C.c_int
         lib.ss_kernel_timing_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
@@ -139,7 +140,8 @@ class SpectrumEngine(abi.Chain):
         wait_fallbacks — as far as the device has got: sync() first for exact figures). `state` is decoded into booleans."""
         st = abi.SsStats()
         st.size = C.sizeof(abi.SsStats)
-        self._check(self._lib.ss_get_stats(self._h, C.byref(st)))
+        if hasattr(self._lib, "ss_get_stats"):
+            self._check(self._lib.ss_get_stats(self._h, C.byref(st)))
         out = {k: int(getattr(st, k)) for k, _ in abi.SsStats._fields_ if k not in ("size", "state")}
         out.update(culling=bool(st.state & abi.SS_STATE_CULLING), overlap=bool(st.state & abi.SS_STATE_OVERLAP),
                    demoted=bool(st.state & abi.SS_STATE_DEMOTED), eager=bool(st.state & abi.SS_STATE_EAGER))

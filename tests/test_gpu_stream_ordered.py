@@ -38,6 +38,7 @@ def _compare(got_psd, got_off, got_idx, ref, what):
 @pytest.mark.parametrize("n,fs,nb,ncalls,fmt", [(8192, 2_048_000, 256, 8, "cf32"), (65536, 20_000_000, 32, 5, "cs8")])
 def test_stream_ordered_producer_and_consumer_on_the_chains_stream(ref_mod, n, fs, nb, ncalls, fmt):
     import torch
+    import hipapi
     dev = torch.device("cuda", 0)
     band = pkg.synth.SyntheticBand(n, seed=61, on_frame=130, off_frame=nb * ncalls - 40)
     total = nb * ncalls
@@ -52,7 +53,7 @@ def test_stream_ordered_producer_and_consumer_on_the_chains_stream(ref_mod, n, f
     ref = _ref(ref_mod, n, fs, iq, t)
     eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, max_batch=nb, learn_frames=101, flags=pkg.abi.SS_FLAG_STREAM_ORDERED,
                              in_format=pkg.abi.SS_FMT_CS8 if fmt == "cs8" else pkg.abi.SS_FMT_CF32)
-    s = torch.cuda.ExternalStream(eng.stream_handle, device=dev)
+    s = eng.stream_handle
     d_iq = torch.empty_like(host[:nb], device=dev)  # ONE input buffer, ONE output set: refilled / copied away on the chain's stream
     d_psd = torch.empty((nb, n), dtype=torch.float32, device=dev)
     d_off = torch.zeros(nb + 1, dtype=torch.int32, device=dev)
@@ -61,24 +62,26 @@ def test_stream_ordered_producer_and_consumer_on_the_chains_stream(ref_mod, n, f
     h_off = torch.empty((ncalls, nb + 1), dtype=torch.int32).pin_memory()
     h_idx = torch.empty((ncalls, nb * 1024), dtype=torch.int32).pin_memory()
     torch.cuda.synchronize()
-    with torch.cuda.stream(s):
-        for k in range(ncalls):
-            d_iq.copy_(host[k * nb:(k + 1) * nb], non_blocking=True)       # producer: ordered behind the previous call's last read
-            eng.process_device(d_iq, nb, psd=d_psd, cand_off=d_off, cand_idx=d_idx)
-            h_psd[k].copy_(d_psd, non_blocking=True)                      # consumer: ordered behind every stage of this call
-            h_off[k].copy_(d_off, non_blocking=True)
-            h_idx[k].copy_(d_idx, non_blocking=True)
-    s.synchronize()  # (not ss_sync: a plain wait for the stream)
+    in_bytes = host[:nb].numel() * host.element_size()
+    for k in range(ncalls):
+        hipapi.copy_async(d_iq.data_ptr(), host[k * nb:(k + 1) * nb].data_ptr(), in_bytes, hipapi.H2D, s)  # producer: ordered behind the previous call's last read
+        eng.process_device(d_iq, nb, psd=d_psd, cand_off=d_off, cand_idx=d_idx)
+        hipapi.copy_async(h_psd[k].data_ptr(), d_psd.data_ptr(), nb * n * 4, hipapi.D2H, s)               # consumer: ordered behind every stage of this call
+        hipapi.copy_async(h_off[k].data_ptr(), d_off.data_ptr(), (nb + 1) * 4, hipapi.D2H, s)
+        hipapi.copy_async(h_idx[k].data_ptr(), d_idx.data_ptr(), nb * 1024 * 4, hipapi.D2H, s)
+    hipapi.stream_sync(s)  # (not ss_sync: a plain wait for the stream)
     counts = np.concatenate([np.diff(h_off[k].numpy()) for k in range(ncalls)])
     off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
     idx = np.concatenate([h_idx[k].numpy()[:h_off[k].numpy()[-1]] for k in range(ncalls)])
     _compare(h_psd.numpy().reshape(total, n), off, idx, ref, f"SS_FLAG_STREAM_ORDERED, {n} points, {ncalls} x {nb} frames through one buffer set")
     st = eng.stats()
     assert st["calls_overlapped"] == 0 and st["calls_in_order"] == ncalls and not st["overlap"], st
+    eng.close()
 
 
 def test_input_wait_lets_a_producer_rotate_three_buffers_under_overlapped_calls(ref_mod):
     import torch
+    import hipapi
     dev = torch.device("cuda", 0)
     n, fs, nb, ncalls, m = 8192, 2_048_000, 256, 14, 3
     band = pkg.synth.SyntheticBand(n, seed=62, on_frame=130, off_frame=nb * ncalls - 40)
@@ -88,21 +91,22 @@ def test_input_wait_lets_a_producer_rotate_three_buffers_under_overlapped_calls(
     ref = _ref(ref_mod, n, fs, iq, t)
     host = torch.from_numpy(iq.view(np.float32)).pin_memory()
     eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, max_batch=nb, learn_frames=101)
-    chain = torch.cuda.ExternalStream(eng.stream_handle, device=dev)
-    prod = torch.cuda.Stream(device=dev)
+    chain = eng.stream_handle
+    prod, ev = hipapi.stream_create(), hipapi.event_create()
     bufs = [torch.empty_like(host[:nb], device=dev) for _ in range(m)]
     outs = [dict(psd=torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
                  idx=torch.empty(nb * 1024, dtype=torch.int32, device=dev)) for _ in range(ncalls)]
     torch.cuda.synchronize()
+    in_bytes = host[:nb].numel() * host.element_size()
     for k in range(ncalls):
         if k >= m:
-            eng.input_wait(prod.cuda_stream, m - 1)  # buffer k mod m held call k - m: dead once call k - m + 1's launch has read its tail
-        with torch.cuda.stream(prod):
-            bufs[k % m].copy_(host[k * nb:(k + 1) * nb], non_blocking=True)
-        chain.wait_stream(prod)  # work on ss_stream before a call (the producer of d_iq) is waited for by the call
+            eng.input_wait(prod, m - 1)  # buffer k mod m held call k - m: dead once call k - m + 1's launch has read its tail
+        hipapi.copy_async(bufs[k % m].data_ptr(), host[k * nb:(k + 1) * nb].data_ptr(), in_bytes, hipapi.H2D, prod)
+        hipapi.stream_wait_stream(chain, prod, ev)  # work on ss_stream before a call (the producer of d_iq) is waited for by the call
         o = outs[k]
         eng.process_device(bufs[k % m], nb, psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"])
     eng.sync()
+    hipapi.stream_sync(prod)
     st = eng.stats()
     assert st["calls_overlapped"] >= ncalls - 2 and not st["demoted"], st  # (the learning call runs in order)
     offs = [o["off"].cpu().numpy() for o in outs]
@@ -111,3 +115,6 @@ def test_input_wait_lets_a_producer_rotate_three_buffers_under_overlapped_calls(
     idx = np.concatenate([o["idx"].cpu().numpy()[:x[-1]] for o, x in zip(outs, offs)])
     psd = np.concatenate([o["psd"].cpu().numpy() for o in outs])
     _compare(psd, off, idx, ref, f"ss_input_wait: {ncalls} x {nb} frames, {m} input buffers refilled in flight")
+    eng.close()
+    hipapi.event_destroy(ev)
+    hipapi.stream_destroy(prod)
