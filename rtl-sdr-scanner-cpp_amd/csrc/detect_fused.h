@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include "detect_kernels.h"
+#include "fft1024_kernels.h"
 #include "fft256_kernels.h"
 #include "fft8192_v2.h"
 
@@ -81,12 +82,16 @@ enum { kStatTested = 0, kStatCulled = 1, kStatWaitFallbacks = 2, kStatWords = 4 
 // s / D for a compile-time integer D, correctly rounded like the reference's `sum / count`
 // (float / int -> IEEE division): q0 = s * RN(1/D), one Newton correction with exact residuals (FMA).
 // Verified against the hardware division for every finite float by ss_selftest (tests/test_gpu_selftest.py).
+// An infinite sum (a -inf dB row inside the window: a frame of zeros) stays the infinity the IEEE division gives — the residual
+// inf - inf is not a number, and then the first quotient is the answer (round 4: until then the engine's avg plane held NaN where
+// the reference's holds -inf; no candidate either way).
 template <int D>
 __device__ __forceinline__ float div_const(float s) {
   constexpr float r = 1.0f / (float)D;
   const float q0 = s * r;
   const float e = fmaf(-(float)D, q0, s);
-  return fmaf(e, r, q0);
+  const float q1 = fmaf(e, r, q0);
+  return q1 == q1 ? q1 : q0;
 }
 
 template <int G, int GX, int TF, int TB_ = 256>
@@ -472,6 +477,9 @@ struct PlanLongArgs {
   int cols;       // C: tile columns per workgroup
   int logn;
   int* list;
+  // 0: the ring holds dB values where k_fft_rows256_psd puts them (rows_smax_index); 1: 2^20 points in two passes
+  // (fft1024_kernels.h): max_key values at rows1024_smax_index(run) — [k1 group][k2], gathered by atomic maxima
+  int layout;
 };
 constexpr int kPlanLongFloats = 8192;  // LDS of a plan workgroup: C x (16 nft + 20) values of M
 __host__ __device__ inline int plan_long_cols(int nframes, int shift, int tile_cols) {  // 0: the stage cannot be planned
@@ -497,8 +505,14 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
   // this workgroup's C tile columns: the ones whose run maxima lie side by side in a frame's row of smax (rows_smax_index: the
   // same c, consecutive d) — any C columns would do, these are read with 32-byte requests instead of 4-byte ones
   const int C = p.cols, lognsub = p.logn - 16;
-  const int wc = (int)blockIdx.x & ((1 << lognsub) - 1), d0 = ((int)blockIdx.x >> lognsub) * C;
-  const auto column = [&](int i) { return d0 + i < 256 ? (wc + ((d0 + i) << lognsub)) ^ (tiles_per_row >> 1) : tiles_per_row; };
+  // layout 0: workgroup (wc, d0) takes the columns whose unshifted number is wc + nsub d; layout 1: the columns 4 k2 + wc of C
+  // consecutive k2 — either way the ones whose maxima lie side by side in a frame's row of the ring
+  const int wc = p.layout ? (int)blockIdx.x & 3 : (int)blockIdx.x & ((1 << lognsub) - 1);
+  const int d0 = (p.layout ? (int)blockIdx.x >> 2 : (int)blockIdx.x >> lognsub) * C;
+  const auto column = [&](int i) {
+    if (p.layout) return d0 + i < 1024 ? 4 * (d0 + i) + wc : tiles_per_row;
+    return d0 + i < 256 ? (wc + ((d0 + i) << lognsub)) ^ (tiles_per_row >> 1) : tiles_per_row;
+  };
   for (int e = tid; e < C * rows; e += 256) {
     const int i = e % C, r = e / C, col = column(i);
     float m = -__builtin_inff();
@@ -507,10 +521,18 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
       const float* row = p.smax + ((size_t)((p.abs0 + frame) & p.smax_mask) * groups);
       // the column's eight runs, the last run of the column below and the first of the one above (the band's edges: its own once more)
       float v[10];
+      if (p.layout) {
+        const unsigned* krow = reinterpret_cast<const unsigned*>(row);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v[g] = max_key_value(krow[rows1024_smax_index(8 * col + g)]);
+        v[8] = max_key_value(krow[rows1024_smax_index(col > 0 ? 8 * col - 1 : 8 * col)]);
+        v[9] = max_key_value(krow[rows1024_smax_index(col + 1 < tiles_per_row ? 8 * col + 8 : 8 * col + 7)]);
+      } else {
 #pragma unroll
       for (int g = 0; g < 8; ++g) v[g] = row[rows_smax_index(col, g, p.logn)];
       v[8] = row[col > 0 ? rows_smax_index(col - 1, 7, p.logn) : rows_smax_index(col, 0, p.logn)];
       v[9] = row[col + 1 < tiles_per_row ? rows_smax_index(col + 1, 0, p.logn) : rows_smax_index(col, 7, p.logn)];
+      }
       bool bad = false;
 #pragma unroll
       for (int g = 0; g < 10; ++g) {

@@ -1,0 +1,267 @@
+// fft1024_kernels.h — TWO-pass front end for N = 2^20 = 1024 x 1024 (BASELINE.json config 5: 1M-point FFT at 61.44 MS/s).
+//
+// Same contract as the kernels of fft256_kernels.h (Decimator + fft_v(Hamming, forward, shift) + PSD::work: reference
+// sources/radio/blocks/decimator.h:15-22, sources/radio/sdr_device.cpp:164, sources/radio/blocks/psd.cpp:18-20). Until round 3 a
+// 2^20-point frame took three passes over a 128 MiB work buffer (256-point columns, a radix-16 step, 256-point rows: 32 B per sample
+// of work-buffer traffic on top of the 8 + 4 that are the job). Here it takes two:
+//   n = n1 * 1024 + n2,  k = k1 + 1024 * k2
+//   step A (k_fft_cols1024):      for every n2 the 1024-point FFT over n1, times W_N^(n2 k1)   -> work[k1 * 1024 + n2]
+//   step B (k_fft_rows1024_psd):  for every k1 the 1024-point FFT over n2 -> X[k1 + 1024 k2]   -> dB
+// What a workgroup of 8192 points can do about coalescing is bounded — C columns in and R rows out with C * R = 64 — so both
+// kernels sit in the middle: the column tiles are 8 columns wide (64-byte runs of CF32 in, 64-byte runs of the work buffer out),
+// the row tiles 8 rows (32-byte runs of dB values out), and the block index is decoded so that the tiles that share a 128-byte
+// line run on the same XCD at about the same time (block b runs on XCD b mod 8 — observed, not promised: it only matters for speed)
+// and meet in that XCD's L2.
+//
+// A 1024-point FFT in registers is four interleaved 256-point FFTs (fft256_passes: two radix-16 passes, one exchange) and a
+// radix-4 step across them — n = 4 m + q: X[k' + 256 kap] = sum_q W_4^(q kap) W_1024^(q k') Z_q[k'] — with a second exchange
+// through LDS in between, the shape of k_fft256xR_psd<., 2>. 16 points per thread, 512 threads, <= 61 VGPRs, 39-40 KiB of LDS (the
+// W_256 and W_1024 tables sit there too: a table read from global memory waits behind the CU's streaming loads, fft8192_v2.h):
+// four workgroups per CU, and the column tile is the FFT role of k_scan_step (KIND 3) like the 256-point column tiles of the
+// other long transforms, the deferred detect / emit stages of earlier calls riding on its launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft256_kernels.h"
+
+namespace ss {
+
+constexpr int kFft1024Pitch2 = 261;  // second exchange of the column tiles, [sub][k']: 5 mod 32 — writers (lanes along sub) conflict-free, readers (8 columns x 4 k') two-way at worst
+constexpr int kFft1024ColsPlaneBytes = 32 * kFft256PitchCols * 4;                 // 34 944 (>= 32 x 261 words)
+constexpr int kFft1024RowsPlaneBytes = 1024 * 9 * 4;                              // 36 864: the read-out tile [k2][row], pitch 9 (>= 32 x 273 words)
+constexpr int kFft1024TableBytes = (256 + 256) * 8;                               // W_256 [16][16], then W_1024^k' [256]
+constexpr int kFft1024ColsLdsBytes = kFft1024ColsPlaneBytes + kFft1024TableBytes; // 39 040: fits k_scan_step's 39 936 (the column tiles are its FFT role, KIND 3)
+constexpr int kFft1024RowsLdsBytes = kFft1024RowsPlaneBytes + kFft1024TableBytes; // 40 960: four workgroups per CU, to the byte
+static_assert(32 * kFft1024Pitch2 * 4 <= kFft1024ColsPlaneBytes && 32 * kFft256PitchCols * 4 <= kFft1024RowsPlaneBytes, "exchange planes");
+constexpr int kFft1024TwA = 0, kFft1024TwB = 64 * 1024, kFft1024Tw1024 = 66 * 1024, kFft1024TableEntries = 66 * 1024 + 256;  // offsets into ColsArgs::twc
+
+// Host side: the tables of both kernels in one block of kFft1024TableEntries entries (double precision, rounded once).
+//   [kFft1024TwA]    [64][1024] W_N^(n2 h)                  step-A twiddle W_N^(n2 k1), k1 = h + 64 u + 256 kap, factored as
+//   [kFft1024TwB]    [2][1024]  W_N^(64 n2), W_N^(256 n2)   W_N^(n2 h) * (W_N^(64 n2))^u * (W_N^(256 n2))^kap
+//   [kFft1024Tw1024] [256]      W_1024^k'                   (the radix-4 step's W_1024^(q k') are its first three powers)
+inline void fft1024_host_tables(float2* tab) {
+  const auto W = [](double num, double den) {
+    const double ang = -2.0 * 3.14159265358979323846 * num / den;
+    return make_float2((float)cos(ang), (float)sin(ang));
+  };
+  const double n = 1048576.0;
+  for (int h = 0; h < 64; ++h)
+    for (int n2 = 0; n2 < 1024; ++n2) tab[kFft1024TwA + h * 1024 + n2] = W((double)n2 * h, n);
+  for (int n2 = 0; n2 < 1024; ++n2) {
+    tab[kFft1024TwB + n2] = W(64.0 * n2, n);
+    tab[kFft1024TwB + 1024 + n2] = W(256.0 * n2, n);
+  }
+  for (int k = 0; k < 256; ++k) tab[kFft1024Tw1024 + k] = W((double)k, 1024.0);
+}
+
+// One column tile: 8 columns x 1024 rows; `block` = frame * 128 + w. XCD (w mod 8) takes the 16 neighbouring tiles
+// [16 (w mod 8), 16 (w mod 8) + 16): two tiles that share the 128-byte lines of the frame and of the work buffer are consecutive
+// blocks of one XCD. `g`: ColsArgs of fft256_kernels.h with twc = the block of fft1024_host_tables (logn2 is 10).
+template <int FMT>
+__device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, unsigned char* __restrict__ smem_raw, int t) {
+  float* s = reinterpret_cast<float*>(smem_raw);
+  float2* tw_lds = reinterpret_cast<float2*>(smem_raw + kFft1024ColsPlaneBytes);
+  float2* tw1024_lds = tw_lds + 256;
+  tw_lds[t] = t < 256 ? g.tw256[t] : g.twc[kFft1024Tw1024 + t - 256];  // (tw_lds and tw1024_lds are contiguous: entries 0..511)
+  const int f = block >> 7, w = block & 127;
+  const int tile = ((w & 7) << 4) | (w >> 3);
+  const int c0 = tile << 3;
+  // tile culling: the run maxima of a frame are gathered by atomic maxima in the rows kernel, so the frame's row of the ring
+  // starts from zero — cleared here, one launch earlier
+  if (g.smax && t < 256) g.smax[((size_t)((g.abs0 + f) & g.smax_mask) << 15) + (tile << 8) + t] = 0u;
+  // after the second exchange thread t owns column c2 and the outputs k1 = h + 64 u + 256 kap: its step-A twiddles are asked for
+  // first, ahead of the frame's own loads in the vector-memory queue
+  const int c2 = t & 7, h = t >> 3;
+  const int n2b = c0 + c2;
+  float2 pu = g.twc[kFft1024TwA + (h << 10) + n2b];
+  const float2 t64 = g.twc[kFft1024TwB + n2b], g1 = g.twc[kFft1024TwB + 1024 + n2b];
+  // first half: sub-sequence q of column c, butterfly j of its 256-point FFT — sample n1 = 4 (j + 16 r) + q of column c0 + c
+  const int sub = t & 31, j = t >> 5;
+  const int c = sub & 7, q = sub >> 3;
+  constexpr int kIn = FMT == FMT_CF32 ? 8 : 2;
+  const uint32_t tn = ((uint32_t)(4 * j + q) << 10) + (uint32_t)(c0 + c);
+  const __amdgpu_buffer_rsrc_t rin = buffer_of(reinterpret_cast<const char*>(g.iq) + (size_t)f * (size_t)g.item_stride * kIn, (1 << 20) * kIn);
+  const __amdgpu_buffer_rsrc_t rwin = buffer_of(g.win, (1 << 20) * 4);
+  float2 a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float2 x;
+    if constexpr (FMT == FMT_CF32) {
+      x = buffer_load_f2<2>(rin, (int)(tn * 8u), r * (65536 * 8));
+    } else {
+      const unsigned short raw = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rin, (int)(tn * 2u), r * (65536 * 2), 2);
+      if constexpr (FMT == FMT_CS8) x = make_float2((float)(signed char)(raw & 0xff) * g.scale, (float)(signed char)(raw >> 8) * g.scale);
+      else x = make_float2(((float)(raw & 0xff) - 127.5f) * g.scale, ((float)(raw >> 8) - 127.5f) * g.scale);
+    }
+    const float wv = buffer_load_f1(rwin, (int)(tn * 4u), r * (65536 * 4));
+    a[r] = make_float2(x.x * wv, x.y * wv);  // volk_32fc_32f_multiply_32fc
+  }
+  float2 cc[16];
+  fft256_passes<kFft256PitchCols>(a, cc, s, tw_lds, sub, j);  // Z_q[j + 16 k] of column c in cc[slot16(k)]
+  __syncthreads();
+  // second exchange: Z_q[k'] of column c to word (c + 8 q) * 261 + k'; thread (c2, h) reads its four q's for k' = h + 64 u
+  float* zp = s + sub * kFft1024Pitch2 + j;
+  const float* zr = s + c2 * kFft1024Pitch2 + h;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) zp[16 * k] = cc[slot16(k)].x;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) a[4 * u + qq].x = zr[8 * qq * kFft1024Pitch2 + 64 * u];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) zp[16 * k] = cc[slot16(k)].y;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float2 w1 = tw1024_lds[h + 64 * u], w2 = cmul(w1, w1), w3 = cmul(w2, w1);  // W_1024^(q k'), q = 1, 2, 3
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const float2 v = make_float2(a[4 * u + qq].x, zr[8 * qq * kFft1024Pitch2 + 64 * u]);
+      a[4 * u + qq] = qq == 0 ? v : cmul(v, qq == 1 ? w1 : qq == 2 ? w2 : w3);
+    }
+    dft4(a[4 * u], a[4 * u + 1], a[4 * u + 2], a[4 * u + 3]);  // Y[h + 64 u + 256 kap] in a[4 u + kap]
+  }
+  // step-A twiddle W_N^(n2 k1) and out: work[k1 * 1024 + n2], lanes along the 8 columns (64-byte runs)
+  const float2 g2 = cmul(g1, g1), g3 = cmul(g2, g1);
+  const __amdgpu_buffer_rsrc_t rw = buffer_of(g.work + ((size_t)f << 20), (1 << 20) * 8);
+  const int voff = ((h << 10) + n2b) * 8;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+#pragma unroll
+    for (int kap = 0; kap < 4; ++kap) {
+      const float2 tw = kap == 0 ? pu : cmul(pu, kap == 1 ? g1 : kap == 2 ? g2 : g3);
+      const float2 y = cmul(a[4 * u + kap], tw);
+      __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned*>(&y), rw, voff, ((64 * u + 256 * kap) << 10) * 8, 0);
+    }
+    if (u < 3) pu = cmul(pu, t64);
+  }
+}
+
+// Stand-alone launch (contexts without the step kernel: learning is launched through k_scan_step too).
+template <int FMT>
+__global__ __launch_bounds__(512, 8) void k_fft_cols1024(ColsArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  fft_cols1024_tile<FMT>(g, (int)blockIdx.x, smem_raw, (int)threadIdx.x);
+}
+
+// An order-preserving key for atomic maxima of dB values: larger float <-> larger unsigned; 0 = nothing seen (below -inf),
+// 0xffffffff = NaN (wins: "cannot be bounded").
+__device__ __forceinline__ unsigned max_key(float x) {
+  const unsigned u = __float_as_uint(x);
+  return x != x ? 0xffffffffu : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+}
+__device__ __forceinline__ float max_key_value(unsigned key) {
+  if (key == 0u) return -__builtin_inff();
+  if (key == 0xffffffffu) return __builtin_nanf("");
+  return __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+}
+// where the maximum of 32-bin run R (= bin >> 5, output order: DC in the middle) lies in a frame's row of the ring: the rows
+// kernel's lanes run along k2, so [k1 group][k2] makes its atomics contiguous
+__host__ __device__ inline int rows1024_smax_index(int run) { return ((run & 31) << 10) | (run >> 5); }
+
+struct Rows1024Args {
+  const float2* work;
+  const float2* tw256;
+  const float2* tw1024;  // W_1024^k' [256]
+  float db_off;
+  float* psd;  // null: no dB plane wanted (detect mode with calls shorter than the averager ring: the ring rows are all there is)
+  RowsExtra x; // (smax holds max_key values here)
+};
+
+// One row tile: 8 rows k1 x 1024 points. blockIdx = ((f * 16) + v) * 8 + x: XCD x takes rows [128 x, 128 x + 128) of every
+// frame, v its 16 tiles in turn — the four tiles that fill the 128-byte lines of the dB plane (32 consecutive k1 for every k2)
+// are consecutive blocks of one XCD.
+__global__ __launch_bounds__(512, 8) void k_fft_rows1024_psd(Rows1024Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* s = reinterpret_cast<float*>(smem_raw);
+  float2* tw_lds = reinterpret_cast<float2*>(smem_raw + kFft1024RowsPlaneBytes);
+  float2* tw1024_lds = tw_lds + 256;
+  const int t = threadIdx.x;
+  tw_lds[t] = t < 256 ? g.tw256[t] : g.tw1024[t - 256];
+  const RowsExtra& x = g.x;
+  if (x.zero_word && blockIdx.x == 0 && t == 0) *x.zero_word = 0;
+  const int xc = (int)blockIdx.x & 7, v = (int)blockIdx.x >> 3;
+  const int f = v >> 4, r0 = (xc << 7) + ((v & 15) << 3);
+  const int fl = t >> 6, tt = t & 63;
+  const int q = tt & 3, j = tt >> 2;
+  const float2* row = g.work + ((size_t)f << 20) + ((size_t)(r0 + fl) << 10);
+  float2 a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = row[tt + 64 * r];
+  float2 c[16];
+  const int sub = (fl << 2) | q;
+  fft256_passes<kFft256PitchCols>(a, c, s, tw_lds, sub, j);
+  __syncthreads();
+  float* zp = s + sub * 257 + j;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) zp[16 * k] = c[slot16(k)].x;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int p = t + 512 * u;
+    const float* zr = s + ((p >> 8) << 2) * 257 + (p & 255);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) a[u * 4 + qq].x = zr[qq * 257];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) zp[16 * k] = c[slot16(k)].y;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int p = t + 512 * u;
+    const int kp = p & 255;
+    const float* zr = s + ((p >> 8) << 2) * 257 + kp;
+    const float2 w1 = tw1024_lds[kp], w2 = cmul(w1, w1), w3 = cmul(w2, w1);  // W_1024^(q k'), q = 1, 2, 3
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const float2 vv = make_float2(a[u * 4 + qq].x, zr[qq * 257]);
+      a[u * 4 + qq] = qq == 0 ? vv : cmul(vv, qq == 1 ? w1 : qq == 2 ? w2 : w3);
+    }
+    dft4(a[4 * u], a[4 * u + 1], a[4 * u + 2], a[4 * u + 3]);  // X_row[kp + 256 kap] in a[4 u + kap]
+  }
+  float dbv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dbv[i] = psd_db(a[i], g.db_off);
+  __syncthreads();  // every Z read is done before the plane is reused for the read-out
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int p = t + 512 * u;
+#pragma unroll
+    for (int kap = 0; kap < 4; ++kap) s[((p & 255) + 256 * kap) * 9 + (p >> 8)] = dbv[u * 4 + kap];
+  }
+  __syncthreads();
+  constexpr int half = 1 << 19;
+  if (x.smax) {  // the largest dB value of this tile's 8 rows for every k2: a quarter of the 32-bin run (r0 / 32, k2)
+    unsigned* srow = reinterpret_cast<unsigned*>(x.smax) + ((size_t)((x.abs0 + f) & x.smax_mask) << 15);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k2 = t + 512 * e;
+      float m = s[k2 * 9];
+      bool bad = m != m;
+#pragma unroll
+      for (int r = 1; r < 8; ++r) {
+        const float vv = s[k2 * 9 + r];
+        bad = bad || (vv != vv);
+        m = fmaxf(m, vv);
+      }
+      atomicMax(&srow[rows1024_smax_index((((r0 + (k2 << 10)) ^ half) >> 5))], bad ? 0xffffffffu : max_key(m));
+    }
+  }
+  float* out = g.psd ? g.psd + ((size_t)f << 20) : nullptr;
+  float* hrow = (x.hist_out && f >= x.first_hist) ? x.hist_out + ((size_t)(f - x.first_hist) << 20) : nullptr;  // (workgroup-uniform)
+  const int rr = t & 7, kb = t >> 3;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k2 = kb + 64 * i;
+    const int bin = ((r0 + rr) + (k2 << 10)) ^ half;  // fft_v shift=true: X[k] lands at k ^ (N/2)
+    const float vv = s[k2 * 9 + rr];
+    if (out) out[bin] = vv;
+    if (hrow) hrow[bin] = vv - x.thr[bin];  // noise_learner.cpp:55, as detect_tile forms it
+  }
+}
+
+}  // namespace ss

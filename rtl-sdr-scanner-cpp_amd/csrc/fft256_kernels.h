@@ -69,6 +69,10 @@ struct ColsArgs {
   float scale;
   float2* work;
   int logn2;
+  // N = 1024 x 1024 (fft1024_kernels.h): twc is the block of fft1024_host_tables; with tile culling the column tiles clear the
+  // frame's row of the run-maxima ring (null: nothing to clear)
+  unsigned* smax;
+  int smax_mask, abs0;
 };
 
 // One column tile (32 columns x 256 rows) by one workgroup of 512 threads; `block` = frame * (N2 / 32) + tile.

@@ -40,6 +40,7 @@
 #include <stdint.h>
 
 #include "detect_fused.h"
+#include "fft1024_kernels.h"
 #include "fft256_kernels.h"
 #include "fft8192_v2.h"
 
@@ -52,7 +53,7 @@ struct StepArgs {
   const void* halo_iq;  // first of those frames
   float* halo_psd;      // [n_halo][8192]
   int n_halo;
-  ColsArgs cols;    // KIND 1, 2: 256-point column tiles of a long transform (fft256_kernels.h)
+  ColsArgs cols;    // KIND 1, 2: 256-point column tiles of a long transform (fft256_kernels.h); KIND 3: 1024-point column tiles of a 2^20-point frame (fft1024_kernels.h)
   DetectArgs det;
   EmitArgs emit;
   int n_fft;   // frames (KIND 0, n_halo included) or column tiles (KIND 1) of the FFT role (0: role absent)
@@ -96,7 +97,7 @@ constexpr int kStepThreads = 512;
 constexpr int kStepLdsBytes = kFft8192V2LdsBytes;
 static_assert(2 * (16 * DetectTile<21, 21, 16, 256>::P * 4 + 64) <= kFft8192V2LdsBytes, "two detect tiles per workgroup");
 static_assert((8 * kEmitList + 9) * 4 <= kFft8192V2LdsBytes, "eight emit lists per workgroup");
-static_assert(kFft256ColsLdsBytes <= kFft8192V2LdsBytes, "a column tile");
+static_assert(kFft256ColsLdsBytes <= kFft8192V2LdsBytes && kFft1024ColsLdsBytes <= kFft8192V2LdsBytes, "a column tile");
 static_assert((kPlanLdsFloats + 64) * 4 <= kFft8192V2LdsBytes, "a plan workgroup's staging area");
 __host__ __device__ inline int step_fft_wgs(const StepArgs& a) { return a.n_fft; }
 __host__ __device__ inline int step_emit_wgs(const StepArgs& a) { return a.emit_per_wg == 1 ? a.n_emit : (a.n_emit + 7) / 8; }
@@ -124,7 +125,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
   // the plan workgroup in vain (detect_fused.h: nothing in a launch waits without bound)
   int consumer = -1, word = 0, plan_seg = -1;
   if (role == ROLE_EMIT) {
-    if constexpr (KIND == 2) {
+    if constexpr (KIND >= 2) {
       // ---- emit role, long rows: the eight waves share one frame ----
       cand_emit_frame_wide<8>(a.emit, item, tid, reinterpret_cast<int*>(smem_raw));
     } else {
@@ -152,8 +153,9 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     if (a.hint_mode == 3) plan_seg = -1;  // test switch: the plan workgroups never publish anything — every consumer has to help itself
 #endif
   } else if constexpr (KIND >= 1) {
-    // ---- FFT role, long transforms: one tile of 32 columns ----
-    fft_cols256_tile<FMT>(a.cols, item, smem_raw, tid);
+    // ---- FFT role, long transforms: one tile of 32 columns x 256 rows (KIND 3: 8 columns x 1024 rows of a 2^20-point frame) ----
+    if constexpr (KIND == 3) fft_cols1024_tile<FMT>(a.cols, item, smem_raw, tid);
+    else fft_cols256_tile<FMT>(a.cols, item, smem_raw, tid);
     // ... then this workgroup's share of the tiles k_plan_long listed for the detect stage that rides on the launch. (The other
     // way round — the pairs first, while the memory system is still idle, then the column tile — was 5 us slower per launch at
     // 65536 points x 128 frames: the two dozen workgroups that find a pair then finish their column tile last.)

@@ -24,6 +24,7 @@
 #include "../../include/specscan.h"
 #include "detect_fused.h"
 #include "detect_kernels.h"
+#include "fft1024_kernels.h"
 #include "fft256_kernels.h"
 #include "reference_nan.h"
 #include "fft_kernels.h"
@@ -93,6 +94,8 @@ struct ss_ctx {
     bool fft_generic = false;      // radix-4 LDS kernels instead of the register-pass ones
     int fft_rows_r = -1;           // 0 never / 1 always use k_fft_rows256xR_psd for N2 = 512..4096 (-1: up to 2048)
     int fft_sub = -1;              // 0 never / 1 always split N2 > 256 rows into radix-A step + 256-point rows (-1: from 2048)
+    bool fft_twopass = true;       // 2^20 points as 1024 x 1024 in two passes (SS_FFT_TWOPASS=0: 256 x 4096 in three, as until round 3)
+    bool ring_only = true;         // 2^20 points, detect mode, calls shorter than the ring: no dB plane is written (SS_RING_ONLY=0: written as ever)
     bool fft_xcd_map = true;       // XCD-aware tile order in k_fft_rows256xR_psd
     bool spec_standalone = false;  // spectrogram by its own two kernels instead of inside the detect tiles
     bool pipeline = true;          // 8192 points: defer detect / emit of a call into the next calls' launches (scan_step.h)
@@ -150,6 +153,8 @@ struct ss_ctx {
       fft_generic = is("SS_FFT_IMPL", "generic");
       fft_rows_r = tri("SS_FFT_ROWSR");
       fft_sub = tri("SS_FFT_SUB");
+      fft_twopass = tri("SS_FFT_TWOPASS") != 0;
+      ring_only = tri("SS_RING_ONLY") != 0;
       fft_xcd_map = tri("SS_FFT_XCDMAP") != 0;
       spec_standalone = is("SS_SPEC_IMPL", "standalone");
       pipeline = tri("SS_PIPELINE") != 0;
@@ -375,6 +380,13 @@ struct ss_ctx {
   float2* d_tw_small = nullptr;  // N = 1024, 2048, 4096: [q][k'] W_N^(q k') for the final radix-R pass of k_fft256xR_psd
   float2* d_tw_sub = nullptr;   // N = 2^19, 2^20: [c][b] W_N2^(b c) for k_fft_sub_dft (N2 = N / 256 = 256 A)
   float2* d_tw_cols = nullptr;  // N >= 65536: step-A twiddle factored for k_fft_cols256, [j][n2] W_N^(n2 j) then [k][n2] W_N^(16 n2 k)
+  // N = 2^20 as 1024 x 1024 (fft1024_kernels.h): two passes over the work buffer instead of three
+  bool two_pass = false;  // (its tables: one block in d_tw_cols)
+  // Detect mode, calls shorter than the averager ring (2^20 points in 16-frame calls: BASELINE config 5): every row of the batch
+  // is a ring row, which the rows kernel writes (rel = dB - thr); no dB plane is written at all — the detect tiles take the batch's
+  // rows from the ring, with a ceiling of zeros to subtract (x - 0.0f is x: the same bits) — unless somebody wants one.
+  float* d_zero_row = nullptr;       // n zeros
+  const float* last_rel_rows = nullptr;  // the last batch's rows as rel values (ring-only calls: last_psd is null then)
   bool use_fft256 = false;
   int* d_counts = nullptr;
   int* d_off = nullptr;
@@ -552,8 +564,33 @@ ss::ColsArgs cols256_args(ss_ctx* c, const void* d_iq, long long item_stride) {
   g.twc = c->d_tw_cols;
   g.scale = c->cfg.int_scale;
   g.work = c->d_work;
-  g.logn2 = c->logn - 8;
+  g.logn2 = c->two_pass ? 10 : c->logn - 8;
+  if (c->two_pass && c->cull_long) {  // (the column tiles clear the frames' rows of the run-maxima ring: the rows kernel gathers them by atomic maxima)
+    g.smax = reinterpret_cast<unsigned*>(c->d_smax);
+    g.smax_mask = c->smax_rows - 1;
+    g.abs0 = (int)(c->abs_frames & 0x3fffffff);
+  }
   return g;
+}
+
+// N = 2^20 in two passes (fft1024_kernels.h): the column tiles are k_scan_step's FFT role (KIND 3) or, for contexts without the
+// step kernel, a launch of their own; the rows follow as their own launch either way.
+template <int FMT>
+void launch_cols1024_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nframes) {
+  const ss::ColsArgs g = cols256_args(c, d_iq, item_stride);
+  hipEvent_t e0, e1;
+  if (prof_pair(c, &e0, &e1)) hipExtLaunchKernelGGL((ss::k_fft_cols1024<FMT>), dim3(nframes * 128), dim3(512), ss::kFft1024ColsLdsBytes, c->stream, e0, e1, 0, g);
+  else hipLaunchKernelGGL((ss::k_fft_cols1024<FMT>), dim3(nframes * 128), dim3(512), ss::kFft1024ColsLdsBytes, c->stream, g);
+}
+void launch_rows1024(ss_ctx* c, int nframes, float* d_psd, const ss::RowsExtra& rx) {
+  ss::Rows1024Args g{};
+  g.work = c->d_work;
+  g.tw256 = c->d_tw256;
+  g.tw1024 = c->d_tw_cols + ss::kFft1024Tw1024;
+  g.db_off = c->db_off;
+  g.psd = d_psd;
+  g.x = rx;
+  SS_LAUNCH_SLOT(c, SS_KSLOT_ROWS, ss::k_fft_rows1024_psd, dim3(nframes * 128), dim3(512), ss::kFft1024RowsLdsBytes, g);
 }
 
 // with_cols = false: the column half ran as a role of k_scan_step (run_batch), only the row half is launched here
@@ -698,6 +735,7 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
     if (e0) hipExtLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, stream, e0, e1, 0, a);
     else hipLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, stream, a);
   };
+  if (c->two_pass) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 3>);  // (2^20 points: rows of 32768 mask words, the emit role gives a frame to all eight waves)
   if (!c->use_fft8192) return a.emit_per_wg == 1 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 2>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 1>);
 #ifdef SS_DIAG
   if (c->diag.fft_tw == 0) return go(ss::k_scan_step<FMT, SPEC, 0, false>);
@@ -726,7 +764,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   if (c->diag.ablate_roles & 2) emit = nullptr;
 #endif
   ss::StepArgs a{};
-  a.emit_per_wg = (!c->use_fft8192 && c->diag.emit_wide && c->n / 32 >= 2048) ? 1 : 8;
+  a.emit_per_wg = (!c->use_fft8192 && (c->diag.emit_wide || c->two_pass) && c->n / 32 >= 2048) ? 1 : 8;
   if (fft && fft->frames) {
     const int n_fft = fft->n + fft->n_halo;
     a.fft = *fft->frames;
@@ -986,7 +1024,16 @@ int launch_fft_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nfram
     case 17: c->use_fft256 ? launch_four_step256<9, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<8, 9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 18: c->use_fft256 ? launch_four_step256<10, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<9, 9, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
     case 19: c->use_fft256 ? launch_four_step256<11, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<9, 10, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
-    case 20: c->use_fft256 ? launch_four_step256<12, FMT>(c, d_iq, item_stride, nframes, d_psd) : launch_four_step<10, 10, FMT>(c, d_iq, item_stride, nframes, d_psd); break;
+    case 20:
+      if (c->two_pass) {
+        launch_cols1024_fmt<FMT>(c, d_iq, item_stride, nframes);
+        launch_rows1024(c, nframes, d_psd, ss::RowsExtra{});
+      } else if (c->use_fft256) {
+        launch_four_step256<12, FMT>(c, d_iq, item_stride, nframes, d_psd);
+      } else {
+        launch_four_step<10, 10, FMT>(c, d_iq, item_stride, nframes, d_psd);
+      }
+      break;
     default: return fail(c, SS_ERR_INVALID, "fft_size 2^%d unsupported", c->logn);
   }
   return SS_OK;
@@ -1010,7 +1057,10 @@ int launch_fft_rows(ss_ctx* c, int nframes, float* d_psd, const ss::RowsExtra& r
     case 17: launch_four_step256<9, F>(c, nullptr, 0, nframes, d_psd, false, rx); break;
     case 18: launch_four_step256<10, F>(c, nullptr, 0, nframes, d_psd, false, rx); break;
     case 19: launch_four_step256<11, F>(c, nullptr, 0, nframes, d_psd, false, rx); break;
-    case 20: launch_four_step256<12, F>(c, nullptr, 0, nframes, d_psd, false, rx); break;
+    case 20:
+      if (c->two_pass) launch_rows1024(c, nframes, d_psd, rx);
+      else launch_four_step256<12, F>(c, nullptr, 0, nframes, d_psd, false, rx);
+      break;
     default: return fail(c, SS_ERR_INVALID, "fft_size 2^%d has no column / row split", c->logn);
   }
   return SS_OK;
@@ -1482,6 +1532,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
   if (!d_psd_out) c->psd_cur = (c->psd_cur + 1) % c->npsd;
   c->prof_call = false;
   int st = SS_OK;
+  const float* ring_only_rows = nullptr;  // set by a call that writes no dB plane (2^20 points, detect mode, shorter than the ring)
   SpecState* spec = nullptr;
   if (c->spec_n > 0) {
     spec = spectrogram_container(c);
@@ -1499,15 +1550,16 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       g = fft8192_args(c, d_iq, item_stride, d_psd);
       role.frames = &g;
       role.n = nframes;
-    } else {  // N = 256 x N2: the column half here, the row half right behind it
+    } else {  // N = 256 x N2 (or 1024 x 1024 at 2^20 points): the column half here, the row half right behind it
       gc = cols256_args(c, d_iq, item_stride);
       role.cols = &gc;
-      role.n = nframes * (c->n >> 13);
+      role.n = nframes * (c->n >> 13);  // tiles of 8192 points either way: 32 columns x 256 rows, or 8 x 1024
     }
     // Tile culling for long transforms: the rows kernel leaves the run maxima of every frame and, in a call without learning
     // frames, writes the ring rows of the batch itself (placed now: moving the ring window drains the deferred stages).
     ss::RowsExtra rx{};
-    bool ring_by_rows = false;
+    bool ring_by_rows = false, ring_only = false;
+    const float* ring_rows = nullptr;
     if (c->cull_long) {
       rx.smax = c->d_smax;
       rx.smax_mask = c->smax_rows - 1;
@@ -1519,6 +1571,10 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         rx.first_hist = nframes - kHistRows;
         rx.zero_word = c->d_tlist[c->buf_cur];  // (the list this call's plan appends to; its last reader was the detect stage of the call before last)
         ring_by_rows = true;
+        // no dB plane at all: a device call that hands out no plane, shorter than the ring, whose rows the new rows kernel writes
+        ring_only = c->two_pass && allow_overlap && !d_psd_out && !d_rel_out && !d_avg_out && !spec && !c->ref_nan && nframes < kHistRows &&
+                    !(c->cfg.flags & SS_FLAG_KEEP_PLANES) && c->diag.ring_only;
+        if (ring_only) ring_rows = rp.in + (size_t)kHistRows * c->n;  // batch frame f = row H + f of the window being read: right behind it (place_ring)
       }
     }
     // (SS_FLAG_STREAM_ORDERED / SS_FLAG_REFERENCE_NAN: every stage of the call before the call returns, in order on the public stream)
@@ -1540,7 +1596,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     c->pend_emit = c->pend_det_emit;
     c->have_det = false;
     if (!c->use_fft8192) {
-      st = launch_fft_rows(c, nframes, d_psd, rx);
+      st = launch_fft_rows(c, nframes, ring_only ? nullptr : d_psd, rx);
       if (st != SS_OK) return st;
     }
     if (spec && !c->spec_in_detect) {
@@ -1560,6 +1616,11 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     if (c->cull_long) {
       c->pend_det.hist_by_fft = ring_by_rows ? 1 : 0;
       c->pend_det.tile_list = nullptr;
+      if (ring_only) {
+        c->pend_det.psd = ring_rows;
+        c->pend_det.thr = c->d_zero_row;
+        ring_only_rows = ring_rows;
+      }
       // the plan: which tiles of this call can hold a candidate at all (k_plan_long) — behind the rows kernel, ahead of the
       // launch that carries the detect stage. Only a stage whose sole products are mask bits and counts is planned.
       const int plan_cols = ss::plan_long_cols(nframes, c->pend_det.shift, c->n / 256);
@@ -1573,7 +1634,9 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         pl.cols = plan_cols;
         pl.logn = c->logn;
         pl.list = list;
-        SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3((c->n >> 16) * ((256 + plan_cols - 1) / plan_cols)), dim3(256), 0, c->pend_det, pl);
+        pl.layout = c->two_pass ? 1 : 0;
+        const int plan_wgs = c->two_pass ? 4 * ((1024 + plan_cols - 1) / plan_cols) : (c->n >> 16) * ((256 + plan_cols - 1) / plan_cols);
+        SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, c->pend_det, pl);
         c->pend_det.tile_list = list;
       }
     }
@@ -1605,6 +1668,11 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
   if (n_learn > 0) c->clean_abs = c->abs_frames + n_learn;  // (tile culling, long transforms: rows before this one hold learning frames)
   c->abs_frames += nframes;
   c->last_psd = d_psd;
+  c->last_rel_rows = nullptr;
+  if (ring_only_rows) {  // a ring-only call (above): no dB plane exists
+    c->last_psd = nullptr;
+    c->last_rel_rows = ring_only_rows;
+  }
   c->last_n = nframes;
   return SS_OK;
 }
@@ -1700,6 +1768,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_work);
   (void)hipFree(c->d_tw256);
   (void)hipFree(c->d_tw_cols);
+  (void)hipFree(c->d_zero_row);
   (void)hipFree(c->d_tw_sub);
   (void)hipFree(c->d_tw_small);
   (void)hipFree(c->d_tw_rowsR);
@@ -1728,7 +1797,7 @@ __global__ void k_selftest_div21(unsigned long long* mismatches) {
   unsigned long long bad = 0;
   for (unsigned long long u = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; u < (1ull << 32); u += stride) {
     const float s = __uint_as_float((unsigned)u);
-    if (!(fabsf(s) <= 1e30f)) continue;  // NaN, inf and the overflow corner are not reachable for dB sums
+    if (s != s || (fabsf(s) > 1e30f && fabsf(s) < __builtin_inff())) continue;  // NaN, and the overflow corner that dB sums cannot reach; the infinities count (a row of zeros)
     const float q = ss::div_const<21>(s);
     const float r = s / 21.0f;
     if (__float_as_uint(q) != __float_as_uint(r) && !(q == 0.0f && r == 0.0f)) ++bad;
@@ -1995,7 +2064,17 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
         }
       CREATE_HIP(hipMalloc(&c->d_tw256, sizeof(float2) * t256.size()));
       CREATE_HIP(hipMemcpy(c->d_tw256, t256.data(), sizeof(float2) * t256.size(), hipMemcpyHostToDevice));
-      {
+      c->two_pass = c->use_fft256 && c->logn == 20 && c->diag.fft_twopass && c->diag.fft_rows_r < 0 && c->diag.fft_sub < 0;
+      if (c->two_pass) {
+        CREATE_HIP(hipMalloc(&c->d_zero_row, sizeof(float) * (size_t)n));
+        CREATE_HIP(hipMemset(c->d_zero_row, 0, sizeof(float) * (size_t)n));
+      }
+      if (c->two_pass) {  // one block of tables for both halves (fft1024_kernels.h), in the place of the 256-point column tiles' tables
+        std::vector<float2> tab((size_t)ss::kFft1024TableEntries);
+        ss::fft1024_host_tables(tab.data());
+        CREATE_HIP(hipMalloc(&c->d_tw_cols, sizeof(float2) * tab.size()));
+        CREATE_HIP(hipMemcpy(c->d_tw_cols, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
+      } else {
         const int n2size = n / 256;
         std::vector<float2> tc((size_t)32 * (size_t)n2size);
         for (int i = 0; i < 16; ++i)
@@ -2058,7 +2137,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   // fabric but loses time since the column tiles got faster (the plan launch and the ring rows cost more than the evaluation
   // they save: 57.1 against 53.4 us per 128-frame call, 37 against 26 for 16 frames, profiles/r03/s53_summary.txt): there only the
   // diagnostics build switches it on (SS_CULL_65536=1; tests/test_gpu_cull.py keeps it honest).
-  c->cull_long = c->step_path && c->use_fft256 && ((n == 65536 && c->diag.cull_65536) || (n > 65536 && c->d_tw_sub && !c->d_tw_rowsR)) &&
+  c->cull_long = c->step_path && c->use_fft256 && ((n == 65536 && c->diag.cull_65536) || (n > 65536 && c->d_tw_sub && !c->d_tw_rowsR) || c->two_pass) &&
                  !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
   if (c->cull_long) {
     int rows = 64;
@@ -2377,10 +2456,20 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
   std::lock_guard<std::mutex> lock(c->mtx);
   const int n = c->n;
   const int G = c->cfg.grouping_y;
-  if (lo < 0 || hi > n || lo > hi || frame >= c->last_n || c->last_n <= 0 || !c->last_psd) return fail(c, SS_ERR_INVALID, "window out of range (or no batch processed yet)");
+  if (lo < 0 || hi > n || lo > hi || frame >= c->last_n || c->last_n <= 0 || (!c->last_psd && !c->last_rel_rows)) return fail(c, SS_ERR_INVALID, "window out of range (or no batch processed yet)");
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
   flush_stages(c);
   const size_t cnt = (size_t)(hi - lo);
+  if (!c->last_psd) {
+    // the last batch kept no dB plane (a 2^20-point device call that handed out no plane: its rows went straight to the averager
+    // ring as noise-relative values): the rel rows are there, bit for bit; a dB window needs a call with d_psd_db
+    if (plane == SS_PLANE_REL && frame >= 0) {
+      SS_HIP(c, hipMemcpyAsync(out, c->last_rel_rows + (size_t)frame * n + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
+      SS_HIP(c, hipStreamSynchronize(c->stream));
+      return SS_OK;
+    }
+    if (frame >= 0) return fail(c, SS_ERR_INVALID, "the last ss_process_device call kept no dB / avg plane (detect mode): pass d_psd_db, or SS_FLAG_KEEP_PLANES at ss_create");
+  }
   if (c->fused && plane == SS_PLANE_REL && frame >= 0) {
     // the fused back end never stores rel: rebuild the window as the kernel computes it,
     // psd - thr in fp32 (noise_learner.cpp:55), or -100 for a learning frame (:49)

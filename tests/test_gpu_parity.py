@@ -108,6 +108,7 @@ ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurem
     ({"SS_EMIT_WIDE": "0"}, 65536, 20_000_000, "cs8"),
     ({"SS_STEP_LONG": "0"}, 65536, 20_000_000, "cs8"),
     ({"SS_STEP_LONG": "0"}, 16384, 4_000_000, "cf32"),
+    ({"SS_FFT_TWOPASS": "0"}, 1 << 20, 61_440_000, "cs8"),  # 2^20 points as 256 x 4096 in three passes (round 3's form; the product takes 1024 x 1024 in two)
 ]
 
 
@@ -126,7 +127,7 @@ def test_alternative_implementations_meet_the_contract(oracle_mod, monkeypatch, 
 
 
 @pytest.mark.parametrize("n,fmt", [(512, "cs8"), (1024, "cf32"), (2048, "cs8"), (2048, "cf32"), (4096, "cu8"), (8192, "cf32"), (16384, "cs8"),
-                                   (65536, "cf32"), (131072, "cs8")])
+                                   (65536, "cf32"), (131072, "cs8"), (1 << 20, "cs8")])
 def test_psd_of_a_frame_does_not_depend_on_its_position_in_the_batch(n, fmt):
     """Kernels that take several frames per workgroup must round every frame the same way (the two unrolled halves of the
     2048-point kernel once did not: the compiler chose the FMA operand per call site): frame-range sharding and

@@ -214,3 +214,41 @@ def test_config5_device_calls_against_the_reference(ref_mod):
           f"tiles {st['tiles_total']}, tested {st['tiles_tested']}, culled {st['tiles_culled']}")
     assert st["culling"] and st["tiles_culled"] > 0 and st["tiles_culled"] <= st["tiles_tested"] <= st["tiles_total"], st
     assert len(b) > 2000 and len(a ^ b) <= dont_care_limit(len(b))
+
+
+def test_config5_calls_that_keep_no_db_plane_serve_the_tracker_all_the_same():
+    """A 2^20-point ss_process_device call in detect mode, shorter than the averager ring, writes no dB plane (its rows go straight
+    to the ring as noise-relative values, include/specscan.h): ss_read_window(SS_PLANE_REL) — what the signal tracker reads — gives
+    the bits a call WITH a plane gives, the ring rows before the batch included; SS_PLANE_PSD says that it is not there; and the
+    candidate lists are those of the call with a plane."""
+    import torch
+    n, fs, chunk, learn = 1 << 20, 61_440_000, 16, 16
+    dev = torch.device("cuda", 0)
+    band = pkg.synth.SyntheticBand(n, seed=44, on_frame=40, off_frame=70)
+    iq = band.frames_cs8(chunk * 5)
+    d_iq = [torch.from_numpy(iq[k * chunk:(k + 1) * chunk]).to(dev) for k in range(5)]
+    res = {}
+    for with_plane in (False, True):
+        eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, in_format=pkg.abi.SS_FMT_CS8, max_batch=chunk, learn_frames=learn)
+        outs = []
+        for d in d_iq:
+            o = dict(psd=torch.empty((chunk, n), dtype=torch.float32, device=dev) if with_plane else None, off=torch.zeros(chunk + 1, dtype=torch.int32, device=dev),
+                     idx=torch.empty(chunk * 1024, dtype=torch.int32, device=dev))
+            eng.process_device(d, chunk, psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"])
+            outs.append(o)
+        eng.sync()
+        wins = [eng.read_window(pkg.abi.SS_PLANE_REL, f, lo, lo + 300) for f in (-20, -1, 0, 7, 15) for lo in (0, 524_000, n - 300)]
+        if with_plane:
+            eng.read_window(pkg.abi.SS_PLANE_PSD, 3, 0, 64)
+        else:
+            with pytest.raises(pkg.abi.SpecscanError, match="kept no dB"):
+                eng.read_window(pkg.abi.SS_PLANE_PSD, 3, 0, 64)
+        offs = [o["off"].cpu().numpy() for o in outs]
+        res[with_plane] = (wins, offs, [o["idx"].cpu().numpy()[:x[-1]] for o, x in zip(outs, offs)])
+        eng.close()
+    for a, b in zip(res[False][0], res[True][0]):
+        np.testing.assert_array_equal(a, b)
+    for k in range(5):
+        np.testing.assert_array_equal(res[False][1][k], res[True][1][k])
+        np.testing.assert_array_equal(res[False][2][k], res[True][2][k])
+    assert sum(int(x[-1]) for x in res[True][1]) > 1000

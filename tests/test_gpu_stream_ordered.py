@@ -31,7 +31,7 @@ def _compare(got_psd, got_off, got_idx, ref, what):
     near = np.abs(ref["avg"] - np.float32(8.0)) < BAND
     outside = [(f, i) for (f, i) in a ^ b if not near[f, i]]
     assert not outside, (what, sorted(outside)[:10])
-    assert len(b) > 20_000 and len(a ^ b) <= dont_care_limit(len(b)), (what, len(b), len(a ^ b))
+    assert len(b) > 5_000 and len(a ^ b) <= dont_care_limit(len(b)), (what, len(b), len(a ^ b))
     print(f"\n[{what}] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band")
 
 
@@ -40,8 +40,9 @@ def test_stream_ordered_producer_and_consumer_on_the_chains_stream(ref_mod, n, f
     import torch
     import hipapi
     dev = torch.device("cuda", 0)
-    band = pkg.synth.SyntheticBand(n, seed=61, on_frame=130, off_frame=nb * ncalls - 40)
     total = nb * ncalls
+    learn, step_ms = (101, 20) if total > 1000 else (41, 50)  # the reference's 2000 ms of learning at 50 / 20 frames per second
+    band = pkg.synth.SyntheticBand(n, seed=61, on_frame=learn + 29, off_frame=total - 10)
     if fmt == "cs8":
         iq8 = band.frames_cs8(total)
         iq = (iq8[..., 0].astype(np.float32) / np.float32(128.0) + 1j * (iq8[..., 1].astype(np.float32) / np.float32(128.0))).astype(np.complex64)
@@ -49,9 +50,9 @@ def test_stream_ordered_producer_and_consumer_on_the_chains_stream(ref_mod, n, f
     else:
         iq = band.frames_cf32(total)
         host = torch.from_numpy(iq.view(np.float32)).pin_memory()
-    t = (10_000 + 20 * np.arange(total)).astype(np.int64)  # learning ends after 101 frames
+    t = (10_000 + step_ms * np.arange(total)).astype(np.int64)
     ref = _ref(ref_mod, n, fs, iq, t)
-    eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, max_batch=nb, learn_frames=101, flags=pkg.abi.SS_FLAG_STREAM_ORDERED,
+    eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, max_batch=nb, learn_frames=learn, flags=pkg.abi.SS_FLAG_STREAM_ORDERED,
                              in_format=pkg.abi.SS_FMT_CS8 if fmt == "cs8" else pkg.abi.SS_FMT_CF32)
     s = eng.stream_handle
     d_iq = torch.empty_like(host[:nb], device=dev)  # ONE input buffer, ONE output set: refilled / copied away on the chain's stream
