@@ -77,7 +77,11 @@ __device__ __forceinline__ float load_row_value(const char* p) {
 // waits without bound (scan_step.h; tests/test_gpu_wait_bound.py runs the chain with plan workgroups that never publish,
 // and under HSA_CU_MASK with a handful of CUs).
 constexpr float kCullMargin = 0.0625f;
-enum { kStatTested = 0, kStatCulled = 1, kStatWaitFallbacks = 2, kStatWords = 4 };
+// (ss_get_stats) The counters live in kStatShards copies a cache line apart and a workgroup adds to the copy of its block index:
+// a thousand plan workgroups adding to ONE word queue up behind each other at 12 ns apiece (measured: k_plan_long went from 7 to
+// 20 us per 16-frame call of 2^20 points); the host adds the copies up.
+enum { kStatTested = 0, kStatCulled = 1, kStatWaitFallbacks = 2, kStatWords = 4, kStatShards = 64, kStatShardStride = 16 };
+__device__ __forceinline__ unsigned long long* stat_word(unsigned long long* stats, int which) { return stats + (blockIdx.x & (kStatShards - 1)) * kStatShardStride + which; }
 
 // s / D for a compile-time integer D, correctly rounded like the reference's `sum / count`
 // (float / int -> IEEE division): q0 = s * RN(1/D), one Newton correction with exact residuals (FMA).
@@ -350,8 +354,8 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
       if (a.stats && first) {  // (wave-uniform)
         const int tested = __popcll(__ballot(exists && plannable && steady && !writes_hist));
         if (lane == 0 && tested) {
-          atomicAdd(&a.stats[kStatTested], (unsigned long long)tested);
-          atomicAdd(&a.stats[kStatCulled], (unsigned long long)__popcll(dead_mask[r]));
+          atomicAdd(stat_word(a.stats, kStatTested), (unsigned long long)tested);
+          atomicAdd(stat_word(a.stats, kStatCulled), (unsigned long long)__popcll(dead_mask[r]));
         }
       }
       if (lane == 0) book[w * 4 + r] = __popcll(live_mask[r]);
@@ -575,11 +579,12 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
   const int lane = tid & 63, w = tid >> 6;
   const unsigned long long mask = __ballot(live);
   if (lane == 0) wave_cnt[w] = __popcll(mask);
-  if (a.stats) {  // ss_get_stats
+  __shared__ int stat_cnt[4][2];
+  if (a.stats) {  // ss_get_stats: one pair of additions per workgroup (below), to the copy of its block index
     const int n_tested = __popcll(__ballot(tested)), n_culled = __popcll(__ballot(tested && !live));
-    if (lane == 0 && n_tested) {
-      atomicAdd(&a.stats[kStatTested], (unsigned long long)n_tested);
-      atomicAdd(&a.stats[kStatCulled], (unsigned long long)n_culled);
+    if (lane == 0) {
+      stat_cnt[w][0] = n_tested;
+      stat_cnt[w][1] = n_culled;
     }
   }
   __syncthreads();
@@ -591,6 +596,13 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
   }
   __shared__ int list_base;
   if (tid == 0) list_base = total ? atomicAdd(&p.list[0], total) : 0;
+  if (tid == 1 && a.stats) {
+    const int nt = stat_cnt[0][0] + stat_cnt[1][0] + stat_cnt[2][0] + stat_cnt[3][0], nc = stat_cnt[0][1] + stat_cnt[1][1] + stat_cnt[2][1] + stat_cnt[3][1];
+    if (nt) {
+      atomicAdd(stat_word(a.stats, kStatTested), (unsigned long long)nt);
+      atomicAdd(stat_word(a.stats, kStatCulled), (unsigned long long)nc);
+    }
+  }
   __syncthreads();
   if (live) p.list[1 + list_base + base + __popcll(mask & ((1ull << lane) - 1ull))] = block;
 }

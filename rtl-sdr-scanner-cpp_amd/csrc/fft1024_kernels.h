@@ -94,7 +94,11 @@ __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, 
       if constexpr (FMT == FMT_CS8) x = make_float2((float)(signed char)(raw & 0xff) * g.scale, (float)(signed char)(raw >> 8) * g.scale);
       else x = make_float2(((float)(raw & 0xff) - 127.5f) * g.scale, ((float)(raw >> 8) - 127.5f) * g.scale);
     }
-    const float wv = buffer_load_f1(rwin, (int)(tn * 4u), r * (65536 * 4));
+#ifndef SS_C1024_ABL  // (A/B builds, scripts/build_ab.py — garbage results, the column tiles' time without: 1 = the window loads, 2 = the work-buffer stores, 4 = the frame loads)
+#define SS_C1024_ABL 0
+#endif
+    if (SS_C1024_ABL & 4) x = make_float2(__int_as_float(0x3f800000 + (int)tn + r), 0.5f);
+    const float wv = (SS_C1024_ABL & 1) ? 1.0f : buffer_load_f1(rwin, (int)(tn * 4u), r * (65536 * 4));
     a[r] = make_float2(x.x * wv, x.y * wv);  // volk_32fc_32f_multiply_32fc
   }
   float2 cc[16];
@@ -134,6 +138,7 @@ __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, 
     for (int kap = 0; kap < 4; ++kap) {
       const float2 tw = kap == 0 ? pu : cmul(pu, kap == 1 ? g1 : kap == 2 ? g2 : g3);
       const float2 y = cmul(a[4 * u + kap], tw);
+      if ((SS_C1024_ABL & 2) && y.x != 12345.678f) continue;
       __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned*>(&y), rw, voff, ((64 * u + 256 * kap) << 10) * 8, 0);
     }
     if (u < 3) pu = cmul(pu, t64);

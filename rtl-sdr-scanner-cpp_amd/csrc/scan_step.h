@@ -216,7 +216,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
         plan_seg = consumer % nseg;
         helped_itself = true;
         __syncthreads();
-        if (tid == 0 && a.det.stats) atomicAdd(&a.det.stats[kStatWaitFallbacks], 1ull);
+        if (tid == 0 && a.det.stats) atomicAdd(stat_word(a.det.stats, kStatWaitFallbacks), 1ull);
       }
     }
     if (plan_seg >= 0) plan_tiles<21, 21, 16, 256>(a.det, plan_seg, a.plan_cols, tid, reinterpret_cast<float*>(smem_raw), !helped_itself);

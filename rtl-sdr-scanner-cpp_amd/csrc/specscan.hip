@@ -1918,8 +1918,8 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   }
   c->deep = c->step_path && n == 8192 && c->diag.deep && !(cfg->flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN)) && cfg->max_batch >= kHistRows && (!(cfg->flags & SS_FLAG_SPECTROGRAM) || c->spec_in_detect);
   if (c->diag.wait_limit > 0) c->wait_limit = c->diag.wait_limit;
-  CREATE_HIP(hipMalloc(&c->d_stats, sizeof(unsigned long long) * ss::kStatWords));
-  CREATE_HIP(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * ss::kStatWords, c->stream));
+  CREATE_HIP(hipMalloc(&c->d_stats, sizeof(unsigned long long) * ss::kStatShards * ss::kStatShardStride));
+  CREATE_HIP(hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * ss::kStatShards * ss::kStatShardStride, c->stream));
   if (c->ref_nan) {
     CREATE_HIP(hipMalloc(&c->d_nf, sizeof(int) * 4 * (size_t)cfg->max_batch));
     CREATE_HIP(hipMalloc(&c->d_bad_from, sizeof(int) * (size_t)cfg->max_batch));
@@ -2213,18 +2213,22 @@ int ss_sync(ss_ctx* ctx) {
   return SS_OK;
 }
 
-// ss_get_stats: the host-side counters as they stand, the device-side ones as far as the device has got (a blocking 32-byte
+// ss_get_stats: the host-side counters as they stand, the device-side ones as far as the device has got (a blocking 8 KiB
 // copy that synchronises with none of the context's streams: they are all non-blocking streams).
 int ss_get_stats(ss_ctx* c, ss_stats* out) {
   if (!c || !out || out->size < sizeof(uint32_t) * 2) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
-  unsigned long long dev[ss::kStatWords] = {};
+  static_assert(ss::kStatWords <= ss::kStatShardStride, "a shard holds every counter");
+  unsigned long long dev[ss::kStatShards * ss::kStatShardStride] = {};
   SS_HIP(c, hipMemcpy(dev, c->d_stats, sizeof(dev), hipMemcpyDeviceToHost));
   ss_stats st = c->stats;
-  st.tiles_tested = dev[ss::kStatTested];
-  st.tiles_culled = dev[ss::kStatCulled];
-  st.wait_fallbacks = dev[ss::kStatWaitFallbacks];
+  st.tiles_tested = st.tiles_culled = st.wait_fallbacks = 0;
+  for (int k = 0; k < ss::kStatShards; ++k) {  // (the device adds to the copy of the workgroup's block index, detect_fused.h)
+    st.tiles_tested += dev[k * ss::kStatShardStride + ss::kStatTested];
+    st.tiles_culled += dev[k * ss::kStatShardStride + ss::kStatCulled];
+    st.wait_fallbacks += dev[k * ss::kStatShardStride + ss::kStatWaitFallbacks];
+  }
   st.state = (c->cull || c->cull_long ? SS_STATE_CULLING : 0u) | (c->deep ? SS_STATE_OVERLAP : 0u) | (c->deep && c->deep_iq_recycled ? SS_STATE_DEMOTED : 0u) |
              (c->deep && c->deep_eager ? SS_STATE_EAGER : 0u);
   const uint32_t want = out->size < sizeof(ss_stats) ? out->size : (uint32_t)sizeof(ss_stats);

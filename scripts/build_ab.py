@@ -21,6 +21,10 @@ VARIANTS = {
     "colstw15": ["SS_COLS_TW6=0"],   # column tiles: one step-A twiddle table entry per k (fifteen loads per thread) instead of six
     "colsnotw": ["SS_COLS_TW6=0", "SS_COLS_ABL=1"],   # column tiles of the long transforms without the step-A twiddle table loads (garbage results: timing only)
     "colsnowin": ["SS_COLS_ABL=2"],  # ... without the window loads
+    "c1024nowin": ["SS_C1024_ABL=1"],    # 2^20 points in two passes: column tiles without the window loads (garbage results: timing only)
+    "c1024nostore": ["SS_C1024_ABL=2"],  # ... without the work-buffer stores
+    "c1024noload": ["SS_C1024_ABL=4"],   # ... without the frame loads
+    "c1024none": ["SS_C1024_ABL=7"],     # ... arithmetic and LDS only
     "colsnone": ["SS_COLS_TW6=0", "SS_COLS_ABL=3"],   # ... without either  # 8192 points, deep pipelining: ring rows written by three frame tiles of every call
 }
 

@@ -140,7 +140,9 @@ def test_reference_nan_flag_follows_the_reference_to_the_end_of_the_stream(ref_m
     ref_chain.reset()
     eng.reset()
     r2 = ref_chain.process(more, t2)
-    g2 = eng.process(more, t_ms=t2)
+    g2s = [eng.process(more[a:a + 30], t_ms=t2[a:a + 30]) for a in (0, 30)]
+    g2 = {k: np.concatenate([o[k] for o in g2s]) for k in ("psd", "rel", "avg", "cand_idx", "cand_avg")}
+    g2["cand_off"] = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o["cand_off"]) for o in g2s]))]).astype(np.int32)
     off2 = np.zeros(61, np.int32)
     off2[1:] = np.cumsum([len(c) for c in r2["cands"]])
     check_all(g2, {"psd": r2["psd"], "rel": r2["rel"], "avg": r2["avg"], "cand_off": off2, "cand_idx": np.concatenate(r2["cands"]).astype(np.int32)})
