@@ -55,34 +55,61 @@ inline void fft1024_host_tables(float2* tab) {
   for (int k = 0; k < 256; ++k) tab[kFft1024Tw1024 + k] = W((double)k, 1024.0);
 }
 
+// Host side: the window taps in the column tiles' own order — out[(tile * threads + t) * 16 + r] = the tap of the sample thread t
+// of tile `tile` loads as its r-th (sample n1 = 4 (j + 16 r) + q of column tile * COLS + c; sub = t mod 4 COLS = c + COLS q,
+// j = t div 4 COLS). logc = 3 (8 columns, 512 threads) or 4 (16 columns, 1024 threads).
+inline void fft1024_window_order(const float* win, float* out, int logc) {
+  const int cols = 1 << logc, nsub = 4 * cols, threads = 16 * nsub, tiles = 1024 / cols;
+  for (int tile = 0; tile < tiles; ++tile)
+    for (int t = 0; t < threads; ++t) {
+      const int sub = t & (nsub - 1), j = t / nsub, c = sub & (cols - 1), q = sub >> logc;
+      for (int r = 0; r < 16; ++r) out[((size_t)tile * threads + t) * 16 + r] = win[((size_t)(4 * (j + 16 * r) + q) << 10) + tile * cols + c];
+    }
+}
+
 // One column tile: 8 columns x 1024 rows; `block` = frame * 128 + w. XCD (w mod 8) takes the 16 neighbouring tiles
 // [16 (w mod 8), 16 (w mod 8) + 16): two tiles that share the 128-byte lines of the frame and of the work buffer are consecutive
 // blocks of one XCD. `g`: ColsArgs of fft256_kernels.h with twc = the block of fft1024_host_tables (logn2 is 10).
-template <int FMT>
+// LOGC = 3: 8 columns by 512 threads (above). LOGC = 4: 16 columns by 1024 threads — whole 128-byte lines on either side, twice
+// the LDS (two workgroups per CU: the same threads per CU); too many threads for a role of k_scan_step, so a launch of its own.
+template <int FMT, int LOGC = 3>
 __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, unsigned char* __restrict__ smem_raw, int t) {
+  constexpr int COLS = 1 << LOGC, NSUB = 4 * COLS, THREADS = 16 * NSUB, TILES = 1024 / COLS;
   float* s = reinterpret_cast<float*>(smem_raw);
-  float2* tw_lds = reinterpret_cast<float2*>(smem_raw + kFft1024ColsPlaneBytes);
+  float2* tw_lds = reinterpret_cast<float2*>(smem_raw + NSUB * kFft256PitchCols * 4);
   float2* tw1024_lds = tw_lds + 256;
-  tw_lds[t] = t < 256 ? g.tw256[t] : g.twc[kFft1024Tw1024 + t - 256];  // (tw_lds and tw1024_lds are contiguous: entries 0..511)
-  const int f = block >> 7, w = block & 127;
-  const int tile = ((w & 7) << 4) | (w >> 3);
-  const int c0 = tile << 3;
+  if (t < 512) tw_lds[t] = t < 256 ? g.tw256[t] : g.twc[kFft1024Tw1024 + t - 256];  // (tw_lds and tw1024_lds are contiguous: entries 0..511)
+  const int f = block / TILES, w = block % TILES;
+  const int tile = LOGC == 3 ? ((w & 7) << 4) | (w >> 3) : w;
+  const int c0 = tile << LOGC;
   // tile culling: the run maxima of a frame are gathered by atomic maxima in the rows kernel, so the frame's row of the ring
   // starts from zero — cleared here, one launch earlier
-  if (g.smax && t < 256) g.smax[((size_t)((g.abs0 + f) & g.smax_mask) << 15) + (tile << 8) + t] = 0u;
+  if (g.smax && t < 32768 / TILES) g.smax[((size_t)((g.abs0 + f) & g.smax_mask) << 15) + tile * (32768 / TILES) + t] = 0u;
   // after the second exchange thread t owns column c2 and the outputs k1 = h + 64 u + 256 kap: its step-A twiddles are asked for
   // first, ahead of the frame's own loads in the vector-memory queue
-  const int c2 = t & 7, h = t >> 3;
+  const int c2 = t & (COLS - 1), h = t >> LOGC;
   const int n2b = c0 + c2;
   float2 pu = g.twc[kFft1024TwA + (h << 10) + n2b];
   const float2 t64 = g.twc[kFft1024TwB + n2b], g1 = g.twc[kFft1024TwB + 1024 + n2b];
   // first half: sub-sequence q of column c, butterfly j of its 256-point FFT — sample n1 = 4 (j + 16 r) + q of column c0 + c
-  const int sub = t & 31, j = t >> 5;
-  const int c = sub & 7, q = sub >> 3;
+  const int sub = t & (NSUB - 1), j = t >> (LOGC + 2);
+  const int c = sub & (COLS - 1), q = sub >> LOGC;
   constexpr int kIn = FMT == FMT_CF32 ? 8 : 2;
   const uint32_t tn = ((uint32_t)(4 * j + q) << 10) + (uint32_t)(c0 + c);
   const __amdgpu_buffer_rsrc_t rin = buffer_of(reinterpret_cast<const char*>(g.iq) + (size_t)f * (size_t)g.item_stride * kIn, (1 << 20) * kIn);
+  // The window taps come in THIS kernel's order (fft1024_window_order, built once per context from whatever taps the context has):
+  // a thread's sixteen taps are 64 consecutive bytes — four 16-byte loads, whole lines per wave — where the frame's own layout
+  // gives sixteen 4-byte loads in 32-byte runs (12 of the column launch's 81 us per 16-frame call, profiles/r04/s4_summary.txt).
   const __amdgpu_buffer_rsrc_t rwin = buffer_of(g.win, (1 << 20) * 4);
+  float wv16[16];
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) {
+    const auto w4 = __builtin_amdgcn_raw_buffer_load_b128(rwin, (tile * THREADS + t) * 64, 16 * r4, 0);
+    wv16[4 * r4] = __uint_as_float(w4[0]);
+    wv16[4 * r4 + 1] = __uint_as_float(w4[1]);
+    wv16[4 * r4 + 2] = __uint_as_float(w4[2]);
+    wv16[4 * r4 + 3] = __uint_as_float(w4[3]);
+  }
   float2 a[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -98,7 +125,7 @@ __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, 
 #define SS_C1024_ABL 0
 #endif
     if (SS_C1024_ABL & 4) x = make_float2(__int_as_float(0x3f800000 + (int)tn + r), 0.5f);
-    const float wv = (SS_C1024_ABL & 1) ? 1.0f : buffer_load_f1(rwin, (int)(tn * 4u), r * (65536 * 4));
+    const float wv = (SS_C1024_ABL & 1) ? 1.0f : wv16[r];
     a[r] = make_float2(x.x * wv, x.y * wv);  // volk_32fc_32f_multiply_32fc
   }
   float2 cc[16];
@@ -113,7 +140,7 @@ __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, 
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) a[4 * u + qq].x = zr[8 * qq * kFft1024Pitch2 + 64 * u];
+    for (int qq = 0; qq < 4; ++qq) a[4 * u + qq].x = zr[COLS * qq * kFft1024Pitch2 + 64 * u];
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; ++k) zp[16 * k] = cc[slot16(k)].y;
@@ -123,7 +150,7 @@ __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, 
     const float2 w1 = tw1024_lds[h + 64 * u], w2 = cmul(w1, w1), w3 = cmul(w2, w1);  // W_1024^(q k'), q = 1, 2, 3
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
-      const float2 v = make_float2(a[4 * u + qq].x, zr[8 * qq * kFft1024Pitch2 + 64 * u]);
+      const float2 v = make_float2(a[4 * u + qq].x, zr[COLS * qq * kFft1024Pitch2 + 64 * u]);
       a[4 * u + qq] = qq == 0 ? v : cmul(v, qq == 1 ? w1 : qq == 2 ? w2 : w3);
     }
     dft4(a[4 * u], a[4 * u + 1], a[4 * u + 2], a[4 * u + 3]);  // Y[h + 64 u + 256 kap] in a[4 u + kap]
@@ -145,12 +172,14 @@ __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, 
   }
 }
 
-// Stand-alone launch (contexts without the step kernel: learning is launched through k_scan_step too).
-template <int FMT>
-__global__ __launch_bounds__(512, 8) void k_fft_cols1024(ColsArgs g) {
+// Stand-alone launch (contexts without the step kernel; and the 16-column form).
+template <int FMT, int LOGC = 3>
+__global__ __launch_bounds__(64 << LOGC, 8) void k_fft_cols1024(ColsArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  fft_cols1024_tile<FMT>(g, (int)blockIdx.x, smem_raw, (int)threadIdx.x);
+  fft_cols1024_tile<FMT, LOGC>(g, (int)blockIdx.x, smem_raw, (int)threadIdx.x);
 }
+constexpr int fft1024_cols_lds_bytes(int logc) { return (4 << logc) * kFft256PitchCols * 4 + kFft1024TableBytes; }
+static_assert(fft1024_cols_lds_bytes(3) == kFft1024ColsLdsBytes && (4 << 4) * kFft1024Pitch2 <= (4 << 4) * kFft256PitchCols, "column tile LDS");
 
 // An order-preserving key for atomic maxima of dB values: larger float <-> larger unsigned; 0 = nothing seen (below -inf),
 // 0xffffffff = NaN (wins: "cannot be bounded").

@@ -96,6 +96,7 @@ struct ss_ctx {
     int fft_sub = -1;              // 0 never / 1 always split N2 > 256 rows into radix-A step + 256-point rows (-1: from 2048)
     bool fft_twopass = true;       // 2^20 points as 1024 x 1024 in two passes (SS_FFT_TWOPASS=0: 256 x 4096 in three, as until round 3)
     bool ring_only = true;         // 2^20 points, detect mode, calls shorter than the ring: no dB plane is written (SS_RING_ONLY=0: written as ever)
+    bool cols1024_wide = false;    // 2^20 points (SS_C1024_WIDE=1): column tiles of 16 columns by 1024 threads as a launch of their own, the deferred stages in a launch without an FFT role
     bool fft_xcd_map = true;       // XCD-aware tile order in k_fft_rows256xR_psd
     bool spec_standalone = false;  // spectrogram by its own two kernels instead of inside the detect tiles
     bool pipeline = true;          // 8192 points: defer detect / emit of a call into the next calls' launches (scan_step.h)
@@ -155,6 +156,7 @@ struct ss_ctx {
       fft_sub = tri("SS_FFT_SUB");
       fft_twopass = tri("SS_FFT_TWOPASS") != 0;
       ring_only = tri("SS_RING_ONLY") != 0;
+      cols1024_wide = tri("SS_C1024_WIDE") == 1;
       fft_xcd_map = tri("SS_FFT_XCDMAP") != 0;
       spec_standalone = is("SS_SPEC_IMPL", "standalone");
       pipeline = tri("SS_PIPELINE") != 0;
@@ -385,6 +387,7 @@ struct ss_ctx {
   // Detect mode, calls shorter than the averager ring (2^20 points in 16-frame calls: BASELINE config 5): every row of the batch
   // is a ring row, which the rows kernel writes (rel = dB - thr); no dB plane is written at all — the detect tiles take the batch's
   // rows from the ring, with a ceiling of zeros to subtract (x - 0.0f is x: the same bits) — unless somebody wants one.
+  float* d_win1024 = nullptr;        // the window taps in the 1024-point column tiles' order
   float* d_zero_row = nullptr;       // n zeros
   const float* last_rel_rows = nullptr;  // the last batch's rows as rel values (ring-only calls: last_psd is null then)
   bool use_fft256 = false;
@@ -559,7 +562,7 @@ ss::ColsArgs cols256_args(ss_ctx* c, const void* d_iq, long long item_stride) {
   ss::ColsArgs g{};
   g.iq = d_iq;
   g.item_stride = item_stride;
-  g.win = c->d_win;
+  g.win = c->two_pass ? c->d_win1024 : c->d_win;
   g.tw256 = c->d_tw256;
   g.twc = c->d_tw_cols;
   g.scale = c->cfg.int_scale;
@@ -578,9 +581,21 @@ ss::ColsArgs cols256_args(ss_ctx* c, const void* d_iq, long long item_stride) {
 template <int FMT>
 void launch_cols1024_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nframes) {
   const ss::ColsArgs g = cols256_args(c, d_iq, item_stride);
-  hipEvent_t e0, e1;
-  if (prof_pair(c, &e0, &e1)) hipExtLaunchKernelGGL((ss::k_fft_cols1024<FMT>), dim3(nframes * 128), dim3(512), ss::kFft1024ColsLdsBytes, c->stream, e0, e1, 0, g);
-  else hipLaunchKernelGGL((ss::k_fft_cols1024<FMT>), dim3(nframes * 128), dim3(512), ss::kFft1024ColsLdsBytes, c->stream, g);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (!prof_pair(c, &e0, &e1)) e0 = e1 = nullptr;
+  auto go = [&](auto kernel, int tiles, int threads, int lds) {
+    if (e0) hipExtLaunchKernelGGL(kernel, dim3(nframes * tiles), dim3(threads), lds, c->stream, e0, e1, 0, g);
+    else hipLaunchKernelGGL(kernel, dim3(nframes * tiles), dim3(threads), lds, c->stream, g);
+  };
+  if (c->diag.cols1024_wide) go(ss::k_fft_cols1024<FMT, 4>, 64, 1024, ss::fft1024_cols_lds_bytes(4));
+  else go(ss::k_fft_cols1024<FMT, 3>, 128, 512, ss::kFft1024ColsLdsBytes);
+}
+void launch_cols1024(ss_ctx* c, const void* d_iq, long long item_stride, int nframes) {
+  switch (c->cfg.in_format) {
+    case SS_FMT_CF32: return launch_cols1024_fmt<ss::FMT_CF32>(c, d_iq, item_stride, nframes);
+    case SS_FMT_CS8: return launch_cols1024_fmt<ss::FMT_CS8>(c, d_iq, item_stride, nframes);
+    default: return launch_cols1024_fmt<ss::FMT_CU8>(c, d_iq, item_stride, nframes);
+  }
 }
 void launch_rows1024(ss_ctx* c, int nframes, float* d_psd, const ss::RowsExtra& rx) {
   ss::Rows1024Args g{};
@@ -1591,6 +1606,10 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     const bool reused = c->have_det && (clash(d_psd, plane_bytes, c->pend_det.psd, pend_bytes) || clash(d_avg_out, plane_bytes, c->pend_det_emit.avg, pend_bytes) ||
                                          clash(d_psd, plane_bytes, c->pend_det.rel_out, pend_bytes) || clash(d_rel_out, plane_bytes, c->pend_det.psd, pend_bytes));
     if (!overlap || reused) flush_stages(c);
+    if (c->two_pass && c->diag.cols1024_wide) {  // (A/B: the column half as a launch of its own, then the deferred stages without an FFT role)
+      launch_cols1024(c, d_iq, item_stride, nframes);
+      launch_step(c, nullptr, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
+    } else
     launch_step(c, &role, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     c->have_emit = c->have_det;
     c->pend_emit = c->pend_det_emit;
@@ -1769,6 +1788,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_tw256);
   (void)hipFree(c->d_tw_cols);
   (void)hipFree(c->d_zero_row);
+  (void)hipFree(c->d_win1024);
   (void)hipFree(c->d_tw_sub);
   (void)hipFree(c->d_tw_small);
   (void)hipFree(c->d_tw_rowsR);
@@ -2130,6 +2150,12 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       CREATE_HIP(hipMemcpy(c->d_tw8v2, v2.data(), sizeof(float2) * v2.size(), hipMemcpyHostToDevice));
     }
     CREATE_HIP(hipMemcpy(c->d_win, win.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    if (c->two_pass) {  // the same taps in the 1024-point column tiles' own order (fft1024_kernels.h)
+      std::vector<float> wk((size_t)n);
+      ss::fft1024_window_order(win.data(), wk.data(), c->diag.cols1024_wide ? 4 : 3);
+      CREATE_HIP(hipMalloc(&c->d_win1024, sizeof(float) * (size_t)n));
+      CREATE_HIP(hipMemcpy(c->d_win1024, wk.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+    }
     CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
   }
   // Tile culling for long transforms: the sizes whose rows go through k_fft_rows256_psd (N2 = 256, or the radix-A step in front).
