@@ -311,6 +311,13 @@ def chain_kernels(n: int, fmt: str):
                  "of call k-4 as further roles of the same launch; consecutive launches alternate over two queues and overlap", in_b + 4.0)]
     if n < 16384:
         return [("step", "k_fft", "load+window+FFT+dB (one launch); detect and emit stages follow as launches of their own", in_b + 4.0)]
+    if n == 1 << 20 and os.environ.get("SS_FFT_TWOPASS") != "0":  # 1024 x 1024 in two passes (csrc/fft1024_kernels.h; the three-pass form is a switch of the diagnostics build)
+        return [("step", "k_fft_cols1024", "k_fft_cols1024: column half of the two-pass FFT (load, window, 1024-point FFTs in registers + LDS, twiddle -> work buffer), "
+                 "16 columns x 1024 rows per 1024-thread workgroup", in_b + 8.0),
+                ("rows", "k_fft_rows1024", "k_fft_rows1024_psd: row half, 1024-point FFTs -> dB -> noise-relative rows straight into the averager ring (no dB plane in detect "
+                 "mode with calls shorter than the ring) + run maxima for the tile culling", 12.0),
+                ("plan", "k_plan_long", "k_plan_long: which averaging tiles of the call can hold a candidate, from the run maxima the rows kernel left (one list per call)", 0.0),
+                ("sub", "k_scan_step", "k_scan_step without an FFT role: the listed averaging tiles of call k-1 (shared out in a loop) and the candidate lists of call k-2", 0.0)]
     n2 = n // 256
     ks = [("step", "k_scan_step", "k_scan_step: column half of the four-step FFT of call k (load, window, 256-point FFTs, twiddle -> work buffer), carrying the "
            "21x21 mean + threshold of call k-1 (the tiles the plan listed) and the candidate lists of call k-2 as further roles", in_b + 8.0)]
@@ -582,7 +589,8 @@ def run(args):
             kb = bps * nb * n / per_call if per_call else 0.0
             # launches of the steady-state shape only. 8192 points: 1024 + 20 FFT, 128 emit and 4 plan workgroups of 512 threads; long
             # transforms: the column tiles + one emit workgroup per frame (the listed tiles ride on the column workgroups)
-            shape = (nb + 20 + nb // 8 + 4) * 512 if n == 8192 else ((nb * (n // 8192) + (nb if n >= 65536 else -(-nb // 8))) * 512 if slot == "step" and n >= 16384 else None)
+            two_pass = n == 1 << 20 and os.environ.get("SS_FFT_TWOPASS") != "0"
+            shape = (nb + 20 + nb // 8 + 4) * 512 if n == 8192 else (None if two_pass else ((nb * (n // 8192) + (nb if n >= 65536 else -(-nb // 8))) * 512 if slot == "step" and n >= 16384 else None))
             tp = traffic_from_profiles(args.config or 2, match, shape) if is_preset(args) else None
             kernels.append({"slot": slot, "what": what, "us": round(us, 2), "launches_timed": cnt_k, "launches_per_call": round(per_call, 2),
                             "bytes_per_launch_it_must_move": kb, "gbs": round(kb / us / 1e3, 1) if us else None,

@@ -486,10 +486,14 @@ struct PlanLongArgs {
   int layout;
 };
 constexpr int kPlanLongFloats = 8192;  // LDS of a plan workgroup: C x (16 nft + 20) values of M
-__host__ __device__ inline int plan_long_cols(int nframes, int shift, int tile_cols) {  // 0: the stage cannot be planned
+// max_c: 8, or 32 for the two-pass layout of 2^20 points — there a workgroup's columns are consecutive floats of a frame's row of
+// the ring, and 32 of them are a whole 128-byte line (with 8 the four workgroups that share a line each fetched all of it:
+// 5.9 against 3.0 MB per launch, 12 against 7 us, profiles/r04/s4_summary.txt)
+__host__ __device__ inline int plan_long_cols(int nframes, int shift, int tile_cols, int max_c = 8) {  // 0: the stage cannot be planned
   const int nft = (nframes + shift + 15) / 16, rows = 16 * nft + 20;
   int c = tile_cols / 256 > 1 ? tile_cols / 256 : 1;  // at least 256 workgroups where there are that many columns
-  if (c > 8) c = 8;
+  if (max_c > 8) c = max_c;
+  if (c > max_c) c = max_c;
   if (c > kPlanLongFloats / rows) c = kPlanLongFloats / rows;
   if (nft > 0 && c > 256 / nft) c = 256 / nft;
   return c;

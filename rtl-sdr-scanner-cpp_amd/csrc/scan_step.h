@@ -73,6 +73,10 @@ struct StepArgs {
   // barriers — the launch grew by the 7 us the plan launch takes: 65536 x 128: 66.0 against 65.3 us per call, 2^20 x 16: 178
   // against 174, profiles/r03/s41.)
   int list_by_fft;
+  // KIND 3 (2^20 points in two passes: the column half is a launch of its own, so the deferred stages ride on no FFT role): the
+  // detect workgroups share k_plan_long's list out in a loop, pair item, item + W, item + 2 W, ... — a workgroup per POSSIBLE pair
+  // (4096 of them, of which a few dozen find one) cost the launch 17 us in dispatch alone
+  int list_loop;
   int n_emit;  // frames of the emit role
   int emit_per_wg;  // 8: one wave per frame; 1 (KIND 2): rows of 2048 mask words and more, the eight waves share one frame
   // One workgroup per work item, dispatched in blockIdx order, four resident per CU. WHICH item a workgroup takes decides
@@ -136,6 +140,27 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     }
   } else if (role == ROLE_DET) {
     // ---- detect role: two tiles ----
+    if constexpr (KIND == 3) {
+      if (a.det.tile_list && a.list_loop) {
+        using T = DetectTile<21, 21, 16, 256>;
+        const int n_tiles = (a.det.n / 256) * plan_frame_tiles(a.det.nframes, a.det.shift);
+        const int cnt = min(a.det.tile_list[0], n_tiles), stride = (a.n_det + 1) / 2;
+        const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
+        float* tile = reinterpret_cast<float*>(smem_raw) + half * (16 * T::P + 16);
+        int* tcnt = reinterpret_cast<int*>(tile + 16 * T::P);
+        for (int p = item; 2 * p < cnt; p += stride) {
+          int ta = a.det.tile_list[1 + 2 * p], tb = 2 * p + 1 < cnt ? a.det.tile_list[2 + 2 * p] : -1;
+          if ((unsigned)ta >= (unsigned)n_tiles) ta = tb = -1;  // (a tile number that is none must not become an address)
+          if ((unsigned)tb >= (unsigned)n_tiles) tb = -1;
+          if (ta >= 0) {
+            const int mine = half ? tb : ta;
+            detect_tile<21, 21, 16, 256, SPEC>(a.det, mine < 0 ? ta : mine, tid & 255, tile, tcnt, mine >= 0);
+            __syncthreads();  // the tile's LDS is free for the next pair
+          }
+        }
+        return;
+      }
+    }
     if (KIND == 0 && a.n_plan) {  // the planned stage's lists (a launch without an FFT role)
       consumer = item;
     } else if (KIND >= 1 && a.det.tile_list) {

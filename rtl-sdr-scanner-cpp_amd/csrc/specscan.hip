@@ -96,7 +96,7 @@ struct ss_ctx {
     int fft_sub = -1;              // 0 never / 1 always split N2 > 256 rows into radix-A step + 256-point rows (-1: from 2048)
     bool fft_twopass = true;       // 2^20 points as 1024 x 1024 in two passes (SS_FFT_TWOPASS=0: 256 x 4096 in three, as until round 3)
     bool ring_only = true;         // 2^20 points, detect mode, calls shorter than the ring: no dB plane is written (SS_RING_ONLY=0: written as ever)
-    bool cols1024_wide = false;    // 2^20 points (SS_C1024_WIDE=1): column tiles of 16 columns by 1024 threads as a launch of their own, the deferred stages in a launch without an FFT role
+    bool cols1024_wide = true;     // 2^20 points: column tiles of 16 columns by 1024 threads as a launch of their own, the deferred stages in a launch without an FFT role (SS_C1024_WIDE=0: 8 columns by 512 threads as k_scan_step's FFT role, KIND 3)
     bool fft_xcd_map = true;       // XCD-aware tile order in k_fft_rows256xR_psd
     bool spec_standalone = false;  // spectrogram by its own two kernels instead of inside the detect tiles
     bool pipeline = true;          // 8192 points: defer detect / emit of a call into the next calls' launches (scan_step.h)
@@ -156,7 +156,7 @@ struct ss_ctx {
       fft_sub = tri("SS_FFT_SUB");
       fft_twopass = tri("SS_FFT_TWOPASS") != 0;
       ring_only = tri("SS_RING_ONLY") != 0;
-      cols1024_wide = tri("SS_C1024_WIDE") == 1;
+      cols1024_wide = tri("SS_C1024_WIDE") != 0;
       fft_xcd_map = tri("SS_FFT_XCDMAP") != 0;
       spec_standalone = is("SS_SPEC_IMPL", "standalone");
       pipeline = tri("SS_PIPELINE") != 0;
@@ -806,6 +806,9 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
     } else if (det->tile_list && fft && fft->cols) {
       a.list_by_fft = 1;  // long transforms, planned stage: column workgroup p takes pair p of the list after its own tile (scan_step.h)
       a.n_det = 2 * std::max(0, (n_det_tiles + 1) / 2 - fft->n);  // detect workgroups for the pairs beyond
+    } else if (det->tile_list && c->two_pass && !fft) {
+      a.list_loop = 1;  // 2^20 points in two passes: 128 detect workgroups share the list out in a loop (scan_step.h)
+      a.n_det = 2 * std::min(128, (n_det_tiles + 1) / 2);
     } else {
       a.n_det = n_det_tiles;
     }
@@ -832,6 +835,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
 #endif
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (fft && !prof_pair(c, &e0, &e1)) e0 = e1 = nullptr;
+  if (!fft && c->two_pass && stream == c->stream && !prof_slot(c, SS_KSLOT_SUB, &e0, &e1)) e0 = e1 = nullptr;  // (2^20 points: the deferred stages' own launch, timed with its call)
   const bool sp = spec && det;
   switch (c->cfg.in_format) {
     case SS_FMT_CF32: sp ? launch_step_variant<ss::FMT_CF32, true>(c, a, e0, e1, stream) : launch_step_variant<ss::FMT_CF32, false>(c, a, e0, e1, stream); break;
@@ -1642,7 +1646,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       }
       // the plan: which tiles of this call can hold a candidate at all (k_plan_long) — behind the rows kernel, ahead of the
       // launch that carries the detect stage. Only a stage whose sole products are mask bits and counts is planned.
-      const int plan_cols = ss::plan_long_cols(nframes, c->pend_det.shift, c->n / 256);
+      const int plan_cols = ss::plan_long_cols(nframes, c->pend_det.shift, c->n / 256, c->two_pass ? 32 : 8);
       if (ring_by_rows && !spec && !c->pend_det.rel_out && !c->pend_det.avg_out && plan_cols > 0) {
         int* list = c->d_tlist[(c->buf_cur + c->nbuf - 1) % c->nbuf];  // (run_backend_fused has moved buf_cur on: the set this call's mask bits go to)
         ss::PlanLongArgs pl{};
