@@ -32,7 +32,10 @@ constexpr int kFft1024ColsPlaneBytes = 32 * kFft256PitchCols * 4;               
 constexpr int kFft1024RowsPlaneBytes = 1024 * 9 * 4;                              // 36 864: the read-out tile [k2][row], pitch 9 (>= 32 x 273 words)
 constexpr int kFft1024TableBytes = (256 + 256) * 8;                               // W_256 [16][16], then W_1024^k' [256]
 constexpr int kFft1024ColsLdsBytes = kFft1024ColsPlaneBytes + kFft1024TableBytes; // 39 040: fits k_scan_step's 39 936 (the column tiles are its FFT role, KIND 3)
-constexpr int kFft1024RowsLdsBytes = kFft1024RowsPlaneBytes + kFft1024TableBytes; // 40 960: four workgroups per CU, to the byte
+// the row tiles' tables sit behind the EXCHANGE plane; the read-out tile, which is larger, overlays the front of them once the
+// transform is done with them: 39 040 bytes, and the row tile fits k_scan_step's 39 936 (it is its FFT role, KIND 4)
+constexpr int kFft1024RowsLdsBytes = kFft1024ColsPlaneBytes + kFft1024TableBytes;
+static_assert(kFft1024RowsPlaneBytes <= kFft1024RowsLdsBytes, "the read-out tile fits");
 static_assert(32 * kFft1024Pitch2 * 4 <= kFft1024ColsPlaneBytes && 32 * kFft256PitchCols * 4 <= kFft1024RowsPlaneBytes, "exchange planes");
 constexpr int kFft1024TwA = 0, kFft1024TwB = 64 * 1024, kFft1024Tw1024 = 66 * 1024, kFft1024TableEntries = 66 * 1024 + 256;  // offsets into ColsArgs::twc
 
@@ -205,19 +208,17 @@ struct Rows1024Args {
   RowsExtra x; // (smax holds max_key values here)
 };
 
-// One row tile: 8 rows k1 x 1024 points. blockIdx = ((f * 16) + v) * 8 + x: XCD x takes rows [128 x, 128 x + 128) of every
+// One row tile: 8 rows k1 x 1024 points. block = ((f * 16) + v) * 8 + x: XCD x takes rows [128 x, 128 x + 128) of every
 // frame, v its 16 tiles in turn — the four tiles that fill the 128-byte lines of the dB plane (32 consecutive k1 for every k2)
 // are consecutive blocks of one XCD.
-__global__ __launch_bounds__(512, 8) void k_fft_rows1024_psd(Rows1024Args g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void fft_rows1024_tile(const Rows1024Args& g, int block, unsigned char* __restrict__ smem_raw, int t) {
   float* s = reinterpret_cast<float*>(smem_raw);
-  float2* tw_lds = reinterpret_cast<float2*>(smem_raw + kFft1024RowsPlaneBytes);
+  float2* tw_lds = reinterpret_cast<float2*>(smem_raw + kFft1024ColsPlaneBytes);
   float2* tw1024_lds = tw_lds + 256;
-  const int t = threadIdx.x;
   tw_lds[t] = t < 256 ? g.tw256[t] : g.tw1024[t - 256];
   const RowsExtra& x = g.x;
-  if (x.zero_word && blockIdx.x == 0 && t == 0) *x.zero_word = 0;
-  const int xc = (int)blockIdx.x & 7, v = (int)blockIdx.x >> 3;
+  if (x.zero_word && block == 0 && t == 0) *x.zero_word = 0;
+  const int xc = block & 7, v = block >> 3;
   const int f = v >> 4, r0 = (xc << 7) + ((v & 15) << 3);
   const int fl = t >> 6, tt = t & 63;
   const int q = tt & 3, j = tt >> 2;
@@ -296,6 +297,12 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows1024_psd(Rows1024Args g) {
     if (out) out[bin] = vv;
     if (hrow) hrow[bin] = vv - x.thr[bin];  // noise_learner.cpp:55, as detect_tile forms it
   }
+}
+
+// Stand-alone launch (contexts without the step kernel; otherwise the row tiles run as a role of k_scan_step, scan_step.h).
+__global__ __launch_bounds__(512, 8) void k_fft_rows1024_psd(Rows1024Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  fft_rows1024_tile(g, (int)blockIdx.x, smem_raw, (int)threadIdx.x);
 }
 
 }  // namespace ss

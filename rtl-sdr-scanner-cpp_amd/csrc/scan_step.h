@@ -53,6 +53,7 @@ struct StepArgs {
   const void* halo_iq;  // first of those frames
   float* halo_psd;      // [n_halo][8192]
   int n_halo;
+  Rows1024Args rows;  // KIND 4: 1024-point ROW tiles of a 2^20-point frame (fft1024_kernels.h) — the column half, 1024 threads per tile, is a launch of its own right before
   ColsArgs cols;    // KIND 1, 2: 256-point column tiles of a long transform (fft256_kernels.h); KIND 3: 1024-point column tiles of a 2^20-point frame (fft1024_kernels.h)
   DetectArgs det;
   EmitArgs emit;
@@ -73,7 +74,7 @@ struct StepArgs {
   // barriers — the launch grew by the 7 us the plan launch takes: 65536 x 128: 66.0 against 65.3 us per call, 2^20 x 16: 178
   // against 174, profiles/r03/s41.)
   int list_by_fft;
-  // KIND 3 (2^20 points in two passes: the column half is a launch of its own, so the deferred stages ride on no FFT role): the
+  // KIND 5 — launches without an FFT role of a 2^20-point context (the drain of its deferred stages): the
   // detect workgroups share k_plan_long's list out in a loop, pair item, item + W, item + 2 W, ... — a workgroup per POSSIBLE pair
   // (4096 of them, of which a few dozen find one) cost the launch 17 us in dispatch alone
   int list_loop;
@@ -101,7 +102,7 @@ constexpr int kStepThreads = 512;
 constexpr int kStepLdsBytes = kFft8192V2LdsBytes;
 static_assert(2 * (16 * DetectTile<21, 21, 16, 256>::P * 4 + 64) <= kFft8192V2LdsBytes, "two detect tiles per workgroup");
 static_assert((8 * kEmitList + 9) * 4 <= kFft8192V2LdsBytes, "eight emit lists per workgroup");
-static_assert(kFft256ColsLdsBytes <= kFft8192V2LdsBytes && kFft1024ColsLdsBytes <= kFft8192V2LdsBytes, "a column tile");
+static_assert(kFft256ColsLdsBytes <= kFft8192V2LdsBytes && kFft1024ColsLdsBytes <= kFft8192V2LdsBytes && kFft1024RowsLdsBytes <= kFft8192V2LdsBytes, "a column / row tile");
 static_assert((kPlanLdsFloats + 64) * 4 <= kFft8192V2LdsBytes, "a plan workgroup's staging area");
 __host__ __device__ inline int step_fft_wgs(const StepArgs& a) { return a.n_fft; }
 __host__ __device__ inline int step_emit_wgs(const StepArgs& a) { return a.emit_per_wg == 1 ? a.n_emit : (a.n_emit + 7) / 8; }
@@ -140,7 +141,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     }
   } else if (role == ROLE_DET) {
     // ---- detect role: two tiles ----
-    if constexpr (KIND == 3) {
+    if constexpr (KIND == 5) {  // (an instantiation of its own: a loop around the tile evaluation costs every role of a kernel registers)
       if (a.det.tile_list && a.list_loop) {
         using T = DetectTile<21, 21, 16, 256>;
         const int n_tiles = (a.det.n / 256) * plan_frame_tiles(a.det.nframes, a.det.shift);
@@ -179,7 +180,9 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
 #endif
   } else if constexpr (KIND >= 1) {
     // ---- FFT role, long transforms: one tile of 32 columns x 256 rows (KIND 3: 8 columns x 1024 rows of a 2^20-point frame) ----
-    if constexpr (KIND == 3) fft_cols1024_tile<FMT>(a.cols, item, smem_raw, tid);
+    if constexpr (KIND == 5) return;  // (the drain of a 2^20-point context: launches without an FFT role only)
+    else if constexpr (KIND == 4) fft_rows1024_tile(a.rows, item, smem_raw, tid);  // (the ROW half of call k: its column half ran as its own launch right before)
+    else if constexpr (KIND == 3) fft_cols1024_tile<FMT>(a.cols, item, smem_raw, tid);
     else fft_cols256_tile<FMT>(a.cols, item, smem_raw, tid);
     // ... then this workgroup's share of the tiles k_plan_long listed for the detect stage that rides on the launch. (The other
     // way round — the pairs first, while the memory system is still idle, then the column tile — was 5 us slower per launch at

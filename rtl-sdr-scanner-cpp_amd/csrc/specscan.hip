@@ -597,7 +597,7 @@ void launch_cols1024(ss_ctx* c, const void* d_iq, long long item_stride, int nfr
     default: return launch_cols1024_fmt<ss::FMT_CU8>(c, d_iq, item_stride, nframes);
   }
 }
-void launch_rows1024(ss_ctx* c, int nframes, float* d_psd, const ss::RowsExtra& rx) {
+ss::Rows1024Args rows1024_args(ss_ctx* c, float* d_psd, const ss::RowsExtra& rx) {
   ss::Rows1024Args g{};
   g.work = c->d_work;
   g.tw256 = c->d_tw256;
@@ -605,6 +605,10 @@ void launch_rows1024(ss_ctx* c, int nframes, float* d_psd, const ss::RowsExtra& 
   g.db_off = c->db_off;
   g.psd = d_psd;
   g.x = rx;
+  return g;
+}
+void launch_rows1024(ss_ctx* c, int nframes, float* d_psd, const ss::RowsExtra& rx) {
+  const ss::Rows1024Args g = rows1024_args(c, d_psd, rx);
   SS_LAUNCH_SLOT(c, SS_KSLOT_ROWS, ss::k_fft_rows1024_psd, dim3(nframes * 128), dim3(512), ss::kFft1024RowsLdsBytes, g);
 }
 
@@ -750,7 +754,11 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
     if (e0) hipExtLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, stream, e0, e1, 0, a);
     else hipLaunchKernelGGL(kernel, grid, block, ss::kStepLdsBytes, stream, a);
   };
-  if (c->two_pass) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 3>);  // (2^20 points: rows of 32768 mask words, the emit role gives a frame to all eight waves)
+  // (2^20 points: rows of 32768 mask words, the emit role gives a frame to all eight waves; the FFT role is the row tiles — KIND 4,
+  // the column half being a launch of its own — or, behind a switch of the diagnostics build, 8-column column tiles, KIND 3)
+  // (KIND 5: a launch without an FFT role — the drain — whose detect workgroups share the plan's list out in a loop)
+  if (c->two_pass && a.list_loop) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 5>);
+  if (c->two_pass) return c->diag.cols1024_wide ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 4>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 3>);
   if (!c->use_fft8192) return a.emit_per_wg == 1 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 2>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 1>);
 #ifdef SS_DIAG
   if (c->diag.fft_tw == 0) return go(ss::k_scan_step<FMT, SPEC, 0, false>);
@@ -765,6 +773,7 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
 struct FftRole {
   const ss::Fft8192Args* frames = nullptr;
   const ss::ColsArgs* cols = nullptr;
+  const ss::Rows1024Args* rows1024 = nullptr;  // 2^20 points in two passes: the ROW tiles (the column half is a launch of its own)
   int n = 0;  // frames / column tiles
   const void* halo_iq = nullptr;  // deep pipelining: n_halo frames of the previous call go through the FFT again, into halo_psd
   float* halo_psd = nullptr;
@@ -790,6 +799,9 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   } else if (fft && fft->cols) {
     a.cols = *fft->cols;
     a.n_fft = fft->n;
+  } else if (fft && fft->rows1024) {
+    a.rows = *fft->rows1024;
+    a.n_fft = fft->n;
   }
   // Tile culling (detect_fused.h): a detect stage whose only products are mask bits and counts is PLANNED — a few plan
   // workgroups list the tiles that may hold a candidate — and the list is evaluated by the launch's FFT workgroups after their
@@ -803,7 +815,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
       a.n_plan = n_det_tiles;
       a.plan_cols = plan_cols;
       a.plan_by_fft = a.n_fft >= ss::step_plan_consumers(a) ? 1 : 0;  // (consumer p serves list p mod S)
-    } else if (det->tile_list && fft && fft->cols) {
+    } else if (det->tile_list && fft && (fft->cols || fft->rows1024)) {
       a.list_by_fft = 1;  // long transforms, planned stage: column workgroup p takes pair p of the list after its own tile (scan_step.h)
       a.n_det = 2 * std::max(0, (n_det_tiles + 1) / 2 - fft->n);  // detect workgroups for the pairs beyond
     } else if (det->tile_list && c->two_pass && !fft) {
@@ -834,8 +846,11 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   }
 #endif
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (fft && !prof_pair(c, &e0, &e1)) e0 = e1 = nullptr;
-  if (!fft && c->two_pass && stream == c->stream && !prof_slot(c, SS_KSLOT_SUB, &e0, &e1)) e0 = e1 = nullptr;  // (2^20 points: the deferred stages' own launch, timed with its call)
+  if (fft && fft->rows1024) {  // (2^20 points: the row half + passengers; the call's column launch has decided whether it is a sampled one)
+    if (!prof_slot(c, SS_KSLOT_ROWS, &e0, &e1)) e0 = e1 = nullptr;
+  } else if (fft && !prof_pair(c, &e0, &e1)) {
+    e0 = e1 = nullptr;
+  }
   const bool sp = spec && det;
   switch (c->cfg.in_format) {
     case SS_FMT_CF32: sp ? launch_step_variant<ss::FMT_CF32, true>(c, a, e0, e1, stream) : launch_step_variant<ss::FMT_CF32, false>(c, a, e0, e1, stream); break;
@@ -1610,15 +1625,23 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     const bool reused = c->have_det && (clash(d_psd, plane_bytes, c->pend_det.psd, pend_bytes) || clash(d_avg_out, plane_bytes, c->pend_det_emit.avg, pend_bytes) ||
                                          clash(d_psd, plane_bytes, c->pend_det.rel_out, pend_bytes) || clash(d_rel_out, plane_bytes, c->pend_det.psd, pend_bytes));
     if (!overlap || reused) flush_stages(c);
-    if (c->two_pass && c->diag.cols1024_wide) {  // (A/B: the column half as a launch of its own, then the deferred stages without an FFT role)
+    const bool rows_by_step = c->two_pass && c->diag.cols1024_wide;
+    if (rows_by_step) {
+      // 2^20 points: the column half of call k as a launch of its own (16 columns x 1024 rows per 1024-thread workgroup: too many
+      // threads for a role), then ONE launch of k_scan_step whose FFT role is the ROW half of call k — 8 rows x 1024 points per
+      // 512-thread workgroup — with detect(k - 1) and emit(k - 2) riding on it as they ride on the column launches of the other sizes
       launch_cols1024(c, d_iq, item_stride, nframes);
-      launch_step(c, nullptr, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
+      const ss::Rows1024Args gr = rows1024_args(c, ring_only ? nullptr : d_psd, rx);
+      FftRole rrole;
+      rrole.rows1024 = &gr;
+      rrole.n = nframes * 128;
+      launch_step(c, &rrole, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     } else
     launch_step(c, &role, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     c->have_emit = c->have_det;
     c->pend_emit = c->pend_det_emit;
     c->have_det = false;
-    if (!c->use_fft8192) {
+    if (!c->use_fft8192 && !rows_by_step) {
       st = launch_fft_rows(c, nframes, ring_only ? nullptr : d_psd, rx);
       if (st != SS_OK) return st;
     }
@@ -1646,7 +1669,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       }
       // the plan: which tiles of this call can hold a candidate at all (k_plan_long) — behind the rows kernel, ahead of the
       // launch that carries the detect stage. Only a stage whose sole products are mask bits and counts is planned.
-      const int plan_cols = ss::plan_long_cols(nframes, c->pend_det.shift, c->n / 256, c->two_pass ? 32 : 8);
+      const int plan_cols = ss::plan_long_cols(nframes, c->pend_det.shift, c->n / 256, 8);  // (32 columns per workgroup — whole lines of the two-pass layout — halved the fetches and doubled the time: 128 workgroups are too few, profiles/r04/s6_summary.txt)
       if (ring_by_rows && !spec && !c->pend_det.rel_out && !c->pend_det.avg_out && plan_cols > 0) {
         int* list = c->d_tlist[(c->buf_cur + c->nbuf - 1) % c->nbuf];  // (run_backend_fused has moved buf_cur on: the set this call's mask bits go to)
         ss::PlanLongArgs pl{};

@@ -109,6 +109,7 @@ ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurem
     ({"SS_STEP_LONG": "0"}, 65536, 20_000_000, "cs8"),
     ({"SS_STEP_LONG": "0"}, 16384, 4_000_000, "cf32"),
     ({"SS_FFT_TWOPASS": "0"}, 1 << 20, 61_440_000, "cs8"),  # 2^20 points as 256 x 4096 in three passes (round 3's form; the product takes 1024 x 1024 in two)
+    ({"SS_C1024_WIDE": "0"}, 1 << 20, 61_440_000, "cs8"),   # ... in two passes with 8-column tiles as k_scan_step's FFT role (the product: 16-column tiles, a launch of their own, the ROW tiles as the role)
 ]
 
 
