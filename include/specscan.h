@@ -246,8 +246,8 @@ int ss_reset_noise(ss_ctx* ctx);
  * negative down to -(grouping_y-1) for SS_PLANE_REL, addressing the averager ring rows that
  * Transmission::getBestIndex walks (transmission.cpp:132-154). SS_PLANE_REL is always there. SS_PLANE_AVG needs
  * SS_FLAG_KEEP_PLANES. SS_PLANE_PSD is there after ss_process and after ss_process_device calls that were given d_psd_db; a
- * 2^20-point ss_process_device call in detect mode (no plane handed out) of fewer frames than the averager ring holds writes no
- * dB plane at all — its rows go straight to the ring as noise-relative values — and SS_PLANE_PSD then fails with SS_ERR_INVALID. */
+ * 2^20-point ss_process_device call in detect mode (no plane handed out) writes no dB plane at all — its rows go straight to the
+ * averager ring's buffer as noise-relative values — and SS_PLANE_PSD then fails with SS_ERR_INVALID. */
 int ss_read_window(ss_ctx* ctx, int32_t plane, int32_t frame, int32_t lo, int32_t hi, float* out);
 
 /* Spectrogram side branch (needs SS_FLAG_SPECTROGRAM). ss_spectrogram_size: number of output bins,

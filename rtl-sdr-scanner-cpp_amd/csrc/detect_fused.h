@@ -515,8 +515,19 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
   const int C = p.cols, lognsub = p.logn - 16;
   // layout 0: workgroup (wc, d0) takes the columns whose unshifted number is wc + nsub d; layout 1: the columns 4 k2 + wc of C
   // consecutive k2 — either way the ones whose maxima lie side by side in a frame's row of the ring
-  const int wc = p.layout ? (int)blockIdx.x & 3 : (int)blockIdx.x & ((1 << lognsub) - 1);
-  const int d0 = (p.layout ? (int)blockIdx.x >> 2 : (int)blockIdx.x >> lognsub) * C;
+  // (layout 1: the 32 / C workgroups whose columns share the 128-byte lines of the ring are consecutive slots of ONE XCD — block b
+  // runs on XCD b mod 8 — as they are in layout 0 by construction; spread over two XCDs they fetched every line twice: 12 against
+  // 7 us per call, profiles/r04/s4_summary.txt)
+  int wc, d0;
+  if (p.layout) {
+    const int M = (C <= 32 && (32 % C) == 0) ? 32 / C : 1;
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    wc = xcd & 3;
+    d0 = ((((slot / M) << 1) | (xcd >> 2)) * M + slot % M) * C;
+  } else {
+    wc = (int)blockIdx.x & ((1 << lognsub) - 1);
+    d0 = ((int)blockIdx.x >> lognsub) * C;
+  }
   const auto column = [&](int i) {
     if (p.layout) return d0 + i < 1024 ? 4 * (d0 + i) + wc : tiles_per_row;
     return d0 + i < 256 ? (wc + ((d0 + i) << lognsub)) ^ (tiles_per_row >> 1) : tiles_per_row;

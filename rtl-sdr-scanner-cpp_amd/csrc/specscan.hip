@@ -384,9 +384,10 @@ struct ss_ctx {
   float2* d_tw_cols = nullptr;  // N >= 65536: step-A twiddle factored for k_fft_cols256, [j][n2] W_N^(n2 j) then [k][n2] W_N^(16 n2 k)
   // N = 2^20 as 1024 x 1024 (fft1024_kernels.h): two passes over the work buffer instead of three
   bool two_pass = false;  // (its tables: one block in d_tw_cols)
-  // Detect mode, calls shorter than the averager ring (2^20 points in 16-frame calls: BASELINE config 5): every row of the batch
-  // is a ring row, which the rows kernel writes (rel = dB - thr); no dB plane is written at all — the detect tiles take the batch's
-  // rows from the ring, with a ceiling of zeros to subtract (x - 0.0f is x: the same bits) — unless somebody wants one.
+  // Detect mode at 2^20 points (BASELINE config 5): the rows kernel writes the batch's rows as noise-relative rows (rel = dB - thr)
+  // into the averager ring's buffer — behind the window for calls shorter than the ring, as a region of their own whose last 35 rows
+  // are the next window otherwise (place_ring) — and no dB plane is written at all: the detect tiles take the batch's rows from
+  // there, with a ceiling of zeros to subtract (x - 0.0f is x: the same bits) — unless somebody wants a plane.
   float* d_win1024 = nullptr;        // the window taps in the 1024-point column tiles' order
   float* d_zero_row = nullptr;       // n zeros
   const float* last_rel_rows = nullptr;  // the last batch's rows as rel values (ring-only calls: last_psd is null then)
@@ -1162,10 +1163,34 @@ struct RingPlace {
   const float* in;
   float* out;
   int next_start;
+  float* batch;  // 2^20 points in two passes, batches of at least H frames: where ALL the batch's rows go when the rows kernel writes them as rel rows (null otherwise)
 };
 RingPlace place_ring(ss_ctx* c, int nframes) {
   const int n = c->n;
   constexpr int H = kHistRows;
+  if (c->two_pass && nframes >= H && H + nframes <= c->hist_rows) {
+    // 2^20 points: room for the WHOLE batch's rows behind the window being read (or at the front of the buffer), the new window
+    // being the last H of them — so that a detect-mode call can write ONE plane, noise-relative rows that are the batch's rows for
+    // its own detect stage and the next call's ring at once, instead of a dB plane and ring rows (run_batch)
+    int b = c->hist_start + H;
+    if (b + nframes > c->hist_rows) {
+      if (nframes <= c->hist_start) {
+        b = 0;
+      } else {  // (stream order: a deferred detect stage that still reads or writes this window goes first)
+        flush_stages(c);
+        hipLaunchKernelGGL(ss::k_hist_shift, dim3(grid_for((size_t)H * n, 256)), dim3(256), 0, c->stream,
+                           (const float*)(c->d_hist + (size_t)c->hist_start * n), c->d_hist, n, H, 0);
+        c->hist_start = 0;
+        b = H;
+      }
+    }
+    RingPlace r{};
+    r.in = c->d_hist + (size_t)c->hist_start * n;
+    r.next_start = b + nframes - H;
+    r.out = c->d_hist + (size_t)r.next_start * n;
+    r.batch = c->d_hist + (size_t)b * n;
+    return r;
+  }
   // The detect stage writes the batch's newest min(nframes, H) rel rows to the LAST rows of hist_out[0..H).
   if (nframes < H && c->hist_start + H + nframes > c->hist_rows) {
     // end of the buffer: move the window to the front once (rare: every (hist_rows - H) / nframes batches).
@@ -1606,9 +1631,15 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         rx.zero_word = c->d_tlist[c->buf_cur];  // (the list this call's plan appends to; its last reader was the detect stage of the call before last)
         ring_by_rows = true;
         // no dB plane at all: a device call that hands out no plane, shorter than the ring, whose rows the new rows kernel writes
-        ring_only = c->two_pass && allow_overlap && !d_psd_out && !d_rel_out && !d_avg_out && !spec && !c->ref_nan && nframes < kHistRows &&
+        ring_only = c->two_pass && allow_overlap && !d_psd_out && !d_rel_out && !d_avg_out && !spec && !c->ref_nan && (nframes < kHistRows || rp.batch) &&
                     !(c->cfg.flags & SS_FLAG_KEEP_PLANES) && c->diag.ring_only;
-        if (ring_only) ring_rows = rp.in + (size_t)kHistRows * c->n;  // batch frame f = row H + f of the window being read: right behind it (place_ring)
+        if (ring_only && nframes < kHistRows) {
+          ring_rows = rp.in + (size_t)kHistRows * c->n;  // batch frame f = row H + f of the window being read: right behind it (place_ring)
+        } else if (ring_only) {  // every frame of the batch as a rel row of the region place_ring reserved; its last H rows are the next call's ring
+          rx.hist_out = rp.batch;
+          rx.first_hist = 0;
+          ring_rows = rp.batch;
+        }
       }
     }
     // (SS_FLAG_STREAM_ORDERED / SS_FLAG_REFERENCE_NAN: every stage of the call before the call returns, in order on the public stream)
@@ -1681,7 +1712,11 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         pl.logn = c->logn;
         pl.list = list;
         pl.layout = c->two_pass ? 1 : 0;
-        const int plan_wgs = c->two_pass ? 4 * ((1024 + plan_cols - 1) / plan_cols) : (c->n >> 16) * ((256 + plan_cols - 1) / plan_cols);
+        // (two passes: 4 quarters x the groups of plan_cols consecutive k2, the groups rounded up to whole lines' worth — 32 / plan_cols
+        // of them — times two, so that the block index decodes as k_plan_long expects; groups past the band's end find no column)
+        const int line_groups = (plan_cols <= 32 && 32 % plan_cols == 0) ? 32 / plan_cols : 1;
+        const int groups = (((1024 + plan_cols - 1) / plan_cols + 2 * line_groups - 1) / (2 * line_groups)) * (2 * line_groups);
+        const int plan_wgs = c->two_pass ? 4 * groups : (c->n >> 16) * ((256 + plan_cols - 1) / plan_cols);
         SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, c->pend_det, pl);
         c->pend_det.tile_list = list;
       }

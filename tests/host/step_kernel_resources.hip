@@ -5,3 +5,4 @@
 
 template __global__ void ss::k_scan_step<ss::FMT_CF32, false, 2, true, false, 0>(ss::StepArgs);  // 8192 points, CF32, no spectrogram branch: what bench.py times
 template __global__ void ss::k_scan_step<ss::FMT_CS8, false, 2, true, false, 2>(ss::StepArgs);   // long transforms, int8: config 3's column launch
+template __global__ void ss::k_scan_step<ss::FMT_CF32, false, 2, true, false, 4>(ss::StepArgs);  // 2^20 points in two passes: the row tiles as the FFT role (config 5)

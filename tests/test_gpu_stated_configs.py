@@ -216,17 +216,18 @@ def test_config5_device_calls_against_the_reference(ref_mod):
     assert len(b) > 2000 and len(a ^ b) <= dont_care_limit(len(b))
 
 
-def test_config5_calls_that_keep_no_db_plane_serve_the_tracker_all_the_same():
-    """A 2^20-point ss_process_device call in detect mode, shorter than the averager ring, writes no dB plane (its rows go straight
-    to the ring as noise-relative values, include/specscan.h): ss_read_window(SS_PLANE_REL) — what the signal tracker reads — gives
-    the bits a call WITH a plane gives, the ring rows before the batch included; SS_PLANE_PSD says that it is not there; and the
-    candidate lists are those of the call with a plane."""
+@pytest.mark.parametrize("chunk,ncalls", [(16, 5), (48, 4), (37, 12)])
+def test_config5_calls_that_keep_no_db_plane_serve_the_tracker_all_the_same(chunk, ncalls):
+    """A 2^20-point ss_process_device call in detect mode writes no dB plane (its rows go straight to the averager ring's buffer as
+    noise-relative values — behind the window for calls shorter than the ring, as a region of their own otherwise, wrapping around
+    the buffer's end in the longest case here —, include/specscan.h): ss_read_window(SS_PLANE_REL) — what the signal tracker reads —
+    gives the bits a call WITH a plane gives, the ring rows before the batch included; SS_PLANE_PSD says that it is not there; and
+    the candidate lists are those of the call with a plane."""
     import torch
-    n, fs, chunk, learn = 1 << 20, 61_440_000, 16, 16
+    n, fs, learn = 1 << 20, 61_440_000, chunk
     dev = torch.device("cuda", 0)
-    band = pkg.synth.SyntheticBand(n, seed=44, on_frame=40, off_frame=70)
-    iq = band.frames_cs8(chunk * 5)
-    d_iq = [torch.from_numpy(iq[k * chunk:(k + 1) * chunk]).to(dev) for k in range(5)]
+    band = pkg.synth.SyntheticBand(n, seed=44, on_frame=chunk + 24, off_frame=chunk * ncalls - 10)
+    d_iq = [torch.from_numpy(band.frames_cs8(chunk)).to(dev) for k in range(ncalls)]
     res = {}
     for with_plane in (False, True):
         eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, in_format=pkg.abi.SS_FMT_CS8, max_batch=chunk, learn_frames=learn)
@@ -237,7 +238,7 @@ def test_config5_calls_that_keep_no_db_plane_serve_the_tracker_all_the_same():
             eng.process_device(d, chunk, psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"])
             outs.append(o)
         eng.sync()
-        wins = [eng.read_window(pkg.abi.SS_PLANE_REL, f, lo, lo + 300) for f in (-20, -1, 0, 7, 15) for lo in (0, 524_000, n - 300)]
+        wins = [eng.read_window(pkg.abi.SS_PLANE_REL, f, lo, lo + 300) for f in (-20, -1, 0, 7, chunk - 1) for lo in (0, 524_000, n - 300)]
         if with_plane:
             eng.read_window(pkg.abi.SS_PLANE_PSD, 3, 0, 64)
         else:
@@ -248,7 +249,7 @@ def test_config5_calls_that_keep_no_db_plane_serve_the_tracker_all_the_same():
         eng.close()
     for a, b in zip(res[False][0], res[True][0]):
         np.testing.assert_array_equal(a, b)
-    for k in range(5):
+    for k in range(ncalls):
         np.testing.assert_array_equal(res[False][1][k], res[True][1][k])
         np.testing.assert_array_equal(res[False][2][k], res[True][2][k])
     assert sum(int(x[-1]) for x in res[True][1]) > 1000
