@@ -264,9 +264,8 @@ def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False):
 
 # ---------------------------------------------------------------------------------------------- launcher
 PMC_FILES = {"fetch": "pmc_fetch.csv", "write": "pmc_write.csv"}  # under profiles/<PMC_SET>/, one counter per rocprofv3 pass
-# the committed passes of each configuration's command line (config 3's are of the culled form, which is no longer the default at
-# 65536 points: DESIGN.md 4.4 quotes them, the bench line does not)
-PMC_SET = {2: "r03/s47_cfg2", 5: "r03/s47_cfg5"}
+# the committed passes of each configuration's command line on the final tree of round 4 (scripts/r04/s8.sh)
+PMC_SET = {2: "r04/s8_cfg2", 3: "r04/s8_cfg3", 5: "r04/s8_cfg5"}
 
 
 def traffic_from_profiles(config: int, kernel_match: str, threads_per_launch: int | None = None):
@@ -314,10 +313,9 @@ def chain_kernels(n: int, fmt: str):
     if n == 1 << 20 and os.environ.get("SS_FFT_TWOPASS") != "0":  # 1024 x 1024 in two passes (csrc/fft1024_kernels.h; the three-pass form is a switch of the diagnostics build)
         return [("step", "k_fft_cols1024", "k_fft_cols1024: column half of the two-pass FFT (load, window, 1024-point FFTs in registers + LDS, twiddle -> work buffer), "
                  "16 columns x 1024 rows per 1024-thread workgroup", in_b + 8.0),
-                ("rows", "k_fft_rows1024", "k_fft_rows1024_psd: row half, 1024-point FFTs -> dB -> noise-relative rows straight into the averager ring (no dB plane in detect "
-                 "mode with calls shorter than the ring) + run maxima for the tile culling", 12.0),
-                ("plan", "k_plan_long", "k_plan_long: which averaging tiles of the call can hold a candidate, from the run maxima the rows kernel left (one list per call)", 0.0),
-                ("sub", "k_scan_step", "k_scan_step without an FFT role: the listed averaging tiles of call k-1 (shared out in a loop) and the candidate lists of call k-2", 0.0)]
+                ("rows", "k_scan_step", "k_scan_step with the ROW half as its FFT role (fft_rows1024_tile: 1024-point FFTs -> dB -> noise-relative rows straight into the averager "
+                 "ring's buffer, no dB plane in detect mode, + run maxima for the tile culling), carrying the listed averaging tiles of call k-1 and the candidate lists of call k-2", 12.0),
+                ("plan", "k_plan_long", "k_plan_long: which averaging tiles of the call can hold a candidate, from the run maxima the rows kernel left (one list per call)", 0.0)]
     n2 = n // 256
     ks = [("step", "k_scan_step", "k_scan_step: column half of the four-step FFT of call k (load, window, 256-point FFTs, twiddle -> work buffer), carrying the "
            "21x21 mean + threshold of call k-1 (the tiles the plan listed) and the candidate lists of call k-2 as further roles", in_b + 8.0)]
@@ -590,7 +588,12 @@ def run(args):
             # launches of the steady-state shape only. 8192 points: 1024 + 20 FFT, 128 emit and 4 plan workgroups of 512 threads; long
             # transforms: the column tiles + one emit workgroup per frame (the listed tiles ride on the column workgroups)
             two_pass = n == 1 << 20 and os.environ.get("SS_FFT_TWOPASS") != "0"
-            shape = (nb + 20 + nb // 8 + 4) * 512 if n == 8192 else (None if two_pass else ((nb * (n // 8192) + (nb if n >= 65536 else -(-nb // 8))) * 512 if slot == "step" and n >= 16384 else None))
+            if n == 8192:
+                shape = (nb + 20 + nb // 8 + 4) * 512
+            elif two_pass:  # column half: 64 workgroups of 1024 threads per frame; row half: 128 of 512 per frame + one emit workgroup per frame
+                shape = {"step": nb * 64 * 1024, "rows": (nb * 128 + nb) * 512}.get(slot)
+            else:
+                shape = (nb * (n // 8192) + (nb if n >= 65536 else -(-nb // 8))) * 512 if slot == "step" and n >= 16384 else None
             tp = traffic_from_profiles(args.config or 2, match, shape) if is_preset(args) else None
             kernels.append({"slot": slot, "what": what, "us": round(us, 2), "launches_timed": cnt_k, "launches_per_call": round(per_call, 2),
                             "bytes_per_launch_it_must_move": kb, "gbs": round(kb / us / 1e3, 1) if us else None,
