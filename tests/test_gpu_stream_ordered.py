@@ -119,3 +119,24 @@ def test_input_wait_lets_a_producer_rotate_three_buffers_under_overlapped_calls(
     eng.close()
     hipapi.event_destroy(ev)
     hipapi.stream_destroy(prod)
+
+
+def test_stats_and_input_wait_say_what_they_are_asked():
+    """ss_get_stats honours the caller's idea of the struct's size (fields are only ever appended); ss_input_wait refuses
+    calls_back < 1 (the latest call's last frames are read once more by the call after it) and is a no-op behind the chain's own
+    stream on a context whose calls run in order."""
+    import ctypes as C
+    eng = pkg.SpectrumEngine(512_000, CENTER, fft_size=2048, decim=1, max_batch=32)
+    lib = eng._lib
+    st = pkg.abi.SsStats()
+    st.size = 24  # size + state + calls + calls_overlapped
+    st.drains = 777
+    assert lib.ss_get_stats(eng._h, C.byref(st)) == 0 and st.size == 24 and st.drains == 777  # nothing behind the 24 bytes is touched
+    st.size = 4
+    assert lib.ss_get_stats(eng._h, C.byref(st)) == pkg.abi.SS_ERR_INVALID
+    with pytest.raises(pkg.abi.SpecscanError, match="calls_back"):
+        eng.input_wait(None, 0)
+    eng.input_wait(None, 1)
+    full = eng.stats()
+    assert full["calls"] == 0 and not full["overlap"] and not full["culling"], full
+    eng.close()
