@@ -499,6 +499,26 @@ __host__ __device__ inline int plan_long_cols(int nframes, int shift, int tile_c
   return c;
 }
 
+// which tile columns a plan workgroup takes: layout 0 — (wc, d0): the columns whose unshifted number is wc + nsub d, d = d0 .. d0 + C;
+// layout 1 — the columns 4 k2 + wc for k2 = d0 .. d0 + C, the 32 / C workgroups whose columns share the 128-byte lines of a frame's row
+// of the ring in consecutive slots of ONE XCD (block b runs on XCD b mod 8)
+__host__ __device__ inline void plan_long_block(int layout, int block, int C, int lognsub, int* wc, int* d0) {
+  if (layout) {
+    const int M = (C <= 32 && (32 % C) == 0) ? 32 / C : 1;
+    const int xcd = block & 7, slot = block >> 3;
+    *wc = xcd & 3;
+    *d0 = ((((slot / M) << 1) | (xcd >> 2)) * M + slot % M) * C;
+  } else {
+    *wc = block & ((1 << lognsub) - 1);
+    *d0 = (block >> lognsub) * C;
+  }
+}
+__host__ __device__ inline int plan_long_blocks(int layout, int C, int n) {  // workgroups of the plan launch
+  if (!layout) return (n >> 16) * ((256 + C - 1) / C);
+  const int line_groups = (C <= 32 && 32 % C == 0) ? 32 / C : 1;
+  return 4 * ((((1024 + C - 1) / C + 2 * line_groups - 1) / (2 * line_groups)) * (2 * line_groups));
+}
+
 template <int G, int GX, int TF, int TB_ = 256>
 __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p) {
   using T = DetectTile<G, GX, TF, TB_>;
@@ -519,15 +539,7 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
   // runs on XCD b mod 8 — as they are in layout 0 by construction; spread over two XCDs they fetched every line twice: 12 against
   // 7 us per call, profiles/r04/s4_summary.txt)
   int wc, d0;
-  if (p.layout) {
-    const int M = (C <= 32 && (32 % C) == 0) ? 32 / C : 1;
-    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    wc = xcd & 3;
-    d0 = ((((slot / M) << 1) | (xcd >> 2)) * M + slot % M) * C;
-  } else {
-    wc = (int)blockIdx.x & ((1 << lognsub) - 1);
-    d0 = ((int)blockIdx.x >> lognsub) * C;
-  }
+  plan_long_block(p.layout, (int)blockIdx.x, C, lognsub, &wc, &d0);
   const auto column = [&](int i) {
     if (p.layout) return d0 + i < 1024 ? 4 * (d0 + i) + wc : tiles_per_row;
     return d0 + i < 256 ? (wc + ((d0 + i) << lognsub)) ^ (tiles_per_row >> 1) : tiles_per_row;

@@ -58,6 +58,14 @@ inline void fft1024_host_tables(float2* tab) {
   for (int k = 0; k < 256; ++k) tab[kFft1024Tw1024 + k] = W((double)k, 1024.0);
 }
 
+// which columns a column tile takes: block = frame * tiles + w -> frame, first column (8-column tiles: XCD (w mod 8) takes the 16
+// neighbouring tiles, so that the two tiles that share a 128-byte line are consecutive blocks of one XCD; 16-column tiles take whole lines)
+__host__ __device__ inline void cols1024_block(int block, int logc, int* f, int* tile) {
+  const int tiles = 1024 >> logc, w = block % tiles;
+  *f = block / tiles;
+  *tile = logc == 3 ? ((w & 7) << 4) | (w >> 3) : w;
+}
+
 // Host side: the window taps in the column tiles' own order — out[(tile * threads + t) * 16 + r] = the tap of the sample thread t
 // of tile `tile` loads as its r-th (sample n1 = 4 (j + 16 r) + q of column tile * COLS + c; sub = t mod 4 COLS = c + COLS q,
 // j = t div 4 COLS). logc = 3 (8 columns, 512 threads) or 4 (16 columns, 1024 threads).
@@ -82,8 +90,8 @@ __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, 
   float2* tw_lds = reinterpret_cast<float2*>(smem_raw + NSUB * kFft256PitchCols * 4);
   float2* tw1024_lds = tw_lds + 256;
   if (t < 512) tw_lds[t] = t < 256 ? g.tw256[t] : g.twc[kFft1024Tw1024 + t - 256];  // (tw_lds and tw1024_lds are contiguous: entries 0..511)
-  const int f = block / TILES, w = block % TILES;
-  const int tile = LOGC == 3 ? ((w & 7) << 4) | (w >> 3) : w;
+  int f, tile;
+  cols1024_block(block, LOGC, &f, &tile);
   const int c0 = tile << LOGC;
   // tile culling: the run maxima of a frame are gathered by atomic maxima in the rows kernel, so the frame's row of the ring
   // starts from zero — cleared here, one launch earlier
@@ -186,14 +194,21 @@ static_assert(fft1024_cols_lds_bytes(3) == kFft1024ColsLdsBytes && (4 << 4) * kF
 
 // An order-preserving key for atomic maxima of dB values: larger float <-> larger unsigned; 0 = nothing seen (below -inf),
 // 0xffffffff = NaN (wins: "cannot be bounded").
-__device__ __forceinline__ unsigned max_key(float x) {
-  const unsigned u = __float_as_uint(x);
+__host__ __device__ __forceinline__ unsigned max_key(float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x);
   return x != x ? 0xffffffffu : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
 }
-__device__ __forceinline__ float max_key_value(unsigned key) {
+__host__ __device__ __forceinline__ float max_key_value(unsigned key) {
   if (key == 0u) return -__builtin_inff();
   if (key == 0xffffffffu) return __builtin_nanf("");
-  return __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+  return __builtin_bit_cast(float, (key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+}
+// which rows a row tile takes: block = ((f * 16) + v) * 8 + x -> frame f, first row r0 (XCD x takes rows [128 x, 128 x + 128) of
+// every frame, v its 16 tiles in turn: the four tiles that fill the 128-byte lines of the dB plane are consecutive blocks of one XCD)
+__host__ __device__ inline void rows1024_block(int block, int* f, int* r0) {
+  const int xc = block & 7, v = block >> 3;
+  *f = v >> 4;
+  *r0 = (xc << 7) + ((v & 15) << 3);
 }
 // where the maximum of 32-bin run R (= bin >> 5, output order: DC in the middle) lies in a frame's row of the ring: the rows
 // kernel's lanes run along k2, so [k1 group][k2] makes its atomics contiguous
@@ -218,8 +233,8 @@ __device__ __forceinline__ void fft_rows1024_tile(const Rows1024Args& g, int blo
   tw_lds[t] = t < 256 ? g.tw256[t] : g.tw1024[t - 256];
   const RowsExtra& x = g.x;
   if (x.zero_word && block == 0 && t == 0) *x.zero_word = 0;
-  const int xc = block & 7, v = block >> 3;
-  const int f = v >> 4, r0 = (xc << 7) + ((v & 15) << 3);
+  int f, r0;
+  rows1024_block(block, &f, &r0);
   const int fl = t >> 6, tt = t & 63;
   const int q = tt & 3, j = tt >> 2;
   const float2* row = g.work + ((size_t)f << 20) + ((size_t)(r0 + fl) << 10);

@@ -1712,11 +1712,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         pl.logn = c->logn;
         pl.list = list;
         pl.layout = c->two_pass ? 1 : 0;
-        // (two passes: 4 quarters x the groups of plan_cols consecutive k2, the groups rounded up to whole lines' worth — 32 / plan_cols
-        // of them — times two, so that the block index decodes as k_plan_long expects; groups past the band's end find no column)
-        const int line_groups = (plan_cols <= 32 && 32 % plan_cols == 0) ? 32 / plan_cols : 1;
-        const int groups = (((1024 + plan_cols - 1) / plan_cols + 2 * line_groups - 1) / (2 * line_groups)) * (2 * line_groups);
-        const int plan_wgs = c->two_pass ? 4 * groups : (c->n >> 16) * ((256 + plan_cols - 1) / plan_cols);
+        const int plan_wgs = ss::plan_long_blocks(pl.layout, plan_cols, c->n);  // (groups past the band's end find no column)
         SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, c->pend_det, pl);
         c->pend_det.tile_list = list;
       }

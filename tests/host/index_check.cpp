@@ -3,7 +3,11 @@
 //   * rows_smax_index is a bijection from (tile column, run) onto a frame's row of run maxima, and it is the place the rows
 //     kernel's workgroup (c, r0) writes for d = t: the 32-bin run that starts at bin (r0 + 256 c + (t << log_row)) ^ (N / 2);
 //   * plan_long_cols keeps a plan workgroup inside its LDS and its 256 threads;
-//   * plan_frame_tiles / plan_cols_per_wg (8192 points) keep the lists inside kLiveCap.
+//   * plan_frame_tiles / plan_cols_per_wg (8192 points) keep the lists inside kLiveCap;
+//   * 2^20 points in two passes (csrc/fft1024_kernels.h): the block decodes of the column tiles, the row tiles and the plan are
+//     bijections that put the workgroups sharing a 128-byte line on one XCD; rows1024_smax_index is where the row tiles write and
+//     the plan reads; the window in the column tiles' order is a permutation of the taps, element by element what the tile loads;
+//     the atomic maxima's keys keep the order of the floats.
 #include <cstdio>
 #include <vector>
 
@@ -42,6 +46,97 @@ int main() {
       const int cols = ss::plan_cols_per_wg(nframes, shift), nft = ss::plan_frame_tiles(nframes, shift);
       if (cols != 0 && (cols * nft > ss::kLiveCap || cols * (nframes + (nframes >> 4) + 1) > ss::kPlanLdsFloats || 32 % cols != 0)) ++bad;
     }
+  // ---- 2^20 points in two passes (csrc/fft1024_kernels.h) ----
+  {
+    const int n = 1 << 20, half = n >> 1, runs = n >> 5;
+    // rows1024_smax_index is a bijection of the runs, and the place the four row tiles that share a run write
+    std::vector<int> seen((size_t)runs, 0), written((size_t)runs, 0);
+    for (int run = 0; run < runs; ++run) {
+      const int idx = ss::rows1024_smax_index(run);
+      if (idx < 0 || idx >= runs || seen[(size_t)idx]++) ++bad;
+    }
+    // the row tiles: every (frame, 8-row group) exactly once; the four tiles of a 32-row group — which fill the dB plane's lines and
+    // share every run — in consecutive slots of one XCD; every run of a frame written (by four tiles each)
+    for (int frames : {1, 3}) {
+      std::vector<int> rows_seen((size_t)frames * 128, 0);
+      for (int b = 0; b < frames * 128; ++b) {
+        int f, r0;
+        ss::rows1024_block(b, &f, &r0);
+        if (f < 0 || f >= frames || r0 < 0 || r0 >= 1024 || (r0 & 7) || rows_seen[(size_t)f * 128 + (r0 >> 3)]++) ++bad;
+        int f2, r2;
+        ss::rows1024_block(b ^ 8, &f2, &r2);  // the neighbouring slot of the same XCD
+        if (((r0 >> 3) & 3) < 2 && (f2 != f || (r2 >> 5) != (r0 >> 5))) ++bad;
+        if (f == 0)
+          for (int k2 = 0; k2 < 1024; ++k2) ++written[(size_t)ss::rows1024_smax_index(((r0 + (k2 << 10)) ^ half) >> 5)];
+      }
+    }
+    for (int run = 0; run < runs; ++run)
+      if (written[(size_t)run] != 8) ++bad;  // (4 tiles x the two `frames` passes above)
+    // the column tiles, 8 and 16 columns wide: every (frame, tile) once; the window in the kernel's order is a permutation of the taps
+    for (int logc : {3, 4}) {
+      const int tiles = 1024 >> logc;
+      std::vector<int> tseen((size_t)2 * tiles, 0);
+      for (int b = 0; b < 2 * tiles; ++b) {
+        int f, tile;
+        ss::cols1024_block(b, logc, &f, &tile);
+        if (f < 0 || f > 1 || tile < 0 || tile >= tiles || tseen[(size_t)f * tiles + tile]++) ++bad;
+        int f2, t2;
+        ss::cols1024_block(b ^ 8, logc, &f2, &t2);
+        if (logc == 3 && (b & 8) == 0 && (f2 != f || (t2 >> 1) != (tile >> 1))) ++bad;  // the two tiles of a 128-byte line: neighbouring slots of one XCD
+      }
+      std::vector<float> win((size_t)n), out((size_t)n, -1.0f);
+      for (int i = 0; i < n; ++i) win[(size_t)i] = (float)i;
+      ss::fft1024_window_order(win.data(), out.data(), logc);
+      std::vector<char> hit((size_t)n, 0);
+      for (int i = 0; i < n; ++i) {
+        const int v = (int)out[(size_t)i];
+        if (v < 0 || v >= n || hit[(size_t)v]++) ++bad;
+      }
+      // thread t of tile `tile`, r-th load: sample 4 (j + 16 r) + q of column tile * cols + c
+      const int cols = 1 << logc, nsub = 4 * cols, threads = 16 * nsub;
+      for (int tile : {0, 5, tiles - 1})
+        for (int t : {0, 1, nsub - 1, nsub, threads - 1})
+          for (int r : {0, 7, 15}) {
+            const int sub = t & (nsub - 1), j = t / nsub, c = sub & (cols - 1), q = sub >> logc;
+            if ((int)out[((size_t)tile * threads + t) * 16 + r] != ((4 * (j + 16 * r) + q) << 10) + tile * cols + c) ++bad;
+          }
+    }
+    // the plan's block decode, layout 1: every (quarter, group of C consecutive k2) exactly once, the groups that share a line on one XCD
+    for (int C : {1, 2, 4, 8, 16, 32, 5}) {
+      const int blocks = ss::plan_long_blocks(1, C, n), groups = blocks / 4;
+      std::vector<int> gseen((size_t)blocks, 0);
+      for (int b = 0; b < blocks; ++b) {
+        int wc, d0;
+        ss::plan_long_block(1, b, C, 4, &wc, &d0);
+        if (wc < 0 || wc > 3 || d0 % C || d0 / C >= groups || gseen[(size_t)wc * groups + d0 / C]++) ++bad;
+        if (32 % C == 0 && C < 32) {
+          int wc2, d2;
+          ss::plan_long_block(1, b ^ 8, C, 4, &wc2, &d2);
+          if (wc2 != wc || (d2 * 4 + wc2) / 128 != (d0 * 4 + wc) / 128) { /* neighbouring slots of an XCD: the same 32 k2, i.e. the same lines */
+            if ((d2 / 32) != (d0 / 32)) ++bad;
+          }
+        }
+      }
+      if (groups * C < 1024) ++bad;
+    }
+    // layout 0 as before
+    for (int C : {1, 2, 4, 8}) {
+      const int blocks = ss::plan_long_blocks(0, C, n);
+      if (blocks != 16 * ((256 + C - 1) / C)) ++bad;
+    }
+    // the keys of the atomic maxima keep the order of the floats; nothing-seen is below everything, NaN above
+    const float vals[] = {-__builtin_inff(), -3.0e38f, -100.0f, -1.0e-30f, -0.0f, 0.0f, 1.0e-30f, 7.5f, 3.0e38f, __builtin_inff()};
+    unsigned prev = 0u;
+    for (float v : vals) {
+      const unsigned k = ss::max_key(v);
+      if (k <= prev && !(v == 0.0f && prev == ss::max_key(-0.0f))) ++bad;
+      if (!(ss::max_key_value(k) == v)) ++bad;
+      prev = k;
+    }
+    if (ss::max_key(__builtin_nanf("")) != 0xffffffffu || ss::max_key(-__builtin_nanf("")) != 0xffffffffu || !(ss::max_key_value(0xffffffffu) != ss::max_key_value(0xffffffffu))) ++bad;
+    if (!(ss::max_key_value(0u) == -__builtin_inff())) ++bad;
+    printf("2^20 in two passes: bad %d\n", bad);
+  }
   printf("bad %d\n", bad);
   return bad ? 1 : 0;
 }
