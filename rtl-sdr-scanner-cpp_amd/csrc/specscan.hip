@@ -413,7 +413,14 @@ struct ss_ctx {
   // ss_get_stats: host-side counters, and the device-side ones (detect_fused.h kStat*: tiles tested / culled, wait fallbacks)
   ss_stats stats{};
   unsigned long long* d_stats = nullptr;
-  int wait_limit = 1 << 14;  // StepArgs::wait_limit (a poll is a ~0.25 us sleep and a load: tens of milliseconds before a consumer plans for itself)
+  // StepArgs::wait_limit. A poll is a ~0.25 us sleep and a load, ~0.75 us in all; the plan role publishes within 5-10 us of its launch's
+  // start, so a consumer normally polls not at all (FFT role: it asks two thirds into its frame) or a dozen times (drain launches);
+  // 128 polls are 0.1 ms. The bound is not decoration: with TWO PROCESSES on one GPU (bench.py --gpus 2 on a one-GPU box) the circular
+  // wait the unbounded spin invited did happen — a launch's plan workgroups waiting for a slot on an XCD full of the other process's
+  // spinning consumers, whose own plan workgroups waited for a slot held by this process's spinning consumers: with a limit of 2^14 every
+  // consumer of such a launch polled for 12 ms, 762 fell back, and the run lost three quarters of its rate to that one launch
+  // (profiles/r04/s9_summary.txt); round 3's spin would have hung there. A consumer that helps itself early costs 5 us.
+  int wait_limit = 128;
   // ss_input_wait: the launches (or, in order on the public stream, the calls) whose events a producer may wait on
   hipEvent_t ev_call[32] = {};   // in-order contexts: recorded on the public stream behind every call once ss_input_wait has been used
   bool input_events = false;
