@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
     // fft_v shift=true: X[k] lands at k ^ (N/2)
     const int bin = ((r0 + rr) + (c << 8) + (d << log_row)) ^ half;
     const float v = s[d * 33 + rr];
-    out[bin] = v;
+    if (psd) out[bin] = v;  // (null: a call that keeps no dB plane, specscan.hip run_batch)
     if (hrow) hrow[bin] = v - x.thr[bin];  // noise_learner.cpp:55, as detect_tile forms it
   }
 }

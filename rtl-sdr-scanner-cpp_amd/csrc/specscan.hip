@@ -124,7 +124,7 @@ struct ss_ctx {
     int hint_mode = 0;             // SS_DIAG timing ablations of the list hand-over (scan_step.h); 3: plan workgroups never publish (tests/test_gpu_wait_bound.py)
     int wait_limit = 0;            // SS_DIAG (SS_WAIT_LIMIT): StepArgs::wait_limit, 0 = the product's
     int queues = 2;                // 8192 points, deep pipelining: launch queues (2 .. 4)
-    bool cull_65536 = false;       // SS_DIAG (SS_CULL_65536=1): tile culling also at 65536 points (see ss_create)
+    bool cull_65536 = true;        // SS_DIAG (SS_CULL_65536=0): no tile culling at 65536 points (see ss_create)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
     bool cull = true;              // 8192 points: detect tiles that cannot hold a candidate are not evaluated (detect_fused.h)
     bool deep = true;              // 8192 points: consecutive step launches independent of each other, alternating over two queues (see ss_ctx::deep)
@@ -170,7 +170,7 @@ struct ss_ctx {
       deep = tri("SS_DEEP") != 0;
       cull = tri("SS_CULL") != 0;
       ablate_roles = num("SS_ABLATE_ROLES", 0);
-      cull_65536 = tri("SS_CULL_65536") == 1;
+      cull_65536 = tri("SS_CULL_65536") != 0;
       canary = tri("SS_CANARY") == 1;
       queues = num("SS_QUEUES", queues);
       hint_mode = num("SS_HINT_MODE", 0);
@@ -1175,8 +1175,8 @@ struct RingPlace {
 RingPlace place_ring(ss_ctx* c, int nframes) {
   const int n = c->n;
   constexpr int H = kHistRows;
-  if (c->two_pass && nframes >= H && H + nframes <= c->hist_rows) {
-    // 2^20 points: room for the WHOLE batch's rows behind the window being read (or at the front of the buffer), the new window
+  if (c->cull_long && nframes >= H && H + nframes <= c->hist_rows) {
+    // long transforms with tile culling: room for the WHOLE batch's rows behind the window being read (or at the front of the buffer), the new window
     // being the last H of them — so that a detect-mode call can write ONE plane, noise-relative rows that are the batch's rows for
     // its own detect stage and the next call's ring at once, instead of a dB plane and ring rows (run_batch)
     int b = c->hist_start + H;
@@ -1638,7 +1638,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         rx.zero_word = c->d_tlist[c->buf_cur];  // (the list this call's plan appends to; its last reader was the detect stage of the call before last)
         ring_by_rows = true;
         // no dB plane at all: a device call that hands out no plane, shorter than the ring, whose rows the new rows kernel writes
-        ring_only = c->two_pass && allow_overlap && !d_psd_out && !d_rel_out && !d_avg_out && !spec && !c->ref_nan && (nframes < kHistRows || rp.batch) &&
+        ring_only = allow_overlap && !d_psd_out && !d_rel_out && !d_avg_out && !spec && !c->ref_nan && (nframes < kHistRows || rp.batch) &&
                     !(c->cfg.flags & SS_FLAG_KEEP_PLANES) && c->diag.ring_only;
         if (ring_only && nframes < kHistRows) {
           ring_rows = rp.in + (size_t)kHistRows * c->n;  // batch frame f = row H + f of the window being read: right behind it (place_ring)
@@ -2150,10 +2150,6 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       CREATE_HIP(hipMalloc(&c->d_tw256, sizeof(float2) * t256.size()));
       CREATE_HIP(hipMemcpy(c->d_tw256, t256.data(), sizeof(float2) * t256.size(), hipMemcpyHostToDevice));
       c->two_pass = c->use_fft256 && c->logn == 20 && c->diag.fft_twopass && c->diag.fft_rows_r < 0 && c->diag.fft_sub < 0;
-      if (c->two_pass) {
-        CREATE_HIP(hipMalloc(&c->d_zero_row, sizeof(float) * (size_t)n));
-        CREATE_HIP(hipMemset(c->d_zero_row, 0, sizeof(float) * (size_t)n));
-      }
       if (c->two_pass) {  // one block of tables for both halves (fft1024_kernels.h), in the place of the 256-point column tiles' tables
         std::vector<float2> tab((size_t)ss::kFft1024TableEntries);
         ss::fft1024_host_tables(tab.data());
@@ -2223,14 +2219,15 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     }
     CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
   }
-  // Tile culling for long transforms: the sizes whose rows go through k_fft_rows256_psd (N2 = 256, or the radix-A step in front).
-  // On by default where it pays — 2^20 points: 163 against 197 us per 16-frame call. At 65536 points it takes 5 B/sample off the
-  // fabric but loses time since the column tiles got faster (the plan launch and the ring rows cost more than the evaluation
-  // they save: 57.1 against 53.4 us per 128-frame call, 37 against 26 for 16 frames, profiles/r03/s53_summary.txt): there only the
-  // diagnostics build switches it on (SS_CULL_65536=1; tests/test_gpu_cull.py keeps it honest).
+  // Tile culling for long transforms: the sizes whose rows go through k_fft_rows256_psd (N2 = 256, or the radix-A step in front)
+  // and the two-pass form of 2^20 points. Until the detect-mode calls stopped writing a dB plane (run_batch: ring_only) culling
+  // lost time at 65536 points — the ring rows were a second plane to write, 57.1 against 53.4 us per 128-frame call,
+  // profiles/r03/s53_summary.txt — and was a switch of the diagnostics build there; SS_CULL_65536=0 is that build's way back.
   c->cull_long = c->step_path && c->use_fft256 && ((n == 65536 && c->diag.cull_65536) || (n > 65536 && c->d_tw_sub && !c->d_tw_rowsR) || c->two_pass) &&
                  !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
   if (c->cull_long) {
+    CREATE_HIP(hipMalloc(&c->d_zero_row, sizeof(float) * (size_t)n));  // (what a ring-only call's detect stage subtracts from rows that are noise-relative already)
+    CREATE_HIP(hipMemset(c->d_zero_row, 0, sizeof(float) * (size_t)n));
     int rows = 64;
     while (rows < cfg->max_batch + kHistRows + 1) rows <<= 1;
     c->smax_rows = rows;
