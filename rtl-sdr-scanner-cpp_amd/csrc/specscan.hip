@@ -124,7 +124,7 @@ struct ss_ctx {
     int hint_mode = 0;             // SS_DIAG timing ablations of the list hand-over (scan_step.h); 3: plan workgroups never publish (tests/test_gpu_wait_bound.py)
     int wait_limit = 0;            // SS_DIAG (SS_WAIT_LIMIT): StepArgs::wait_limit, 0 = the product's
     int queues = 2;                // 8192 points, deep pipelining: launch queues (2 .. 4)
-    bool cull_65536 = true;        // SS_DIAG (SS_CULL_65536=0): no tile culling at 65536 points (see ss_create)
+    bool cull_65536 = false;       // SS_DIAG (SS_CULL_65536=1): tile culling also at 65536 points (see ss_create)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
     bool cull = true;              // 8192 points: detect tiles that cannot hold a candidate are not evaluated (detect_fused.h)
     bool deep = true;              // 8192 points: consecutive step launches independent of each other, alternating over two queues (see ss_ctx::deep)
@@ -170,7 +170,7 @@ struct ss_ctx {
       deep = tri("SS_DEEP") != 0;
       cull = tri("SS_CULL") != 0;
       ablate_roles = num("SS_ABLATE_ROLES", 0);
-      cull_65536 = tri("SS_CULL_65536") != 0;
+      cull_65536 = tri("SS_CULL_65536") == 1;
       canary = tri("SS_CANARY") == 1;
       queues = num("SS_QUEUES", queues);
       hint_mode = num("SS_HINT_MODE", 0);
@@ -2220,9 +2220,11 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
   }
   // Tile culling for long transforms: the sizes whose rows go through k_fft_rows256_psd (N2 = 256, or the radix-A step in front)
-  // and the two-pass form of 2^20 points. Until the detect-mode calls stopped writing a dB plane (run_batch: ring_only) culling
-  // lost time at 65536 points — the ring rows were a second plane to write, 57.1 against 53.4 us per 128-frame call,
-  // profiles/r03/s53_summary.txt — and was a switch of the diagnostics build there; SS_CULL_65536=0 is that build's way back.
+  // and the two-pass form of 2^20 points. On by default where it pays: 2^20 points. At 65536 points it takes 7 B/sample off the
+  // fabric and no time off the call: the column launch gets 10 us shorter, the plan launch costs 6.5 and the ring rows 1.4
+  // (57.4 against 56.9 us per 128-frame call now that detect-mode calls write no dB plane, run_batch: ring_only; 57.1 against
+  // 53.4 before; 38 against 29 us per 16-frame call either way: profiles/r04/s11_summary.txt, profiles/r03/s53_summary.txt).
+  // There only the diagnostics build switches it on (SS_CULL_65536=1; tests/test_gpu_cull.py keeps it honest).
   c->cull_long = c->step_path && c->use_fft256 && ((n == 65536 && c->diag.cull_65536) || (n > 65536 && c->d_tw_sub && !c->d_tw_rowsR) || c->two_pass) &&
                  !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
   if (c->cull_long) {
