@@ -489,12 +489,12 @@ constexpr int kPlanLongFloats = 8192;  // LDS of a plan workgroup: C x (16 nft +
 // max_c: 8, or 32 for the two-pass layout of 2^20 points — there a workgroup's columns are consecutive floats of a frame's row of
 // the ring, and 32 of them are a whole 128-byte line (with 8 the four workgroups that share a line each fetched all of it:
 // 5.9 against 3.0 MB per launch, 12 against 7 us, profiles/r04/s4_summary.txt)
-__host__ __device__ inline int plan_long_cols(int nframes, int shift, int tile_cols, int max_c = 8) {  // 0: the stage cannot be planned
+__host__ __device__ inline int plan_long_cols(int nframes, int shift, int tile_cols, int max_c = 8, int max_floats = 8192) {  // 0: the stage cannot be planned
   const int nft = (nframes + shift + 15) / 16, rows = 16 * nft + 20;
   int c = tile_cols / 256 > 1 ? tile_cols / 256 : 1;  // at least 256 workgroups where there are that many columns
   if (max_c > 8) c = max_c;
   if (c > max_c) c = max_c;
-  if (c > kPlanLongFloats / rows) c = kPlanLongFloats / rows;
+  if (c > max_floats / rows) c = max_floats / rows;
   if (nft > 0 && c > 256 / nft) c = 256 / nft;
   return c;
 }
@@ -519,14 +519,41 @@ __host__ __device__ inline int plan_long_blocks(int layout, int C, int n) {  // 
   return 4 * ((((1024 + C - 1) / C + 2 * line_groups - 1) / (2 * line_groups)) * (2 * line_groups));
 }
 
+// What the plan needs of the call's DetectArgs (the whole struct is 200 bytes of kernel arguments the column launch of a
+// 2^20-point frame — whose first workgroups may run the plan of the call before, k_fft_cols1024_plan — has no use for).
+struct PlanLongDet {
+  int n, nframes, shift, n_learn;
+  int planes_out;  // a rel or avg plane is wanted: nothing is tested, every tile is listed
+  float start_level;
+  const float* thr_tilemin;
+  unsigned long long* stats;
+};
+__host__ __device__ inline PlanLongDet plan_long_det(const DetectArgs& d) {
+  PlanLongDet a{};
+  a.n = d.n;
+  a.nframes = d.nframes;
+  a.shift = d.shift;
+  a.n_learn = d.n_learn;
+  a.planes_out = (d.rel_out || d.avg_out) ? 1 : 0;
+  a.start_level = d.start_level;
+  a.thr_tilemin = d.thr_tilemin;
+  a.stats = d.stats;
+  return a;
+}
+constexpr int kPlanLongInts = 16;  // bookkeeping words of a plan block behind its values of M
+
+// One plan block: 256 threads (`tid`), `block` = its number (what blockIdx.x is for k_plan_long), `mrow` = room for C x (16 nft + 20)
+// floats, `book` = kPlanLongInts ints. Every __syncthreads() below is reached by all threads of the workgroup whatever the block
+// finds: several blocks may share a workgroup (k_fft_cols1024_plan: four of them in 1024 threads).
 template <int G, int GX, int TF, int TB_ = 256>
-__global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p) {
+__device__ __forceinline__ void plan_long_run(const PlanLongDet& a, const PlanLongArgs& p, int block_no, int tid, float* __restrict__ mrow, int* __restrict__ book) {
   using T = DetectTile<G, GX, TF, TB_>;
   constexpr int TB = T::TB;
   static_assert(TB == 256 && T::A <= 32 && TF == 16 && G == 21, "eight 32-bin runs per tile column, one more on either side");
-  __shared__ float mrow[kPlanLongFloats];
-  __shared__ int wave_cnt[4];
-  const int n = a.n, nframes = a.nframes, tid = threadIdx.x;
+  int* wave_cnt = book;             // [4]
+  int* stat_cnt = book + 4;         // [4][2]
+  int* list_base_p = book + 12;
+  const int n = a.n, nframes = a.nframes;
   const int tiles_per_row = n / TB, groups = n >> 5;
   const int nft = (nframes + a.shift + TF - 1) / TF;
   const int rows = TF * nft + (G - 1);  // frames [-shift - 20, 16 nft - shift) of the batch's frame numbering
@@ -539,7 +566,7 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
   // runs on XCD b mod 8 — as they are in layout 0 by construction; spread over two XCDs they fetched every line twice: 12 against
   // 7 us per call, profiles/r04/s4_summary.txt)
   int wc, d0;
-  plan_long_block(p.layout, (int)blockIdx.x, C, lognsub, &wc, &d0);
+  plan_long_block(p.layout, block_no, C, lognsub, &wc, &d0);
   const auto column = [&](int i) {
     if (p.layout) return d0 + i < 1024 ? 4 * (d0 + i) + wc : tiles_per_row;
     return d0 + i < 256 ? (wc + ((d0 + i) << lognsub)) ^ (tiles_per_row >> 1) : tiles_per_row;
@@ -583,7 +610,7 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
     const int f0 = ft * TF - a.shift;
     block = ft_seq * tiles_per_row + column(cl);
     live = true;
-    if (a.n_learn == 0 && f0 - (G - 1) >= p.clean_rel && !a.rel_out && !a.avg_out) {
+    if (a.n_learn == 0 && f0 - (G - 1) >= p.clean_rel && !a.planes_out) {
       tested = true;
       const float* mr = mrow + cl * rows + ft * TF;  // mr[k] = M of frame f0 - 20 + k
       float best = -__builtin_inff();
@@ -606,12 +633,11 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
   const int lane = tid & 63, w = tid >> 6;
   const unsigned long long mask = __ballot(live);
   if (lane == 0) wave_cnt[w] = __popcll(mask);
-  __shared__ int stat_cnt[4][2];
   if (a.stats) {  // ss_get_stats: one pair of additions per workgroup (below), to the copy of its block index
     const int n_tested = __popcll(__ballot(tested)), n_culled = __popcll(__ballot(tested && !live));
     if (lane == 0) {
-      stat_cnt[w][0] = n_tested;
-      stat_cnt[w][1] = n_culled;
+      stat_cnt[2 * w] = n_tested;
+      stat_cnt[2 * w + 1] = n_culled;
     }
   }
   __syncthreads();
@@ -621,18 +647,51 @@ __global__ __launch_bounds__(256) void k_plan_long(DetectArgs a, PlanLongArgs p)
     base += k < w ? wave_cnt[k] : 0;
     total += wave_cnt[k];
   }
-  __shared__ int list_base;
-  if (tid == 0) list_base = total ? atomicAdd(&p.list[0], total) : 0;
+  if (tid == 0) *list_base_p = total ? atomicAdd(&p.list[0], total) : 0;
   if (tid == 1 && a.stats) {
-    const int nt = stat_cnt[0][0] + stat_cnt[1][0] + stat_cnt[2][0] + stat_cnt[3][0], nc = stat_cnt[0][1] + stat_cnt[1][1] + stat_cnt[2][1] + stat_cnt[3][1];
+    const int nt = stat_cnt[0] + stat_cnt[2] + stat_cnt[4] + stat_cnt[6], nc = stat_cnt[1] + stat_cnt[3] + stat_cnt[5] + stat_cnt[7];
     if (nt) {
       atomicAdd(stat_word(a.stats, kStatTested), (unsigned long long)nt);
       atomicAdd(stat_word(a.stats, kStatCulled), (unsigned long long)nc);
     }
   }
   __syncthreads();
-  if (live) p.list[1 + list_base + base + __popcll(mask & ((1ull << lane) - 1ull))] = block;
+  if (live) p.list[1 + *list_base_p + base + __popcll(mask & ((1ull << lane) - 1ull))] = block;
 }
+
+template <int G, int GX, int TF, int TB_ = 256>
+__global__ __launch_bounds__(256) void k_plan_long(PlanLongDet a, PlanLongArgs p) {
+  __shared__ float mrow[kPlanLongFloats];
+  __shared__ int book[kPlanLongInts];
+  plan_long_run<G, GX, TF, TB_>(a, p, (int)blockIdx.x, (int)threadIdx.x, mrow, book);
+}
+
+// 2^20 points in two passes: the plan of call k as the FIRST workgroups of the column launch of call k + 1 (fft1024_kernels.h,
+// 16-column tiles by 1024 threads). As a launch of its own between the row launch of call k and the column launch of call k + 1
+// the plan cost a 16-frame call 11.6 us of a chip that waits for 3 MB of run maxima, plus a launch boundary; here its blocks —
+// four to a workgroup of 1024 threads, so that the blocks whose columns share the 128-byte lines of the ring share a workgroup — hold
+// `plan_wgs` of the launch's first slots for a few microseconds while the column tiles stream in beside them. What the plan reads
+// (the run maxima of frames up to call k's last) was complete before this launch began; the rows of the ring the column tiles clear
+// in the same launch are those of call k + 1's frames (the ring holds two batches and the averager's reach: ss_create), which the
+// plan touches only where a ragged frame tile reaches past its batch and then ignores. Its consumer — the detect stage of call k —
+// rides on the launch AFTER this one (the row half of call k + 1). `plan_wgs` is a multiple of 8: the column tiles keep their XCDs.
+constexpr int kPlanFusedFloats = 4096;  // values of M per plan block when four blocks share the column tile's LDS (plan_long_cols: cap)
+template <int FMT, bool WCALC>
+__global__ __launch_bounds__(1024, 8) void k_fft_cols1024_plan(ColsArgs g, PlanLongDet a, PlanLongArgs p, int plan_wgs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  static_assert(4 * (kPlanFusedFloats + kPlanLongInts) * 4 <= fft1024_cols_lds_bytes(4), "four plan blocks in a column tile's LDS");
+  const int tid = (int)threadIdx.x, b = (int)blockIdx.x;
+  if (b < plan_wgs) {  // (workgroup-uniform)
+    const int sub = tid >> 8;
+    float* mrow = reinterpret_cast<float*>(smem_raw) + sub * (kPlanFusedFloats + kPlanLongInts);
+    // plan block number: XCD b mod 8 as k_plan_long's block numbering has it (plan_long_block), the workgroup's four blocks in
+    // consecutive slots of that XCD
+    plan_long_run<21, 21, 16, 256>(a, p, ((((b >> 3) << 2) + sub) << 3) | (b & 7), tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));
+    return;
+  }
+  fft_cols1024_tile<FMT, 4, WCALC>(g, b - plan_wgs, smem_raw, tid);
+}
+__host__ __device__ inline int plan_fused_wgs(int plan_blocks) { return (((plan_blocks + 3) / 4 + 7) / 8) * 8; }
 
 // min of the noise ceiling over bins [256 c - 32, 256 c + 288) is k_thr_tilemin above, one wave per tile column.
 

@@ -83,7 +83,27 @@ inline void fft1024_window_order(const float* win, float* out, int logc) {
 // blocks of one XCD. `g`: ColsArgs of fft256_kernels.h with twc = the block of fft1024_host_tables (logn2 is 10).
 // LOGC = 3: 8 columns by 512 threads (above). LOGC = 4: 16 columns by 1024 threads — whole 128-byte lines on either side, twice
 // the LDS (two workgroups per CU: the same threads per CU); too many threads for a role of k_scan_step, so a launch of its own.
-template <int FMT, int LOGC = 3>
+// WCALC: the Hamming taps are not loaded but formed (ss_create: only for the default window). A thread's sixteen samples are
+// n = m + 65536 r with m = 1024 (4 j + q) + column < 65536, so
+//   w[n] = 0.54 - 0.46 cos(theta_m + phi_r) = 0.54 + (-0.46 cos phi_r) cos theta_m + (0.46 sin phi_r) sin theta_m,   theta_m = 2 pi m / (N - 1),  phi_r = 2 pi 65536 r / (N - 1):
+// one 8-byte load of (cos theta_m, sin theta_m) per thread (ColsArgs::wtab, 512 KiB) and two FMAs per sample with sixteen pairs
+// of constants, instead of 64 bytes of taps per thread — 4 B/sample through L2 and the vector-memory pipe, a fifth of the tile's
+// loads (12 of the column launch's 81 us per 16-frame call in the 8-column form, profiles/r04/s4_summary.txt). The taps formed
+// this way differ from (float)(0.54 - 0.46 cos(2 pi n / (N - 1))) by 1.2e-7 at most (3.4e-8 rms: the size of the rounding of the
+// exact tap itself), the dB plane by < 1e-5 dB but for the deepest nulls (tests/test_window_rotation.py).
+__device__ constexpr float kWin1024C[16] = {-0.460000008f, -0.424984515f, -0.325268865f, -0.176033899f, 6.89093611e-07f, 0.176035181f, 0.325269848f, 0.424985051f,
+                                            0.460000008f, 0.424983978f, 0.325267911f, 0.176032633f, -2.06728078e-06f, -0.176036447f, -0.325270832f, -0.424985588f};
+__device__ constexpr float kWin1024S[16] = {0.0f, 0.17603454f, 0.325269371f, 0.424984783f, 0.460000008f, 0.424984246f, 0.325268388f, 0.176033258f,
+                                            -1.37818722e-06f, -0.176035807f, -0.325270325f, -0.424985319f, -0.460000008f, -0.42498374f, -0.325267404f, -0.176031992f};
+// Host side: ColsArgs::wtab — (cos, sin)(2 pi m / (N - 1)), m < 65536 (double precision, rounded once).
+inline void fft1024_window_rotation_table(float2* out) {
+  for (int m = 0; m < 65536; ++m) {
+    const double th = 2.0 * 3.14159265358979323846 * (double)m / 1048575.0;
+    out[m] = make_float2((float)cos(th), (float)sin(th));
+  }
+}
+
+template <int FMT, int LOGC = 3, bool WCALC = false>
 __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, unsigned char* __restrict__ smem_raw, int t) {
   constexpr int COLS = 1 << LOGC, NSUB = 4 * COLS, THREADS = 16 * NSUB, TILES = 1024 / COLS;
   float* s = reinterpret_cast<float*>(smem_raw);
@@ -111,15 +131,20 @@ __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, 
   // The window taps come in THIS kernel's order (fft1024_window_order, built once per context from whatever taps the context has):
   // a thread's sixteen taps are 64 consecutive bytes — four 16-byte loads, whole lines per wave — where the frame's own layout
   // gives sixteen 4-byte loads in 32-byte runs (12 of the column launch's 81 us per 16-frame call, profiles/r04/s4_summary.txt).
-  const __amdgpu_buffer_rsrc_t rwin = buffer_of(g.win, (1 << 20) * 4);
   float wv16[16];
+  float2 wt = make_float2(0.0f, 0.0f);
+  if constexpr (WCALC) {
+    wt = buffer_load_f2<0>(buffer_of(g.wtab, 65536 * 8), (int)(tn * 8u), 0);
+  } else {
+    const __amdgpu_buffer_rsrc_t rwin = buffer_of(g.win, (1 << 20) * 4);
 #pragma unroll
-  for (int r4 = 0; r4 < 4; ++r4) {
-    const auto w4 = __builtin_amdgcn_raw_buffer_load_b128(rwin, (tile * THREADS + t) * 64, 16 * r4, 0);
-    wv16[4 * r4] = __uint_as_float(w4[0]);
-    wv16[4 * r4 + 1] = __uint_as_float(w4[1]);
-    wv16[4 * r4 + 2] = __uint_as_float(w4[2]);
-    wv16[4 * r4 + 3] = __uint_as_float(w4[3]);
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const auto w4 = __builtin_amdgcn_raw_buffer_load_b128(rwin, (tile * THREADS + t) * 64, 16 * r4, 0);
+      wv16[4 * r4] = __uint_as_float(w4[0]);
+      wv16[4 * r4 + 1] = __uint_as_float(w4[1]);
+      wv16[4 * r4 + 2] = __uint_as_float(w4[2]);
+      wv16[4 * r4 + 3] = __uint_as_float(w4[3]);
+    }
   }
   float2 a[16];
 #pragma unroll
@@ -136,7 +161,7 @@ __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, 
 #define SS_C1024_ABL 0
 #endif
     if (SS_C1024_ABL & 4) x = make_float2(__int_as_float(0x3f800000 + (int)tn + r), 0.5f);
-    const float wv = (SS_C1024_ABL & 1) ? 1.0f : wv16[r];
+    const float wv = (SS_C1024_ABL & 1) ? 1.0f : WCALC ? fmaf(wt.x, kWin1024C[r], fmaf(wt.y, kWin1024S[r], 0.54f)) : wv16[r];
     a[r] = make_float2(x.x * wv, x.y * wv);  // volk_32fc_32f_multiply_32fc
   }
   float2 cc[16];
@@ -184,10 +209,10 @@ __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, 
 }
 
 // Stand-alone launch (contexts without the step kernel; and the 16-column form).
-template <int FMT, int LOGC = 3>
+template <int FMT, int LOGC = 3, bool WCALC = false>
 __global__ __launch_bounds__(64 << LOGC, 8) void k_fft_cols1024(ColsArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  fft_cols1024_tile<FMT, LOGC>(g, (int)blockIdx.x, smem_raw, (int)threadIdx.x);
+  fft_cols1024_tile<FMT, LOGC, WCALC>(g, (int)blockIdx.x, smem_raw, (int)threadIdx.x);
 }
 constexpr int fft1024_cols_lds_bytes(int logc) { return (4 << logc) * kFft256PitchCols * 4 + kFft1024TableBytes; }
 static_assert(fft1024_cols_lds_bytes(3) == kFft1024ColsLdsBytes && (4 << 4) * kFft1024Pitch2 <= (4 << 4) * kFft256PitchCols, "column tile LDS");

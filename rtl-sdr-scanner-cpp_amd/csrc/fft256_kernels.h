@@ -73,6 +73,7 @@ struct ColsArgs {
   // frame's row of the run-maxima ring (null: nothing to clear)
   unsigned* smax;
   int smax_mask, abs0;
+  const float2* wtab;  // 1024-point column tiles that form their Hamming taps (fft1024_kernels.h, WCALC): (cos, sin)(2 pi m / (N - 1)), m < 65536
 };
 
 // One column tile (32 columns x 256 rows) by one workgroup of 512 threads; `block` = frame * (N2 / 32) + tile.

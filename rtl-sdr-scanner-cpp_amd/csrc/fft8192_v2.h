@@ -36,6 +36,13 @@
 #ifndef SS_AUX_PSD
 #define SS_AUX_PSD 16
 #endif
+// The per-column maxima for the tile culling (Fft8192Args::segsum): 1 = the frame's dB values go through LDS once more and sixteen
+// threads per tile column take its maximum from there (16 LDS stores, five 16-byte LDS loads and ~25 vector instructions per
+// thread); 0 = the first form, in registers: five v_max_f32_dpp per value and a select to gather them, 96 of the frame path's
+// 1082 vector instructions — in a kernel that waits to ISSUE more than it waits for memory (profiles/README.md, SQ counters).
+#ifndef SS_SEGMAX_LDS
+#define SS_SEGMAX_LDS 1
+#endif
 
 namespace ss {
 
@@ -244,6 +251,9 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 16; ++q) a[q].y = s[rbase + 512 * q];
+#if SS_SEGMAX_LDS
+  if (segsum) __syncthreads();  // the exchange plane takes the frame's dB values at the end (the column maxima): every read of z is done
+#endif
 
   // The list header word this workgroup will want when its frame is done (live_hint): asked for NOW — two thirds of a
   // frame after the workgroup began, so the plan role has had time to publish its counts, and with pass 3 left to hide the
@@ -333,6 +343,9 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
   if (g.live_hint && hint_wait && t < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const bool want_max = segsum != nullptr;  // (workgroup-uniform)
   float mine;
+#if SS_SEGMAX_LDS
+  float* dbrow = reinterpret_cast<float*>(smem_raw + voff);  // the frame's dB values at their bin numbers (the exchange plane is idle since pass 3 began)
+#endif
 #pragma unroll
   for (int k2 = 0; k2 < 4; ++k2) {
     float pv[4];  // pv[2 i + s]: the dB value of bin j + 2048 h + 256 (2 k2 + i) + 4096 s
@@ -352,8 +365,14 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
       pv[2 * i] = psd_db(csub(e, o), db_off);
       buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k + 16384, pv[2 * i + 1]);
       buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k, pv[2 * i]);
+#if SS_SEGMAX_LDS
+      if (want_max) {
+        dbrow[256 * k + 4096] = pv[2 * i + 1];
+        dbrow[256 * k] = pv[2 * i];
+      }
+#endif
     }
-    if (want_max) {
+    if (want_max && !SS_SEGMAX_LDS) {
       halfwave_max4_hi16(pv[0], pv[1], pv[2], pv[3]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {  // value index 2 k + s = 4 k2 + q goes to lanes 16 + index and 48 + index (a constant lane mask: no compare)
@@ -363,6 +382,47 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
       }
     }
   }
+#if SS_SEGMAX_LDS
+  (void)mine;
+  if (want_max) {
+    // Tile column c = t / 16 by sixteen threads: bins [256 c - 32, 256 c + 288) — the column and one 32-bin segment either side,
+    // clipped at the band's edges — in sixteen runs of 20 (a run that would start outside the band starts at its edge instead: it
+    // reads bins of the same column's range once more). Lanes of a column are 20 words apart: sixteen 16-byte loads hit 64 banks.
+    __syncthreads();
+    if (g.live_hint) *hdr = __builtin_amdgcn_readfirstlane(__float_as_int(*hint_slot));
+    // the thread number comes back out of the PSD stores' own offset (j + 2048 h) * 4, j = 32 w + lane mod 32 — the one per-thread
+    // value that is alive here anyway; anything else kept alive through pass 3 for this gets spilled (64 VGPRs)
+    int vv = voff;
+    asm volatile("" : "+v"(vv));
+    const int tt = ((vv >> 1) & 0x1c0) | ((vv >> 8) & 32) | ((vv >> 2) & 31);  // 64 w + 32 h + lane mod 32
+    const int c = tt >> 4;
+    const int start = min(max(256 * c - 32 + 20 * (tt & 15), 0), 8192 - 20);
+    const float4* run = reinterpret_cast<const float4*>(s + start);
+    float m = -__builtin_inff();  // (fmaxf ignores a NaN operand like v_max_f32 does: NaN bins cannot make a candidate)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const float4 v = run[q];
+      m = fmaxf(fmaxf(m, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+    }
+    // the column's sixteen lanes are one row of the wave: four butterfly steps leave the row's maximum in every lane
+    asm volatile("s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 1\n"
+                 "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"
+                 : "+v"(m));
+    if ((tt & 15) == 0) {
+      const __amdgpu_buffer_rsrc_t rseg = buffer_of(segsum, 32 * g.seg_pitch * 4);
+      buffer_store_f1(rseg, c * g.seg_pitch * 4, (int)frame * 4, m);
+    }
+  } else if (g.live_hint) {
+    __syncthreads();
+    *hdr = __builtin_amdgcn_readfirstlane(__float_as_int(*hint_slot));
+  }
+#else
   if (want_max) {
     // wave, half and lane come back out of the PSD stores' own offset (j + 2048 h) * 4, j = 32 w + lane mod 32 — the one
     // per-thread value that is alive here anyway; anything else kept alive through pass 3 for this gets spilled (64 VGPRs)
@@ -386,6 +446,7 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
     __syncthreads();
     *hdr = __builtin_amdgcn_readfirstlane(__float_as_int(*hint_slot));
   }
+#endif
 }
 
 }  // namespace ss

@@ -125,6 +125,8 @@ struct ss_ctx {
     int wait_limit = 0;            // SS_DIAG (SS_WAIT_LIMIT): StepArgs::wait_limit, 0 = the product's
     int queues = 2;                // 8192 points, deep pipelining: launch queues (2 .. 4)
     bool cull_65536 = false;       // SS_DIAG (SS_CULL_65536=1): tile culling also at 65536 points (see ss_create)
+    bool win_calc = true;          // 2^20 points in two passes, default window: the column tiles form their Hamming taps instead of loading them (SS_WIN_CALC=0: the table as ever)
+    bool plan_fused = true;        // 2^20 points in two passes: the plan of call k at the front of call k + 1's column launch (SS_PLAN_FUSED=0: a launch of its own behind call k's rows, as until session 14 of round 4)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
     bool cull = true;              // 8192 points: detect tiles that cannot hold a candidate are not evaluated (detect_fused.h)
     bool deep = true;              // 8192 points: consecutive step launches independent of each other, alternating over two queues (see ss_ctx::deep)
@@ -171,6 +173,8 @@ struct ss_ctx {
       cull = tri("SS_CULL") != 0;
       ablate_roles = num("SS_ABLATE_ROLES", 0);
       cull_65536 = tri("SS_CULL_65536") == 1;
+      plan_fused = tri("SS_PLAN_FUSED") != 0;
+      win_calc = tri("SS_WIN_CALC") != 0;
       canary = tri("SS_CANARY") == 1;
       queues = num("SS_QUEUES", queues);
       hint_mode = num("SS_HINT_MODE", 0);
@@ -249,6 +253,12 @@ struct ss_ctx {
   // reads while a later call already writes its own are doubled: mask bits, sparse avg plane, internal PSD plane.
   bool step_path = false;
   bool have_det = false, have_emit = false;
+  // 2^20 points in two passes: the plan of the last call (which of its tiles the detect stage must evaluate, k_plan_long) is not a
+  // launch of its own but rides at the front of the NEXT call's column launch (k_fft_cols1024_plan, detect_fused.h); until then
+  // — or until flush_stages launches it on its own — its arguments wait here. pend_det.tile_list points at the list it fills.
+  bool have_plan = false;
+  ss::PlanLongDet pend_plan_det{};
+  ss::PlanLongArgs pend_plan{};
   ss::DetectArgs pend_det{};
   int pend_det_tiles = 0;
   bool pend_det_spec = false;
@@ -389,6 +399,7 @@ struct ss_ctx {
   // are the next window otherwise (place_ring) — and no dB plane is written at all: the detect tiles take the batch's rows from
   // there, with a ceiling of zeros to subtract (x - 0.0f is x: the same bits) — unless somebody wants a plane.
   float* d_win1024 = nullptr;        // the window taps in the 1024-point column tiles' order
+  float2* d_wtab1024 = nullptr;      // the default window only: (cos, sin)(2 pi m / (N - 1)), m < 65536 — the column tiles form their taps from it (fft1024_kernels.h, WCALC)
   float* d_zero_row = nullptr;       // n zeros
   const float* last_rel_rows = nullptr;  // the last batch's rows as rel values (ring-only calls: last_psd is null then)
   bool use_fft256 = false;
@@ -581,6 +592,7 @@ ss::ColsArgs cols256_args(ss_ctx* c, const void* d_iq, long long item_stride) {
     g.smax_mask = c->smax_rows - 1;
     g.abs0 = (int)(c->abs_frames & 0x3fffffff);
   }
+  g.wtab = c->d_wtab1024;
   return g;
 }
 
@@ -595,7 +607,21 @@ void launch_cols1024_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int
     if (e0) hipExtLaunchKernelGGL(kernel, dim3(nframes * tiles), dim3(threads), lds, c->stream, e0, e1, 0, g);
     else hipLaunchKernelGGL(kernel, dim3(nframes * tiles), dim3(threads), lds, c->stream, g);
   };
-  if (c->diag.cols1024_wide) go(ss::k_fft_cols1024<FMT, 4>, 64, 1024, ss::fft1024_cols_lds_bytes(4));
+  const bool wcalc = g.wtab != nullptr;
+  if (c->have_plan && c->diag.cols1024_wide) {  // the plan of the call before at the front of this launch (detect_fused.h)
+    const int plan_wgs = ss::plan_fused_wgs(ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n));
+    const dim3 grid((unsigned)(plan_wgs + nframes * 64)), block(1024);
+    auto gop = [&](auto kernel) {
+      if (e0) hipExtLaunchKernelGGL(kernel, grid, block, ss::fft1024_cols_lds_bytes(4), c->stream, e0, e1, 0, g, c->pend_plan_det, c->pend_plan, plan_wgs);
+      else hipLaunchKernelGGL(kernel, grid, block, ss::fft1024_cols_lds_bytes(4), c->stream, g, c->pend_plan_det, c->pend_plan, plan_wgs);
+    };
+    if (wcalc) gop(ss::k_fft_cols1024_plan<FMT, true>);
+    else gop(ss::k_fft_cols1024_plan<FMT, false>);
+    c->have_plan = false;
+    return;
+  }
+  if (c->diag.cols1024_wide && wcalc) go(ss::k_fft_cols1024<FMT, 4, true>, 64, 1024, ss::fft1024_cols_lds_bytes(4));
+  else if (c->diag.cols1024_wide) go(ss::k_fft_cols1024<FMT, 4>, 64, 1024, ss::fft1024_cols_lds_bytes(4));
   else go(ss::k_fft_cols1024<FMT, 3>, 128, 512, ss::kFft1024ColsLdsBytes);
 }
 void launch_cols1024(ss_ctx* c, const void* d_iq, long long item_stride, int nframes) {
@@ -1002,6 +1028,14 @@ void launch_nan_stage(ss_ctx* c, const NanStage& g) {
   hipLaunchKernelGGL(ss::k_nan_apply, dim3(g.nframes), dim3(256), 0, c->stream, (const int*)c->d_bad_from, c->n, g.maskbits, g.counts, g.avg_full);
 }
 
+// The plan of the last call as a launch of its own (it would have ridden on the next call's column launch, ss_ctx::have_plan).
+void launch_pending_plan(ss_ctx* c) {
+  if (!c->have_plan) return;
+  const int plan_wgs = ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n);  // (groups past the band's end find no column)
+  hipLaunchKernelGGL((ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, c->stream, c->pend_plan_det, c->pend_plan);
+  c->have_plan = false;
+}
+
 // Drain the deferred stages: detect (+ the emit stage before it), then the last emit. Nothing is synchronised.
 void flush_stages(ss_ctx* c) {
   if (c->deep) {
@@ -1009,6 +1043,7 @@ void flush_stages(ss_ctx* c) {
     return drain_deep(c);
   }
   if (c->have_det || c->have_emit) ++c->stats.drains;
+  launch_pending_plan(c);  // (the detect stage that waits reads its list)
   while (c->have_det || c->have_emit) {
     launch_step(c, nullptr, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     if (c->have_det && c->ref_nan) {  // (such contexts never defer a stage across calls: no emit stage rode on that launch)
@@ -1707,7 +1742,9 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       }
       // the plan: which tiles of this call can hold a candidate at all (k_plan_long) — behind the rows kernel, ahead of the
       // launch that carries the detect stage. Only a stage whose sole products are mask bits and counts is planned.
-      const int plan_cols = ss::plan_long_cols(nframes, c->pend_det.shift, c->n / 256, 8);  // (32 columns per workgroup — whole lines of the two-pass layout — halved the fetches and doubled the time: 128 workgroups are too few, profiles/r04/s6_summary.txt)
+      // (the plan of call k rides at the front of call k + 1's column launch: four plan blocks share a column tile's LDS)
+      const bool plan_fused = rows_by_step && c->diag.plan_fused && overlap;
+      const int plan_cols = ss::plan_long_cols(nframes, c->pend_det.shift, c->n / 256, 8, plan_fused ? ss::kPlanFusedFloats : ss::kPlanLongFloats);  // (32 columns per workgroup — whole lines of the two-pass layout — halved the fetches and doubled the time: 128 workgroups are too few, profiles/r04/s6_summary.txt)
       if (ring_by_rows && !spec && !c->pend_det.rel_out && !c->pend_det.avg_out && plan_cols > 0) {
         int* list = c->d_tlist[(c->buf_cur + c->nbuf - 1) % c->nbuf];  // (run_backend_fused has moved buf_cur on: the set this call's mask bits go to)
         ss::PlanLongArgs pl{};
@@ -1720,7 +1757,13 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         pl.list = list;
         pl.layout = c->two_pass ? 1 : 0;
         const int plan_wgs = ss::plan_long_blocks(pl.layout, plan_cols, c->n);  // (groups past the band's end find no column)
-        SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, c->pend_det, pl);
+        if (plan_fused) {
+          c->have_plan = true;
+          c->pend_plan = pl;
+          c->pend_plan_det = ss::plan_long_det(c->pend_det);
+        } else {
+          SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, ss::plan_long_det(c->pend_det), pl);
+        }
         c->pend_det.tile_list = list;
       }
     }
@@ -1854,6 +1897,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_tw_cols);
   (void)hipFree(c->d_zero_row);
   (void)hipFree(c->d_win1024);
+  (void)hipFree(c->d_wtab1024);
   (void)hipFree(c->d_tw_sub);
   (void)hipFree(c->d_tw_small);
   (void)hipFree(c->d_tw_rowsR);
@@ -2216,6 +2260,12 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       ss::fft1024_window_order(win.data(), wk.data(), c->diag.cols1024_wide ? 4 : 3);
       CREATE_HIP(hipMalloc(&c->d_win1024, sizeof(float) * (size_t)n));
       CREATE_HIP(hipMemcpy(c->d_win1024, wk.data(), sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+      if (!cfg->window && c->diag.cols1024_wide && c->diag.win_calc) {  // the default window: Hamming taps formed in the kernel
+        std::vector<float2> wt(65536);
+        ss::fft1024_window_rotation_table(wt.data());
+        CREATE_HIP(hipMalloc(&c->d_wtab1024, sizeof(float2) * wt.size()));
+        CREATE_HIP(hipMemcpy(c->d_wtab1024, wt.data(), sizeof(float2) * wt.size(), hipMemcpyHostToDevice));
+      }
     }
     CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
   }
@@ -2231,7 +2281,9 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipMalloc(&c->d_zero_row, sizeof(float) * (size_t)n));  // (what a ring-only call's detect stage subtracts from rows that are noise-relative already)
     CREATE_HIP(hipMemset(c->d_zero_row, 0, sizeof(float) * (size_t)n));
     int rows = 64;
-    while (rows < cfg->max_batch + kHistRows + 1) rows <<= 1;
+    // (two batches and the averager's reach: the plan of call k — which reads the maxima of its frames and of the 35 before —
+    // runs beside the column tiles of call k + 1, which clear the rows of THEIR frames: k_fft_cols1024_plan)
+    while (rows < 2 * cfg->max_batch + kHistRows + 1) rows <<= 1;
     c->smax_rows = rows;
     CREATE_HIP(hipMalloc(&c->d_smax, sizeof(float) * (size_t)rows * (size_t)(n / 32)));
     const size_t max_tiles = ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256);

@@ -8,6 +8,7 @@
 //     bijections that put the workgroups sharing a 128-byte line on one XCD; rows1024_smax_index is where the row tiles write and
 //     the plan reads; the window in the column tiles' order is a permutation of the taps, element by element what the tile loads;
 //     the atomic maxima's keys keep the order of the floats.
+#include <cmath>
 #include <cstdio>
 #include <vector>
 
@@ -118,6 +119,55 @@ int main() {
         }
       }
       if (groups * C < 1024) ++bad;
+    }
+    // the plan at the front of the next call's column launch (k_fft_cols1024_plan): workgroup b < plan_fused_wgs(blocks) runs, in its
+    // four groups of 256 threads, the plan blocks ((b >> 3) * 4 + sub) * 8 + (b & 7): every block of k_plan_long's numbering exactly
+    // once, on the XCD that numbering gives it (b mod 8), the workgroup's four in consecutive slots; the blocks past the numbering's
+    // end find no column; the workgroup count is a multiple of 8 (the column tiles behind it keep their XCDs); what a block needs of
+    // LDS fits a quarter of a column tile's
+    for (int C : {1, 2, 4, 8}) {
+      const int blocks = ss::plan_long_blocks(1, C, n), wgs = ss::plan_fused_wgs(blocks);
+      std::vector<int> bseen((size_t)4 * wgs, 0);
+      if (wgs % 8 || 4 * wgs < blocks) ++bad;
+      for (int b = 0; b < wgs; ++b)
+        for (int sub = 0; sub < 4; ++sub) {
+          const int vb = ((((b >> 3) << 2) + sub) << 3) | (b & 7);
+          if (vb < 0 || vb >= 4 * wgs || bseen[(size_t)vb]++ || (vb & 7) != (b & 7) || (vb >> 3) != (b >> 3) * 4 + sub) ++bad;
+          if (vb >= blocks) {
+            int wc, d0;
+            ss::plan_long_block(1, vb, C, 4, &wc, &d0);
+            if (d0 < 1024) ++bad;
+          }
+        }
+      for (int vb = 0; vb < blocks; ++vb)
+        if (!bseen[(size_t)vb]) ++bad;
+    }
+    for (int nframes = 1; nframes <= 600; ++nframes)
+      for (int shift = 0; shift < 16; ++shift) {
+        const int c = ss::plan_long_cols(nframes, shift, 4096, 8, ss::kPlanFusedFloats), nft = (nframes + shift + 15) / 16, rows = 16 * nft + 20;
+        if (c < 0 || c > 8 || (c > 0 && (c * rows > ss::kPlanFusedFloats || c * nft > 256))) ++bad;
+        if (nframes <= 128 && c < 1) ++bad;
+      }
+    if (4 * (ss::kPlanFusedFloats + ss::kPlanLongInts) * 4 > ss::fft1024_cols_lds_bytes(4)) ++bad;
+    // the Hamming taps the column tiles form (WCALC) against the taps as ss_create computes them: at most 1.2e-7 apart
+    {
+      std::vector<float2> wt(65536);
+      ss::fft1024_window_rotation_table(wt.data());
+      double worst = 0.0, sq = 0.0;
+      for (int r = 0; r < 16; ++r) {
+        const double phi = 2.0 * 3.14159265358979323846 * 65536.0 * r / 1048575.0;
+        if (ss::kWin1024C[r] != (float)(-0.46 * cos(phi)) || ss::kWin1024S[r] != (float)(0.46 * sin(phi))) ++bad;
+        for (int m = 0; m < 65536; ++m) {
+          const float w = __builtin_fmaf(wt[(size_t)m].x, ss::kWin1024C[r], __builtin_fmaf(wt[(size_t)m].y, ss::kWin1024S[r], 0.54f));
+          const float M = (float)(n - 1);
+          const float ref = (float)(0.54 - 0.46 * cos((2.0 * 3.14159265358979323846 * (double)(m + 65536 * r)) / M));
+          const double d = (double)w - (double)ref;
+          worst = d < 0 ? (-d > worst ? -d : worst) : (d > worst ? d : worst);
+          sq += d * d;
+        }
+      }
+      printf("formed Hamming taps: worst %.3g, rms %.3g\n", worst, sqrt(sq / n));
+      if (worst > 1.5e-7 || sqrt(sq / n) > 5e-8) ++bad;
     }
     // layout 0 as before
     for (int C : {1, 2, 4, 8}) {
