@@ -311,11 +311,12 @@ def chain_kernels(n: int, fmt: str):
     if n < 16384:
         return [("step", "k_fft", "load+window+FFT+dB (one launch); detect and emit stages follow as launches of their own", in_b + 4.0)]
     if n == 1 << 20 and os.environ.get("SS_FFT_TWOPASS") != "0":  # 1024 x 1024 in two passes (csrc/fft1024_kernels.h; the three-pass form is a switch of the diagnostics build)
-        return [("step", "k_fft_cols1024", "k_fft_cols1024: column half of the two-pass FFT (load, window, 1024-point FFTs in registers + LDS, twiddle -> work buffer), "
-                 "16 columns x 1024 rows per 1024-thread workgroup", in_b + 8.0),
+        return [("step", "k_fft_cols1024", "k_fft_cols1024_plan: column half of the two-pass FFT (load, Hamming taps formed from one table entry per thread, 1024-point FFTs in "
+                 "registers + LDS, twiddle -> work buffer), 16 columns x 1024 rows per 1024-thread workgroup; its first 128 workgroups run the plan of the call before "
+                 "(which averaging tiles can hold a candidate, from the run maxima that call's row half left)", in_b + 8.0),
                 ("rows", "k_scan_step", "k_scan_step with the ROW half as its FFT role (fft_rows1024_tile: 1024-point FFTs -> dB -> noise-relative rows straight into the averager "
                  "ring's buffer, no dB plane in detect mode, + run maxima for the tile culling), carrying the listed averaging tiles of call k-1 and the candidate lists of call k-2", 12.0),
-                ("plan", "k_plan_long", "k_plan_long: which averaging tiles of the call can hold a candidate, from the run maxima the rows kernel left (one list per call)", 0.0)]
+                ("plan", "k_plan_long", "k_plan_long as a launch of its own (SS_PLAN_FUSED=0 of the diagnostics build; the product runs the plan at the front of the next column launch)", 0.0)]
     n2 = n // 256
     ks = [("step", "k_scan_step", "k_scan_step: column half of the four-step FFT of call k (load, window, 256-point FFTs, twiddle -> work buffer), carrying the "
            "21x21 mean + threshold of call k-1 (the tiles the plan listed) and the candidate lists of call k-2 as further roles", in_b + 8.0)]
@@ -590,8 +591,8 @@ def run(args):
             two_pass = n == 1 << 20 and os.environ.get("SS_FFT_TWOPASS") != "0"
             if n == 8192:
                 shape = (nb + 20 + nb // 8 + 4) * 512
-            elif two_pass:  # column half: 64 workgroups of 1024 threads per frame; row half: 128 of 512 per frame + one emit workgroup per frame
-                shape = {"step": nb * 64 * 1024, "rows": (nb * 128 + nb) * 512}.get(slot)
+            elif two_pass:  # column half: 64 workgroups of 1024 threads per frame behind the 128 that run the plan of the call before; row half: 128 of 512 per frame + one emit workgroup per frame
+                shape = {"step": (nb * 64 + 128) * 1024, "rows": (nb * 128 + nb) * 512}.get(slot)
             else:
                 shape = (nb * (n // 8192) + (nb if n >= 65536 else -(-nb // 8))) * 512 if slot == "step" and n >= 16384 else None
             tp = traffic_from_profiles(args.config or 2, match, shape) if is_preset(args) else None

@@ -76,6 +76,23 @@ struct ColsArgs {
   const float2* wtab;  // 1024-point column tiles that form their Hamming taps (fft1024_kernels.h, WCALC): (cos, sin)(2 pi m / (N - 1)), m < 65536
 };
 
+// N = 65536, default window: the column tiles form their Hamming taps instead of loading them (the 2^20-point tiles' way,
+// fft1024_kernels.h): a thread's sixteen samples are n = m + 4096 r with m = 256 j + n2 < 4096, so
+//   w[n] = 0.54 + (-0.46 cos phi_r) cos theta_m + (0.46 sin phi_r) sin theta_m,   theta_m = 2 pi m / 65535,  phi_r = 2 pi 4096 r / 65535
+// — one 8-byte table entry per thread (ColsArgs::wtab: 4096 entries) and two FMAs per sample in the place of sixteen 4-byte loads
+// from a 256 KiB table: with int8 IQ the taps were two thirds of the bytes the tile loads. Within 1.2e-7 of the table's taps
+// (3.4e-8 rms), checked on the CPU (tests/host/index_check.cpp).
+__device__ constexpr float kWin65536C[16] = {-0.460000008f, -0.424983531f, -0.325265229f, -0.176026732f, 1.10256551e-05f, 0.176047117f, 0.325280815f, 0.424991965f,
+                                             0.460000008f, 0.424975097f, 0.325249642f, 0.176006362f, -3.30769653e-05f, -0.176067486f, -0.325296402f, -0.425000399f};
+__device__ constexpr float kWin65536S[16] = {0.0f, 0.176036924f, 0.325273007f, 0.424987763f, 0.460000008f, 0.424979299f, 0.325257421f, 0.176016554f,
+                                             -2.20513102e-05f, -0.176057294f, -0.325288624f, -0.424996197f, -0.460000008f, -0.424970865f, -0.325241834f, -0.175996184f};
+inline void fft65536_window_rotation_table(float2* out) {  // host side: ColsArgs::wtab for N = 65536
+  for (int m = 0; m < 4096; ++m) {
+    const double th = 2.0 * 3.14159265358979323846 * (double)m / 65535.0;
+    out[m] = make_float2((float)cos(th), (float)sin(th));
+  }
+}
+
 // One column tile (32 columns x 256 rows) by one workgroup of 512 threads; `block` = frame * (N2 / 32) + tile.
 template <int FMT>
 __device__ __forceinline__ void fft_cols256_tile(const ColsArgs& g, int block, unsigned char* __restrict__ smem_raw, int t) {
@@ -97,6 +114,16 @@ __device__ __forceinline__ void fft_cols256_tile(const ColsArgs& g, int block, u
   const char* win_b = reinterpret_cast<const char*>(g.win);
   const uint32_t tn = ((uint32_t)j << logn2) + (uint32_t)n2;
   float2 a[16];
+  if (g.wtab && logn2 == 8) {  // (workgroup-uniform; a loop of its own: a branch around every tap load would cost the loads their interleaving)
+    const float2 wt = g.wtab[tn];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const size_t un = (size_t)(16 * r) << 8;
+      const float2 x = load_iq<FMT>(in_frame + un * kInBytes + tn * kInBytes, 0, g.scale);
+      const float w = fmaf(wt.x, kWin65536C[r], fmaf(wt.y, kWin65536S[r], 0.54f));
+      a[r] = make_float2(x.x * w, x.y * w);
+    }
+  } else
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const size_t un = (size_t)(16 * r) << logn2;
@@ -233,14 +260,21 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
     x.smax[((size_t)((x.abs0 + f) & x.smax_mask) << (logn - 5)) + ((r0 >> 5) << (logn - 8)) + (c << 8) + t] = bound;  // rows_smax_index
   }
   float* hrow = (x.hist_out && f >= x.first_hist && SS_ROWS_ABL != 2) ? x.hist_out + ((size_t)(f - x.first_hist) << logn) : nullptr;  // (workgroup-uniform)
+  // fft_v shift=true: X[k] lands at k ^ (N/2)
+  const auto bin_of = [&](int i) { return ((r0 + rr) + (c << 8) + ((kb + 16 * i) << log_row)) ^ half; };
+  if (psd) {  // (null: a call that keeps no dB plane, specscan.hip run_batch)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int d = kb + 16 * i;
-    // fft_v shift=true: X[k] lands at k ^ (N/2)
-    const int bin = ((r0 + rr) + (c << 8) + (d << log_row)) ^ half;
-    const float v = s[d * 33 + rr];
-    if (psd) out[bin] = v;  // (null: a call that keeps no dB plane, specscan.hip run_batch)
-    if (hrow) hrow[bin] = v - x.thr[bin];  // noise_learner.cpp:55, as detect_tile forms it
+    for (int i = 0; i < 16; ++i) out[bin_of(i)] = s[(kb + 16 * i) * 33 + rr];
+  }
+  if (hrow) {
+    // the ceiling values first, all in flight together, then the stores: load, subtract, store per output is what the compiler keeps
+    // when written that way (it cannot know that ceiling and ring are different memory), and then every store waits for its own
+    // load and for the store before it (fft1024_kernels.h: fft_rows1024_tile)
+    float th[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) th[i] = x.thr[bin_of(i)];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hrow[bin_of(i)] = s[(kb + 16 * i) * 33 + rr] - th[i];  // noise_learner.cpp:55, as detect_tile forms it
   }
 }
 

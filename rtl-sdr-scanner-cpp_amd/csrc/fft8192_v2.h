@@ -252,7 +252,7 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
 #pragma unroll
   for (int q = 0; q < 16; ++q) a[q].y = s[rbase + 512 * q];
 #if SS_SEGMAX_LDS
-  if (segsum) __syncthreads();  // the exchange plane takes the frame's dB values at the end (the column maxima): every read of z is done
+  __syncthreads();  // the exchange plane takes the frame's dB values at the end (the column maxima): every read of z is done
 #endif
 
   // The list header word this workgroup will want when its frame is done (live_hint): asked for NOW — two thirds of a
@@ -366,10 +366,9 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
       buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k + 16384, pv[2 * i + 1]);
       buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k, pv[2 * i]);
 #if SS_SEGMAX_LDS
-      if (want_max) {
-        dbrow[256 * k + 4096] = pv[2 * i + 1];
-        dbrow[256 * k] = pv[2 * i];
-      }
+      // (whether or not the frame leaves a summary: a branch here costs the dB stores their interleaving and the kernel registers)
+      dbrow[256 * k + 4096] = pv[2 * i + 1];
+      dbrow[256 * k] = pv[2 * i];
 #endif
     }
     if (want_max && !SS_SEGMAX_LDS) {

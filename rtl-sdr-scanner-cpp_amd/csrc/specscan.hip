@@ -125,7 +125,7 @@ struct ss_ctx {
     int wait_limit = 0;            // SS_DIAG (SS_WAIT_LIMIT): StepArgs::wait_limit, 0 = the product's
     int queues = 2;                // 8192 points, deep pipelining: launch queues (2 .. 4)
     bool cull_65536 = false;       // SS_DIAG (SS_CULL_65536=1): tile culling also at 65536 points (see ss_create)
-    bool win_calc = true;          // 2^20 points in two passes, default window: the column tiles form their Hamming taps instead of loading them (SS_WIN_CALC=0: the table as ever)
+    bool win_calc = true;          // 2^20 points in two passes and 65536 points, default window: the column tiles form their Hamming taps instead of loading them (SS_WIN_CALC=0: the table as ever)
     bool plan_fused = true;        // 2^20 points in two passes: the plan of call k at the front of call k + 1's column launch (SS_PLAN_FUSED=0: a launch of its own behind call k's rows, as until session 14 of round 4)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
     bool cull = true;              // 8192 points: detect tiles that cannot hold a candidate are not evaluated (detect_fused.h)
@@ -399,7 +399,7 @@ struct ss_ctx {
   // are the next window otherwise (place_ring) — and no dB plane is written at all: the detect tiles take the batch's rows from
   // there, with a ceiling of zeros to subtract (x - 0.0f is x: the same bits) — unless somebody wants a plane.
   float* d_win1024 = nullptr;        // the window taps in the 1024-point column tiles' order
-  float2* d_wtab1024 = nullptr;      // the default window only: (cos, sin)(2 pi m / (N - 1)), m < 65536 — the column tiles form their taps from it (fft1024_kernels.h, WCALC)
+  float2* d_wtab1024 = nullptr;      // the default window only: (cos, sin)(2 pi m / (N - 1)), m < N / 16 — the column tiles of 2^20-point (fft1024_kernels.h, WCALC) and of 65536-point frames (fft256_kernels.h) form their taps from it
   float* d_zero_row = nullptr;       // n zeros
   const float* last_rel_rows = nullptr;  // the last batch's rows as rel values (ring-only calls: last_psd is null then)
   bool use_fft256 = false;
@@ -2268,6 +2268,12 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       }
     }
     CREATE_HIP(hipMemcpy(c->d_tw, tw.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    if (n == 65536 && c->use_fft256 && !cfg->window && c->diag.win_calc) {  // the default window: the 256-point column tiles form their Hamming taps (fft256_kernels.h)
+      std::vector<float2> wt(4096);
+      ss::fft65536_window_rotation_table(wt.data());
+      CREATE_HIP(hipMalloc(&c->d_wtab1024, sizeof(float2) * wt.size()));
+      CREATE_HIP(hipMemcpy(c->d_wtab1024, wt.data(), sizeof(float2) * wt.size(), hipMemcpyHostToDevice));
+    }
   }
   // Tile culling for long transforms: the sizes whose rows go through k_fft_rows256_psd (N2 = 256, or the radix-A step in front)
   // and the two-pass form of 2^20 points. On by default where it pays: 2^20 points. At 65536 points it takes 7 B/sample off the

@@ -25,6 +25,7 @@ VARIANTS = {
     "c1024nostore": ["SS_C1024_ABL=2"],  # ... without the work-buffer stores
     "c1024noload": ["SS_C1024_ABL=4"],   # ... without the frame loads
     "c1024none": ["SS_C1024_ABL=7"],     # ... arithmetic and LDS only
+    "segdpp": ["SS_SEGMAX_LDS=0"],   # 8192 points: the per-column maxima for the tile culling in registers (v_max_f32_dpp), as until session 15 of round 4
     "colsnone": ["SS_COLS_TW6=0", "SS_COLS_ABL=3"],   # ... without either  # 8192 points, deep pipelining: ring rows written by three frame tiles of every call
 }
 

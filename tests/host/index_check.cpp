@@ -169,6 +169,26 @@ int main() {
       printf("formed Hamming taps: worst %.3g, rms %.3g\n", worst, sqrt(sq / n));
       if (worst > 1.5e-7 || sqrt(sq / n) > 5e-8) ++bad;
     }
+    // the same for the 256-point column tiles of a 65536-point frame (fft256_kernels.h): n = m + 4096 r, m < 4096
+    {
+      std::vector<float2> wt(4096);
+      ss::fft65536_window_rotation_table(wt.data());
+      double worst = 0.0, sq = 0.0;
+      for (int r = 0; r < 16; ++r) {
+        const double phi = 2.0 * 3.14159265358979323846 * 4096.0 * r / 65535.0;
+        if (ss::kWin65536C[r] != (float)(-0.46 * cos(phi)) || ss::kWin65536S[r] != (float)(0.46 * sin(phi))) ++bad;
+        for (int m = 0; m < 4096; ++m) {
+          const float w = __builtin_fmaf(wt[(size_t)m].x, ss::kWin65536C[r], __builtin_fmaf(wt[(size_t)m].y, ss::kWin65536S[r], 0.54f));
+          const float M = 65535.0f;
+          const float ref = (float)(0.54 - 0.46 * cos((2.0 * 3.14159265358979323846 * (double)(m + 4096 * r)) / M));
+          const double d = (double)w - (double)ref;
+          worst = d < 0 ? (-d > worst ? -d : worst) : (d > worst ? d : worst);
+          sq += d * d;
+        }
+      }
+      printf("formed Hamming taps, 65536 points: worst %.3g, rms %.3g\n", worst, sqrt(sq / 65536.0));
+      if (worst > 1.5e-7 || sqrt(sq / 65536.0) > 5e-8) ++bad;
+    }
     // layout 0 as before
     for (int C : {1, 2, 4, 8}) {
       const int blocks = ss::plan_long_blocks(0, C, n);
