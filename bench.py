@@ -291,6 +291,45 @@ def traffic_from_profiles(config: int, kernel_match: str, threads_per_launch: in
             "source": f"profiles/{base}_pmc_fetch.csv, _pmc_write.csv (rocprofv3 --pmc passes of this configuration's command line, not this run)"}
 
 
+def live_pmc_traffic(sub_argv, kernel_match: str, threads_per_launch: int | None, timeout_s: float = 150.0):
+    """roofline.traffic, live: counters cannot be read from inside a run, so rank 0 — once the timed region is over and the GPU idle —
+    runs this command line once more in a short form under `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE`
+    (separate passes, --kernel-trace only, from /tmp with TMPDIR=/tmp: MI355X_MICROARCH.md's recipe) on the same box, and averages
+    the counter over the launches of the dominant kernel's steady-state shape. bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+    (gfx950's FETCH_SIZE counts 64-byte requests in KiB as if they were 32-byte ones: round-1 calibration against a copy kernel,
+    DESIGN.md 4). None, with the reason, when rocprofv3 is not there, times out or finds no such launch."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    out, n_launches = {}, 0
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        with tempfile.TemporaryDirectory(dir="/tmp", prefix="ss_pmc_") as d:
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), *sub_argv]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter}: no answer within {timeout_s:.0f} s"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(files)} counter files: {(r.stderr or r.stdout)[-160:]}"
+            vals = [float(row["Counter_Value"]) for f in files for row in csv.DictReader(open(f))
+                    if row.get("Counter_Name") == counter and kernel_match in row["Kernel_Name"] and (threads_per_launch is None or int(row["Grid_Size"]) == threads_per_launch)]
+            if not vals:
+                return None, f"rocprofv3 --pmc {counter}: no launch of {kernel_match} with {threads_per_launch} threads in the pass"
+            out[kind] = sum(vals) / len(vals)
+            n_launches = len(vals)
+    return {"bytes_per_launch": round((2.0 * out["fetch"] + out["write"]) * 1024.0), "fetch_kib": round(out["fetch"], 1), "write_kib": round(out["write"], 1),
+            "launches_averaged": n_launches, "seconds": round(time.perf_counter() - t0, 1),
+            "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes, --kernel-trace only) of this command line with --steps 30, run by this process on this box "
+                   "behind the timed region; launches of the steady-state shape; bytes = (2 FETCH_SIZE + WRITE_SIZE) KiB"}, None
+
+
 def is_preset(args) -> bool:
     """The command line is the configuration's own (the committed PMC passes are of that one)."""
     want = dict(fft=8192, frames=1024, fmt="cf32", sample_rate=None, no_psd_out=False)
@@ -380,6 +419,7 @@ def parse_args(argv):
     ap.add_argument("--sync-engine-first", action="store_true", help="end of the timed region as in round 2: ss_sync, then torch.cuda.synchronize() (A/B; the default lets the device-wide synchronisation do the waiting)")
     ap.add_argument("--no-also", action="store_true", help="default line only: do not append the short runs of BASELINE configs 3 and 5 (`also`)")
     ap.add_argument("--sub", action="store_true", help="(internal) this process is one of the `also` runs of another bench.py")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic stays null: do not run the two short rocprofv3 --pmc passes of this command line behind the timed region (default line of config 2 at N = 1 only)")
     ap.add_argument("--no-parity", action="store_true", help="no parity sample beside the numbers (the `also` runs carry one each unless told otherwise)")
     args = ap.parse_args(argv)
     preset = dict(CONFIGS.get(args.config or 2, {}))
@@ -641,7 +681,7 @@ def run(args):
                          "launches_in_flight": round(in_flight, 2) if dom else None,
                          "achieved_if_launches_did_not_overlap": None if literal is None else round(literal, 1),
                          "algorithmic_bytes_per_launch": abps * nb * n if n == 8192 else (dom["bytes_per_launch_it_must_move"] if dom else None),
-                         "traffic": None,  # PMC counters cannot be read from inside the run ...
+                         "traffic": None,  # (filled in below by two short rocprofv3 --pmc passes of this command line on this box: live_pmc_traffic) ...
                          # ... the committed passes of the same command line (for 8192 points: launches of the steady-state shape, 1024 + 20 FFT, 128 emit and 4 plan workgroups of 512 threads)
                          "traffic_from_profiles": ({"bytes_per_launch": dom["pmc_bytes_per_launch_from_profiles"]} if dom and dom["pmc_bytes_per_launch_from_profiles"] else None),
                          "kernels": kernels},
@@ -650,6 +690,16 @@ def run(args):
                                "frac": round(chain_gbs / HBM_PEAK_GBS, 4),
                                "pmc_bytes_per_sample_from_profiles": round(sum(pmc_chain) / (nb * n), 2) if pmc_chain else None},
         }
+        if world == 1 and not args.sub and not args.no_live_pmc and is_preset(args) and (args.config or 2) == 2 and n == 8192 and dom:
+            sub_argv = ["--gpus", "1", "--steps", "30", "--warmup", "5", "--preheat-ms", "0", "--no-cpu-baseline", "--no-also", "--no-parity", "--no-live-pmc", "--sub"]
+            try:
+                live, why = live_pmc_traffic(sub_argv, "k_scan_step", (nb + 20 + nb // 8 + 4) * 512)
+            except Exception as e:  # (the line must come out whatever the profiler does)
+                live, why = None, f"{type(e).__name__}: {e}"[:200]
+            out["roofline"]["traffic"] = live["bytes_per_launch"] if live else None
+            out["roofline"]["traffic_live"] = live if live else {"unavailable": why}
+            if live:
+                out["roofline"]["traffic_over_algorithmic"] = round(live["bytes_per_launch"] / (abps * nb * n), 3)
         if world == 1 and not args.sub and not args.no_also and (args.config or 2) == 2 and n == 8192 and not (args.diag_lib or args.lib):
             out["also"] = also_lines()
         if not args.no_cpu_baseline and world == 1:

@@ -215,21 +215,34 @@ __host__ __device__ inline int rows_smax_index(int col, int run, int logn) {
 // Rows of 256 points spaced row_stride apart: N2 = 256 (row_stride 256, nsub 1) directly after the columns pass, or
 // N2 = 256 A after k_fft_sub_dft (row_stride N2, nsub = A sub-rows c per row). Output bin of X_row[d] is
 // k1 + 256 c + 256 nsub d; a workgroup takes 32 consecutive k1 of one c so that stores run along k1.
-__global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __restrict__ work, const float2* __restrict__ tw256, float db_off,
-                                                            float* __restrict__ psd, int logn, int lognsub, RowsExtra x) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+struct Rows256Args {
+  const float2* work;
+  const float2* tw256;
+  float db_off;
+  float* psd;  // null: a call that keeps no dB plane
+  int logn, lognsub;
+  RowsExtra x;
+};
+// One row tile: 32 rows k1 x 256 points of one sub-row c of one frame; `block` = ((f * nsub) + c) * 8 + k1 tile. A launch of its own
+// (k_fft_rows256_psd) or the FFT role of k_scan_step (KIND 6, scan_step.h: 65536 points with tile culling — the column half is
+// then a launch of its own right before, as at 2^20 points).
+__device__ __forceinline__ void fft_rows256_tile(const Rows256Args& g, int block, unsigned char* __restrict__ smem_raw, int t) {
+  const float2* __restrict__ work = g.work;
+  const float2* __restrict__ tw256 = g.tw256;
+  const float db_off = g.db_off;
+  float* __restrict__ psd = g.psd;
+  const int logn = g.logn, lognsub = g.lognsub;
+  const RowsExtra& x = g.x;
   float* s = reinterpret_cast<float*>(smem_raw);
-  const int t = threadIdx.x;
   float2* tw_lds = reinterpret_cast<float2*>(smem_raw + kFft256LdsBytes);  // W_256 in LDS, as in fft_cols256_tile
   unsigned* pmax = reinterpret_cast<unsigned*>(smem_raw + kFft256ColsLdsBytes);
   if (t < 256) tw_lds[t] = tw256[t];
   if (x.smax && t < 256) pmax[t] = 0u;  // (the barriers of the register passes come before the first atomic)
-  if (x.zero_word && blockIdx.x == 0 && t == 0) *x.zero_word = 0;
+  if (x.zero_word && block == 0 && t == 0) *x.zero_word = 0;
   const int rho = t >> 4, j = t & 15;
-  // blockIdx = ((f * nsub) + c) * 8 + k1 tile
-  const int r0 = (blockIdx.x & 7) << 5;
-  const int c = (blockIdx.x >> 3) & ((1 << lognsub) - 1);
-  const int f = blockIdx.x >> (3 + lognsub);
+  const int r0 = (block & 7) << 5;
+  const int c = (block >> 3) & ((1 << lognsub) - 1);
+  const int f = block >> (3 + lognsub);
   const int log_row = 8 + lognsub;  // log2 of the row stride
   const float2* row = work + ((size_t)f << logn) + ((size_t)(r0 + rho) << log_row) + ((size_t)c << 8);
   float2 a[16];
@@ -276,6 +289,19 @@ __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __rest
 #pragma unroll
     for (int i = 0; i < 16; ++i) hrow[bin_of(i)] = s[(kb + 16 * i) * 33 + rr] - th[i];  // noise_learner.cpp:55, as detect_tile forms it
   }
+}
+__global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __restrict__ work, const float2* __restrict__ tw256, float db_off,
+                                                            float* __restrict__ psd, int logn, int lognsub, RowsExtra x) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Rows256Args g;
+  g.work = work;
+  g.tw256 = tw256;
+  g.db_off = db_off;
+  g.psd = psd;
+  g.logn = logn;
+  g.lognsub = lognsub;
+  g.x = x;
+  fft_rows256_tile(g, (int)blockIdx.x, smem_raw, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

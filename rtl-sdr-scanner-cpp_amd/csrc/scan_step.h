@@ -53,6 +53,7 @@ struct StepArgs {
   const void* halo_iq;  // first of those frames
   float* halo_psd;      // [n_halo][8192]
   int n_halo;
+  Rows256Args rows256;  // KIND 6: 256-point ROW tiles of a long transform (fft256_kernels.h: fft_rows256_tile) — 65536 points with tile culling: the column half is a launch of its own right before, the plan of the call before at its front
   Rows1024Args rows;  // KIND 4: 1024-point ROW tiles of a 2^20-point frame (fft1024_kernels.h) — the column half, 1024 threads per tile, is a launch of its own right before
   ColsArgs cols;    // KIND 1, 2: 256-point column tiles of a long transform (fft256_kernels.h); KIND 3: 1024-point column tiles of a 2^20-point frame (fft1024_kernels.h)
   DetectArgs det;
@@ -74,10 +75,22 @@ struct StepArgs {
   // barriers — the launch grew by the 7 us the plan launch takes: 65536 x 128: 66.0 against 65.3 us per call, 2^20 x 16: 178
   // against 174, profiles/r03/s41.)
   int list_by_fft;
+  // ... but the first list_first pairs go to detect workgroups of their own, dispatched ahead of the FFT role: an FFT workgroup that
+  // finds a pair behind its tile lives twice as long as the others and is the launch's tail — a row launch of 65536-point frames
+  // took 30 us with 22 listed pairs riding on it and takes 17 alone (profiles/r04/s18_summary.txt). Detect workgroup i < list_first
+  // serves pair i (and leaves at once when the list is shorter), FFT workgroup p pair list_first + p, detect workgroup
+  // i >= list_first pair n_fft + i.
+  int list_first;
   // KIND 5 — launches without an FFT role of a 2^20-point context (the drain of its deferred stages): the
   // detect workgroups share k_plan_long's list out in a loop, pair item, item + W, item + 2 W, ... — a workgroup per POSSIBLE pair
   // (4096 of them, of which a few dozen find one) cost the launch 17 us in dispatch alone
   int list_loop;
+  // KIND 1, 2 — a long transform's PLAN as a role (k_plan_long's blocks, two to a workgroup: block 2 item + tid / 256): 65536 points
+  // with tile culling, where the plan of call k - 1 rides at the front of the column launch of call k together with emit(k - 2), and
+  // the detect stage it plans on the row launch right behind (KIND 6). 0: no such role.
+  int n_plan_long;  // workgroups
+  PlanLongDet plan_det;
+  PlanLongArgs plan_long;
   int n_emit;  // frames of the emit role
   int emit_per_wg;  // 8: one wave per frame; 1 (KIND 2): rows of 2048 mask words and more, the eight waves share one frame
   // One workgroup per work item, dispatched in blockIdx order, four resident per CU. WHICH item a workgroup takes decides
@@ -102,11 +115,12 @@ constexpr int kStepThreads = 512;
 constexpr int kStepLdsBytes = kFft8192V2LdsBytes;
 static_assert(2 * (16 * DetectTile<21, 21, 16, 256>::P * 4 + 64) <= kFft8192V2LdsBytes, "two detect tiles per workgroup");
 static_assert((8 * kEmitList + 9) * 4 <= kFft8192V2LdsBytes, "eight emit lists per workgroup");
-static_assert(kFft256ColsLdsBytes <= kFft8192V2LdsBytes && kFft1024ColsLdsBytes <= kFft8192V2LdsBytes && kFft1024RowsLdsBytes <= kFft8192V2LdsBytes, "a column / row tile");
+static_assert(kFft256ColsLdsBytes <= kFft8192V2LdsBytes && kFft1024ColsLdsBytes <= kFft8192V2LdsBytes && kFft1024RowsLdsBytes <= kFft8192V2LdsBytes && kFft256RowsPsdLdsBytes <= kFft8192V2LdsBytes, "a column / row tile");
 static_assert((kPlanLdsFloats + 64) * 4 <= kFft8192V2LdsBytes, "a plan workgroup's staging area");
+static_assert(2 * (kPlanFusedFloats + kPlanLongInts) * 4 <= kFft8192V2LdsBytes, "two blocks of a long transform's plan");
 __host__ __device__ inline int step_fft_wgs(const StepArgs& a) { return a.n_fft; }
 __host__ __device__ inline int step_emit_wgs(const StepArgs& a) { return a.emit_per_wg == 1 ? a.n_emit : (a.n_emit + 7) / 8; }
-__host__ __device__ inline int step_plan_wgs(const StepArgs& a) { return a.n_plan ? 32 / a.plan_cols : 0; }
+__host__ __device__ inline int step_plan_wgs(const StepArgs& a) { return a.n_plan ? 32 / a.plan_cols : a.n_plan_long; }
 // consumers a planned stage needs: per list, a pair for every two tiles it may hold
 __host__ __device__ inline int step_plan_consumers(const StepArgs& a) { return step_plan_wgs(a) * ((a.plan_cols * (a.n_plan / 32) + 1) / 2); }
 // (Tried for the launches without an FFT role — the drain at the end of a run of calls: 32 detect workgroups per list, each taking
@@ -168,12 +182,18 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       // long transforms: the tiles k_plan_long listed. With an FFT role in the launch its workgroups take pairs 0 .. n_fft - 1
       // (below) and the detect workgroups the pairs beyond (calls that are no multiple of 16 frames have a few); without one,
       // a workgroup per possible pair. Workgroups beyond the list's end leave at once.
-      list_pair_no = item + (a.list_by_fft ? a.n_fft : 0);
+      list_pair_no = (a.list_by_fft && item >= a.list_first) ? item + a.n_fft : item;
     } else {
       tile_a = 2 * item;
       tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;
     }
   } else if (role == ROLE_PLAN) {
+    if constexpr (KIND == 1 || KIND == 2) {  // a long transform's plan: two blocks of k_plan_long's numbering
+      const int sub = tid >> 8;
+      float* mrow = reinterpret_cast<float*>(smem_raw) + sub * (kPlanFusedFloats + kPlanLongInts);
+      plan_long_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));
+      return;
+    }
     if constexpr (KIND == 0) plan_seg = item;
 #ifdef SS_DIAG
     if (a.hint_mode == 3) plan_seg = -1;  // test switch: the plan workgroups never publish anything — every consumer has to help itself
@@ -181,13 +201,14 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
   } else if constexpr (KIND >= 1) {
     // ---- FFT role, long transforms: one tile of 32 columns x 256 rows (KIND 3: 8 columns x 1024 rows of a 2^20-point frame) ----
     if constexpr (KIND == 5) return;  // (the drain of a 2^20-point context: launches without an FFT role only)
+    else if constexpr (KIND == 6) fft_rows256_tile(a.rows256, item, smem_raw, tid);  // (the ROW half of call k: its column half ran as its own launch right before)
     else if constexpr (KIND == 4) fft_rows1024_tile(a.rows, item, smem_raw, tid);  // (the ROW half of call k: its column half ran as its own launch right before)
     else if constexpr (KIND == 3) fft_cols1024_tile<FMT>(a.cols, item, smem_raw, tid);
     else fft_cols256_tile<FMT>(a.cols, item, smem_raw, tid);
     // ... then this workgroup's share of the tiles k_plan_long listed for the detect stage that rides on the launch. (The other
     // way round — the pairs first, while the memory system is still idle, then the column tile — was 5 us slower per launch at
     // 65536 points x 128 frames: the two dozen workgroups that find a pair then finish their column tile last.)
-    if (a.list_by_fft) list_pair_no = item;
+    if (a.list_by_fft) list_pair_no = a.list_first + item;
   } else {
     // ---- FFT role: one frame ----
     int hdr;

@@ -124,8 +124,10 @@ struct ss_ctx {
     int hint_mode = 0;             // SS_DIAG timing ablations of the list hand-over (scan_step.h); 3: plan workgroups never publish (tests/test_gpu_wait_bound.py)
     int wait_limit = 0;            // SS_DIAG (SS_WAIT_LIMIT): StepArgs::wait_limit, 0 = the product's
     int queues = 2;                // 8192 points, deep pipelining: launch queues (2 .. 4)
-    bool cull_65536 = false;       // SS_DIAG (SS_CULL_65536=1): tile culling also at 65536 points (see ss_create)
+    bool cull_65536 = true;        // tile culling at 65536 points (SS_CULL_65536=0: every averaging tile evaluated, as the product did until session 17 of round 4; see ss_create)
+    bool rows256_step = true;      // 65536 points with tile culling: the column half as a launch of its own (the plan of the call before at its front), the ROW tiles as k_scan_step's FFT role (KIND 6) with the deferred stages riding on them (SS_ROWS256_STEP=0: columns as the FFT role, rows and plan as launches of their own)
     bool win_calc = true;          // 2^20 points in two passes and 65536 points, default window: the column tiles form their Hamming taps instead of loading them (SS_WIN_CALC=0: the table as ever)
+    int list_first = 64;           // long transforms with tile culling: the first pairs of the plan's list go to detect workgroups of their own, dispatched ahead of the launch's FFT role (SS_LIST_FIRST=0: every pair behind an FFT workgroup's tile, as until session 19 of round 4)
     bool plan_fused = true;        // 2^20 points in two passes: the plan of call k at the front of call k + 1's column launch (SS_PLAN_FUSED=0: a launch of its own behind call k's rows, as until session 14 of round 4)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
     bool cull = true;              // 8192 points: detect tiles that cannot hold a candidate are not evaluated (detect_fused.h)
@@ -172,8 +174,10 @@ struct ss_ctx {
       deep = tri("SS_DEEP") != 0;
       cull = tri("SS_CULL") != 0;
       ablate_roles = num("SS_ABLATE_ROLES", 0);
-      cull_65536 = tri("SS_CULL_65536") == 1;
+      cull_65536 = tri("SS_CULL_65536") != 0;
+      rows256_step = tri("SS_ROWS256_STEP") != 0;
       plan_fused = tri("SS_PLAN_FUSED") != 0;
+      list_first = num("SS_LIST_FIRST", list_first);
       win_calc = tri("SS_WIN_CALC") != 0;
       canary = tri("SS_CANARY") == 1;
       queues = num("SS_QUEUES", queues);
@@ -256,6 +260,7 @@ struct ss_ctx {
   // 2^20 points in two passes: the plan of the last call (which of its tiles the detect stage must evaluate, k_plan_long) is not a
   // launch of its own but rides at the front of the NEXT call's column launch (k_fft_cols1024_plan, detect_fused.h); until then
   // — or until flush_stages launches it on its own — its arguments wait here. pend_det.tile_list points at the list it fills.
+  bool rows256_step = false;  // 65536 points with tile culling: columns as their own launch, rows as k_scan_step's FFT role (see Diag::rows256_step)
   bool have_plan = false;
   ss::PlanLongDet pend_plan_det{};
   ss::PlanLongArgs pend_plan{};
@@ -641,6 +646,17 @@ ss::Rows1024Args rows1024_args(ss_ctx* c, float* d_psd, const ss::RowsExtra& rx)
   g.x = rx;
   return g;
 }
+ss::Rows256Args rows256_args(ss_ctx* c, float* d_psd, const ss::RowsExtra& rx) {
+  ss::Rows256Args g{};
+  g.work = c->d_work;
+  g.tw256 = c->d_tw256;
+  g.db_off = c->db_off;
+  g.psd = d_psd;
+  g.logn = c->logn;
+  g.lognsub = c->logn - 16;
+  g.x = rx;
+  return g;
+}
 void launch_rows1024(ss_ctx* c, int nframes, float* d_psd, const ss::RowsExtra& rx) {
   const ss::Rows1024Args g = rows1024_args(c, d_psd, rx);
   SS_LAUNCH_SLOT(c, SS_KSLOT_ROWS, ss::k_fft_rows1024_psd, dim3(nframes * 128), dim3(512), ss::kFft1024RowsLdsBytes, g);
@@ -793,6 +809,7 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
   // (KIND 5: a launch without an FFT role — the drain — whose detect workgroups share the plan's list out in a loop)
   if (c->two_pass && a.list_loop) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 5>);
   if (c->two_pass) return c->diag.cols1024_wide ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 4>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 3>);
+  if (!c->use_fft8192 && a.n_fft && a.rows256.work) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 6>);  // (65536 points: the row tiles as the FFT role; rows of 2048 mask words: the wide emit role)
   if (!c->use_fft8192) return a.emit_per_wg == 1 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 2>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 1>);
 #ifdef SS_DIAG
   if (c->diag.fft_tw == 0) return go(ss::k_scan_step<FMT, SPEC, 0, false>);
@@ -808,6 +825,7 @@ struct FftRole {
   const ss::Fft8192Args* frames = nullptr;
   const ss::ColsArgs* cols = nullptr;
   const ss::Rows1024Args* rows1024 = nullptr;  // 2^20 points in two passes: the ROW tiles (the column half is a launch of its own)
+  const ss::Rows256Args* rows256 = nullptr;    // 65536 points with tile culling: the ROW tiles (the column half is a launch of its own)
   int n = 0;  // frames / column tiles
   const void* halo_iq = nullptr;  // deep pipelining: n_halo frames of the previous call go through the FFT again, into halo_psd
   float* halo_psd = nullptr;
@@ -815,7 +833,8 @@ struct FftRole {
 };
 
 // fft / det / emit: null = role absent. Start/stop events ride on launches that carry an FFT role (the dominant work).
-void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n_det_tiles, bool spec, const ss::EmitArgs* emit, hipStream_t stream = nullptr) {
+void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n_det_tiles, bool spec, const ss::EmitArgs* emit, hipStream_t stream = nullptr,
+                 bool with_long_plan = false) {
   if (!stream) stream = c->stream;
 #ifdef SS_DIAG
   if (c->diag.ablate_roles & 1) det = nullptr;
@@ -836,6 +855,9 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   } else if (fft && fft->rows1024) {
     a.rows = *fft->rows1024;
     a.n_fft = fft->n;
+  } else if (fft && fft->rows256) {
+    a.rows256 = *fft->rows256;
+    a.n_fft = fft->n;
   }
   // Tile culling (detect_fused.h): a detect stage whose only products are mask bits and counts is PLANNED — a few plan
   // workgroups list the tiles that may hold a candidate — and the list is evaluated by the launch's FFT workgroups after their
@@ -849,9 +871,10 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
       a.n_plan = n_det_tiles;
       a.plan_cols = plan_cols;
       a.plan_by_fft = a.n_fft >= ss::step_plan_consumers(a) ? 1 : 0;  // (consumer p serves list p mod S)
-    } else if (det->tile_list && fft && (fft->cols || fft->rows1024)) {
-      a.list_by_fft = 1;  // long transforms, planned stage: column workgroup p takes pair p of the list after its own tile (scan_step.h)
-      a.n_det = 2 * std::max(0, (n_det_tiles + 1) / 2 - fft->n);  // detect workgroups for the pairs beyond
+    } else if (det->tile_list && fft && (fft->cols || fft->rows1024 || fft->rows256)) {
+      a.list_by_fft = 1;  // long transforms, planned stage: FFT workgroup p takes pair list_first + p of the list after its own tile (scan_step.h)
+      a.list_first = c->diag.list_first;  // (the first pairs on detect workgroups of their own, ahead of the FFT role: no tail)
+      a.n_det = 2 * (a.list_first + std::max(0, (n_det_tiles + 1) / 2 - a.list_first - fft->n));  // detect workgroups for the first pairs and for the pairs beyond
     } else if (det->tile_list && c->two_pass && !fft) {
       a.list_loop = 1;  // 2^20 points in two passes: 128 detect workgroups share the list out in a loop (scan_step.h)
       a.n_det = 2 * std::min(128, (n_det_tiles + 1) / 2);
@@ -862,6 +885,12 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   if (emit) {
     a.emit = *emit;
     a.n_emit = emit->nframes;
+  }
+  if (with_long_plan && c->have_plan) {  // 65536 points: the plan of the call before as a role of this (column) launch
+    a.plan_det = c->pend_plan_det;
+    a.plan_long = c->pend_plan;
+    a.n_plan_long = (ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n) + 1) / 2;
+    c->have_plan = false;
   }
   if (ss::step_items(a) == 0) return;
   a.wait_limit = c->wait_limit;
@@ -880,7 +909,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   }
 #endif
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (fft && fft->rows1024) {  // (2^20 points: the row half + passengers; the call's column launch has decided whether it is a sampled one)
+  if (fft && (fft->rows1024 || fft->rows256)) {  // (the row half + passengers; the call's column launch has decided whether it is a sampled one)
     if (!prof_slot(c, SS_KSLOT_ROWS, &e0, &e1)) e0 = e1 = nullptr;
   } else if (fft && !prof_pair(c, &e0, &e1)) {
     e0 = e1 = nullptr;
@@ -1698,8 +1727,20 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     const bool reused = c->have_det && (clash(d_psd, plane_bytes, c->pend_det.psd, pend_bytes) || clash(d_avg_out, plane_bytes, c->pend_det_emit.avg, pend_bytes) ||
                                          clash(d_psd, plane_bytes, c->pend_det.rel_out, pend_bytes) || clash(d_rel_out, plane_bytes, c->pend_det.psd, pend_bytes));
     if (!overlap || reused) flush_stages(c);
-    const bool rows_by_step = c->two_pass && c->diag.cols1024_wide;
-    if (rows_by_step) {
+    const bool rows_by_step = (c->two_pass && c->diag.cols1024_wide) || c->rows256_step;
+    if (c->rows256_step) {
+      // 65536 points with tile culling: both halves of the FFT as FFT roles of k_scan_step, the deferred stages shared out between
+      // them — the column launch of call k carries the plan of call k - 1 (which of its tiles the detect stage must evaluate) and
+      // emit(k - 2), the row launch right behind it detect(k - 1) on the tiles that plan listed. (All of them on the row launch:
+      // 29.5 us for a launch that takes 17 alone; on the column launch the plan would have to be a launch of its own between the
+      // two, 6.5 us: profiles/r04/s17_summary.txt.)
+      launch_step(c, &role, nullptr, 0, false, c->have_emit ? &c->pend_emit : nullptr, nullptr, true);
+      const ss::Rows256Args gr = rows256_args(c, ring_only ? nullptr : d_psd, rx);
+      FftRole rrole;
+      rrole.rows256 = &gr;
+      rrole.n = nframes * 8;
+      launch_step(c, &rrole, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, nullptr);
+    } else if (rows_by_step) {
       // 2^20 points: the column half of call k as a launch of its own (16 columns x 1024 rows per 1024-thread workgroup: too many
       // threads for a role), then ONE launch of k_scan_step whose FFT role is the ROW half of call k — 8 rows x 1024 points per
       // 512-thread workgroup — with detect(k - 1) and emit(k - 2) riding on it as they ride on the column launches of the other sizes
@@ -1756,12 +1797,12 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         pl.logn = c->logn;
         pl.list = list;
         pl.layout = c->two_pass ? 1 : 0;
-        const int plan_wgs = ss::plan_long_blocks(pl.layout, plan_cols, c->n);  // (groups past the band's end find no column)
         if (plan_fused) {
           c->have_plan = true;
           c->pend_plan = pl;
           c->pend_plan_det = ss::plan_long_det(c->pend_det);
         } else {
+          const int plan_wgs = ss::plan_long_blocks(pl.layout, plan_cols, c->n);  // (groups past the band's end find no column)
           SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, ss::plan_long_det(c->pend_det), pl);
         }
         c->pend_det.tile_list = list;
@@ -2283,6 +2324,9 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   // There only the diagnostics build switches it on (SS_CULL_65536=1; tests/test_gpu_cull.py keeps it honest).
   c->cull_long = c->step_path && c->use_fft256 && ((n == 65536 && c->diag.cull_65536) || (n > 65536 && c->d_tw_sub && !c->d_tw_rowsR) || c->two_pass) &&
                  !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
+  // 65536 points: with the plan of call k at the front of call k + 1's column launch — which therefore is a launch of its own, the
+  // row tiles taking the FFT role of k_scan_step in its place (KIND 6) — the culling pays there too (session 17 of round 4).
+  c->rows256_step = c->cull_long && !c->two_pass && c->logn == 16 && c->diag.rows256_step && c->diag.emit_wide && c->diag.step_long;
   if (c->cull_long) {
     CREATE_HIP(hipMalloc(&c->d_zero_row, sizeof(float) * (size_t)n));  // (what a ring-only call's detect stage subtracts from rows that are noise-relative already)
     CREATE_HIP(hipMemset(c->d_zero_row, 0, sizeof(float) * (size_t)n));
