@@ -127,6 +127,7 @@ struct ss_ctx {
     bool cull_65536 = true;        // tile culling at 65536 points (SS_CULL_65536=0: every averaging tile evaluated, as the product did until session 17 of round 4; see ss_create)
     bool rows256_step = true;      // 65536 points with tile culling: the column half as a launch of its own (the plan of the call before at its front), the ROW tiles as k_scan_step's FFT role (KIND 6) with the deferred stages riding on them (SS_ROWS256_STEP=0: columns as the FFT role, rows and plan as launches of their own)
     bool win_calc = true;          // 2^20 points in two passes and 65536 points, default window: the column tiles form their Hamming taps instead of loading them (SS_WIN_CALC=0: the table as ever)
+    bool det_lag2 = true;          // 65536 points with tile culling: detect(k - 2) on the column launch of call k (SS_DET_LAG2=0: detect(k - 1) on the row launch, session 19's form)
     int list_first = 64;           // long transforms with tile culling: the first pairs of the plan's list go to detect workgroups of their own, dispatched ahead of the launch's FFT role (SS_LIST_FIRST=0: every pair behind an FFT workgroup's tile, as until session 19 of round 4)
     bool plan_fused = true;        // 2^20 points in two passes: the plan of call k at the front of call k + 1's column launch (SS_PLAN_FUSED=0: a launch of its own behind call k's rows, as until session 14 of round 4)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
@@ -178,6 +179,7 @@ struct ss_ctx {
       rows256_step = tri("SS_ROWS256_STEP") != 0;
       plan_fused = tri("SS_PLAN_FUSED") != 0;
       list_first = num("SS_LIST_FIRST", list_first);
+      det_lag2 = tri("SS_DET_LAG2") != 0;
       win_calc = tri("SS_WIN_CALC") != 0;
       canary = tri("SS_CANARY") == 1;
       queues = num("SS_QUEUES", queues);
@@ -269,6 +271,18 @@ struct ss_ctx {
   bool pend_det_spec = false;
   ss::EmitArgs pend_det_emit{};  // the emit stage that follows pend_det
   ss::EmitArgs pend_emit{};
+  // 65536 points with tile culling (det_lag2): a call's detect stage rides on the COLUMN launch two calls later — the longer of a
+  // call's two launches, where the quarter of a hundred workgroups that evaluate listed tiles (20 us apiece under the launch's
+  // streaming loads) end with the column tiles instead of being the row launch's tail — because the plan it needs rides on the
+  // column launch of the call in between. So two detect stages wait: pend_det (planned: rides on the next column launch) and
+  // pend_det2 (its plan is have_plan / pend_plan).
+  bool det_lag2 = false;
+  bool have_det2 = false;
+  ss::DetectArgs pend_det2{};
+  int pend_det2_tiles = 0;
+  bool pend_det2_spec = false;
+  ss::EmitArgs pend_det2_emit{};
+  int hist_start_prev = 0;  // hist_start before the last call moved it (place_ring: what the waiting detect stage of the call before still reads)
   int buf_cur = 0;               // which of the rotating buffers the NEXT batch writes
   int psd_cur = 0;
   // Deep pipelining (8192 points; diag.deep). With the stages of three consecutive calls in one
@@ -382,7 +396,7 @@ struct ss_ctx {
   bool cull_long = false;
   float* d_smax = nullptr;
   int smax_rows = 0;
-  int* d_tlist[2] = {};
+  int* d_tlist[2 * kMaxQueues] = {};
   long long clean_abs = 0;
   const float* last_avg = nullptr;  // the avg plane (sparse or kept) of the last batch
   const float* last_hist = nullptr;       // ring rows as they were before the last batch
@@ -1065,23 +1079,36 @@ void launch_pending_plan(ss_ctx* c) {
   c->have_plan = false;
 }
 
+// A launch has carried the planned detect stage and the emit stage that waited: the detect stage's emit waits now, and the detect
+// stage whose plan has run (det_lag2 contexts; none elsewhere) is the planned one.
+void shift_pending(ss_ctx* c) {
+  c->have_emit = c->have_det;
+  c->pend_emit = c->pend_det_emit;
+  c->have_det = c->have_det2;
+  if (c->have_det2) {
+    c->pend_det = c->pend_det2;
+    c->pend_det_tiles = c->pend_det2_tiles;
+    c->pend_det_spec = c->pend_det2_spec;
+    c->pend_det_emit = c->pend_det2_emit;
+    c->have_det2 = false;
+  }
+}
+
 // Drain the deferred stages: detect (+ the emit stage before it), then the last emit. Nothing is synchronised.
 void flush_stages(ss_ctx* c) {
   if (c->deep) {
     if (c->deep_L > 0 || !c->pd.empty() || !c->pe.empty()) ++c->stats.drains;
     return drain_deep(c);
   }
-  if (c->have_det || c->have_emit) ++c->stats.drains;
+  if (c->have_det || c->have_det2 || c->have_emit) ++c->stats.drains;
   launch_pending_plan(c);  // (the detect stage that waits reads its list)
-  while (c->have_det || c->have_emit) {
+  while (c->have_det || c->have_det2 || c->have_emit) {
     launch_step(c, nullptr, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     if (c->have_det && c->ref_nan) {  // (such contexts never defer a stage across calls: no emit stage rode on that launch)
       launch_nan_stage(c, c->nan_pending);
       c->nan_pending = NanStage{};
     }
-    c->have_emit = c->have_det;
-    c->pend_emit = c->pend_det_emit;
-    c->have_det = false;
+    shift_pending(c);
   }
 }
 
@@ -1245,7 +1272,9 @@ RingPlace place_ring(ss_ctx* c, int nframes) {
     // its own detect stage and the next call's ring at once, instead of a dB plane and ring rows (run_batch)
     int b = c->hist_start + H;
     if (b + nframes > c->hist_rows) {
-      if (nframes <= c->hist_start) {
+      // (det_lag2: the detect stage of the call before still waits when this call's rows are written — its window and its batch's
+      // rows start at hist_start_prev)
+      if (nframes <= (c->det_lag2 ? std::min(c->hist_start, c->hist_start_prev) : c->hist_start)) {
         b = 0;
       } else {  // (stream order: a deferred detect stage that still reads or writes this window goes first)
         flush_stages(c);
@@ -1359,6 +1388,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   c->buf_cur = (b + 1) % c->nbuf;
   c->last_avg = ea.avg;
   c->last_hist = hist_in;
+  c->hist_start_prev = c->hist_start;
   c->hist_start = next_start;
   c->last_n_learn = n_learn;
   c->last_thr = z->d_thr;
@@ -1723,9 +1753,12 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       const char *pa = static_cast<const char*>(a), *pb = static_cast<const char*>(b);
       return a && b && pa < pb + bbytes && pb < pa + abytes;
     };
-    const size_t pend_bytes = sizeof(float) * (size_t)c->pend_det.nframes * (size_t)c->n;
-    const bool reused = c->have_det && (clash(d_psd, plane_bytes, c->pend_det.psd, pend_bytes) || clash(d_avg_out, plane_bytes, c->pend_det_emit.avg, pend_bytes) ||
-                                         clash(d_psd, plane_bytes, c->pend_det.rel_out, pend_bytes) || clash(d_rel_out, plane_bytes, c->pend_det.psd, pend_bytes));
+    const auto clashes = [&](const ss::DetectArgs& pd, const ss::EmitArgs& pe) {
+      const size_t pend_bytes = sizeof(float) * (size_t)pd.nframes * (size_t)c->n;
+      return clash(d_psd, plane_bytes, pd.psd, pend_bytes) || clash(d_avg_out, plane_bytes, pe.avg, pend_bytes) || clash(d_psd, plane_bytes, pd.rel_out, pend_bytes) ||
+             clash(d_rel_out, plane_bytes, pd.psd, pend_bytes);
+    };
+    const bool reused = (c->have_det && clashes(c->pend_det, c->pend_det_emit)) || (c->have_det2 && clashes(c->pend_det2, c->pend_det2_emit));
     if (!overlap || reused) flush_stages(c);
     const bool rows_by_step = (c->two_pass && c->diag.cols1024_wide) || c->rows256_step;
     if (c->rows256_step) {
@@ -1734,12 +1767,16 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       // emit(k - 2), the row launch right behind it detect(k - 1) on the tiles that plan listed. (All of them on the row launch:
       // 29.5 us for a launch that takes 17 alone; on the column launch the plan would have to be a launch of its own between the
       // two, 6.5 us: profiles/r04/s17_summary.txt.)
-      launch_step(c, &role, nullptr, 0, false, c->have_emit ? &c->pend_emit : nullptr, nullptr, true);
+      // det_lag2 (what ships): the planned detect stage — detect(k - 2), whose plan rode on the column launch of call k - 1 — rides on
+      // the COLUMN launch as well, and the row launch carries nothing: a workgroup that evaluates a pair of tiles lives ~20 us under
+      // the streaming loads of its neighbours, longer than the row launch (17 us) and shorter than the column launch (24).
+      const bool det_on_cols = c->det_lag2;
+      launch_step(c, &role, (det_on_cols && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr, nullptr, true);
       const ss::Rows256Args gr = rows256_args(c, ring_only ? nullptr : d_psd, rx);
       FftRole rrole;
       rrole.rows256 = &gr;
       rrole.n = nframes * 8;
-      launch_step(c, &rrole, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, nullptr);
+      launch_step(c, &rrole, (!det_on_cols && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, nullptr);
     } else if (rows_by_step) {
       // 2^20 points: the column half of call k as a launch of its own (16 columns x 1024 rows per 1024-thread workgroup: too many
       // threads for a role), then ONE launch of k_scan_step whose FFT role is the ROW half of call k — 8 rows x 1024 points per
@@ -1752,9 +1789,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       launch_step(c, &rrole, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     } else
     launch_step(c, &role, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
-    c->have_emit = c->have_det;
-    c->pend_emit = c->pend_det_emit;
-    c->have_det = false;
+    shift_pending(c);
     if (!c->use_fft8192 && !rows_by_step) {
       st = launch_fft_rows(c, nframes, ring_only ? nullptr : d_psd, rx);
       if (st != SS_OK) return st;
@@ -1768,25 +1803,32 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
       if (c->cull || c->cull_long) hipLaunchKernelGGL(ss::k_thr_tilemin, dim3(c->n / 256), dim3(64), 0, c->stream, (const float*)z->d_thr, c->n, z->d_thr + c->n);
     }
+    // (det_lag2: this call's detect stage waits for its plan, behind the planned one — which, if there is one, rode on this call's column launch)
+    ss::DetectArgs& nd = c->det_lag2 ? c->pend_det2 : c->pend_det;
     st = run_backend_fused(c, d_psd, nframes, n_learn, z, c->spec_in_detect ? spec : nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg,
-                           cand_cap, true, &c->pend_det, &c->pend_det_tiles, &c->pend_det_emit);
+                           cand_cap, true, &nd, c->det_lag2 ? &c->pend_det2_tiles : &c->pend_det_tiles, c->det_lag2 ? &c->pend_det2_emit : &c->pend_det_emit);
     if (st != SS_OK) return st;
-    c->have_det = true;
-    c->pend_det_spec = c->spec_in_detect && spec != nullptr;
+    if (c->det_lag2) {
+      c->have_det2 = true;
+      c->pend_det2_spec = c->spec_in_detect && spec != nullptr;
+    } else {
+      c->have_det = true;
+      c->pend_det_spec = c->spec_in_detect && spec != nullptr;
+    }
     if (c->cull_long) {
-      c->pend_det.hist_by_fft = ring_by_rows ? 1 : 0;
-      c->pend_det.tile_list = nullptr;
+      nd.hist_by_fft = ring_by_rows ? 1 : 0;
+      nd.tile_list = nullptr;
       if (ring_only) {
-        c->pend_det.psd = ring_rows;
-        c->pend_det.thr = c->d_zero_row;
+        nd.psd = ring_rows;
+        nd.thr = c->d_zero_row;
         ring_only_rows = ring_rows;
       }
       // the plan: which tiles of this call can hold a candidate at all (k_plan_long) — behind the rows kernel, ahead of the
       // launch that carries the detect stage. Only a stage whose sole products are mask bits and counts is planned.
       // (the plan of call k rides at the front of call k + 1's column launch: four plan blocks share a column tile's LDS)
       const bool plan_fused = rows_by_step && c->diag.plan_fused && overlap;
-      const int plan_cols = ss::plan_long_cols(nframes, c->pend_det.shift, c->n / 256, 8, plan_fused ? ss::kPlanFusedFloats : ss::kPlanLongFloats);  // (32 columns per workgroup — whole lines of the two-pass layout — halved the fetches and doubled the time: 128 workgroups are too few, profiles/r04/s6_summary.txt)
-      if (ring_by_rows && !spec && !c->pend_det.rel_out && !c->pend_det.avg_out && plan_cols > 0) {
+      const int plan_cols = ss::plan_long_cols(nframes, nd.shift, c->n / 256, 8, plan_fused ? ss::kPlanFusedFloats : ss::kPlanLongFloats);  // (32 columns per workgroup — whole lines of the two-pass layout — halved the fetches and doubled the time: 128 workgroups are too few, profiles/r04/s6_summary.txt)
+      if (ring_by_rows && !spec && !nd.rel_out && !nd.avg_out && plan_cols > 0) {
         int* list = c->d_tlist[(c->buf_cur + c->nbuf - 1) % c->nbuf];  // (run_backend_fused has moved buf_cur on: the set this call's mask bits go to)
         ss::PlanLongArgs pl{};
         pl.smax = c->d_smax;
@@ -1800,12 +1842,12 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         if (plan_fused) {
           c->have_plan = true;
           c->pend_plan = pl;
-          c->pend_plan_det = ss::plan_long_det(c->pend_det);
+          c->pend_plan_det = ss::plan_long_det(nd);
         } else {
           const int plan_wgs = ss::plan_long_blocks(pl.layout, plan_cols, c->n);  // (groups past the band's end find no column)
-          SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, ss::plan_long_det(c->pend_det), pl);
+          SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, ss::plan_long_det(nd), pl);
         }
-        c->pend_det.tile_list = list;
+        nd.tile_list = list;
       }
     }
     if (!overlap) flush_stages(c);
@@ -2097,9 +2139,13 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     hipLaunchKernelGGL(ss::k_nan_state_reset, dim3(1), dim3(64), 0, c->stream, reinterpret_cast<ss::NanState*>(c->d_nan_state), n);
   }
   c->nq = c->deep ? std::min(std::max(c->diag.queues, 2), kMaxQueues) : 1;
-  c->lag = c->deep ? c->nq : 1;
-  c->ncnt = c->deep ? 3 * c->nq : 3;
-  c->nbuf = c->deep ? 2 * c->nq : (c->step_path ? 2 : 1);
+  // 65536 points with tile culling: a call's detect stage rides two calls later (ss_ctx::det_lag2) — decided here, where the rotating
+  // buffers are sized: two more sets than launches in order need
+  c->det_lag2 = !c->deep && c->step_path && n == 65536 && !c->diag.fft_generic && c->diag.cull_65536 && c->diag.cull && !(cfg->flags & SS_FLAG_NO_CULL) &&
+                c->diag.rows256_step && c->diag.emit_wide && c->diag.step_long && c->diag.det_lag2 && c->fused;
+  c->lag = c->deep ? c->nq : (c->det_lag2 ? 2 : 1);
+  c->ncnt = c->deep ? 3 * c->nq : (c->det_lag2 ? 6 : 3);
+  c->nbuf = c->deep ? 2 * c->nq : (c->det_lag2 ? 4 : (c->step_path ? 2 : 1));
   c->npsd = c->deep ? 2 * c->nq : (c->step_path ? 2 : 1);  // (deep: written by launch L, read by launch L + nq, written again by launch L + 2 nq on the same queue)
   if (c->fused) {
     {
@@ -2111,6 +2157,9 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       const long long min_rows = (long long)n >= 65536 ? 10 * kHistRows : 3 * kHistRows;
       if (rows < min_rows) rows = min_rows;
       if (rows > 64 * kHistRows) rows = 64 * kHistRows;
+      // (det_lag2: three batches and the averager's reach, so that a batch can go back to the front of the buffer while the two
+      // before it are still to be read — place_ring)
+      if (c->det_lag2 && rows < 3ll * cfg->max_batch + 3 * kHistRows) rows = 3ll * cfg->max_batch + 3 * kHistRows;
       c->hist_rows = (int)rows;
       CREATE_HIP(hipMalloc(&c->d_hist, sizeof(float) * (size_t)n * (size_t)rows));
       CREATE_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(float) * (size_t)n * (size_t)kHistRows, c->stream));  // Averager ctor, averager.cpp:7-12
@@ -2327,6 +2376,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   // 65536 points: with the plan of call k at the front of call k + 1's column launch — which therefore is a launch of its own, the
   // row tiles taking the FFT role of k_scan_step in its place (KIND 6) — the culling pays there too (session 17 of round 4).
   c->rows256_step = c->cull_long && !c->two_pass && c->logn == 16 && c->diag.rows256_step && c->diag.emit_wide && c->diag.step_long;
+  if (!c->rows256_step) c->det_lag2 = false;  // (never: the two are decided from the same switches; the rotating buffers sized for it do no harm)
   if (c->cull_long) {
     CREATE_HIP(hipMalloc(&c->d_zero_row, sizeof(float) * (size_t)n));  // (what a ring-only call's detect stage subtracts from rows that are noise-relative already)
     CREATE_HIP(hipMemset(c->d_zero_row, 0, sizeof(float) * (size_t)n));
@@ -2337,7 +2387,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     c->smax_rows = rows;
     CREATE_HIP(hipMalloc(&c->d_smax, sizeof(float) * (size_t)rows * (size_t)(n / 32)));
     const size_t max_tiles = ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256);
-    for (int k = 0; k < 2; ++k) CREATE_HIP(hipMalloc(&c->d_tlist[k], sizeof(int) * (max_tiles + 2)));  // (count, entries, one slot behind an odd count)
+    for (int k = 0; k < std::max(2, c->nbuf); ++k) CREATE_HIP(hipMalloc(&c->d_tlist[k], sizeof(int) * (max_tiles + 2)));  // (count, entries, one slot behind an odd count)
   }
   // 64 KiB of dynamic LDS needs no opt-in on gfx950 (160 KiB/CU), but say so explicitly for clarity
   CREATE_HIP(hipStreamSynchronize(c->stream));
