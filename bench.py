@@ -291,7 +291,7 @@ def traffic_from_profiles(config: int, kernel_match: str, threads_per_launch: in
             "source": f"profiles/{base}_pmc_fetch.csv, _pmc_write.csv (rocprofv3 --pmc passes of this configuration's command line, not this run)"}
 
 
-def live_pmc_traffic(sub_argv, kernel_match: str, threads_per_launch: int | None, timeout_s: float = 150.0):
+def live_pmc_traffic(sub_argv, kernel_match: str, threads_per_launch: int | None, timeout_s: float = 90.0):
     """roofline.traffic, live: counters cannot be read from inside a run, so rank 0 — once the timed region is over and the GPU idle —
     runs this command line once more in a short form under `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE`
     (separate passes, --kernel-trace only, from /tmp with TMPDIR=/tmp: MI355X_MICROARCH.md's recipe) on the same box, and averages
@@ -356,6 +356,14 @@ def chain_kernels(n: int, fmt: str):
                 ("rows", "k_scan_step", "k_scan_step with the ROW half as its FFT role (fft_rows1024_tile: 1024-point FFTs -> dB -> noise-relative rows straight into the averager "
                  "ring's buffer, no dB plane in detect mode, + run maxima for the tile culling), carrying the listed averaging tiles of call k-1 and the candidate lists of call k-2", 12.0),
                 ("plan", "k_plan_long", "k_plan_long as a launch of its own (SS_PLAN_FUSED=0 of the diagnostics build; the product runs the plan at the front of the next column launch)", 0.0)]
+    if n == 65536 and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0":
+        # 65536 points as the product runs them since round 4: both halves of the FFT are FFT roles of k_scan_step launches
+        return [("step", "k_scan_step", "k_scan_step (KIND 2): column half of the four-step FFT of call k (load, Hamming taps formed from one table entry per thread, 256-point FFTs, "
+                 "twiddle -> work buffer), carrying the plan of call k-1 (which averaging tiles can hold a candidate), the listed tiles of call k-2 (21x21 mean + threshold, "
+                 "the first 64 pairs on workgroups of their own) and the candidate lists of call k-3", in_b + 8.0),
+                ("rows", "k_scan_step", "k_scan_step (KIND 6): row half (256-point FFTs -> dB -> noise-relative rows straight into the averager ring's buffer, no dB plane in "
+                 "detect mode, + run maxima for the tile culling); carries nothing", 12.0),
+                ("plan", "k_plan_long", "k_plan_long as a launch of its own (drains only: in a run of calls the plan is a role of the column launch)", 0.0)]
     n2 = n // 256
     ks = [("step", "k_scan_step", "k_scan_step: column half of the four-step FFT of call k (load, window, 256-point FFTs, twiddle -> work buffer), carrying the "
            "21x21 mean + threshold of call k-1 (the tiles the plan listed) and the candidate lists of call k-2 as further roles", in_b + 8.0)]
@@ -633,6 +641,9 @@ def run(args):
                 shape = (nb + 20 + nb // 8 + 4) * 512
             elif two_pass:  # column half: 64 workgroups of 1024 threads per frame behind the 128 that run the plan of the call before; row half: 128 of 512 per frame + one emit workgroup per frame
                 shape = {"step": (nb * 64 + 128) * 1024, "rows": (nb * 128 + nb) * 512}.get(slot)
+            elif n == 65536 and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0":
+                # column launch: 8 column tiles per frame + 128 plan + one emit workgroup per frame + 64 detect workgroups; row launch: 8 row tiles per frame
+                shape = {"step": (nb * 8 + 128 + nb + 64) * 512, "rows": nb * 8 * 512}.get(slot)
             else:
                 shape = (nb * (n // 8192) + (nb if n >= 65536 else -(-nb // 8))) * 512 if slot == "step" and n >= 16384 else None
             tp = traffic_from_profiles(args.config or 2, match, shape) if is_preset(args) else None

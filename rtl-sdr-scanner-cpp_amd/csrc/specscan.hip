@@ -127,6 +127,7 @@ struct ss_ctx {
     bool cull_65536 = true;        // tile culling at 65536 points (SS_CULL_65536=0: every averaging tile evaluated, as the product did until session 17 of round 4; see ss_create)
     bool rows256_step = true;      // 65536 points with tile culling: the column half as a launch of its own (the plan of the call before at its front), the ROW tiles as k_scan_step's FFT role (KIND 6) with the deferred stages riding on them (SS_ROWS256_STEP=0: columns as the FFT role, rows and plan as launches of their own)
     bool win_calc = true;          // 2^20 points in two passes and 65536 points, default window: the column tiles form their Hamming taps instead of loading them (SS_WIN_CALC=0: the table as ever)
+    bool emit_on_rows = false;     // SS_DIAG (SS_EMIT_ON_ROWS=1): 65536 points, the emit stage on the row launch instead of the column launch (A/B)
     bool det_lag2 = true;          // 65536 points with tile culling: detect(k - 2) on the column launch of call k (SS_DET_LAG2=0: detect(k - 1) on the row launch, session 19's form)
     int list_first = 64;           // long transforms with tile culling: the first pairs of the plan's list go to detect workgroups of their own, dispatched ahead of the launch's FFT role (SS_LIST_FIRST=0: every pair behind an FFT workgroup's tile, as until session 19 of round 4)
     bool plan_fused = true;        // 2^20 points in two passes: the plan of call k at the front of call k + 1's column launch (SS_PLAN_FUSED=0: a launch of its own behind call k's rows, as until session 14 of round 4)
@@ -180,6 +181,7 @@ struct ss_ctx {
       plan_fused = tri("SS_PLAN_FUSED") != 0;
       list_first = num("SS_LIST_FIRST", list_first);
       det_lag2 = tri("SS_DET_LAG2") != 0;
+      emit_on_rows = tri("SS_EMIT_ON_ROWS") == 1;
       win_calc = tri("SS_WIN_CALC") != 0;
       canary = tri("SS_CANARY") == 1;
       queues = num("SS_QUEUES", queues);
@@ -1771,12 +1773,17 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       // the COLUMN launch as well, and the row launch carries nothing: a workgroup that evaluates a pair of tiles lives ~20 us under
       // the streaming loads of its neighbours, longer than the row launch (17 us) and shorter than the column launch (24).
       const bool det_on_cols = c->det_lag2;
-      launch_step(c, &role, (det_on_cols && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr, nullptr, true);
+#ifdef SS_DIAG
+      const bool emit_on_rows = c->diag.emit_on_rows;
+#else
+      const bool emit_on_rows = false;
+#endif
+      launch_step(c, &role, (det_on_cols && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, (!emit_on_rows && c->have_emit) ? &c->pend_emit : nullptr, nullptr, true);
       const ss::Rows256Args gr = rows256_args(c, ring_only ? nullptr : d_psd, rx);
       FftRole rrole;
       rrole.rows256 = &gr;
       rrole.n = nframes * 8;
-      launch_step(c, &rrole, (!det_on_cols && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, nullptr);
+      launch_step(c, &rrole, (!det_on_cols && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, (emit_on_rows && c->have_emit) ? &c->pend_emit : nullptr);
     } else if (rows_by_step) {
       // 2^20 points: the column half of call k as a launch of its own (16 columns x 1024 rows per 1024-thread workgroup: too many
       // threads for a role), then ONE launch of k_scan_step whose FFT role is the ROW half of call k — 8 rows x 1024 points per
@@ -2142,7 +2149,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   // 65536 points with tile culling: a call's detect stage rides two calls later (ss_ctx::det_lag2) — decided here, where the rotating
   // buffers are sized: two more sets than launches in order need
   c->det_lag2 = !c->deep && c->step_path && n == 65536 && !c->diag.fft_generic && c->diag.cull_65536 && c->diag.cull && !(cfg->flags & SS_FLAG_NO_CULL) &&
-                c->diag.rows256_step && c->diag.emit_wide && c->diag.step_long && c->diag.det_lag2 && c->fused;
+                c->diag.rows256_step && c->diag.step_long && c->diag.det_lag2 && c->fused;
   c->lag = c->deep ? c->nq : (c->det_lag2 ? 2 : 1);
   c->ncnt = c->deep ? 3 * c->nq : (c->det_lag2 ? 6 : 3);
   c->nbuf = c->deep ? 2 * c->nq : (c->det_lag2 ? 4 : (c->step_path ? 2 : 1));
@@ -2375,7 +2382,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
                  !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
   // 65536 points: with the plan of call k at the front of call k + 1's column launch — which therefore is a launch of its own, the
   // row tiles taking the FFT role of k_scan_step in its place (KIND 6) — the culling pays there too (session 17 of round 4).
-  c->rows256_step = c->cull_long && !c->two_pass && c->logn == 16 && c->diag.rows256_step && c->diag.emit_wide && c->diag.step_long;
+  c->rows256_step = c->cull_long && !c->two_pass && c->logn == 16 && c->diag.rows256_step && c->diag.step_long;  // (no emit stage ever rides on the row launch — KIND 6, whose emit role is the wide one — but under SS_EMIT_ON_ROWS)
   if (!c->rows256_step) c->det_lag2 = false;  // (never: the two are decided from the same switches; the rotating buffers sized for it do no harm)
   if (c->cull_long) {
     CREATE_HIP(hipMalloc(&c->d_zero_row, sizeof(float) * (size_t)n));  // (what a ring-only call's detect stage subtracts from rows that are noise-relative already)

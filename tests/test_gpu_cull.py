@@ -224,10 +224,13 @@ def test_long_rows_one_million_points_short_calls():
     assert sum(len(x) for x in res["cull"][0]) > 1_000
 
 
-def test_long_rows_device_calls_without_sync_culled_equal_unculled(cull_65536):
+@pytest.mark.parametrize("nb,ncalls", [(64, 6), (128, 11), (48, 14)])
+def test_long_rows_device_calls_without_sync_culled_equal_unculled(cull_65536, nb, ncalls):
+    """(128 x 11, 48 x 14: the averager ring of a 65536-point context holds three batches and the averager's reach, so these calls
+    send it back to the front of its buffer several times while two detect stages still wait — specscan.hip: place_ring, det_lag2.)"""
     import torch
-    n, fs, nb, ncalls = 65536, 20_000_000, 64, 6
-    band = pkg.synth.SyntheticBand(n, seed=49, on_frame=70, off_frame=300)
+    n, fs = 65536, 20_000_000
+    band = pkg.synth.SyntheticBand(n, seed=49, on_frame=70, off_frame=nb * ncalls - 90)
     iq8 = band.frames_cs8(nb * ncalls)
     dev = torch.device("cuda", 0)
     res = {}
