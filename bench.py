@@ -265,7 +265,7 @@ def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False):
 # ---------------------------------------------------------------------------------------------- launcher
 PMC_FILES = {"fetch": "pmc_fetch.csv", "write": "pmc_write.csv"}  # under profiles/<PMC_SET>/, one counter per rocprofv3 pass
 # the committed passes of each configuration's command line on the final tree of round 4 (scripts/r04/s8.sh)
-PMC_SET = {2: "r04/s8_cfg2", 3: "r04/s8_cfg3", 5: "r04/s8_cfg5"}
+PMC_SET = {2: "r04/s8_cfg2", 3: "r04/s22_cfg3", 5: "r04/s22_cfg5"}  # (config 2's kernel has not changed its traffic since; its default line measures it live: live_pmc_traffic)
 
 
 def traffic_from_profiles(config: int, kernel_match: str, threads_per_launch: int | None = None):
@@ -640,7 +640,7 @@ def run(args):
             if n == 8192:
                 shape = (nb + 20 + nb // 8 + 4) * 512
             elif two_pass:  # column half: 64 workgroups of 1024 threads per frame behind the 128 that run the plan of the call before; row half: 128 of 512 per frame + one emit workgroup per frame
-                shape = {"step": (nb * 64 + 128) * 1024, "rows": (nb * 128 + nb) * 512}.get(slot)
+                shape = {"step": (nb * 64 + 128) * 1024, "rows": (nb * 128 + nb + 64) * 512}.get(slot)  # (+ 64 detect workgroups for the first listed pairs)
             elif n == 65536 and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0":
                 # column launch: 8 column tiles per frame + 128 plan + one emit workgroup per frame + 64 detect workgroups; row launch: 8 row tiles per frame
                 shape = {"step": (nb * 8 + 128 + nb + 64) * 512, "rows": nb * 8 * 512}.get(slot)
