@@ -68,7 +68,7 @@ typedef enum ss_plane {
 /* Also run the Spectrogram side branch (sources/radio/blocks/spectrogram.cpp): accumulate the bin-decimated raw
  * PSD per centre frequency; read it back with ss_spectrogram_read. */
 #define SS_FLAG_SPECTROGRAM 2u
-/* 8192-point and 2^20-point frames: evaluate every averaging tile, also those whose per-frame maxima show that no window
+/* 8192-, 65536- and 2^20-point frames: evaluate every averaging tile, also those whose per-frame maxima show that no window
  * mean of the tile can reach start_level (csrc/detect_fused.h, tile culling). Results are identical either way; the flag
  * exists so that the data-independent cost of the chain can be measured (bench.py reports both). */
 #define SS_FLAG_NO_CULL 4u
@@ -203,7 +203,7 @@ typedef struct ss_stats {
   uint64_t drains;            /* times the deferred stages were drained (ss_sync, ss_flush, reads, retunes, resets, buffer clashes) */
   uint64_t demotions;         /* times a caller refilling an input buffer in flight took the context off the overlapped path */
   uint64_t tiles_total;       /* 16-frame x 256-bin averaging tiles of the batches processed (21 x 21 grouping) */
-  uint64_t tiles_tested;      /* ... that went through the culling test (tile culling: 8192 and 2^20 points, not with SS_FLAG_NO_CULL) */
+  uint64_t tiles_tested;      /* ... that went through the culling test (tile culling: 8192, 65536 and 2^20 points, not with SS_FLAG_NO_CULL) */
   uint64_t tiles_culled;      /* ... that the test proved empty and nobody evaluated (tiles evaluated = tiles_total - tiles_culled) */
   uint64_t wait_fallbacks;    /* workgroups that stopped waiting for a launch's tile plan and made it themselves (csrc/detect_fused.h) */
 } ss_stats;

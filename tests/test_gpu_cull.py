@@ -146,8 +146,9 @@ def test_short_calls_between_long_ones():
 # ---- long transforms (N = 256 x N2: csrc/detect_fused.h, k_plan_long): the rows kernel leaves the maximum of every 32-bin run
 # per frame and writes the averager ring itself; tiles whose 36 rows cannot reach start_level are not evaluated — rows from
 # BEFORE the batch included, so short calls cull too. Same bar: culled == unculled, list by list, key by key.
-# The product library culls at 2^20 points only (at 65536 points the plan launch costs more than it saves); the
-# 65536-point cases below run on the diagnostics build with SS_CULL_65536=1, so the path stays tested.
+# The product library culls at 65536 points too since session 20 of round 4 (the plan, detect and emit stages of a call ride on the
+# column launches of the next three calls); the 65536-point cases below run on the diagnostics build with the switch
+# set explicitly, so that they test the culling path whatever the default is.
 @pytest.fixture
 def cull_65536(monkeypatch, diag_lib):
     monkeypatch.setenv("SS_CULL_65536", "1")
