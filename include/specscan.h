@@ -226,8 +226,10 @@ int ss_kernel_timing_read(ss_ctx* ctx, double* total_ms, int32_t* launches);
  * dB, the tile-culling plan): a sampled call attaches events to every one of its launches. ms_by_slot and launches_by_slot
  * hold SS_KSLOT_COUNT entries each; ss_kernel_timing_read is entry SS_KSLOT_STEP of this. Either call clears the tally. */
 enum { SS_KSLOT_STEP = 0, SS_KSLOT_ROWS = 1, SS_KSLOT_SUB = 2, SS_KSLOT_PLAN = 3, SS_KSLOT_COUNT = 4 };
-/* (2^20-point frames take two passes since round 4: SS_KSLOT_STEP is the column half there — a launch of its own —, SS_KSLOT_ROWS the
- * row half + dB, SS_KSLOT_SUB the launch that carries the deferred detect / emit stages of earlier calls, SS_KSLOT_PLAN the plan.) */
+/* (2^20-point frames take two passes since round 4: SS_KSLOT_STEP is the column half there — a launch of its own, the plan of the call
+ * before in its first workgroups —, SS_KSLOT_ROWS the row half + dB with the deferred detect / emit stages of earlier calls riding on
+ * it. 65536-point frames: SS_KSLOT_STEP the column half with the plan, detect and emit stages of earlier calls, SS_KSLOT_ROWS the row
+ * half. SS_KSLOT_PLAN: the plan as a launch of its own — drains only.) */
 int ss_kernel_timing_read_slots(ss_ctx* ctx, double* ms_by_slot, int32_t* launches_by_slot);
 
 /* Device self-test of arithmetic shortcuts used by the kernels (which = 0: the 3-instruction division by

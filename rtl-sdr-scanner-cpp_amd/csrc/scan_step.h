@@ -73,6 +73,10 @@ struct StepArgs {
   int n_plan;
   int plan_cols;
   int plan_by_fft;
+  // plan_by_fft, and the first plan_first consumers are detect workgroups of their own, dispatched ahead of the FFT role (FFT
+  // workgroup i is consumer plan_first + i): they wait for the plan at the START of the launch and evaluate their pair while the
+  // frames stream — an FFT workgroup that finds a pair behind its frame lives twice as long as its neighbours.
+  int plan_first;
   // KIND 1, 2, tile culling (k_plan_long): the launch's column workgroups take the pairs of the detect stage's list once their
   // tile is done, pair p to column workgroup p; detect workgroups of their own only for the pairs beyond (n_det counts those).
   // (Evaluated BEFORE the column tile the same pairs cost the launch 5 us more: the workgroups that find one finish last. And
@@ -131,7 +135,7 @@ __host__ __device__ inline int step_plan_consumers(const StepArgs& a) { return s
 // (Tried for the launches without an FFT role — the drain at the end of a run of calls: 32 detect workgroups per list, each taking
 // every 32nd pair of it, instead of one per possible pair of which most leave at once. The tiles that must be evaluated sit in
 // the lists of a few tile columns, a hundred pairs and more each: the launch went from 24 to 40 us, profiles/r03/s38_timeline_k20.txt.)
-__host__ __device__ inline int step_det_wgs(const StepArgs& a) { return (a.n_det + 1) / 2 + (a.plan_by_fft ? 0 : step_plan_consumers(a)); }
+__host__ __device__ inline int step_det_wgs(const StepArgs& a) { return (a.n_det + 1) / 2 + (a.plan_by_fft ? a.plan_first : step_plan_consumers(a)); }
 inline int step_items(const StepArgs& a) { return step_fft_wgs(a) + step_det_wgs(a) + step_emit_wgs(a) + step_plan_wgs(a); }
 
 enum { ROLE_NONE = 0, ROLE_FFT = 1, ROLE_DET = 2, ROLE_EMIT = 3, ROLE_PLAN = 4 };
@@ -222,7 +226,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     g.iq = halo ? a.halo_iq : a.fft.iq;
     g.psd = halo ? a.halo_psd : a.fft.psd;
     g.segsum = halo ? nullptr : a.fft.segsum;  // (the tiles that read halo rows are not culled)
-    g.live_hint = a.plan_by_fft ? a.det.live + live_count_word(item, step_plan_wgs(a)) : nullptr;  // the list this workgroup serves for the detect stage that rides on the launch
+    g.live_hint = a.plan_by_fft ? a.det.live + live_count_word(a.plan_first + item, step_plan_wgs(a)) : nullptr;  // the list this workgroup serves for the detect stage that rides on the launch
 #ifdef SS_DIAG
     if (a.hint_mode == 1) g.live_hint = nullptr;
     g.hint_nowait = a.hint_mode == 2;
@@ -232,7 +236,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     if (a.hint_mode == 1 || a.hint_mode == 2) hdr = kLiveReady;  // "complete, empty"
 #endif
     if (a.plan_by_fft) {
-      consumer = item;
+      consumer = a.plan_first + item;
       word = hdr;
     }
   }

@@ -129,6 +129,7 @@ struct ss_ctx {
     bool win_calc = true;          // 2^20 points in two passes and 65536 points, default window: the column tiles form their Hamming taps instead of loading them (SS_WIN_CALC=0: the table as ever)
     bool emit_on_rows = false;     // SS_DIAG (SS_EMIT_ON_ROWS=1): 65536 points, the emit stage on the row launch instead of the column launch (A/B)
     bool det_lag2 = true;          // 65536 points with tile culling: detect(k - 2) on the column launch of call k (SS_DET_LAG2=0: detect(k - 1) on the row launch, session 19's form)
+    int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
     int list_first = 64;           // long transforms with tile culling: the first pairs of the plan's list go to detect workgroups of their own, dispatched ahead of the launch's FFT role (SS_LIST_FIRST=0: every pair behind an FFT workgroup's tile, as until session 19 of round 4)
     bool plan_fused = true;        // 2^20 points in two passes: the plan of call k at the front of call k + 1's column launch (SS_PLAN_FUSED=0: a launch of its own behind call k's rows, as until session 14 of round 4)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
@@ -180,6 +181,7 @@ struct ss_ctx {
       rows256_step = tri("SS_ROWS256_STEP") != 0;
       plan_fused = tri("SS_PLAN_FUSED") != 0;
       list_first = num("SS_LIST_FIRST", list_first);
+      plan_first = num("SS_PLAN_FIRST", plan_first);
       det_lag2 = tri("SS_DET_LAG2") != 0;
       emit_on_rows = tri("SS_EMIT_ON_ROWS") == 1;
       win_calc = tri("SS_WIN_CALC") != 0;
@@ -886,7 +888,9 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
     if (planned) {
       a.n_plan = n_det_tiles;
       a.plan_cols = plan_cols;
-      a.plan_by_fft = a.n_fft >= ss::step_plan_consumers(a) ? 1 : 0;  // (consumer p serves list p mod S)
+      a.plan_first = c->diag.plan_first * ss::step_plan_wgs(a);  // (the first pairs of every list on detect workgroups of their own: scan_step.h)
+      a.plan_by_fft = a.n_fft > 0 && a.n_fft + a.plan_first >= ss::step_plan_consumers(a) ? 1 : 0;  // (consumer p serves list p mod S)
+      if (!a.plan_by_fft) a.plan_first = 0;
     } else if (det->tile_list && fft && (fft->cols || fft->rows1024 || fft->rows256)) {
       a.list_by_fft = 1;  // long transforms, planned stage: FFT workgroup p takes pair list_first + p of the list after its own tile (scan_step.h)
       a.list_first = c->diag.list_first;  // (the first pairs on detect workgroups of their own, ahead of the FFT role: no tail)
