@@ -12,7 +12,7 @@ LIB = os.path.join(CSRC, "libspecscan.so")
 # Used by the A/B tests and the measurement scripts only; the product library never reads the environment.
 LIB_DIAG = os.path.join(CSRC, "libspecscan_diag.so")
 SOURCES = ["specscan.hip", "channelizer.hip"]
-HEADERS = ["fft_kernels.h", "fft8192_kernel.h", "fft8192_v2.h", "scan_step.h", "fft256_kernels.h", "detect_kernels.h", "detect_fused.h", "reference_nan.h", "fft1024_kernels.h",
+HEADERS = ["fft_kernels.h", "fft8192_kernel.h", "fft8192_v2.h", "scan_step.h", "fft256_kernels.h", "detect_kernels.h", "detect_fused.h", "reference_nan.h", "fft1024_kernels.h", "ring_place.h",
            os.path.join("..", "..", "include", "specscan.h"), os.path.join("..", "..", "include", "specscan_channelizer.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"]
 

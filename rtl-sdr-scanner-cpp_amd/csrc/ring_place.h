@@ -1,0 +1,71 @@
+// ring_place.h — where a batch reads the averager ring and where its newest rows go: the decision of specscan.hip's place_ring as a
+// function of a few integers (no HIP in here: tests/host/ring_check.cpp runs it on the CPU against the invariant it exists for).
+//
+// The ring (Averager::m_rows of the reference, sources/radio/averager.cpp:14-25: the newest G - 1 rows, here H = G - 1 + TF - 1 = 35
+// so that frame tiles align to the absolute frame index) is a window [start, start + H) sliding over a longer buffer of `rows` rows:
+//   * a batch shorter than H appends its rows behind the window (the window moves on by the batch's frames);
+//   * a batch of H frames and more writes a whole new window clear of the one being read (three windows rotate) — or, in a context
+//     whose rows kernel writes ALL the batch's rows into the buffer (long transforms with tile culling: `whole`), a region for the
+//     whole batch behind the window, whose last H rows are the next window; at the end of the buffer the region goes back to the front;
+//   * when the rows would land on something that is still to be read, the pending stages are drained and the window is copied to the
+//     front first (`shift_first`).
+// The invariant (ring_check.cpp): the rows a call's FFT stage writes never overlap what the detect stage of the call BEFORE still
+// has to read — its window and, in `whole` contexts, its batch's rows: that stage runs beside or after this call's FFT stage,
+// wherever it rides (scan_step.h) — nor this call's own window. With the buffer ss_create allocates (three of the largest batches
+// and three windows for long transforms) a stream of calls goes round the buffer without ever draining.
+#pragma once
+
+namespace ss {
+
+struct RingPrev {  // what the detect stage of the call before reads (none: n = 0)
+  int start;       // its window [start, start + H)
+  int batch;       // its batch's rows [batch, batch + n) in the buffer (-1: they are not in the buffer)
+  int n;
+};
+struct RingDecision {
+  bool shift_first;  // drain the pending stages and copy the window [start, start + H) to [0, H) before anything else
+  int in;            // first row of the window this call reads (after the shift, if any)
+  int next_start;    // first row of the window the NEXT call reads; this call's newest min(nframes, H) rows are its last ones
+  int batch;         // first row of the batch's own rows in the buffer: the region of a `whole` batch of >= H frames, the rows a
+                     // batch of < H frames appends behind its window; -1: a batch of >= H frames that writes only its newest H rows
+  int write_lo, write_hi;  // the rows this call's stages write
+};
+
+inline RingDecision ring_place_at(int start, int rows, int nframes, int H, bool whole) {
+  RingDecision d{};
+  d.in = start;
+  if (nframes < H) {  // old rows [nframes, H) stay where they are, new ones land behind them
+    d.next_start = start + nframes;
+    d.batch = start + H;
+    d.write_lo = start + H;
+    d.write_hi = start + H + nframes;
+  } else if (whole && H + nframes <= rows) {  // the whole batch behind the window, or at the front of the buffer
+    int b = start + H;
+    if (b + nframes > rows) b = 0;
+    d.next_start = b + nframes - H;
+    d.batch = b;
+    d.write_lo = b;
+    d.write_hi = b + nframes;
+  } else {  // a whole new window, clear of the one being read (the ring holds at least three)
+    d.next_start = start + 2 * H <= rows ? start + H : 0;
+    d.batch = -1;
+    d.write_lo = d.next_start;
+    d.write_hi = d.next_start + H;
+  }
+  return d;
+}
+
+inline RingDecision ring_place_decide(int start, const RingPrev& prev, int rows, int nframes, int H, bool whole) {
+  const auto hits = [](int lo, int hi, int a, int b) { return lo < b && a < hi && a < b; };
+  RingDecision d = ring_place_at(start, rows, nframes, H, whole);
+  const bool bad = d.write_lo < 0 || d.write_hi > rows || d.next_start + H > rows || hits(d.write_lo, d.write_hi, start, start + H) ||
+                   (prev.n > 0 && (hits(d.write_lo, d.write_hi, prev.start, prev.start + H) ||
+                                   (prev.batch >= 0 && hits(d.write_lo, d.write_hi, prev.batch, prev.batch + prev.n))));
+  if (bad) {  // drain, window to the front, place again (nothing before it to protect then)
+    d = ring_place_at(0, rows, nframes, H, whole);
+    d.shift_first = true;
+  }
+  return d;
+}
+
+}  // namespace ss

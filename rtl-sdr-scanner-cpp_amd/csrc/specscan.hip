@@ -28,6 +28,7 @@
 #include "fft256_kernels.h"
 #include "reference_nan.h"
 #include "fft_kernels.h"
+#include "ring_place.h"
 #include "scan_step.h"
 
 namespace {
@@ -286,7 +287,7 @@ struct ss_ctx {
   int pend_det2_tiles = 0;
   bool pend_det2_spec = false;
   ss::EmitArgs pend_det2_emit{};
-  int hist_start_prev = 0;  // hist_start before the last call moved it (place_ring: what the waiting detect stage of the call before still reads)
+  ss::RingPrev hist_prev{0, -1, 0};  // what the detect stage of the last call reads of the ring's buffer (ring_place.h)
   int buf_cur = 0;               // which of the rotating buffers the NEXT batch writes
   int psd_cur = 0;
   // Deep pipelining (8192 points; diag.deep). With the stages of three consecutive calls in one
@@ -1268,49 +1269,27 @@ struct RingPlace {
   float* out;
   int next_start;
   float* batch;  // 2^20 points in two passes, batches of at least H frames: where ALL the batch's rows go when the rows kernel writes them as rel rows (null otherwise)
+  int batch_row; // ring_place.h: RingDecision::batch
 };
 RingPlace place_ring(ss_ctx* c, int nframes) {
   const int n = c->n;
   constexpr int H = kHistRows;
-  if (c->cull_long && nframes >= H && H + nframes <= c->hist_rows) {
-    // long transforms with tile culling: room for the WHOLE batch's rows behind the window being read (or at the front of the buffer), the new window
-    // being the last H of them — so that a detect-mode call can write ONE plane, noise-relative rows that are the batch's rows for
-    // its own detect stage and the next call's ring at once, instead of a dB plane and ring rows (run_batch)
-    int b = c->hist_start + H;
-    if (b + nframes > c->hist_rows) {
-      // (det_lag2: the detect stage of the call before still waits when this call's rows are written — its window and its batch's
-      // rows start at hist_start_prev)
-      if (nframes <= (c->det_lag2 ? std::min(c->hist_start, c->hist_start_prev) : c->hist_start)) {
-        b = 0;
-      } else {  // (stream order: a deferred detect stage that still reads or writes this window goes first)
-        flush_stages(c);
-        hipLaunchKernelGGL(ss::k_hist_shift, dim3(grid_for((size_t)H * n, 256)), dim3(256), 0, c->stream,
-                           (const float*)(c->d_hist + (size_t)c->hist_start * n), c->d_hist, n, H, 0);
-        c->hist_start = 0;
-        b = H;
-      }
-    }
-    RingPlace r{};
-    r.in = c->d_hist + (size_t)c->hist_start * n;
-    r.next_start = b + nframes - H;
-    r.out = c->d_hist + (size_t)r.next_start * n;
-    r.batch = c->d_hist + (size_t)b * n;
-    return r;
-  }
-  // The detect stage writes the batch's newest min(nframes, H) rel rows to the LAST rows of hist_out[0..H).
-  if (nframes < H && c->hist_start + H + nframes > c->hist_rows) {
-    // end of the buffer: move the window to the front once (rare: every (hist_rows - H) / nframes batches).
-    // (stream order: a deferred detect stage that still has to write this window must go first)
+  // (the decision is ring_place.h's — a function of five integers that tests/host/ring_check.cpp runs on the CPU; here its consequences)
+  const ss::RingDecision d = ss::ring_place_decide(c->hist_start, c->hist_prev, c->hist_rows, nframes, H, c->cull_long);
+  if (d.shift_first) {  // (stream order: a deferred detect stage that still reads or writes this window goes first)
     flush_stages(c);
-    hipLaunchKernelGGL(ss::k_hist_shift, dim3(grid_for((size_t)H * n, 256)), dim3(256), 0, c->stream,
-                       (const float*)(c->d_hist + (size_t)c->hist_start * n), c->d_hist, n, H, 0);
+    if (c->hist_start != 0)
+      hipLaunchKernelGGL(ss::k_hist_shift, dim3(grid_for((size_t)H * n, 256)), dim3(256), 0, c->stream,
+                         (const float*)(c->d_hist + (size_t)c->hist_start * n), c->d_hist, n, H, 0);
     c->hist_start = 0;
+    c->hist_prev = ss::RingPrev{0, -1, 0};
   }
   RingPlace r{};
-  r.in = c->d_hist + (size_t)c->hist_start * n;
-  if (nframes < H) r.next_start = c->hist_start + nframes;  // old rows [nframes, H) stay where they are, new ones land behind them
-  else r.next_start = c->hist_start + 2 * H <= c->hist_rows ? c->hist_start + H : 0;  // a whole new window, clear of the one being read (the ring holds at least three)
-  r.out = c->d_hist + (size_t)r.next_start * n;
+  r.in = c->d_hist + (size_t)d.in * n;
+  r.next_start = d.next_start;
+  r.out = c->d_hist + (size_t)d.next_start * n;
+  r.batch = (d.batch >= 0 && nframes >= H) ? c->d_hist + (size_t)d.batch * n : nullptr;
+  r.batch_row = d.batch;
   return r;
 }
 
@@ -1394,7 +1373,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   c->buf_cur = (b + 1) % c->nbuf;
   c->last_avg = ea.avg;
   c->last_hist = hist_in;
-  c->hist_start_prev = c->hist_start;
+  c->hist_prev = ss::RingPrev{c->hist_start, c->cull_long ? ring.batch_row : -1, nframes};  // (what this call's detect stage reads: ring_place.h)
   c->hist_start = next_start;
   c->last_n_learn = n_learn;
   c->last_thr = z->d_thr;
@@ -2168,9 +2147,9 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       const long long min_rows = (long long)n >= 65536 ? 10 * kHistRows : 3 * kHistRows;
       if (rows < min_rows) rows = min_rows;
       if (rows > 64 * kHistRows) rows = 64 * kHistRows;
-      // (det_lag2: three batches and the averager's reach, so that a batch can go back to the front of the buffer while the two
-      // before it are still to be read — place_ring)
-      if (c->det_lag2 && rows < 3ll * cfg->max_batch + 3 * kHistRows) rows = 3ll * cfg->max_batch + 3 * kHistRows;
+      // (long transforms, whose rows kernel may write ALL of a batch's rows into this buffer: three batches and the averager's reach,
+      // so that a batch can go back to the front of the buffer while the one before it is still to be read — ring_place.h)
+      if (n >= 65536 && c->step_path && rows < 3ll * cfg->max_batch + 3 * kHistRows) rows = 3ll * cfg->max_batch + 3 * kHistRows;
       c->hist_rows = (int)rows;
       CREATE_HIP(hipMalloc(&c->d_hist, sizeof(float) * (size_t)n * (size_t)rows));
       CREATE_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(float) * (size_t)n * (size_t)kHistRows, c->stream));  // Averager ctor, averager.cpp:7-12
@@ -2680,6 +2659,7 @@ int ss_reset(ss_ctx* c) {  // Transmission::resetBuffers -> Averager::reset: row
   const int G = c->cfg.grouping_y;
   if (c->fused) {
     c->hist_start = 0;
+    c->hist_prev = ss::RingPrev{0, -1, 0};
     SS_HIP(c, hipMemsetAsync(c->d_hist, 0, sizeof(float) * (size_t)c->n * (size_t)kHistRows, c->stream));
   } else if (G > 1) {
     SS_HIP(c, hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)c->n * (size_t)(G - 1), c->stream));

@@ -20,3 +20,16 @@ def test_smax_index_and_plan_shapes(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "bad 0" in out.stdout.splitlines()[-1]
+
+
+def test_the_averager_ring_never_hands_out_rows_that_are_still_to_be_read(tmp_path):
+    """csrc/ring_place.h — where a batch's rows go in the averager ring's buffer — against its invariant: 1.2 million calls of random
+    streams (tests/host/ring_check.cpp; plain C++, no HIP)."""
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not found")
+    exe = tmp_path / "ring_check"
+    subprocess.run([gxx, "-std=c++17", "-O1", "-Wall", "-Werror", "-o", str(exe), os.path.join(ROOT, "tests", "host", "ring_check.cpp")], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("bad 0")
