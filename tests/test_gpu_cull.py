@@ -228,11 +228,30 @@ def test_long_rows_one_million_points_short_calls():
 @pytest.mark.parametrize("nb,ncalls", [(64, 6), (128, 11), (48, 14)])
 def test_long_rows_device_calls_without_sync_culled_equal_unculled(cull_65536, nb, ncalls):
     """(128 x 11, 48 x 14: the averager ring of a 65536-point context holds three batches and the averager's reach, so these calls
-    send it back to the front of its buffer several times while two detect stages still wait — specscan.hip: place_ring, det_lag2.)"""
+    send it back to the front of its buffer several times while two detect stages still wait — csrc/ring_place.h, det_lag2.)"""
+    _device_calls_culled_equal_unculled(65536, 20_000_000, nb, ncalls)
+
+
+# the forms the 65536- and 2^20-point chains went through in round 4 (switches of the diagnostics build, DESIGN.md 4.4 / 8): each of
+# them in detect mode with calls in flight, culled == unculled
+@pytest.mark.parametrize("env,n,fs,nb,ncalls", [
+    ({"SS_DET_LAG2": "0"}, 65536, 20_000_000, 128, 7),
+    ({"SS_ROWS256_STEP": "0"}, 65536, 20_000_000, 128, 7),
+    ({"SS_LIST_FIRST": "0", "SS_EMIT_ON_ROWS": "1"}, 65536, 20_000_000, 48, 9),
+    ({"SS_PLAN_FUSED": "0", "SS_WIN_CALC": "0"}, 65536, 20_000_000, 64, 6),
+    ({"SS_PLAN_FUSED": "0", "SS_WIN_CALC": "0", "SS_LIST_FIRST": "0"}, 1 << 20, 61_440_000, 16, 7),
+], ids=lambda v: "-".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
+def test_long_rows_intermediate_forms_culled_equal_unculled(cull_65536, monkeypatch, env, n, fs, nb, ncalls):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _device_calls_culled_equal_unculled(n, fs, nb, ncalls, min_candidates=500)
+
+
+def _device_calls_culled_equal_unculled(n, fs, nb, ncalls, min_candidates=5_000):
     import torch
-    n, fs = 65536, 20_000_000
-    band = pkg.synth.SyntheticBand(n, seed=49, on_frame=70, off_frame=nb * ncalls - 90)
-    iq8 = band.frames_cs8(nb * ncalls)
+    total = nb * ncalls
+    band = pkg.synth.SyntheticBand(n, seed=49, on_frame=min(70, total // 3), off_frame=total - min(90, total // 5))
+    iq8 = band.frames_cs8(total)
     dev = torch.device("cuda", 0)
     res = {}
     for name, flags in (("cull", 0), ("nocull", pkg.abi.SS_FLAG_NO_CULL)):
@@ -250,7 +269,7 @@ def test_long_rows_device_calls_without_sync_culled_equal_unculled(cull_65536, n
             lists += [off.copy()] if k == ncalls - 2 else [idx[off[f]:off[f + 1]].copy() for f in range(nb)]
         res[name] = lists
     _same(res["cull"], res["nocull"])
-    assert sum(len(x) for x in res["cull"]) > 5_000
+    assert sum(len(x) for x in res["cull"]) > min_candidates
 
 
 # ---- random detect-mode sessions: what test_gpu_fuzz.py does not reach (it asks for every plane, and a stage that hands out rel /

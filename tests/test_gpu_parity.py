@@ -110,6 +110,12 @@ ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurem
     ({"SS_STEP_LONG": "0"}, 16384, 4_000_000, "cf32"),
     ({"SS_FFT_TWOPASS": "0"}, 1 << 20, 61_440_000, "cs8"),  # 2^20 points as 256 x 4096 in three passes (round 3's form; the product takes 1024 x 1024 in two)
     ({"SS_C1024_WIDE": "0"}, 1 << 20, 61_440_000, "cs8"),   # ... in two passes with 8-column tiles as k_scan_step's FFT role (the product: 16-column tiles, a launch of their own, the ROW tiles as the role)
+    ({"SS_PLAN_FUSED": "0", "SS_WIN_CALC": "0"}, 1 << 20, 61_440_000, "cf32"),  # the plan as a launch of its own, window taps from the table (round 4 before session 14)
+    ({"SS_CULL_65536": "0"}, 65536, 20_000_000, "cs8"),     # 65536 points as until session 19 of round 4: every tile evaluated, columns as the FFT role with all passengers
+    ({"SS_ROWS256_STEP": "0", "SS_WIN_CALC": "0"}, 65536, 20_000_000, "cs8"),  # ... culled, rows and plan as launches of their own
+    ({"SS_DET_LAG2": "0"}, 65536, 20_000_000, "cs8"),       # ... detect(k - 1) on the row launch
+    ({"SS_EMIT_ON_ROWS": "1", "SS_LIST_FIRST": "0"}, 65536, 20_000_000, "cf32"),
+    ({"SS_PLAN_FIRST": "32"}, 8192, 2_048_000, "cf32"),     # 8192 points: the first pairs of every list on detect workgroups of their own
 ]
 
 
