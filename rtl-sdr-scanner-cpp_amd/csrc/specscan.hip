@@ -131,6 +131,7 @@ struct ss_ctx {
     bool emit_on_rows = false;     // SS_DIAG (SS_EMIT_ON_ROWS=1): 65536 points, the emit stage on the row launch instead of the column launch (A/B)
     bool det_lag2 = true;          // 65536 points with tile culling: detect(k - 2) on the column launch of call k (SS_DET_LAG2=0: detect(k - 1) on the row launch, session 19's form)
     int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
+    int chunk_long = 16;           // 2^20 points in two passes: calls of more frames go through in chunks of this many (SS_CHUNK_LONG=0: in one piece)
     int list_first = 64;           // long transforms with tile culling: the first pairs of the plan's list go to detect workgroups of their own, dispatched ahead of the launch's FFT role (SS_LIST_FIRST=0: every pair behind an FFT workgroup's tile, as until session 19 of round 4)
     bool plan_fused = true;        // 2^20 points in two passes: the plan of call k at the front of call k + 1's column launch (SS_PLAN_FUSED=0: a launch of its own behind call k's rows, as until session 14 of round 4)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
@@ -182,6 +183,7 @@ struct ss_ctx {
       rows256_step = tri("SS_ROWS256_STEP") != 0;
       plan_fused = tri("SS_PLAN_FUSED") != 0;
       list_first = num("SS_LIST_FIRST", list_first);
+      chunk_long = num("SS_CHUNK_LONG", chunk_long);
       plan_first = num("SS_PLAN_FIRST", plan_first);
       det_lag2 = tri("SS_DET_LAG2") != 0;
       emit_on_rows = tri("SS_EMIT_ON_ROWS") == 1;
@@ -622,9 +624,11 @@ ss::ColsArgs cols256_args(ss_ctx* c, const void* d_iq, long long item_stride) {
 
 // N = 2^20 in two passes (fft1024_kernels.h): the column tiles are k_scan_step's FFT role (KIND 3) or, for contexts without the
 // step kernel, a launch of their own; the rows follow as their own launch either way.
+// frame0: the first of these frames within its call (a call of many frames goes through in chunks, run_batch)
 template <int FMT>
-void launch_cols1024_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nframes) {
-  const ss::ColsArgs g = cols256_args(c, d_iq, item_stride);
+void launch_cols1024_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int frame0 = 0) {
+  ss::ColsArgs g = cols256_args(c, d_iq, item_stride);
+  g.abs0 += frame0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (!prof_pair(c, &e0, &e1)) e0 = e1 = nullptr;
   auto go = [&](auto kernel, int tiles, int threads, int lds) {
@@ -648,11 +652,13 @@ void launch_cols1024_fmt(ss_ctx* c, const void* d_iq, long long item_stride, int
   else if (c->diag.cols1024_wide) go(ss::k_fft_cols1024<FMT, 4>, 64, 1024, ss::fft1024_cols_lds_bytes(4));
   else go(ss::k_fft_cols1024<FMT, 3>, 128, 512, ss::kFft1024ColsLdsBytes);
 }
-void launch_cols1024(ss_ctx* c, const void* d_iq, long long item_stride, int nframes) {
+void launch_cols1024(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, int frame0 = 0) {
+  const size_t sample = c->cfg.in_format == SS_FMT_CF32 ? 8 : 2;
+  const void* iq = static_cast<const char*>(d_iq) + (size_t)frame0 * (size_t)item_stride * sample;
   switch (c->cfg.in_format) {
-    case SS_FMT_CF32: return launch_cols1024_fmt<ss::FMT_CF32>(c, d_iq, item_stride, nframes);
-    case SS_FMT_CS8: return launch_cols1024_fmt<ss::FMT_CS8>(c, d_iq, item_stride, nframes);
-    default: return launch_cols1024_fmt<ss::FMT_CU8>(c, d_iq, item_stride, nframes);
+    case SS_FMT_CF32: return launch_cols1024_fmt<ss::FMT_CF32>(c, iq, item_stride, nframes, frame0);
+    case SS_FMT_CS8: return launch_cols1024_fmt<ss::FMT_CS8>(c, iq, item_stride, nframes, frame0);
+    default: return launch_cols1024_fmt<ss::FMT_CU8>(c, iq, item_stride, nframes, frame0);
   }
 }
 ss::Rows1024Args rows1024_args(ss_ctx* c, float* d_psd, const ss::RowsExtra& rx) {
@@ -1771,12 +1777,26 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       // 2^20 points: the column half of call k as a launch of its own (16 columns x 1024 rows per 1024-thread workgroup: too many
       // threads for a role), then ONE launch of k_scan_step whose FFT role is the ROW half of call k — 8 rows x 1024 points per
       // 512-thread workgroup — with detect(k - 1) and emit(k - 2) riding on it as they ride on the column launches of the other sizes
-      launch_cols1024(c, d_iq, item_stride, nframes);
-      const ss::Rows1024Args gr = rows1024_args(c, ring_only ? nullptr : d_psd, rx);
-      FftRole rrole;
-      rrole.rows1024 = &gr;
-      rrole.n = nframes * 128;
-      launch_step(c, &rrole, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
+      // A call of many frames goes through in chunks of 16: the work buffer of a chunk (128 MiB) is still in the 256 MiB Infinity
+      // Cache when the chunk's row half reads it — 2.8 us per frame for the row half against 4.1-4.3 when a 32- or 64-frame call's
+      // work buffer has to come back from HBM (profiles/r04/s26_summary.txt). The deferred stages ride on the first chunk's row launch,
+      // the plan of the call before on its column launch.
+      const int chunk = (c->diag.chunk_long > 0 && nframes > c->diag.chunk_long) ? c->diag.chunk_long : nframes;
+      for (int f0 = 0; f0 < nframes; f0 += chunk) {
+        const int nf = std::min(chunk, nframes - f0);
+        launch_cols1024(c, d_iq, item_stride, nf, f0);
+        ss::RowsExtra rxc = rx;
+        rxc.abs0 += f0;
+        rxc.first_hist -= f0;                  // (hist_out takes the call's frames >= first_hist; the tile sees chunk-local frame numbers)
+        if (f0 > 0) rxc.zero_word = nullptr;   // (the first chunk's launch zeroes the count of the list this call's plan appends to)
+        float* psd_c = (ring_only || !d_psd) ? nullptr : d_psd + (size_t)f0 * (size_t)c->n;
+        const ss::Rows1024Args gr = rows1024_args(c, psd_c, rxc);
+        FftRole rrole;
+        rrole.rows1024 = &gr;
+        rrole.n = nf * 128;
+        const bool first = f0 == 0;
+        launch_step(c, &rrole, (first && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, (first && c->have_emit) ? &c->pend_emit : nullptr);
+      }
     } else
     launch_step(c, &role, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     shift_pending(c);
