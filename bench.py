@@ -453,7 +453,8 @@ def also_lines():
     kernel of the chain with its own duration and rate, what the library says it culled (ss_get_stats), and — except the last — a
     parity sample of its own against the reference (host path with every plane, and the timed device path in the entry's own mode)."""
     res = []
-    runs = ((2, 40, ["--no-cull"], "no_cull"), (3, 200, [], None), (5, 100, [], None), (5, 40, ["--frames", "64", "--no-parity"], None))  # (config 5 also in 64-frame calls: 35 of 64 rows are ring rows instead of all)
+    runs = ((2, 40, ["--no-cull"], "no_cull"), (3, 200, [], None), (3, 100, ["--frames", "256", "--no-parity"], None), (5, 100, [], None),
+            (5, 40, ["--frames", "64", "--no-parity"], None))  # (config 3 also in 256-frame calls — two rounds of workgroups per launch instead of one —, config 5 also in 64-frame calls: four chunks of 16)
     for cfg_no, steps, extra, variant in runs:
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg_no), "--gpus", "1", "--steps", str(steps), "--warmup", "5",
                "--preheat-ms", "150", "--no-cpu-baseline", "--sub", *extra]

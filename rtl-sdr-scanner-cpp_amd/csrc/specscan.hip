@@ -131,6 +131,7 @@ struct ss_ctx {
     bool emit_on_rows = false;     // SS_DIAG (SS_EMIT_ON_ROWS=1): 65536 points, the emit stage on the row launch instead of the column launch (A/B)
     bool det_lag2 = true;          // 65536 points with tile culling: detect(k - 2) on the column launch of call k (SS_DET_LAG2=0: detect(k - 1) on the row launch, session 19's form)
     int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
+    int chunk_65536 = 256;         // 65536 points with tile culling: calls of more frames go through in chunks of this many (SS_CHUNK_65536=0: in one piece)
     int chunk_long = 16;           // 2^20 points in two passes: calls of more frames go through in chunks of this many (SS_CHUNK_LONG=0: in one piece)
     int list_first = 64;           // long transforms with tile culling: the first pairs of the plan's list go to detect workgroups of their own, dispatched ahead of the launch's FFT role (SS_LIST_FIRST=0: every pair behind an FFT workgroup's tile, as until session 19 of round 4)
     bool plan_fused = true;        // 2^20 points in two passes: the plan of call k at the front of call k + 1's column launch (SS_PLAN_FUSED=0: a launch of its own behind call k's rows, as until session 14 of round 4)
@@ -184,6 +185,7 @@ struct ss_ctx {
       plan_fused = tri("SS_PLAN_FUSED") != 0;
       list_first = num("SS_LIST_FIRST", list_first);
       chunk_long = num("SS_CHUNK_LONG", chunk_long);
+      chunk_65536 = num("SS_CHUNK_65536", chunk_65536);
       plan_first = num("SS_PLAN_FIRST", plan_first);
       det_lag2 = tri("SS_DET_LAG2") != 0;
       emit_on_rows = tri("SS_EMIT_ON_ROWS") == 1;
@@ -1767,12 +1769,32 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
 #else
       const bool emit_on_rows = false;
 #endif
-      launch_step(c, &role, (det_on_cols && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, (!emit_on_rows && c->have_emit) ? &c->pend_emit : nullptr, nullptr, true);
-      const ss::Rows256Args gr = rows256_args(c, ring_only ? nullptr : d_psd, rx);
-      FftRole rrole;
-      rrole.rows256 = &gr;
-      rrole.n = nframes * 8;
-      launch_step(c, &rrole, (!det_on_cols && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, (emit_on_rows && c->have_emit) ? &c->pend_emit : nullptr);
+      // A call of many frames goes through in chunks of 256 (a chunk's work buffer: 128 MiB, still in the Infinity Cache when its row
+      // half reads it: the row half of a 512-frame call took 0.206 us per frame against 0.132, profiles/r04/s28_summary.txt); the
+      // deferred stages ride on the first chunk's launches.
+      const size_t sample = c->cfg.in_format == SS_FMT_CF32 ? 8 : 2;
+      const int chunk = (c->diag.chunk_65536 > 0 && nframes > c->diag.chunk_65536) ? c->diag.chunk_65536 : nframes;
+      for (int f0 = 0; f0 < nframes; f0 += chunk) {
+        const int nf = std::min(chunk, nframes - f0);
+        const bool first = f0 == 0;
+        ss::ColsArgs gcc = gc;
+        gcc.iq = static_cast<const char*>(d_iq) + (size_t)f0 * (size_t)item_stride * sample;
+        FftRole crole;
+        crole.cols = &gcc;
+        crole.n = nf * (c->n >> 13);
+        launch_step(c, &crole, (first && det_on_cols && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec,
+                    (first && !emit_on_rows && c->have_emit) ? &c->pend_emit : nullptr, nullptr, first);
+        ss::RowsExtra rxc = rx;
+        rxc.abs0 += f0;
+        rxc.first_hist -= f0;                 // (hist_out takes the call's frames >= first_hist; the tile sees chunk-local frame numbers)
+        if (!first) rxc.zero_word = nullptr;  // (the first chunk's launch zeroes the count of the list this call's plan appends to)
+        const ss::Rows256Args gr = rows256_args(c, (ring_only || !d_psd) ? nullptr : d_psd + (size_t)f0 * (size_t)c->n, rxc);
+        FftRole rrole;
+        rrole.rows256 = &gr;
+        rrole.n = nf * 8;
+        launch_step(c, &rrole, (first && !det_on_cols && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec,
+                    (first && emit_on_rows && c->have_emit) ? &c->pend_emit : nullptr);
+      }
     } else if (rows_by_step) {
       // 2^20 points: the column half of call k as a launch of its own (16 columns x 1024 rows per 1024-thread workgroup: too many
       // threads for a role), then ONE launch of k_scan_step whose FFT role is the ROW half of call k — 8 rows x 1024 points per

@@ -169,9 +169,12 @@ def test_config2_the_timed_path_against_the_reference(ref_mod):
     assert len(b) > 300_000 and len(a ^ b) <= dont_care_limit(len(b))
 
 
-def test_config3_device_calls_against_the_reference(ref_mod):
-    n, fs, chunk, ncalls = 65536, 20_000_000, 128, 3
-    band = pkg.synth.SyntheticBand(n, seed=42, on_frame=60, off_frame=330)
+@pytest.mark.parametrize("chunk,ncalls", [(128, 3), (300, 2)])
+def test_config3_device_calls_against_the_reference(ref_mod, chunk, ncalls):
+    """(300-frame calls: the library takes a 65536-point call of more than 256 frames through in chunks of 256 — a chunk's work buffer
+    stays in the Infinity Cache between its column and its row half —, the deferred stages riding on the first chunk's launches.)"""
+    n, fs = 65536, 20_000_000
+    band = pkg.synth.SyntheticBand(n, seed=42, on_frame=60, off_frame=chunk * ncalls - 54)
     iq8 = band.frames_cs8(chunk * ncalls)
     iq = (iq8[..., 0].astype(np.float32) / np.float32(128.0) + 1j * (iq8[..., 1].astype(np.float32) / np.float32(128.0))).astype(np.complex64)
     t = (10_000 + 50 * np.arange(chunk * ncalls)).astype(np.int64)  # learning ends after 41 frames
@@ -184,15 +187,17 @@ def test_config3_device_calls_against_the_reference(ref_mod):
     near = np.abs(ref["avg"] - np.float32(8.0)) < BAND
     outside = [(f, i) for (f, i) in a ^ b if not near[f, i]]
     assert not outside, sorted(outside)[:10]
-    print(f"\n[config 3, device calls: {ncalls} x 128 frames of 65536 points, CS8] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band")
+    print(f"\n[config 3, device calls: {ncalls} x {chunk} frames of 65536 points, CS8] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band")
     assert len(b) > 10_000 and len(a ^ b) <= dont_care_limit(len(b))
 
 
-def test_config5_device_calls_against_the_reference(ref_mod):
+@pytest.mark.parametrize("chunk,ncalls", [(16, 8), (40, 3)])
+def test_config5_device_calls_against_the_reference(ref_mod, chunk, ncalls):
     """Config 5 as it ships and as bench.py times it: 2^20-point CF32 frames in 16-frame ss_process_device calls, detect mode (no
-    plane handed out), tile culling on, six calls enqueued back to back with no synchronisation — compared DIRECTLY with the
-    reference's own code. ss_get_stats shows that tiles really were culled."""
-    n, fs, chunk, ncalls, learn = 1 << 20, 61_440_000, 16, 8, 32
+    plane handed out), tile culling on, eight calls enqueued back to back with no synchronisation — compared DIRECTLY with the
+    reference's own code. ss_get_stats shows that tiles really were culled. (40-frame calls: the library takes a call of more than 16
+    frames through in chunks of 16, 16 + 16 + 8 here, the first of them holding the 32 learning frames.)"""
+    n, fs, learn = 1 << 20, 61_440_000, 32
     band = pkg.synth.SyntheticBand(n, seed=43, on_frame=70, off_frame=118)
     iq = band.frames_cf32(chunk * ncalls)
     t = (10_000 + 30 * np.arange(chunk * ncalls)).astype(np.int64)
@@ -210,7 +215,7 @@ def test_config5_device_calls_against_the_reference(ref_mod):
     assert not outside, sorted(outside)[:10]
     frames = np.repeat(np.arange(chunk * ncalls), np.diff(got["cand_off"]))
     check_plane("cand_avg", got["cand_avg"][None], ref["avg"][frames, got["cand_idx"]][None], floor=np.full((1, len(frames)), 2e-3))
-    print(f"\n[config 5, device calls: {ncalls} x 16 frames of 2^20 points, detect mode, culled] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band; "
+    print(f"\n[config 5, device calls: {ncalls} x {chunk} frames of 2^20 points, detect mode, culled] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band; "
           f"tiles {st['tiles_total']}, tested {st['tiles_tested']}, culled {st['tiles_culled']}")
     assert st["culling"] and st["tiles_culled"] > 0 and st["tiles_culled"] <= st["tiles_tested"] <= st["tiles_total"], st
     assert len(b) > 2000 and len(a ^ b) <= dont_care_limit(len(b))
