@@ -691,7 +691,7 @@ __global__ __launch_bounds__(1024, 8) void k_fft_cols1024_plan(ColsArgs g, PlanL
   }
   fft_cols1024_tile<FMT, 4, WCALC>(g, b - plan_wgs, smem_raw, tid);
 }
-__host__ __device__ inline int plan_fused_wgs(int plan_blocks, int per_wg = 4) { return (((plan_blocks + per_wg - 1) / per_wg + 7) / 8) * 8; }
+__host__ __device__ inline int plan_fused_wgs(int plan_blocks) { return (((plan_blocks + 3) / 4 + 7) / 8) * 8; }
 
 // min of the noise ceiling over bins [256 c - 32, 256 c + 288) is k_thr_tilemin above, one wave per tile column.
 

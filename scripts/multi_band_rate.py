@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--fft", type=int, default=8192)
     ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--cs8", action="store_true", help="int8 IQ (BASELINE config 3's format)")
+    ap.add_argument("--detect", action="store_true", help="detect mode: no dB plane handed out")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     n, nb = a.fft, a.frames
@@ -30,11 +32,16 @@ def main():
     for nbands in a.bands:
         engines, inputs, outs = [], [], []
         for b in range(nbands):
-            eng = pkg.SpectrumEngine(250 * n, 140_000_000 + 2_000_000 * b, fft_size=n, decim=1, learn_frames=100, max_batch=nb)
+            eng = pkg.SpectrumEngine(250 * n, 140_000_000 + 2_000_000 * b, fft_size=n, decim=1, learn_frames=min(100, nb), max_batch=nb,
+                                     in_format=pkg.abi.SS_FMT_CS8 if a.cs8 else pkg.abi.SS_FMT_CF32)
             iq = dist.synthetic_batch(cfg, b, nb)
             engines.append(eng)
-            inputs.append(torch.from_numpy(iq.view(np.float32)).to(dev))
-            outs.append([dict(psd=torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
+            if a.cs8:
+                v = iq.view(np.float32).reshape(nb, n, 2)
+                inputs.append(torch.from_numpy(np.clip(np.rint(v * 127.0 / max(1e-9, float(np.abs(v).max()))), -127, 127).astype(np.int8)).to(dev))
+            else:
+                inputs.append(torch.from_numpy(iq.view(np.float32)).to(dev))
+            outs.append([dict(psd=None if a.detect else torch.empty((nb, n), dtype=torch.float32, device=dev), off=torch.zeros(nb + 1, dtype=torch.int32, device=dev),
                               idx=torch.empty(nb * 1024, dtype=torch.int32, device=dev), avg=torch.empty(nb * 1024, dtype=torch.float32, device=dev))
                          for _ in range(2)])
         torch.cuda.synchronize()
