@@ -712,6 +712,10 @@ def run(args):
             out["roofline"]["traffic_live"] = live if live else {"unavailable": why}
             if live:
                 out["roofline"]["traffic_over_algorithmic"] = round(live["bytes_per_launch"] / (abps * nb * n), 3)
+                # what the memory system really moves per second of the timed region: the counted bytes of a launch over the wall time a
+                # launch takes (= ms_per_step: one launch per step) — beside `achieved`, which counts the algorithmic bytes only
+                out["roofline"]["traffic_gbs"] = round(live["bytes_per_launch"] / step_s / 1e9, 1)
+                out["roofline"]["traffic_frac_of_peak"] = round(live["bytes_per_launch"] / step_s / 1e9 / HBM_PEAK_GBS, 4)
         if world == 1 and not args.sub and not args.no_also and (args.config or 2) == 2 and n == 8192 and not (args.diag_lib or args.lib):
             out["also"] = also_lines()
         if not args.no_cpu_baseline and world == 1:
