@@ -19,13 +19,17 @@ Prints ONE JSON line on rank 0:
                         overlap on two queues, so a launch lasts ~2x the time the GPU spends per launch: kernel_us is the
                         measured mean duration (what rocprofv3 --stats reports), launches_in_flight = kernel_us / wall time
                         per launch, achieved = bytes / (kernel_us / launches_in_flight)
+  roofline.traffic      (default line, one GPU) fabric bytes per launch of that kernel, counted on this box: behind the timed region the
+                        process runs its own command line once more under `rocprofv3 --pmc FETCH_SIZE` and under `--pmc WRITE_SIZE`
+                        (two short passes); traffic_over_algorithmic = wasted re-reads, traffic_gbs = the counted bytes per second of
+                        the timed region
   roofline.kernels      every launch of the chain with its own event-timed duration, what it must move per sample given the
                         decomposition, and the fabric bytes of the committed PMC passes (one entry at 8192 points; column half,
                         radix-A step, row half and plan launch for the long transforms)
   roofline_chain        the same algorithmic bytes / the whole step's time (every kernel of the chain, launch gaps included)
   also                  (default line, one GPU) short runs in processes of their own: the default configuration with every averaging tile
-                        evaluated (variant no_cull: the data-independent cost), BASELINE configs 3 and 5 (65536 x 128 CS8, 2^20 x 16 and
-                        2^20 x 64), each with ms_per_step, its chain figure, its kernels, the tiles the library culled and a parity sample
+                        evaluated (variant no_cull: the data-independent cost), BASELINE configs 3 and 5 (65536 x 128 and x 256 CS8, 2^20 x 16
+                        and x 64), each with ms_per_step, its chain figure, its kernels, the tiles the library culled and a parity sample
   cpu_baseline          the reference's own compiled sources (oracle/_ref; the C restatement where that is absent) on the
                         host cores over a bounded sample of the same workload, one thread and all threads
 """
