@@ -102,6 +102,13 @@ __device__ __forceinline__ void fft_cols256_tile(const ColsArgs& g, int block, u
   // first exchange come before its first use.
   float2* tw_lds = reinterpret_cast<float2*>(smem_raw + kFft256LdsBytes);
   if (t < 256) tw_lds[t] = g.tw256[t];
+#ifndef SS_COLS_STAGGER  // (A/B builds, scripts/build_ab.py: every other column tile starts SS_COLS_STAGGER x ~3.4 us late — do a launch's load, compute and store phases overlap better out of step?)
+#define SS_COLS_STAGGER 0
+#endif
+  if (SS_COLS_STAGGER && (block & 1)) {
+#pragma unroll
+    for (int k = 0; k < SS_COLS_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+  }
   const int logn2 = g.logn2;
   const int q = t & 31, j = t >> 5;
   const int n2size = 1 << logn2;
@@ -239,6 +246,13 @@ __device__ __forceinline__ void fft_rows256_tile(const Rows256Args& g, int block
   if (t < 256) tw_lds[t] = tw256[t];
   if (x.smax && t < 256) pmax[t] = 0u;  // (the barriers of the register passes come before the first atomic)
   if (x.zero_word && block == 0 && t == 0) *x.zero_word = 0;
+#ifndef SS_ROWS_STAGGER  // (A/B builds: as SS_COLS_STAGGER, for the row tiles)
+#define SS_ROWS_STAGGER 0
+#endif
+  if (SS_ROWS_STAGGER && (block & 8)) {
+#pragma unroll
+    for (int k = 0; k < SS_ROWS_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+  }
   const int rho = t >> 4, j = t & 15;
   const int r0 = (block & 7) << 5;
   const int c = (block >> 3) & ((1 << lognsub) - 1);

@@ -25,6 +25,12 @@ VARIANTS = {
     "c1024nostore": ["SS_C1024_ABL=2"],  # ... without the work-buffer stores
     "c1024noload": ["SS_C1024_ABL=4"],   # ... without the frame loads
     "c1024none": ["SS_C1024_ABL=7"],     # ... arithmetic and LDS only
+    "colsstag1": ["SS_COLS_STAGGER=1"],   # long transforms: every other column tile starts ~3.4 us late (do the phases of a one-round launch overlap better out of step?)
+    "colsstag2": ["SS_COLS_STAGGER=2"],
+    "colsstag3": ["SS_COLS_STAGGER=3"],
+    "rowsstag1": ["SS_ROWS_STAGGER=1"],   # ... every other group of eight row tiles
+    "rowsstag2": ["SS_ROWS_STAGGER=2"],
+    "bothstag2": ["SS_COLS_STAGGER=2", "SS_ROWS_STAGGER=1"],
     "segdpp": ["SS_SEGMAX_LDS=0"],   # 8192 points: the per-column maxima for the tile culling in registers (v_max_f32_dpp), as until session 15 of round 4
     "colsnone": ["SS_COLS_TW6=0", "SS_COLS_ABL=3"],   # ... without either  # 8192 points, deep pipelining: ring rows written by three frame tiles of every call
 }
