@@ -344,7 +344,7 @@ def is_preset(args) -> bool:
             and not args.sync_every_step and not (args.diag_lib or args.lib) and args.start_level == 8.0)
 
 
-def chain_kernels(n: int, fmt: str):
+def chain_kernels(n: int, fmt: str, nb: int | None = None):
     """The launches one call of the chain takes, as the library's timing slots name them (include/specscan.h SS_KSLOT_*), with
     what each must move per sample given the decomposition (its inputs once + its outputs once)."""
     in_b = 8.0 if fmt == "cf32" else 2.0
@@ -360,8 +360,14 @@ def chain_kernels(n: int, fmt: str):
                 ("rows", "k_scan_step", "k_scan_step with the ROW half as its FFT role (fft_rows1024_tile: 1024-point FFTs -> dB -> noise-relative rows straight into the averager "
                  "ring's buffer, no dB plane in detect mode, + run maxima for the tile culling), carrying the listed averaging tiles of call k-1 and the candidate lists of call k-2", 12.0),
                 ("plan", "k_plan_long", "k_plan_long as a launch of its own (SS_PLAN_FUSED=0 of the diagnostics build; the product runs the plan at the front of the next column launch)", 0.0)]
+    if n == 65536 and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0" and os.environ.get("SS_MERGE_65536") != "0" and (nb is None or nb <= 128):
+        # 65536 points, detect-mode calls of up to 128 frames as the product runs them since session 36 of round 4: ONE launch per call
+        return [("step", "k_scan_step", "k_scan_step (KIND 7), one launch per call: the column half of the four-step FFT of call k (load, Hamming taps formed from one table entry per "
+                 "thread, 256-point FFTs, twiddle -> one of two work buffers) and, dispatched behind its tiles, the ROW half of call k-1 (256-point FFTs -> dB -> noise-relative rows "
+                 "straight into the averager ring's buffer, no dB plane in detect mode, + run maxima for the tile culling), carrying the plan of call k-2 (which averaging tiles can hold "
+                 "a candidate), the listed tiles of call k-3 (21x21 mean + threshold) and the candidate lists of call k-4", in_b + 8.0 + 12.0)]
     if n == 65536 and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0":
-        # 65536 points as the product runs them since round 4: both halves of the FFT are FFT roles of k_scan_step launches
+        # ... calls of more frames (and SS_MERGE_65536=0): both halves of the FFT are FFT roles of k_scan_step launches of their own
         return [("step", "k_scan_step", "k_scan_step (KIND 2): column half of the four-step FFT of call k (load, Hamming taps formed from one table entry per thread, 256-point FFTs, "
                  "twiddle -> work buffer), carrying the plan of call k-1 (which averaging tiles can hold a candidate), the listed tiles of call k-2 (21x21 mean + threshold, "
                  "the first 64 pairs on workgroups of their own) and the candidate lists of call k-3", in_b + 8.0),
@@ -632,7 +638,7 @@ def run(args):
         step_s = elapsed / args.steps
         # every launch of the chain, kernel by kernel (start/stop events on the launches of the sampled calls)
         kernels = []
-        for slot, match, what, bps in chain_kernels(n, args.fmt):
+        for slot, match, what, bps in chain_kernels(n, args.fmt, nb):
             ms_k, cnt_k = slots.get(slot, (0.0, 0))
             if not cnt_k:
                 continue
@@ -646,6 +652,9 @@ def run(args):
                 shape = (nb + 20 + nb // 8 + 4) * 512
             elif two_pass:  # column half: 64 workgroups of 1024 threads per frame behind the 128 that run the plan of the call before; row half: 128 of 512 per frame + one emit workgroup per frame
                 shape = {"step": (nb * 64 + 128) * 1024, "rows": (nb * 128 + nb + 64) * 512}.get(slot)  # (+ 64 detect workgroups for the first listed pairs)
+            elif n == 65536 and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0" and os.environ.get("SS_MERGE_65536") != "0" and nb <= 128:
+                # one launch per call: 8 column tiles and 8 row tiles per frame + 128 plan + one emit workgroup per frame + 64 detect workgroups
+                shape = {"step": (nb * 16 + 128 + nb + 64) * 512}.get(slot)
             elif n == 65536 and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0":
                 # column launch: 8 column tiles per frame + 128 plan + one emit workgroup per frame + 64 detect workgroups; row launch: 8 row tiles per frame
                 shape = {"step": (nb * 8 + 128 + nb + 64) * 512, "rows": nb * 8 * 512}.get(slot)

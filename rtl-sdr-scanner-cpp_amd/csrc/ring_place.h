@@ -55,17 +55,24 @@ inline RingDecision ring_place_at(int start, int rows, int nframes, int H, bool 
   return d;
 }
 
-inline RingDecision ring_place_decide(int start, const RingPrev& prev, int rows, int nframes, int H, bool whole) {
+// prev[0 .. nprev): what the detect stages of the calls before still read when this call's rows are written — one in the chains
+// whose detect stage rides beside or right behind the next call's FFT stage, two where it rides a launch later still (65536 points,
+// one launch per call: SS_MERGE_65536)
+inline RingDecision ring_place_decide(int start, const RingPrev* prev, int nprev, int rows, int nframes, int H, bool whole) {
   const auto hits = [](int lo, int hi, int a, int b) { return lo < b && a < hi && a < b; };
   RingDecision d = ring_place_at(start, rows, nframes, H, whole);
-  const bool bad = d.write_lo < 0 || d.write_hi > rows || d.next_start + H > rows || hits(d.write_lo, d.write_hi, start, start + H) ||
-                   (prev.n > 0 && (hits(d.write_lo, d.write_hi, prev.start, prev.start + H) ||
-                                   (prev.batch >= 0 && hits(d.write_lo, d.write_hi, prev.batch, prev.batch + prev.n))));
+  bool bad = d.write_lo < 0 || d.write_hi > rows || d.next_start + H > rows || hits(d.write_lo, d.write_hi, start, start + H);
+  for (int k = 0; k < nprev && !bad; ++k)
+    bad = prev[k].n > 0 && (hits(d.write_lo, d.write_hi, prev[k].start, prev[k].start + H) ||
+                            (prev[k].batch >= 0 && hits(d.write_lo, d.write_hi, prev[k].batch, prev[k].batch + prev[k].n)));
   if (bad) {  // drain, window to the front, place again (nothing before it to protect then)
     d = ring_place_at(0, rows, nframes, H, whole);
     d.shift_first = true;
   }
   return d;
+}
+inline RingDecision ring_place_decide(int start, const RingPrev& prev, int rows, int nframes, int H, bool whole) {
+  return ring_place_decide(start, &prev, 1, rows, nframes, H, whole);
 }
 
 }  // namespace ss

@@ -100,6 +100,10 @@ struct StepArgs {
   int n_plan_long;  // workgroups
   PlanLongDet plan_det;
   PlanLongArgs plan_long;
+  // KIND 7 — 65536 points, ONE launch per call (what ships for detect-mode calls of up to 128 frames): the column tiles of call k (the FFT role)
+  // beside the ROW tiles of call k - 1 (ROLE_ROWS: rows256, n_rows of them, reading the other of two work buffers), the plan of call
+  // k - 2, detect(k - 3) and emit(k - 4). 0: no such role.
+  int n_rows;
   int n_emit;  // frames of the emit role
   int emit_per_wg;  // 8: one wave per frame; 1 (KIND 2): rows of 2048 mask words and more, the eight waves share one frame
   // One workgroup per work item, dispatched in blockIdx order, four resident per CU. WHICH item a workgroup takes decides
@@ -136,9 +140,9 @@ __host__ __device__ inline int step_plan_consumers(const StepArgs& a) { return s
 // every 32nd pair of it, instead of one per possible pair of which most leave at once. The tiles that must be evaluated sit in
 // the lists of a few tile columns, a hundred pairs and more each: the launch went from 24 to 40 us, profiles/r03/s38_timeline_k20.txt.)
 __host__ __device__ inline int step_det_wgs(const StepArgs& a) { return (a.n_det + 1) / 2 + (a.plan_by_fft ? a.plan_first : step_plan_consumers(a)); }
-inline int step_items(const StepArgs& a) { return step_fft_wgs(a) + step_det_wgs(a) + step_emit_wgs(a) + step_plan_wgs(a); }
+inline int step_items(const StepArgs& a) { return step_fft_wgs(a) + step_det_wgs(a) + step_emit_wgs(a) + step_plan_wgs(a) + a.n_rows; }
 
-enum { ROLE_NONE = 0, ROLE_FFT = 1, ROLE_DET = 2, ROLE_EMIT = 3, ROLE_PLAN = 4 };
+enum { ROLE_NONE = 0, ROLE_FFT = 1, ROLE_DET = 2, ROLE_EMIT = 3, ROLE_PLAN = 4, ROLE_ROWS = 5 };
 
 template <int FMT, bool SPEC, int TW, bool SWZ, int KIND>
 __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int item, unsigned char* smem_raw, int tid) {
@@ -196,8 +200,11 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       tile_a = 2 * item;
       tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;
     }
+  } else if (role == ROLE_ROWS) {
+    if constexpr (KIND == 7) fft_rows256_tile(a.rows256, item, smem_raw, tid);  // (the row half of the call before: its column half ran in the launch before)
+    return;
   } else if (role == ROLE_PLAN) {
-    if constexpr (KIND == 1 || KIND == 2) {  // a long transform's plan: two blocks of k_plan_long's numbering
+    if constexpr (KIND == 1 || KIND == 2 || KIND == 7) {  // a long transform's plan: two blocks of k_plan_long's numbering
       const int sub = tid >> 8;
       float* mrow = reinterpret_cast<float*>(smem_raw) + sub * (kPlanFusedFloats + kPlanLongInts);
       plan_long_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));
@@ -340,9 +347,11 @@ __global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a_by_val
       role = ROLE_EMIT;
     } else if ((b -= ne) < nd) {
       role = ROLE_DET;
+    } else if ((b -= nd) < a.n_rows) {
+      role = ROLE_ROWS;
     } else {
       role = ROLE_FFT;
-      b -= nd;
+      b -= a.n_rows;
     }
     item = b;
   }

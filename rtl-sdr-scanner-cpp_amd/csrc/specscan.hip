@@ -129,6 +129,8 @@ struct ss_ctx {
     bool rows256_step = true;      // 65536 points with tile culling: the column half as a launch of its own (the plan of the call before at its front), the ROW tiles as k_scan_step's FFT role (KIND 6) with the deferred stages riding on them (SS_ROWS256_STEP=0: columns as the FFT role, rows and plan as launches of their own)
     bool win_calc = true;          // 2^20 points in two passes and 65536 points, default window: the column tiles form their Hamming taps instead of loading them (SS_WIN_CALC=0: the table as ever)
     bool emit_on_rows = false;     // SS_DIAG (SS_EMIT_ON_ROWS=1): 65536 points, the emit stage on the row launch instead of the column launch (A/B)
+    int merge_max_frames = 128;    // ... calls of up to this many frames (SS_MERGE_MAX)
+    bool merge_65536 = true;       // 65536 points, detect-mode calls: ONE launch per call — the column half of call k beside the row half of call k - 1 (scan_step.h KIND 7; SS_MERGE_65536=0: two launches per call, session 20's form)
     bool det_lag2 = true;          // 65536 points with tile culling: detect(k - 2) on the column launch of call k (SS_DET_LAG2=0: detect(k - 1) on the row launch, session 19's form)
     int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
     int chunk_65536 = 256;         // 65536 points with tile culling: calls of more frames go through in chunks of this many (SS_CHUNK_65536=0: in one piece)
@@ -146,6 +148,10 @@ struct ss_ctx {
     // n >= 16384 (the FFT role is the column half, short workgroups): detect first. 65536 x 128 frames: 63.3 us per step
     // against 64.7 with the order above and 70.7 with one launch per stage; 2^20 x 16: 216.8 / 235 / 216.9 (profiles/r02/s18).
     std::string step_order_long = "E*|D*,F*";
+    // one launch per call (KIND 7): the column tiles of this call first, the row tiles of the call before behind them — two rounds of
+    // workgroups whose phases overlap. In turn (R1,F1) they took 45.7 us per 128-frame call against 41.0-41.7 in two runs, 26.2 against
+    // 24.0 per 64-frame call (rows first: 41.0 / 26.7): profiles/r04/s35_summary.txt
+    std::string step_order_merged = "E*|D*,F*,R*";
 #ifdef SS_DIAG
     void read() {
       const auto is = [](const char* name, const char* value) {
@@ -189,6 +195,8 @@ struct ss_ctx {
       plan_first = num("SS_PLAN_FIRST", plan_first);
       det_lag2 = tri("SS_DET_LAG2") != 0;
       emit_on_rows = tri("SS_EMIT_ON_ROWS") == 1;
+      merge_65536 = tri("SS_MERGE_65536") != 0;
+      merge_max_frames = num("SS_MERGE_MAX", merge_max_frames);
       win_calc = tri("SS_WIN_CALC") != 0;
       canary = tri("SS_CANARY") == 1;
       queues = num("SS_QUEUES", queues);
@@ -198,6 +206,7 @@ struct ss_ctx {
       if (tri("SS_PLAN_NOZERO") == 1) d_cull_stats = reinterpret_cast<unsigned*>(1);
       else if (tri("SS_CULL_STATS") == 1 && hipMalloc(&d_cull_stats, 3 * sizeof(unsigned)) == hipSuccess) (void)hipMemset(d_cull_stats, 0, 3 * sizeof(unsigned));
       if (const char* v = getenv("SS_STEP_ORDER")) step_order = step_order_long = v;
+      if (const char* v = getenv("SS_STEP_ORDER_MERGED")) step_order_merged = v;
     }
 #else
     void read() {}
@@ -292,6 +301,25 @@ struct ss_ctx {
   bool pend_det2_spec = false;
   ss::EmitArgs pend_det2_emit{};
   ss::RingPrev hist_prev{0, -1, 0};  // what the detect stage of the last call reads of the ring's buffer (ring_place.h)
+  ss::RingPrev hist_prev2{0, -1, 0}; // ... of the call before it (merged contexts protect two)
+  // 65536 points, ONE launch per call (scan_step.h KIND 7; calls that keep no dB plane, up to 128 frames): the launch of call k carries
+  // the column half of call k, the ROW half of call k - 1 (two work buffers), the plan of call k - 2, detect(k - 3) and emit(k - 4).
+  // Waiting on the host besides pend_det / pend_det2 / pend_plan / pend_emit: the row stage of the last call, its plan (not ready
+  // before that row stage has run) and its detect stage.
+  bool merge = false;
+  float2* d_work2 = nullptr;
+  int work_cur = 0;
+  bool have_rows = false;
+  ss::Rows256Args pend_rows{};
+  int pend_rows_tiles = 0;
+  bool have_plan2 = false;
+  ss::PlanLongDet pend_plan2_det{};
+  ss::PlanLongArgs pend_plan2{};
+  bool have_det3 = false;
+  ss::DetectArgs pend_det3{};
+  int pend_det3_tiles = 0;
+  bool pend_det3_spec = false;
+  ss::EmitArgs pend_det3_emit{};
   int buf_cur = 0;               // which of the rotating buffers the NEXT batch writes
   int psd_cur = 0;
   // Deep pipelining (8192 points; diag.deep). With the stages of three consecutive calls in one
@@ -377,7 +405,7 @@ struct ss_ctx {
   // k_scan_step's dispatch-order table for the current launch shape (rebuilt when the shape changes; two buffers so that a
   // launch still in flight keeps the table it was given)
   struct OrderTable {
-    int key[4];  // FFT / detect / emit / plan workgroups of the launch shape
+    int key[5];  // FFT / detect / emit / plan / row workgroups of the launch shape
     uint32_t* d;
     unsigned long long used;       // 0: free
     std::vector<uint32_t> host;    // what was uploaded (kept alive: the copy is asynchronous)
@@ -732,13 +760,13 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
 // Dispatch order of a launch that carries more than one role, from the pattern in diag.step_order (see there): one word per
 // workgroup (role << 24 | item) in device memory, rebuilt only when the launch shape changes.
 void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
-  const int n_fft = ss::step_fft_wgs(a), wg_det = ss::step_det_wgs(a), wg_emit = ss::step_emit_wgs(a), wg_plan = ss::step_plan_wgs(a);  // (FFT WORKGROUPS)
+  const int n_fft = ss::step_fft_wgs(a), wg_det = ss::step_det_wgs(a), wg_emit = ss::step_emit_wgs(a), wg_plan = ss::step_plan_wgs(a), wg_rows = a.n_rows;  // (FFT WORKGROUPS)
   a.order = nullptr;
   a.prio_fft = c->diag.prio_fft;
   a.prio_other = c->diag.prio_other;
-  if (n_fft == 0 || wg_det == 0 || c->diag.no_order_table) return;  // nothing to interleave: the kernel takes the roles one after the other (plan, emit, detect, FFT)
+  if (n_fft == 0 || (wg_det == 0 && wg_rows == 0) || c->diag.no_order_table) return;  // nothing to interleave: the kernel takes the roles one after the other (plan, emit, detect, FFT)
   for (auto& t : c->order_tables)
-    if (t.used && t.stream == stream && t.key[0] == n_fft && t.key[1] == wg_det && t.key[2] == wg_emit && t.key[3] == wg_plan) {  // (uploaded on this stream: complete for this launch by stream order)
+    if (t.used && t.stream == stream && t.key[0] == n_fft && t.key[1] == wg_det && t.key[2] == wg_emit && t.key[3] == wg_plan && t.key[4] == wg_rows) {  // (uploaded on this stream: complete for this launch by stream order)
       t.used = ++c->order_clock;
       a.order = t.d;
       return;
@@ -749,7 +777,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
   std::vector<Seg> prefix, cycle;
   {
     std::vector<Seg>* into = &prefix;
-    const std::string& sp = c->use_fft8192 ? c->diag.step_order : c->diag.step_order_long;
+    const std::string& sp = wg_rows ? c->diag.step_order_merged : c->use_fft8192 ? c->diag.step_order : c->diag.step_order_long;
     for (size_t i = 0; i < sp.size();) {
       const char ch = sp[i];
       if (ch == '|') {
@@ -757,7 +785,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
         ++i;
         continue;
       }
-      const int role = ch == 'F' ? ss::ROLE_FFT : ch == 'D' ? ss::ROLE_DET : ch == 'E' ? ss::ROLE_EMIT : ss::ROLE_NONE;
+      const int role = ch == 'F' ? ss::ROLE_FFT : ch == 'D' ? ss::ROLE_DET : ch == 'E' ? ss::ROLE_EMIT : ch == 'R' ? ss::ROLE_ROWS : ss::ROLE_NONE;
       ++i;
       int count = 0;
       if (i < sp.size() && sp[i] == '*') {
@@ -770,8 +798,8 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
       while (i < sp.size() && sp[i] != '|' && !(sp[i] >= 'A' && sp[i] <= 'Z')) ++i;  // separators
     }
   }
-  const int total[5] = {0, n_fft, wg_det, wg_emit, wg_plan};
-  int next[5] = {0, 0, 0, 0, 0};
+  const int total[6] = {0, n_fft, wg_det, wg_emit, wg_plan, wg_rows};
+  int next[6] = {0, 0, 0, 0, 0, 0};
   std::vector<uint32_t> out;
   out.clear();
   for (int k = 0; k < wg_plan; ++k) out.push_back((uint32_t)ss::ROLE_PLAN << 24 | (uint32_t)k);  // the few plan workgroups first: the launch's other workgroups wait for their list, never the other way round
@@ -779,12 +807,13 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
     for (int k = 0; k < sg.count && next[sg.role] < total[sg.role]; ++k) out.push_back((uint32_t)sg.role << 24 | (uint32_t)next[sg.role]++);
   };
   for (const Seg& sg : prefix) place(sg);
-  const size_t want = (size_t)n_fft + (size_t)wg_det + (size_t)wg_emit + (size_t)wg_plan;
+  const size_t want = (size_t)n_fft + (size_t)wg_det + (size_t)wg_emit + (size_t)wg_plan + (size_t)wg_rows;
   while (out.size() < want) {
     const size_t before = out.size();
     for (const Seg& sg : cycle) place(sg);
     if (out.size() == before) {  // the cycle does not reach what is left: whatever remains, FFT first
       place(Seg{ss::ROLE_FFT, 1 << 27});
+      place(Seg{ss::ROLE_ROWS, 1 << 27});
       place(Seg{ss::ROLE_DET, 1 << 27});
       place(Seg{ss::ROLE_EMIT, 1 << 27});
     }
@@ -820,6 +849,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
   slot->key[1] = wg_det;
   slot->key[2] = wg_emit;
   slot->key[3] = wg_plan;
+  slot->key[4] = wg_rows;
   slot->used = ++c->order_clock;
   a.order = slot->d;
 }
@@ -836,7 +866,8 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
   // (KIND 5: a launch without an FFT role — the drain — whose detect workgroups share the plan's list out in a loop)
   if (c->two_pass && a.list_loop) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 5>);
   if (c->two_pass) return c->diag.cols1024_wide ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 4>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 3>);
-  if (!c->use_fft8192 && a.n_fft && a.rows256.work) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 6>);  // (65536 points: the row tiles as the FFT role; rows of 2048 mask words: the wide emit role)
+  if (!c->use_fft8192 && a.n_fft && a.rows256.work && !a.n_rows) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 6>);  // (65536 points: the row tiles as the FFT role; rows of 2048 mask words: the wide emit role)
+  if (!c->use_fft8192 && c->merge) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 7>);  // (one launch per call: KIND 2's roles and the row tiles as one more; its drains too)
   if (!c->use_fft8192) return a.emit_per_wg == 1 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 2>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 1>);
 #ifdef SS_DIAG
   if (c->diag.fft_tw == 0) return go(ss::k_scan_step<FMT, SPEC, 0, false>);
@@ -861,7 +892,7 @@ struct FftRole {
 
 // fft / det / emit: null = role absent. Start/stop events ride on launches that carry an FFT role (the dominant work).
 void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n_det_tiles, bool spec, const ss::EmitArgs* emit, hipStream_t stream = nullptr,
-                 bool with_long_plan = false) {
+                 bool with_long_plan = false, const ss::Rows256Args* rows_role = nullptr, int n_rows = 0) {
   if (!stream) stream = c->stream;
 #ifdef SS_DIAG
   if (c->diag.ablate_roles & 1) det = nullptr;
@@ -914,6 +945,10 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   if (emit) {
     a.emit = *emit;
     a.n_emit = emit->nframes;
+  }
+  if (rows_role && n_rows > 0) {  // one launch per call (KIND 7): the row half of the call before beside this call's column half
+    a.rows256 = *rows_role;
+    a.n_rows = n_rows;
   }
   if (with_long_plan && c->have_plan) {  // 65536 points: the plan of the call before as a role of this (column) launch
     a.plan_det = c->pend_plan_det;
@@ -1107,6 +1142,22 @@ void shift_pending(ss_ctx* c) {
     c->pend_det_emit = c->pend_det2_emit;
     c->have_det2 = false;
   }
+  // one launch per call: the row stage that waited has run — the detect stage behind it waits for its plan now, and that plan is ready
+  if (c->have_det3) {
+    c->have_det2 = true;
+    c->pend_det2 = c->pend_det3;
+    c->pend_det2_tiles = c->pend_det3_tiles;
+    c->pend_det2_spec = c->pend_det3_spec;
+    c->pend_det2_emit = c->pend_det3_emit;
+    c->have_det3 = false;
+  }
+  if (c->have_plan2) {  // (launch_step took the ready plan, if there was one)
+    c->have_plan = true;
+    c->pend_plan = c->pend_plan2;
+    c->pend_plan_det = c->pend_plan2_det;
+    c->have_plan2 = false;
+  }
+  c->have_rows = false;
 }
 
 // Drain the deferred stages: detect (+ the emit stage before it), then the last emit. Nothing is synchronised.
@@ -1115,7 +1166,17 @@ void flush_stages(ss_ctx* c) {
     if (c->deep_L > 0 || !c->pd.empty() || !c->pe.empty()) ++c->stats.drains;
     return drain_deep(c);
   }
-  if (c->have_det || c->have_det2 || c->have_emit) ++c->stats.drains;
+  if (c->have_det || c->have_det2 || c->have_det3 || c->have_emit || c->have_rows) ++c->stats.drains;
+  if (c->have_rows || c->have_plan2 || c->have_det3) {
+    // one launch per call (KIND 7): row stage, ready plan, planned detect stage and emit stage of four different calls per launch until
+    // nothing waits (a plan is a ROLE of these launches: a launch boundary orders it ahead of the detect stage it plans)
+    while (c->have_rows || c->have_plan || c->have_plan2 || c->have_det || c->have_det2 || c->have_det3 || c->have_emit) {
+      launch_step(c, nullptr, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr, nullptr, true,
+                  c->have_rows ? &c->pend_rows : nullptr, c->have_rows ? c->pend_rows_tiles : 0);
+      shift_pending(c);
+    }
+    return;
+  }
   launch_pending_plan(c);  // (the detect stage that waits reads its list)
   while (c->have_det || c->have_det2 || c->have_emit) {
     launch_step(c, nullptr, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
@@ -1283,14 +1344,15 @@ RingPlace place_ring(ss_ctx* c, int nframes) {
   const int n = c->n;
   constexpr int H = kHistRows;
   // (the decision is ring_place.h's — a function of five integers that tests/host/ring_check.cpp runs on the CPU; here its consequences)
-  const ss::RingDecision d = ss::ring_place_decide(c->hist_start, c->hist_prev, c->hist_rows, nframes, H, c->cull_long);
+  const ss::RingPrev prevs[2] = {c->hist_prev, c->hist_prev2};
+  const ss::RingDecision d = ss::ring_place_decide(c->hist_start, prevs, c->merge ? 2 : 1, c->hist_rows, nframes, H, c->cull_long);
   if (d.shift_first) {  // (stream order: a deferred detect stage that still reads or writes this window goes first)
     flush_stages(c);
     if (c->hist_start != 0)
       hipLaunchKernelGGL(ss::k_hist_shift, dim3(grid_for((size_t)H * n, 256)), dim3(256), 0, c->stream,
                          (const float*)(c->d_hist + (size_t)c->hist_start * n), c->d_hist, n, H, 0);
     c->hist_start = 0;
-    c->hist_prev = ss::RingPrev{0, -1, 0};
+    c->hist_prev = c->hist_prev2 = ss::RingPrev{0, -1, 0};
   }
   RingPlace r{};
   r.in = c->d_hist + (size_t)d.in * n;
@@ -1381,6 +1443,7 @@ int run_backend_fused(ss_ctx* c, const float* d_psd, int nframes, int n_learn, N
   c->buf_cur = (b + 1) % c->nbuf;
   c->last_avg = ea.avg;
   c->last_hist = hist_in;
+  c->hist_prev2 = c->hist_prev;
   c->hist_prev = ss::RingPrev{c->hist_start, c->cull_long ? ring.batch_row : -1, nframes};  // (what this call's detect stage reads: ring_place.h)
   c->hist_start = next_start;
   c->last_n_learn = n_learn;
@@ -1754,7 +1817,21 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     const bool reused = (c->have_det && clashes(c->pend_det, c->pend_det_emit)) || (c->have_det2 && clashes(c->pend_det2, c->pend_det2_emit));
     if (!overlap || reused) flush_stages(c);
     const bool rows_by_step = (c->two_pass && c->diag.cols1024_wide) || c->rows256_step;
-    if (c->rows256_step) {
+    // one launch per call (SS_MERGE_65536): calls that keep no dB plane, in one piece, with stages allowed to overlap; any other call
+    // drains what waits in that form and goes the two-launch way
+    // (up to 128 frames: two 64 MiB work buffers in flight are what the Infinity Cache holds beside the rest — 256-frame calls lose a tenth
+    // this way and have two rounds of workgroups per launch anyway, profiles/r04/s34_summary.txt)
+    const bool merged_call = c->merge && c->rows256_step && overlap && ring_only && !spec && nframes <= c->diag.merge_max_frames;
+    if (c->merge && !merged_call && (c->have_rows || c->have_plan2 || c->have_det3)) flush_stages(c);
+    if (merged_call) {
+      ss::ColsArgs gcm = gc;
+      gcm.work = c->work_cur ? c->d_work2 : c->d_work;
+      FftRole crole;
+      crole.cols = &gcm;
+      crole.n = nframes * (c->n >> 13);
+      launch_step(c, &crole, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr, nullptr, true,
+                  c->have_rows ? &c->pend_rows : nullptr, c->have_rows ? c->pend_rows_tiles : 0);
+    } else if (c->rows256_step) {
       // 65536 points with tile culling: both halves of the FFT as FFT roles of k_scan_step, the deferred stages shared out between
       // them — the column launch of call k carries the plan of call k - 1 (which of its tiles the detect stage must evaluate) and
       // emit(k - 2), the row launch right behind it detect(k - 1) on the tiles that plan listed. (All of them on the row launch:
@@ -1822,6 +1899,13 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     } else
     launch_step(c, &role, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     shift_pending(c);
+    if (merged_call) {  // this call's row half waits for the next launch; it reads the work buffer this call's column half has just been told to fill
+      c->pend_rows = rows256_args(c, nullptr, rx);
+      c->pend_rows.work = c->work_cur ? c->d_work2 : c->d_work;
+      c->pend_rows_tiles = nframes * 8;
+      c->have_rows = true;
+      c->work_cur ^= 1;
+    }
     if (!c->use_fft8192 && !rows_by_step) {
       st = launch_fft_rows(c, nframes, ring_only ? nullptr : d_psd, rx);
       if (st != SS_OK) return st;
@@ -1836,11 +1920,15 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       if (c->cull || c->cull_long) hipLaunchKernelGGL(ss::k_thr_tilemin, dim3(c->n / 256), dim3(64), 0, c->stream, (const float*)z->d_thr, c->n, z->d_thr + c->n);
     }
     // (det_lag2: this call's detect stage waits for its plan, behind the planned one — which, if there is one, rode on this call's column launch)
-    ss::DetectArgs& nd = c->det_lag2 ? c->pend_det2 : c->pend_det;
+    ss::DetectArgs& nd = merged_call ? c->pend_det3 : c->det_lag2 ? c->pend_det2 : c->pend_det;
     st = run_backend_fused(c, d_psd, nframes, n_learn, z, c->spec_in_detect ? spec : nullptr, d_rel_out, d_avg_out, d_cand_off, d_cand_idx, d_cand_avg,
-                           cand_cap, true, &nd, c->det_lag2 ? &c->pend_det2_tiles : &c->pend_det_tiles, c->det_lag2 ? &c->pend_det2_emit : &c->pend_det_emit);
+                           cand_cap, true, &nd, merged_call ? &c->pend_det3_tiles : c->det_lag2 ? &c->pend_det2_tiles : &c->pend_det_tiles,
+                           merged_call ? &c->pend_det3_emit : c->det_lag2 ? &c->pend_det2_emit : &c->pend_det_emit);
     if (st != SS_OK) return st;
-    if (c->det_lag2) {
+    if (merged_call) {
+      c->have_det3 = true;
+      c->pend_det3_spec = false;
+    } else if (c->det_lag2) {
       c->have_det2 = true;
       c->pend_det2_spec = c->spec_in_detect && spec != nullptr;
     } else {
@@ -1871,7 +1959,11 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         pl.logn = c->logn;
         pl.list = list;
         pl.layout = c->two_pass ? 1 : 0;
-        if (plan_fused) {
+        if (merged_call) {  // (not ready before this call's row half has run: one launch from now)
+          c->have_plan2 = true;
+          c->pend_plan2 = pl;
+          c->pend_plan2_det = ss::plan_long_det(nd);
+        } else if (plan_fused) {
           c->have_plan = true;
           c->pend_plan = pl;
           c->pend_plan_det = ss::plan_long_det(nd);
@@ -2013,6 +2105,7 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_zero_row);
   (void)hipFree(c->d_win1024);
   (void)hipFree(c->d_wtab1024);
+  (void)hipFree(c->d_work2);
   (void)hipFree(c->d_tw_sub);
   (void)hipFree(c->d_tw_small);
   (void)hipFree(c->d_tw_rowsR);
@@ -2175,9 +2268,10 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   // buffers are sized: two more sets than launches in order need
   c->det_lag2 = !c->deep && c->step_path && n == 65536 && !c->diag.fft_generic && c->diag.cull_65536 && c->diag.cull && !(cfg->flags & SS_FLAG_NO_CULL) &&
                 c->diag.rows256_step && c->diag.step_long && c->diag.det_lag2 && c->fused;
+  c->merge = c->det_lag2 && c->diag.merge_65536 && c->diag.emit_wide;  // (one launch per call: scan_step.h KIND 7, whose emit role is the wide one)
   c->lag = c->deep ? c->nq : (c->det_lag2 ? 2 : 1);
-  c->ncnt = c->deep ? 3 * c->nq : (c->det_lag2 ? 6 : 3);
-  c->nbuf = c->deep ? 2 * c->nq : (c->det_lag2 ? 4 : (c->step_path ? 2 : 1));
+  c->ncnt = c->deep ? 3 * c->nq : (c->merge ? 8 : c->det_lag2 ? 6 : 3);
+  c->nbuf = c->deep ? 2 * c->nq : (c->merge ? 6 : c->det_lag2 ? 4 : (c->step_path ? 2 : 1));
   c->npsd = c->deep ? 2 * c->nq : (c->step_path ? 2 : 1);  // (deep: written by launch L, read by launch L + nq, written again by launch L + 2 nq on the same queue)
   if (c->fused) {
     {
@@ -2192,6 +2286,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       // (long transforms, whose rows kernel may write ALL of a batch's rows into this buffer: three batches and the averager's reach,
       // so that a batch can go back to the front of the buffer while the one before it is still to be read — ring_place.h)
       if (n >= 65536 && c->step_path && rows < 3ll * cfg->max_batch + 3 * kHistRows) rows = 3ll * cfg->max_batch + 3 * kHistRows;
+      if (c->merge && rows < 4ll * (cfg->max_batch + kHistRows)) rows = 4ll * (cfg->max_batch + kHistRows);  // (two spans to protect: ring_place.h)
       c->hist_rows = (int)rows;
       CREATE_HIP(hipMalloc(&c->d_hist, sizeof(float) * (size_t)n * (size_t)rows));
       CREATE_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(float) * (size_t)n * (size_t)kHistRows, c->stream));  // Averager ctor, averager.cpp:7-12
@@ -2243,6 +2338,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     CREATE_HIP(hipGetDeviceProperties(&prop, cfg->device_id));
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const size_t max_items = (size_t)(cfg->max_batch + kHistRows) * (size_t)(n / 8192) + ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256) / 2 + (size_t)cfg->max_batch + 4 +
+                             (n >= 65536 ? (size_t)cfg->max_batch * (size_t)(n / 8192) + 512 : 0) +  // (one launch per call: the row tiles of the call before, the plan workgroups)
                              (size_t)ss::kLiveLists * (ss::kLiveCap / 2 + 1);  // (a planned detect stage without an FFT role: 256 consumers per list, + the plan workgroups)
     c->order_capacity = max_items;
     c->order_tables.resize(16);
@@ -2271,6 +2367,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     }
   }
   if (c->logn > 13) CREATE_HIP(hipMalloc(&c->d_work, sizeof(float2) * (size_t)n * (size_t)cfg->max_batch));
+  if (c->merge) CREATE_HIP(hipMalloc(&c->d_work2, sizeof(float2) * (size_t)n * (size_t)cfg->max_batch));
 
   // window: caller's taps or gr::fft::window::hamming(N) (sdr_device.cpp:164; GNU Radio's definition:
   // 0.54 - 0.46*cos(2*pi*n/(N-1)) in double, stored as float). Twiddles W_N^k from double.
@@ -2701,7 +2798,7 @@ int ss_reset(ss_ctx* c) {  // Transmission::resetBuffers -> Averager::reset: row
   const int G = c->cfg.grouping_y;
   if (c->fused) {
     c->hist_start = 0;
-    c->hist_prev = ss::RingPrev{0, -1, 0};
+    c->hist_prev = c->hist_prev2 = ss::RingPrev{0, -1, 0};
     SS_HIP(c, hipMemsetAsync(c->d_hist, 0, sizeof(float) * (size_t)c->n * (size_t)kHistRows, c->stream));
   } else if (G > 1) {
     SS_HIP(c, hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)c->n * (size_t)(G - 1), c->stream));

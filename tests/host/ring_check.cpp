@@ -23,19 +23,20 @@ int main() {
   std::mt19937 rng(12345);
   for (int trial = 0; trial < 6000; ++trial) {
     const bool whole = trial & 1;
+    const int nprev = 1 + ((trial >> 1) & 1);  // (two spans to protect: the chain whose detect stage rides one launch later still)
     const int max_batch = 1 + (int)(rng() % 300);
     int rows = 3 * H + (int)(rng() % (12 * H));
-    if (whole && (rng() & 1) && rows < 3 * max_batch + 3 * H) rows = 3 * max_batch + 3 * H;  // (ss_create's size for long transforms; the other half: smaller)
+    if (whole && (rng() & 1) && rows < (2 + nprev) * (max_batch + H)) rows = (2 + nprev) * (max_batch + H);  // (ss_create's size for long transforms; the other half: smaller)
     int start = 0;
-    ss::RingPrev prev{0, -1, 0};
+    ss::RingPrev prev[2] = {{0, -1, 0}, {0, -1, 0}};
     const int fixed = (rng() % 3) ? 0 : 1 + (int)(rng() % max_batch);  // (a third of the streams: every call the same size)
     for (int call = 0; call < 200; ++call) {
       const int nframes = fixed ? fixed : 1 + (int)(rng() % max_batch);
-      const ss::RingDecision d = ss::ring_place_decide(start, prev, rows, nframes, H, whole);
+      const ss::RingDecision d = ss::ring_place_decide(start, prev, nprev, rows, nframes, H, whole);
       ++calls;
       if (d.shift_first) {
         ++shifts;
-        prev = ss::RingPrev{0, -1, 0};
+        prev[0] = prev[1] = ss::RingPrev{0, -1, 0};
         if (d.in != 0) ++bad;
       } else if (d.in != start) {
         ++bad;
@@ -43,35 +44,39 @@ int main() {
       if (d.write_lo < 0 || d.write_hi > rows || d.write_lo >= d.write_hi) ++bad;
       if (d.in < 0 || d.in + H > rows || d.next_start < 0 || d.next_start + H > rows) ++bad;
       if (overlap(d.write_lo, d.write_hi, d.in, d.in + H)) ++bad;  // its own window
-      if (prev.n > 0) {
-        if (overlap(d.write_lo, d.write_hi, prev.start, prev.start + H)) ++bad;
-        if (prev.batch >= 0 && overlap(d.write_lo, d.write_hi, prev.batch, prev.batch + prev.n)) ++bad;
-      }
+      for (int k = 0; k < nprev; ++k)
+        if (prev[k].n > 0) {
+          if (overlap(d.write_lo, d.write_hi, prev[k].start, prev[k].start + H)) ++bad;
+          if (prev[k].batch >= 0 && overlap(d.write_lo, d.write_hi, prev[k].batch, prev[k].batch + prev[k].n)) ++bad;
+        }
       // the next window is made of the newest rows: the batch's last H, or the old window's tail and the appended rows
       if (nframes >= H && d.batch >= 0 && (d.next_start != d.batch + nframes - H || d.write_lo != d.batch || d.write_hi != d.batch + nframes)) ++bad;
       if (nframes < H && (d.next_start != d.in + nframes || d.batch != d.in + H || d.write_lo != d.in + H || d.write_hi != d.in + H + nframes)) ++bad;
       if (nframes >= H && d.batch < 0 && (d.write_lo != d.next_start || d.write_hi != d.next_start + H)) ++bad;
       if (nframes >= H && d.batch == 0 && !d.shift_first && start != 0) ++wraps;
-      prev = ss::RingPrev{d.in, whole ? d.batch : -1, nframes};
+      prev[1] = prev[0];
+      prev[0] = ss::RingPrev{d.in, whole ? d.batch : -1, nframes};
       start = d.next_start;
     }
   }
   // with the library's sizing a stream of largest batches never drains: the region goes round the buffer
-  for (int max_batch : {35, 48, 64, 100, 128, 200, 512}) {
-    const int rows = 3 * max_batch + 3 * H;
-    int start = 0, drains = 0;
-    ss::RingPrev prev{0, -1, 0};
-    for (int call = 0; call < 200; ++call) {
-      const ss::RingDecision d = ss::ring_place_decide(start, prev, rows, max_batch, H, true);
-      drains += d.shift_first ? 1 : 0;
-      prev = d.shift_first ? ss::RingPrev{0, d.batch, max_batch} : ss::RingPrev{d.in, d.batch, max_batch};
-      start = d.next_start;
+  for (int nprev : {1, 2})
+    for (int max_batch : {35, 48, 64, 100, 128, 200, 512}) {
+      const int rows = (2 + nprev) * (max_batch + H);
+      int start = 0, drains = 0;
+      ss::RingPrev prev[2] = {{0, -1, 0}, {0, -1, 0}};
+      for (int call = 0; call < 200; ++call) {
+        const ss::RingDecision d = ss::ring_place_decide(start, prev, nprev, rows, max_batch, H, true);
+        drains += d.shift_first ? 1 : 0;
+        prev[1] = d.shift_first ? ss::RingPrev{0, -1, 0} : prev[0];
+        prev[0] = ss::RingPrev{d.in, d.batch, max_batch};
+        start = d.next_start;
+      }
+      if (drains) {
+        printf("%d spans, max_batch %d: %d drains\n", nprev, max_batch, drains);
+        ++bad;
+      }
     }
-    if (drains) {
-      printf("max_batch %d: %d drains\n", max_batch, drains);
-      ++bad;
-    }
-  }
   printf("%lld calls, %lld drains, %lld returns to the front; bad %d\n", calls, shifts, wraps, bad);
   return bad ? 1 : 0;
 }

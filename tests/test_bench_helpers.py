@@ -38,7 +38,9 @@ def test_chain_kernels_and_their_bytes():
     assert [k[0] for k in b.chain_kernels(8192, "cf32")] == ["step"] and b.chain_kernels(8192, "cf32")[0][3] == 12.0
     assert b.chain_kernels(8192, "cs8")[0][3] == 6.0
     k3 = {k[0]: k[3] for k in b.chain_kernels(65536, "cs8")}
-    assert k3 == {"step": 10.0, "rows": 12.0, "plan": 0.0}  # columns: int8 in + work buffer out; rows: work in + dB out
+    assert k3 == {"step": 22.0}  # one launch per call: columns (int8 in + work buffer out) and rows (work in + dB out)
+    k3 = {k[0]: k[3] for k in b.chain_kernels(65536, "cs8", 256)}
+    assert k3 == {"step": 10.0, "rows": 12.0, "plan": 0.0}  # calls of more than 128 frames: two launches
     k5 = {k[0]: k[3] for k in b.chain_kernels(1 << 20, "cf32")}
     assert k5 == {"step": 16.0, "rows": 12.0, "plan": 0.0}  # 2^20 points in two passes: column half (a launch of its own), row half (k_scan_step's FFT role), plan
     os.environ["SS_FFT_TWOPASS"] = "0"  # (a switch of the diagnostics build: round 3's three passes)

@@ -235,6 +235,8 @@ def test_long_rows_device_calls_without_sync_culled_equal_unculled(cull_65536, n
 # the forms the 65536- and 2^20-point chains went through in round 4 (switches of the diagnostics build): each of
 # them in detect mode with calls in flight, culled == unculled
 @pytest.mark.parametrize("env,n,fs,nb,ncalls", [
+    ({"SS_MERGE_65536": "0"}, 65536, 20_000_000, 128, 7),   # two launches per call (session 20's form; still what calls of more than 128 frames and calls that keep a plane take)
+    ({"SS_MERGE_65536": "0"}, 65536, 20_000_000, 48, 9),
     ({"SS_DET_LAG2": "0"}, 65536, 20_000_000, 128, 7),
     ({"SS_ROWS256_STEP": "0"}, 65536, 20_000_000, 128, 7),
     ({"SS_LIST_FIRST": "0", "SS_EMIT_ON_ROWS": "1"}, 65536, 20_000_000, 48, 9),

@@ -114,6 +114,7 @@ ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurem
     ({"SS_CULL_65536": "0"}, 65536, 20_000_000, "cs8"),     # 65536 points as until session 19 of round 4: every tile evaluated, columns as the FFT role with all passengers
     ({"SS_ROWS256_STEP": "0", "SS_WIN_CALC": "0"}, 65536, 20_000_000, "cs8"),  # ... culled, rows and plan as launches of their own
     ({"SS_DET_LAG2": "0"}, 65536, 20_000_000, "cs8"),       # ... detect(k - 1) on the row launch
+    ({"SS_MERGE_65536": "0"}, 65536, 20_000_000, "cs8"),    # ... two launches per call also for detect-mode calls of up to 128 frames
     ({"SS_EMIT_ON_ROWS": "1", "SS_LIST_FIRST": "0"}, 65536, 20_000_000, "cf32"),
     ({"SS_PLAN_FIRST": "32"}, 8192, 2_048_000, "cf32"),     # 8192 points: the first pairs of every list on detect workgroups of their own
 ]
