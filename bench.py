@@ -269,7 +269,7 @@ def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False):
 # ---------------------------------------------------------------------------------------------- launcher
 PMC_FILES = {"fetch": "pmc_fetch.csv", "write": "pmc_write.csv"}  # under profiles/<PMC_SET>/, one counter per rocprofv3 pass
 # the committed passes of each configuration's command line on the final tree of round 4 (scripts/r04/s8.sh)
-PMC_SET = {2: "r04/s8_cfg2", 3: "r04/s30_cfg3", 5: "r04/s30_cfg5"}  # (config 2's kernel has not changed its traffic since; its default line measures it live: live_pmc_traffic)
+PMC_SET = {2: "r04/s8_cfg2", 3: "r04/s38_cfg3", 5: "r04/s38_cfg5"}  # (config 2's kernel has not changed its traffic since; its default line measures it live: live_pmc_traffic)
 
 
 def traffic_from_profiles(config: int, kernel_match: str, threads_per_launch: int | None = None):

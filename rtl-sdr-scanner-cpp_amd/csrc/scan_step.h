@@ -31,10 +31,13 @@
 //
 // Transforms of 16384 points and more are four-step (fft256_kernels.h): their column half — tiles of 32 columns x 256 rows,
 // one per 512-thread workgroup — takes the FFT role's place (KIND 1, 2), the row half follows as a launch of its own, and
-// the deferred stages ride on the column launch in the same way. 65536 points (what ships since round 4): the row half is an FFT
-// role too (KIND 6, a launch that carries nothing else), and the column launch of call k carries the PLAN of call k - 1 (which of
-// its averaging tiles can hold a candidate: ROLE_PLAN, two blocks of k_plan_long's numbering per workgroup), detect(k - 2) on the
-// tiles its plan listed and emit(k - 3): every deferred stage rides on the longer of a call's two launches, ahead of its tiles.
+// the deferred stages ride on the column launch in the same way. 65536 points (what ships since round 4): a detect-mode call of up
+// to 128 frames is ONE launch (KIND 7) — the column tiles of call k (the FFT role) and, dispatched behind them, the row tiles of
+// call k - 1 (ROLE_ROWS, from the other of two work buffers), with the PLAN of call k - 2 (which of its averaging tiles can hold a
+// candidate: ROLE_PLAN, two blocks of k_plan_long's numbering per workgroup), detect(k - 3) on the tiles its plan listed and
+// emit(k - 4) ahead of both: two rounds of workgroups whose phases overlap. Longer calls and calls that keep a plane take two
+// launches: the column launch of call k with the plan of call k - 1, detect(k - 2) and emit(k - 3), and the row half as the FFT role
+// of a launch of its own (KIND 6) that carries nothing else.
 // 2^20 points: 1024 x 1024 in two passes (fft1024_kernels.h) — the column half is a kernel of its own (1024 threads; the plan of the
 // call before runs in its first workgroups), the row half the FFT role here (KIND 4) with detect(k - 1) and emit(k - 2) riding on it.
 //

@@ -56,8 +56,8 @@ def test_traffic_from_the_committed_pmc_passes():
     step = b.traffic_from_profiles(2, "k_scan_step", (1024 + 20 + 128 + 4) * 512)
     assert step and 100.66e6 < step["bytes_per_launch"] < 1.35 * 100.66e6, step  # the review's mark: <= 1.35 x the algorithmic 100.66 MB
     assert b.traffic_from_profiles(2, "k_scan_step", 12345) is None  # no launch of that shape
-    # config 3 as it ships (culled): the column launch (+ 128 plan, 128 emit and 64 detect workgroups) and the row launch, both k_scan_step
-    c3 = sum(b.traffic_from_profiles(3, m, s)["bytes_per_launch"] for m, s in (("k_scan_step", (128 * 8 + 128 + 128 + 64) * 512), ("k_scan_step", 128 * 8 * 512)))
+    # config 3 as it ships (culled, one launch per call): 1024 column tiles, 1024 row tiles, 128 plan, 128 emit and 64 detect workgroups
+    c3 = b.traffic_from_profiles(3, "k_scan_step", (128 * 16 + 128 + 128 + 64) * 512)["bytes_per_launch"]
     # config 5 in two passes: column half (the plan of the call before at its front), row half (+ the deferred stages riding on it)
     c5 = sum(b.traffic_from_profiles(5, m, s)["bytes_per_launch"]
              for m, s in (("k_fft_cols1024", (16 * 64 + 128) * 1024), ("k_scan_step", (16 * 128 + 16 + 64) * 512)))
