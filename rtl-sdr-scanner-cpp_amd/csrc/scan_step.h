@@ -159,6 +159,12 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
   // as it is known; the plan this workgroup makes (-1: none) — its own as a plan workgroup, or its list's when it has waited for
   // the plan workgroup in vain (detect_fused.h: nothing in a launch waits without bound)
   int consumer = -1, word = 0, plan_seg = -1;
+  if constexpr (KIND == 7) {  // (only this instantiation knows the role: the others keep their registers)
+    if (role == ROLE_ROWS) {
+      fft_rows256_tile(a.rows256, item, smem_raw, tid);  // the row half of the call before: its column half ran in the launch before
+      return;
+    }
+  }
   if (role == ROLE_EMIT) {
     if constexpr (KIND >= 2) {
       // ---- emit role, long rows: the eight waves share one frame ----
@@ -203,9 +209,6 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       tile_a = 2 * item;
       tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;
     }
-  } else if (role == ROLE_ROWS) {
-    if constexpr (KIND == 7) fft_rows256_tile(a.rows256, item, smem_raw, tid);  // (the row half of the call before: its column half ran in the launch before)
-    return;
   } else if (role == ROLE_PLAN) {
     if constexpr (KIND == 1 || KIND == 2 || KIND == 7) {  // a long transform's plan: two blocks of k_plan_long's numbering
       const int sub = tid >> 8;
