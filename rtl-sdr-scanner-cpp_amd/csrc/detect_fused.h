@@ -482,7 +482,9 @@ struct PlanLongArgs {
   int logn;
   int* list;
   // 0: the ring holds dB values where k_fft_rows256_psd puts them (rows_smax_index); 1: 2^20 points in two passes
-  // (fft1024_kernels.h): max_key values at rows1024_smax_index(run) — [k1 group][k2], gathered by atomic maxima
+  // (fft1024_kernels.h): max_key values at rows1024_smax_index(run) — [k1 group][k2], gathered by atomic maxima;
+  // 2: 65536 points by the radix-8 fold (fft65536_dif8.h): value g of tile column c is the largest dB value among the column's bins
+  // of residue g, at [g][c] — a column's neighbours then count with all eight of their values, not with their nearest run
   int layout;
 };
 constexpr int kPlanLongFloats = 8192;  // LDS of a plan workgroup: C x (16 nft + 20) values of M
@@ -503,7 +505,10 @@ __host__ __device__ inline int plan_long_cols(int nframes, int shift, int tile_c
 // layout 1 — the columns 4 k2 + wc for k2 = d0 .. d0 + C, the 32 / C workgroups whose columns share the 128-byte lines of a frame's row
 // of the ring in consecutive slots of ONE XCD (block b runs on XCD b mod 8)
 __host__ __device__ inline void plan_long_block(int layout, int block, int C, int lognsub, int* wc, int* d0) {
-  if (layout) {
+  if (layout == 2) {  // C consecutive columns (consecutive floats of each of the eight residue rows)
+    *wc = 0;
+    *d0 = block * C;
+  } else if (layout) {
     const int M = (C <= 32 && (32 % C) == 0) ? 32 / C : 1;
     const int xcd = block & 7, slot = block >> 3;
     *wc = xcd & 3;
@@ -514,7 +519,7 @@ __host__ __device__ inline void plan_long_block(int layout, int block, int C, in
   }
 }
 __host__ __device__ inline int plan_long_blocks(int layout, int C, int n) {  // workgroups of the plan launch
-  if (!layout) return (n >> 16) * ((256 + C - 1) / C);
+  if (!layout || layout == 2) return (n >> 16) * ((256 + C - 1) / C);
   const int line_groups = (C <= 32 && 32 % C == 0) ? 32 / C : 1;
   return 4 * ((((1024 + C - 1) / C + 2 * line_groups - 1) / (2 * line_groups)) * (2 * line_groups));
 }
@@ -568,6 +573,7 @@ __device__ __forceinline__ void plan_long_run(const PlanLongDet& a, const PlanLo
   int wc, d0;
   plan_long_block(p.layout, block_no, C, lognsub, &wc, &d0);
   const auto column = [&](int i) {
+    if (p.layout == 2) return d0 + i < 256 ? d0 + i : tiles_per_row;
     if (p.layout) return d0 + i < 1024 ? 4 * (d0 + i) + wc : tiles_per_row;
     return d0 + i < 256 ? (wc + ((d0 + i) << lognsub)) ^ (tiles_per_row >> 1) : tiles_per_row;
   };
@@ -579,7 +585,17 @@ __device__ __forceinline__ void plan_long_run(const PlanLongDet& a, const PlanLo
       const float* row = p.smax + ((size_t)((p.abs0 + frame) & p.smax_mask) * groups);
       // the column's eight runs, the last run of the column below and the first of the one above (the band's edges: its own once more)
       float v[10];
-      if (p.layout) {
+      if (p.layout == 2) {
+        float lo = -__builtin_inff(), hi = -__builtin_inff();  // (this layout's values never hold a NaN: fft8192_v2.h takes the maxima with fmaxf)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          v[g] = row[256 * g + col];
+          lo = fmaxf(lo, row[256 * g + (col > 0 ? col - 1 : col)]);
+          hi = fmaxf(hi, row[256 * g + (col + 1 < tiles_per_row ? col + 1 : col)]);
+        }
+        v[8] = lo;
+        v[9] = hi;
+      } else if (p.layout) {
         const unsigned* krow = reinterpret_cast<const unsigned*>(row);
 #pragma unroll
         for (int g = 0; g < 8; ++g) v[g] = max_key_value(krow[rows1024_smax_index(8 * col + g)]);
@@ -699,7 +715,11 @@ __host__ __device__ inline int plan_fused_wgs(int plan_blocks) { return (((plan_
 // `tile` / `cnt` = this tile's LDS (TF * P floats, TF ints). `valid` = false: the caller has no tile for these threads (odd
 // tile count in a two-tile workgroup) — they only keep the workgroup's barriers company. Every __syncthreads() below is
 // reached by all threads of the workgroup whatever `valid`, `steady` or `interior` are.
-template <int G, int GX, int TF, int TB_ = 256, bool SPEC = false>
+// PERM8: the rows the tile reads (a.psd, the ring) and writes (the ring) are RESIDUE-MAJOR rows of 65536 bins — bin i at
+// (i & 7) * 8192 + (i >> 3), fft65536_dif8.h: the rows the radix-8 fold leaves; calls that hand out no plane only (no rel_out). A lane's
+// 36 row loads then sit in eight runs of 32 bytes per wave instead of one of 256; everything else — the noise ceiling, the pass mask,
+// mask bits, sparse averages — stays in bin order.
+template <int G, int GX, int TF, int TB_ = 256, bool SPEC = false, bool PERM8 = false>
 __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int tid, float* __restrict__ tile, int* __restrict__ cnt, bool valid) {
   using T = DetectTile<G, GX, TF, TB_>;
   constexpr int A = T::A, TB = T::TB, P = T::P, ROWS = T::ROWS, H = T::H, SEGW = T::SEGW, NSEG = T::NSEG, YW = T::YW;
@@ -743,7 +763,7 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
         const float t = a.thr[colc];
         // block-uniform row base (scalar registers) + one 32-bit per-thread byte offset
         const char* p = reinterpret_cast<const char*>(a.psd + (size_t)(f0 - (G - 1)) * n);
-        const uint32_t coff = (uint32_t)colc * 4u;
+        const uint32_t coff = (uint32_t)(PERM8 ? dif8_bin_offset(colc) : colc) * 4u;
         float x[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) x[r] = load_row_value(p + (size_t)r * n * 4 + coff) - t;
@@ -785,7 +805,7 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
         // all loads first, unconditional, on always-legal addresses: independent and in flight together; a
         // branch around each load would serialise them on s_waitcnt. The row pointer is block-uniform:
         // frames before the batch come from the ring (row H + frame), frames past its end are clamped.
-        const uint32_t coff = (uint32_t)col * 4u;
+        const uint32_t coff = (uint32_t)(PERM8 ? dif8_bin_offset(col) : col) * 4u;
         float x[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {

@@ -1,0 +1,287 @@
+// fft65536_dif8.h — N = 65536 without a work buffer: a radix-8 decimation-in-frequency step folded into the load stage of the
+// 8192-point transform (BASELINE.json config 3: 65536 points, 20 MS/s, int8 IQ).
+//
+// Same contract as the other front ends (Decimator + fft_v(Hamming, forward, shift) + PSD::work: reference
+// sources/radio/blocks/decimator.h:15-22, sources/radio/sdr_device.cpp:164, sources/radio/blocks/psd.cpp:18-20). With
+// N = 65536, m = n + 8192 q (n < 8192, q < 8) and k = 8 k' + r:
+//
+//     X[8 k' + r] = sum_n W_8192^(n k') * y_r[n],      y_r[n] = W_N^(n r) * sum_q w[n + 8192 q] x[n + 8192 q] W_8^(q r)
+//
+// so EIGHT workgroups per frame — one per residue r — each fold the whole int8 frame (128 KiB, which the other seven read
+// from the same XCD's L2 at the same time) into the 8192 points y_r and run the 8192-point transform that ships for 8192-point
+// frames on them (fft8192_v2_frame, fft8192_v2.h). What the four-step form pays for (fft256_kernels.h: a CF32 work buffer of
+// 8 B/sample written by the column half and read back by the row half, 16 of the 25.9 B/sample a call moved over the fabric
+// in round 4) is gone; what this form pays instead is arithmetic: every workgroup converts and windows all 65536 samples of
+// its frame, ~10 vector instructions per sample on top of the transform's own.
+//
+// The workgroup's thread t holds, for the transform's first pass, y_r[t + 512 rho], rho < 16: 128 samples x[t + 512 (rho + 16 q)].
+// The fold is a LOOP over q (the code of a 128-sample straight line is 13 KiB, and this chip wants its hot code small:
+// profiles/README.md, ifetch2), q and q + 4 together — W_8^((q + 4) r) = (-1)^r W_8^(q r) — sixteen accumulators in registers:
+//     acc[rho] += W_8^(q r) * ( w[m] x[m] + (-1)^r w[m'] x[m'] ),      m = t + 512 rho + 8192 q,  m' = m + 32768
+// The Hamming taps are formed, not loaded (as the column tiles of the four-step form do, fft256_kernels.h): with
+// theta = 2 pi (t + 8192 q) / (N - 1) — one table entry per thread, rotated once per q — and Phi_rho = 2 pi 512 rho / (N - 1)
+//     w[t + 512 rho + 8192 q] = 0.54 + (-0.46 cos Phi_rho) cos theta + (0.46 sin Phi_rho) sin theta
+// — two FMAs per sample with literal constants. Behind the loop  a[rho] = acc[rho] * W_N^(t r) * W_128^(rho r)  (a per-thread table
+// entry and sixteen wave-uniform ones): sixteen vector instructions per pair of samples on top of the transform's own.
+//
+// The bins of residue r leave the transform in the order k' — X[8 k' + r], k' = 0 .. 8191 — and are stored that way: a frame's
+// row is RESIDUE-MAJOR, eight runs of 8192 floats, bin i (DC in the middle: fft_v's shift) at (i & 7) * 8192 + (i >> 3). (The
+// half rotation adds N/2 = 0 mod 8 to a bin number: it stays inside the residue and becomes the 8192-point transform's own half
+// rotation.) Whoever reads such rows — the detect tiles, ss_read_window — permutes the bin number; nothing is transposed.
+//
+// How the samples reach the threads: LOADV = 0 — 128 two-byte loads per thread straight from global memory (each wave-load is
+// one 128-byte line); LOADV = 1 — the frame comes through LDS in eight pieces of 16 KiB (eight values of rho x {q, q + 4}: sixteen
+// runs of 512 samples), fetched by LDS-DMA in 16-byte lanes (two 1 KiB wave-instructions per wave and piece, against 128
+// two-byte ones per thread) into the two halves of the exchange plane, which is idle until the transform's first exchange;
+// the piece of one half is fetched while the other half's is folded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft8192_kernel.h"
+
+namespace ss {
+
+struct Dif8Front {
+  const void* iq;          // the batch's frames, item_stride samples apart, 2 bytes per sample (CS8 / CU8)
+  long long item_stride;
+  const float2* wt;        // [8][512]  W_65536^(t r) times the input format's scale
+  const float2* wrho;      // [8][16]   W_128^(rho r)                                          (wave-uniform: scalar loads)
+  const float2* w8;        // [8][8]    W_8^(q r)                                              (wave-uniform: scalar loads)
+  const float2* wthe;      // [512]     (cos, sin)(2 pi t / 65535)
+  const float2* wq;        // [8]       (cos, sin)(2 pi 8192 q / 65535)                        (wave-uniform: scalar loads)
+  // What a residue leaves for the detect stage besides its row (the transform's own epilogue, fft8192_v2.h):
+  //   smax   the largest dB value of every 32-bin run of the residue's row — run j holds the bins 8 k' + r, k' in [32 j, 32 j + 32): the
+  //          bins of residue r of the 256-bin tile column j — at smax[(abs0 + frame) & smax_mask][r * 256 + j]: a ring over the frames
+  //          since the last reset, like the four-step form's (fft256_kernels.h RowsExtra::smax), in the layout the plan knows as 2
+  //          (detect_fused.h PlanLongArgs::layout). Null: no maxima.
+  float* smax;
+  int smax_mask, abs0;
+  int first_hist;          // frame f's row is row f - first_hist of Fft8192Args::psd (RowsExtra::first_hist; <= 0 here: every frame has a row)
+  int nframes;             // frames of the launch (the workgroup -> (frame, residue) map, dif8_item)
+  int* zero_word;          // set to zero by the first workgroup: the count of the list the plan behind this launch appends to (or null)
+};
+// Which (frame, residue) the j-th of a launch's 8 nframes fold workgroups takes. Workgroups go round the eight XCDs in dispatch
+// order, so — as long as the launch's fold workgroups are consecutive blocks — the eight residues of a frame are given 64
+// consecutive numbers of ONE residue class mod 8: one XCD, one L2, and the frame crosses the fabric once (measured,
+// scripts/ubench/dif8_lab: 19 MB of fetches per 128-frame launch against 135 MB with a frame's residues on eight XCDs).
+__host__ __device__ inline void dif8_item(int j, int nframes, int* frame, int* residue) {
+  const int full = nframes >> 3;
+  if (j < 64 * full) {
+    *residue = (j >> 3) & 7;
+    *frame = ((j >> 6) << 3) + (j & 7);
+  } else {  // the frames beyond the last whole group of eight: in turn
+    const int jj = j - 64 * full;
+    *residue = jj & 7;
+    *frame = 8 * full + (jj >> 3);
+  }
+}
+
+// (-0.46 cos Phi_rho, 0.46 sin Phi_rho), Phi_rho = 2 pi 512 rho / 65535, rounded from double
+__device__ constexpr float kDif8P[16] = {-0.46000000834465027f, -0.45944589376449585f, -0.4577849209308624f, -0.45502105355262756f, -0.4511609673500061f, -0.446213960647583f,
+                                         -0.44019195437431335f, -0.43310946226119995f, -0.42498353123664856f, -0.4158337414264679f, -0.40568214654922485f, -0.39455321431159973f,
+                                         -0.38247373700141907f, -0.36947280168533325f, -0.35558176040649414f, -0.3408340513706207f};
+__device__ constexpr float kDif8Q[16] = {0.0f, 0.022571474313735962f, 0.045088570564985275f, 0.06749703735113144f, 0.08974289894104004f, 0.1117725521326065f,
+                                         0.13353292644023895f, 0.15497159957885742f, 0.17603692412376404f, 0.19667814671993256f, 0.2168455421924591f, 0.23649051785469055f,
+                                         0.25556573271751404f, 0.2740252912044525f, 0.2918246388435364f, 0.3089209496974945f};
+
+constexpr int kDif8TableFloat2 = 8 * 512 + 8 * 16 + 8 * 8 + 512 + 8;
+// Host side: the five tables in one block (wt, wrho, w8, wthe, wq in this order), double precision rounded once; `scale` is what
+// load_iq multiplies the format's integers with.
+inline void dif8_host_tables(float2* tab, double scale) {
+  const double two_pi = 2.0 * 3.14159265358979323846;
+  float2 *wt = tab, *wrho = wt + 8 * 512, *w8 = wrho + 8 * 16, *wthe = w8 + 8 * 8, *wq = wthe + 512;
+  for (int r = 0; r < 8; ++r) {
+    for (int t = 0; t < 512; ++t) {
+      const double ang = -two_pi * (double)(t * r) / 65536.0;
+      wt[r * 512 + t] = make_float2((float)(scale * cos(ang)), (float)(scale * sin(ang)));
+    }
+    for (int rho = 0; rho < 16; ++rho) {
+      const double ang = -two_pi * (double)((rho * r) & 127) / 128.0;
+      wrho[r * 16 + rho] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    for (int q = 0; q < 8; ++q) {
+      // exact values for the multiples of a right angle, 0.70710678 for the others
+      const int k = (q * r) & 7;
+      const double ang = -two_pi * (double)k / 8.0;
+      const double c = (k & 1) ? cos(ang) : (k == 0 ? 1.0 : k == 4 ? -1.0 : 0.0), s_ = (k & 1) ? sin(ang) : (k == 2 ? -1.0 : k == 6 ? 1.0 : 0.0);
+      w8[r * 8 + q] = make_float2((float)c, (float)s_);
+    }
+  }
+  for (int t = 0; t < 512; ++t) {
+    const double th = two_pi * (double)t / 65535.0;
+    wthe[t] = make_float2((float)cos(th), (float)sin(th));
+  }
+  for (int q = 0; q < 8; ++q) {
+    const double ph = two_pi * 8192.0 * (double)q / 65535.0;
+    wq[q] = make_float2((float)cos(ph), (float)sin(ph));
+  }
+}
+inline Dif8Front dif8_front_of(const void* iq, long long item_stride, const float2* tab) {
+  Dif8Front d{};
+  d.iq = iq;
+  d.item_stride = item_stride;
+  d.wt = tab;
+  d.wrho = tab + 8 * 512;
+  d.w8 = d.wrho + 8 * 16;
+  d.wthe = d.w8 + 8 * 8;
+  d.wq = d.wthe + 512;
+  return d;
+}
+
+// bin i of a 65536-bin row (DC at 32768) in a residue-major row
+__host__ __device__ inline int dif8_bin_offset(int i) { return ((i & 7) << 13) + (i >> 3); }
+
+// `rows` rows of 65536 floats from bin order to residue-major order (to_perm8 != 0) or back; in and out are different memory.
+// (The averager ring's window when a context changes between the fold and the four-step form, the noise ceiling once per learning call.)
+__global__ void k_rows_perm8(const float* __restrict__ in, float* __restrict__ out, int rows, int to_perm8) {
+  const size_t total = (size_t)rows << 16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // i walks the residue-major side (whole lines there, 32-byte pieces on the other): position r * 8192 + k' holds bin 8 k' + r
+    const size_t bin_order = ((i >> 16) << 16) | (size_t)(((int)(i & 8191) << 3) | (int)((i >> 13) & 7));
+    if (to_perm8) out[i] = in[bin_order];
+    else out[bin_order] = in[i];
+  }
+}
+
+typedef const __attribute__((address_space(4))) float* dif8_const_fp;
+
+// re, im of one two-byte sample (re in byte 0, im in byte 1) as floats: CS8 two's complement, CU8 offset binary (minus 127.5,
+// sdr_device / SoapySDR's convention as load_iq has it). One instruction per component: the byte select and the sign extension
+// ride on the conversion (SDWA) — the compiler's own sequence is a bit-field extract or a 16-bit shift first.
+template <int FMT>
+__device__ __forceinline__ void dif8_convert(unsigned raw, float& re, float& im) {
+  if constexpr (FMT == FMT_CS8) {
+    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(re) : "v"(raw));
+    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(im) : "v"(raw));
+  } else {
+    re = (float)(raw & 0xff) - 127.5f;          // v_cvt_f32_ubyte0
+    im = (float)((raw >> 8) & 0xff) - 127.5f;   // v_cvt_f32_ubyte1
+  }
+}
+
+// The rotated table entries of one trip: (cos, sin)(theta_t + 2 pi 8192 q / 65535) for q and, times sg = (-1)^r, for q + 4
+struct Dif8Trip {
+  float c1, s1, c2, s2, k2;  // k2 = 0.54 sg
+  float w8c, w8s;            // W_8^(q r)
+};
+__device__ __forceinline__ Dif8Trip dif8_trip(float2 th, dif8_const_fp cq, dif8_const_fp c8, int q, float sg) {
+  Dif8Trip x;
+  const float qc1 = cq[2 * q], qs1 = cq[2 * q + 1], qc2 = cq[2 * q + 8] * sg, qs2 = cq[2 * q + 9] * sg;
+  x.c1 = fmaf(th.x, qc1, -(th.y * qs1));
+  x.s1 = fmaf(th.y, qc1, th.x * qs1);
+  x.c2 = fmaf(th.x, qc2, -(th.y * qs2));
+  x.s2 = fmaf(th.y, qc2, th.x * qs2);
+  x.k2 = 0.54f * sg;
+  x.w8c = c8[2 * q];
+  x.w8s = c8[2 * q + 1];
+  return x;
+}
+// two samples of run rho — q and q + 4 — into the run's accumulator
+template <int FMT>
+__device__ __forceinline__ void dif8_accumulate(float2& acc, unsigned raw1, unsigned raw2, const Dif8Trip& x, int rho) {
+  float re1, im1, re2, im2;
+  dif8_convert<FMT>(raw1, re1, im1);
+  dif8_convert<FMT>(raw2, re2, im2);
+  const float t1 = fmaf(x.c1, kDif8P[rho], fmaf(x.s1, kDif8Q[rho], 0.54f));
+  const float t2 = fmaf(x.c2, kDif8P[rho], fmaf(x.s2, kDif8Q[rho], x.k2));
+  const float ur = fmaf(t2, re2, t1 * re1), ui = fmaf(t2, im2, t1 * im1);  // volk_32fc_32f_multiply_32fc (the format's scale rides on wt)
+  acc.x = fmaf(ur, x.w8c, fmaf(-ui, x.w8s, acc.x));
+  acc.y = fmaf(ur, x.w8s, fmaf(ui, x.w8c, acc.y));
+}
+
+// The load stage: a[rho] = y_r[t + 512 rho] for the workgroup's residue r. `smem_raw`: the transform's exchange plane (32 KiB of it,
+// LOADV = 1 only). Every thread of the workgroup calls it (barriers inside for LOADV = 1). `after_first_issue()` is called once the
+// first fetches are on their way: the place for the caller's own table loads (they land behind the first pieces, which the fold
+// waits for anyway, and ahead of nothing).
+template <int FMT, int LOADV, class F>
+__device__ __forceinline__ void dif8_front(const Dif8Front& d, size_t frame_in, int residue, unsigned char* __restrict__ smem_raw, int t, float2 (&a)[16],
+                                           F&& after_first_issue) {
+  static_assert(FMT == FMT_CS8 || FMT == FMT_CU8, "two-byte samples");
+  const char* fb = reinterpret_cast<const char*>(d.iq) + frame_in * (size_t)d.item_stride * 2;
+  const __amdgpu_buffer_rsrc_t rin = buffer_of(fb, 65536 * 2);
+  const dif8_const_fp cq = (dif8_const_fp)(uintptr_t)d.wq;
+  const dif8_const_fp c8 = (dif8_const_fp)(uintptr_t)(d.w8 + residue * 8);
+  const dif8_const_fp crho = (dif8_const_fp)(uintptr_t)(d.wrho + residue * 16);
+  const float sg = (residue & 1) ? -1.0f : 1.0f;
+#pragma unroll
+  for (int rho = 0; rho < 16; ++rho) a[rho] = make_float2(0.f, 0.f);
+  if constexpr (LOADV == 0) {
+    after_first_issue();
+    const float2 th = d.wthe[t];
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      const Dif8Trip x = dif8_trip(th, cq, c8, q, sg);
+      const int so = 16384 * q;  // bytes: 8192 q samples
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        unsigned raw1[4], raw2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          raw1[i] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rin, t * 2 + 1024 * (4 * sub + i), so, SS_AUX_DIF_IQ);
+          raw2[i] = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rin, t * 2 + 1024 * (4 * sub + i) + 65536, so, SS_AUX_DIF_IQ);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dif8_accumulate<FMT>(a[4 * sub + i], raw1[i], raw2[i], x, 4 * sub + i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = t & 63;
+    // piece (q, half): rho = 8 half + i, i < 8, of q and of q + 4; run (i, j) (j = 0: q, 1: q + 4) at half * 16 KiB + (2 i + j) KiB;
+    // wave w fetches the two runs of i = w
+    const auto issue = [&](int q, int half) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem_raw + half * 16384 + (2 * w + j) * 1024), 16, lane * 16,
+                                                 1024 * (8 * half + w) + 65536 * j + 16384 * q, 0, SS_AUX_DIF_IQ);
+    };
+    issue(0, 0);
+    issue(0, 1);
+    after_first_issue();
+    const float2 th = d.wthe[t];
+    const unsigned short* mine = reinterpret_cast<const unsigned short*>(smem_raw) + t;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      const Dif8Trip x = dif8_trip(th, cq, c8, q, sg);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        // this half's piece has landed for every wave once all have waited for their own fetches and met here — at which point
+        // everybody is also done reading the OTHER half's previous piece, whose place the next fetch may take. (The table loads
+        // behind the first two pieces make the first wait one for everything.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!(q == 0 && half == 0) && !(q == 3 && half == 1)) {
+          if (half == 0) issue(q, 1);       // (the other half's piece of this trip: its place was read a piece ago)
+          else issue(q + 1, 0);
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          unsigned raw1[4], raw2[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            raw1[i] = mine[half * 8192 + 1024 * (4 * sub + i)];
+            raw2[i] = mine[half * 8192 + 1024 * (4 * sub + i) + 512];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float2& acc = a[8 * half + 4 * sub + i];
+            dif8_accumulate<FMT>(acc, raw1[i], raw2[i], x, 8 * half + 4 * sub + i);
+            // (the sums are formed HERE: left to itself the compiler sinks half of a piece's arithmetic below the next barrier and
+            // spills the converted samples it then has to keep)
+            asm volatile("" : "+v"(acc.x), "+v"(acc.y));
+          }
+          __builtin_amdgcn_sched_barrier(0);  // (the next four pairs are read when these are done: sixteen at once spill)
+        }
+      }
+    }
+    __syncthreads();  // the plane goes back to the transform
+  }
+  const float2 wt = d.wt[residue * 512 + t];
+#pragma unroll
+  for (int rho = 0; rho < 16; ++rho) a[rho] = cmul(a[rho], cmul(wt, make_float2(crho[2 * rho], crho[2 * rho + 1])));
+}
+
+}  // namespace ss

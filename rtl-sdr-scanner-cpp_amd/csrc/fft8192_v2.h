@@ -26,6 +26,13 @@
 
 #include "fft8192_kernel.h"
 
+// Cache policy of a 65536-point frame's samples in the radix-8 fold (fft65536_dif8.h): eight workgroups read every frame,
+// so the default policy (0), not the read-once nt of the 8192-point frames
+#ifndef SS_AUX_DIF_IQ
+#define SS_AUX_DIF_IQ 0
+#endif
+#include "fft65536_dif8.h"
+
 // Cache policy of the frame loads (read once, never again: nt = 2 measured 2.5 % faster per step than the default policy,
 // sc0 / sc1 variants the same as nt) and of the dB row stores (sc1 = 16, write-through: 2.5 % faster per step in a long run, 5 % in a
 // 20-step run — the end of a launch no longer has an L2 full of dirty rows to write back before the queue's next launch may start).
@@ -92,6 +99,10 @@ struct Fft8192Args {
   // rides on the launch (scan_step.h). It is asked for before the frame's own loads and handed back in `hdr` when they have
   // landed: the answer costs the workgroup nothing.
   const int* live_hint;
+  // FRONT != 0 (a residue of a 65536-point frame): the rows take NOISE-RELATIVE values, dB - rel_thr[residue * 8192 + k'] (the noise
+  // ceiling in the rows' own residue-major order; noise_learner.cpp:55) — the averager ring's rows, written by the transform itself
+  // as the row half of the four-step form does (fft256_kernels.h, RowsExtra::hist_out). The maxima for the tile culling stay dB values.
+  const float* rel_thr;
 #ifdef SS_DIAG
   int hint_nowait;  // timing ablation: do not wait for the header word (garbage result)
 #endif
@@ -124,8 +135,12 @@ __device__ __forceinline__ void halfwave_max4_hi16(float& a, float& b, float& c,
 // SWZ: exchange 1 as four 16-byte LDS stores per plane into an unpadded, quad-rotated image instead of sixteen 4-byte
 //      stores into the 17-word pitch.
 // One frame by one workgroup of 512 threads; `smem_raw` = kFft8192V2LdsBytes of LDS, `t` = threadIdx.x.
-template <int FMT, int TW, bool SWZ = false, bool NOWIN = false>
-__device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t frame, unsigned char* __restrict__ smem_raw, int t, int* hdr) {
+// FRONT: 0 = an 8192-point frame of its own; 1, 2 = residue `residue` of the 65536-point frame `frame_in` of `dif` (fft65536_dif8.h,
+//        LOADV = FRONT - 1: the load stage is the radix-8 fold, g.iq / g.win / g.item_stride are not read), `frame` = the row
+//        of 8192 floats the residue's bins go to (8 frame_in + residue in a plane of residue-major rows).
+template <int FMT, int TW, bool SWZ = false, bool NOWIN = false, int FRONT = 0>
+__device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t frame, unsigned char* __restrict__ smem_raw, int t, int* hdr,
+                                                 const Dif8Front* dif = nullptr, size_t frame_in = 0, int residue = 0) {
   float* s = reinterpret_cast<float*>(smem_raw);
   float2* tw2_l = reinterpret_cast<float2*>(smem_raw + kFft8192V2PlaneBytes);
   float2* lane_l = tw2_l + 256;
@@ -139,7 +154,9 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
 
   // ---- tables first: these loads are ahead of the frame's own in the vector-memory queue ----
   float2 tf0 = make_float2(0.f, 0.f), tf1 = make_float2(0.f, 0.f);
-  if constexpr (TW == 1) {
+  if constexpr (FRONT != 0) {
+    static_assert(TW == 2, "the fold keeps the transform's tables in LDS");
+  } else if constexpr (TW == 1) {
     if (t < 256) tf0 = tabs.tw2[t];
   } else if constexpr (TW == 2) {
     tf0 = t < 256 ? tabs.tw2[t] : tabs.lane[t - 256];
@@ -148,7 +165,14 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
 
   // ---------------- pass 1: radix 16, Ns = 1, butterfly j = t ----------------
   float2 a[16];
-  {
+  if constexpr (FRONT != 0) {
+    // (the tables go to LDS at once — their place behind the exchange plane is free — instead of through registers that would
+    // have to live through the fold)
+    dif8_front<FMT, FRONT - 1>(*dif, frame_in, residue, smem_raw, t, a, [&]() {
+      tw2_l[t] = t < 256 ? tabs.tw2[t] : tabs.lane[t - 256];
+      if (t < 128) lane_l[256 + t] = tabs.lane[256 + t];
+    });
+  } else {
     constexpr int kSample = FMT == FMT_CF32 ? 8 : 2;  // bytes per IQ sample
     const __amdgpu_buffer_rsrc_t rin = buffer_of(reinterpret_cast<const char*>(iq) + in_base * kSample, 8192 * kSample);
     const __amdgpu_buffer_rsrc_t rwin = buffer_of(win, 8192 * 4);
@@ -170,7 +194,9 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
       }
     }
   }
-  if constexpr (TW == 1) {
+  if constexpr (FRONT != 0) {
+    // (written by the fold's prologue)
+  } else if constexpr (TW == 1) {
     if (t < 256) tw2_l[t] = tf0;
   } else if constexpr (TW == 2) {
     tw2_l[t] = tf0;  // tw2_l and lane_l are contiguous: entries 0..511
@@ -328,6 +354,10 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
   float* out = psd + frame * 8192;
   const __amdgpu_buffer_rsrc_t rout = buffer_of(out, 8192 * 4);
   const int voff = (j + 2048 * h) * 4;
+#ifndef SS_DIF_NOTHR  // (lab builds: the residue rows keep their dB values — what the ceiling loads cost)
+#define SS_DIF_NOTHR 0
+#endif
+  const __amdgpu_buffer_rsrc_t rthr = buffer_of(FRONT != 0 && !SS_DIF_NOTHR ? g.rel_thr + residue * 8192 : nullptr, 8192 * 4);
   // Per-segment maxima for the detect stage's tile culling: the 32 lanes of a half-wave hold, for every (k, s), the 32
   // consecutive bins of segment w + 8 k + 64 h + 128 s; lane 16 + i of each half keeps the maximum of value i = 2 k + s.
   // The 256 segment maxima of the frame meet in LDS (the 512 floats behind the exchange plane, idle since exchange 1) and the
@@ -363,8 +393,14 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
       // X[kk] to bin0 + 4096 and X[kk + 16] to bin0
       pv[2 * i + 1] = psd_db(cadd(e, o), db_off);
       pv[2 * i] = psd_db(csub(e, o), db_off);
-      buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k + 16384, pv[2 * i + 1]);
-      buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k, pv[2 * i]);
+      if constexpr (FRONT != 0 && !SS_DIF_NOTHR) {
+        const float t1 = buffer_load_f1(rthr, voff, 1024 * k + 16384), t0 = buffer_load_f1(rthr, voff, 1024 * k);
+        buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k + 16384, pv[2 * i + 1] - t1);
+        buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k, pv[2 * i] - t0);
+      } else {
+        buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k + 16384, pv[2 * i + 1]);
+        buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k, pv[2 * i]);
+      }
 #if SS_SEGMAX_LDS
       // (whether or not the frame leaves a summary: a branch here costs the dB stores their interleaving and the kernel registers)
       dbrow[256 * k + 4096] = pv[2 * i + 1];
@@ -380,6 +416,35 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
         else asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(mine) : "v"(pv[q]), "s"(keep));
       }
     }
+  }
+  if constexpr (FRONT != 0) {
+    // ---- a residue of a 65536-point frame: the maxima of its 256 runs of 32 bins, two threads per run (fft65536_dif8.h) ----
+    static_assert(SS_SEGMAX_LDS, "the residue rows' maxima come out of the LDS image of the row");
+    (void)mine;
+    (void)want_max;
+    __syncthreads();  // the row's dB values are all in the plane
+    if (dif->zero_word && frame_in == 0 && residue == 0 && t == 0) *dif->zero_word = 0;
+    if (dif->smax) {  // (workgroup-uniform)
+      int vv = voff;
+      asm volatile("" : "+v"(vv));
+      const int tt = ((vv >> 1) & 0x1c0) | ((vv >> 8) & 32) | ((vv >> 2) & 31);  // the thread number, out of the one per-thread value alive here (below)
+      const int run = tt >> 1;
+      const float4* half_run = reinterpret_cast<const float4*>(s + 16 * tt);  // bins [32 run + 16 (tt & 1), + 16) of the row
+      float m = -__builtin_inff();  // (fmaxf ignores a NaN operand like v_max_f32 does: NaN bins cannot make a candidate)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = half_run[(q + run) & 3];  // (rotated by the run number: the lanes of a 16-lane group meet on two banks, not four)
+        m = fmaxf(fmaxf(m, v.x), fmaxf(fmaxf(v.y, v.z), v.w));
+      }
+      asm volatile("s_nop 1\n"
+                   "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                   : "+v"(m));
+      if ((tt & 1) == 0) {
+        const __amdgpu_buffer_rsrc_t rs = buffer_of(dif->smax + ((size_t)((dif->abs0 + (int)frame_in) & dif->smax_mask) << 11), 2048 * 4);
+        buffer_store_f1(rs, run * 4, residue * 1024, m);
+      }
+    }
+    return;
   }
 #if SS_SEGMAX_LDS
   (void)mine;

@@ -107,6 +107,12 @@ struct StepArgs {
   // beside the ROW tiles of call k - 1 (ROLE_ROWS: rows256, n_rows of them, reading the other of two work buffers), the plan of call
   // k - 2, detect(k - 3) and emit(k - 4). 0: no such role.
   int n_rows;
+  // KIND 8 — 65536 points, int8 IQ, NO work buffer: the FFT role is a residue of a frame — the radix-8 fold in the load stage of the
+  // 8192-point transform (fft65536_dif8.h), eight workgroups per frame, n_fft = 8 x frames, item j -> dif8_item — whose rows (noise-
+  // relative, residue-major: `fft.psd` is the ring's buffer, `fft.rel_thr` the ceiling in the same order) and run maxima the detect
+  // stage of two calls later reads; the plan of call k - 1, detect(k - 2) (PERM8 tiles) and emit(k - 3) ride on the launch as they ride
+  // on the column launch of the four-step form (KIND 2). `fft` carries the transform's tables and the rows' place, `dif` the fold's.
+  Dif8Front dif;
   int n_emit;  // frames of the emit role
   int emit_per_wg;  // 8: one wave per frame; 1 (KIND 2): rows of 2048 mask words and more, the eight waves share one frame
   // One workgroup per work item, dispatched in blockIdx order, four resident per CU. WHICH item a workgroup takes decides
@@ -210,7 +216,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;
     }
   } else if (role == ROLE_PLAN) {
-    if constexpr (KIND == 1 || KIND == 2 || KIND == 7) {  // a long transform's plan: two blocks of k_plan_long's numbering
+    if constexpr (KIND == 1 || KIND == 2 || KIND == 7 || KIND == 8) {  // a long transform's plan: two blocks of k_plan_long's numbering
       const int sub = tid >> 8;
       float* mrow = reinterpret_cast<float*>(smem_raw) + sub * (kPlanFusedFloats + kPlanLongInts);
       plan_long_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));
@@ -223,6 +229,13 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
   } else if constexpr (KIND >= 1) {
     // ---- FFT role, long transforms: one tile of 32 columns x 256 rows (KIND 3: 8 columns x 1024 rows of a 2^20-point frame) ----
     if constexpr (KIND == 5) return;  // (the drain of a 2^20-point context: launches without an FFT role only)
+    else if constexpr (KIND == 8) {  // a residue of a 65536-point frame: fold + 8192-point transform + dB -> the ring's rows
+      if constexpr (FMT != FMT_CF32) {
+        int f, r, hdr;
+        dif8_item(item, a.dif.nframes, &f, &r);
+        fft8192_v2_frame<FMT, 2, true, false, 2>(a.fft, (size_t)(8 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
+      }
+    }
     else if constexpr (KIND == 6) fft_rows256_tile(a.rows256, item, smem_raw, tid);  // (the ROW half of call k: its column half ran as its own launch right before)
     else if constexpr (KIND == 4) fft_rows1024_tile(a.rows, item, smem_raw, tid);  // (the ROW half of call k: its column half ran as its own launch right before)
     else if constexpr (KIND == 3) fft_cols1024_tile<FMT>(a.cols, item, smem_raw, tid);
@@ -324,7 +337,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     float* tile = reinterpret_cast<float*>(smem_raw) + half * (16 * T::P + 16);
     int* cnt = reinterpret_cast<int*>(tile + 16 * T::P);
     const int mine = half ? tile_b : tile_a;
-    detect_tile<21, 21, 16, 256, SPEC>(a.det, mine < 0 ? tile_a : mine, tid & 255, tile, cnt, mine >= 0);
+    detect_tile<21, 21, 16, 256, SPEC, KIND == 8>(a.det, mine < 0 ? tile_a : mine, tid & 255, tile, cnt, mine >= 0);
   }
 }
 

@@ -132,6 +132,7 @@ struct ss_ctx {
     int merge_max_frames = 128;    // ... calls of up to this many frames (SS_MERGE_MAX)
     bool merge_65536 = true;       // 65536 points, detect-mode calls: ONE launch per call — the column half of call k beside the row half of call k - 1 (scan_step.h KIND 7; SS_MERGE_65536=0: two launches per call, session 20's form)
     bool det_lag2 = true;          // 65536 points with tile culling: detect(k - 2) on the column launch of call k (SS_DET_LAG2=0: detect(k - 1) on the row launch, session 19's form)
+    bool dif8 = true;              // 65536 points, int8 IQ, default window, calls that keep no plane: NO work buffer — the radix-8 fold in the load stage of the 8192-point transform, eight workgroups per frame, one launch per call whatever its length (scan_step.h KIND 8, fft65536_dif8.h; SS_DIF8=0: the four-step forms of round 4)
     int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
     int chunk_65536 = 256;         // 65536 points with tile culling: calls of more frames go through in chunks of this many (SS_CHUNK_65536=0: in one piece)
     int chunk_long = 16;           // 2^20 points in two passes: calls of more frames go through in chunks of this many (SS_CHUNK_LONG=0: in one piece)
@@ -194,6 +195,7 @@ struct ss_ctx {
       chunk_65536 = num("SS_CHUNK_65536", chunk_65536);
       plan_first = num("SS_PLAN_FIRST", plan_first);
       det_lag2 = tri("SS_DET_LAG2") != 0;
+      dif8 = tri("SS_DIF8") != 0;
       emit_on_rows = tri("SS_EMIT_ON_ROWS") == 1;
       merge_65536 = tri("SS_MERGE_65536") != 0;
       merge_max_frames = num("SS_MERGE_MAX", merge_max_frames);
@@ -295,6 +297,16 @@ struct ss_ctx {
   // column launch of the call in between. So two detect stages wait: pend_det (planned: rides on the next column launch) and
   // pend_det2 (its plan is have_plan / pend_plan).
   bool det_lag2 = false;
+  // 65536 points, int8 IQ (fft65536_dif8.h): calls that keep no plane go through the radix-8 fold — one launch of 8 x frames
+  // workgroups that leaves noise-relative rows in RESIDUE-MAJOR order in the averager ring's buffer and run maxima in the plan's
+  // layout 2; every other call (learning frames, planes handed out, stream-ordered contexts) takes the four-step form, whose rows
+  // are in bin order. ring_perm8 says which order the ring's window and the stages that wait are in; a call of the other kind
+  // drains what waits and has the window's 35 rows rewritten first (set_ring_form).
+  bool dif8 = false;
+  bool ring_perm8 = false;
+  bool last_rows_perm8 = false;   // ... and the rows ss_read_window serves (last_hist, last_rel_rows)
+  float2* d_dif8_tab = nullptr;   // the fold's tables (dif8_host_tables)
+  float* d_perm_tmp = nullptr;    // 35 rows: the window on its way from one order to the other
   bool have_det2 = false;
   ss::DetectArgs pend_det2{};
   int pend_det2_tiles = 0;
@@ -866,6 +878,9 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
   // (KIND 5: a launch without an FFT role — the drain — whose detect workgroups share the plan's list out in a loop)
   if (c->two_pass && a.list_loop) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 5>);
   if (c->two_pass) return c->diag.cols1024_wide ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 4>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 3>);
+  if constexpr (FMT != ss::FMT_CF32 && !SPEC) {  // (the fold's launches, and the drains of the stages that wait behind them: their tiles read residue-major rows)
+    if (!c->use_fft8192 && c->ring_perm8) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 8>);
+  }
   if (!c->use_fft8192 && a.n_fft && a.rows256.work && !a.n_rows) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 6>);  // (65536 points: the row tiles as the FFT role; rows of 2048 mask words: the wide emit role)
   if (!c->use_fft8192 && c->merge) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 7>);  // (one launch per call: KIND 2's roles and the row tiles as one more; its drains too)
   if (!c->use_fft8192) return a.emit_per_wg == 1 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 2>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 1>);
@@ -884,6 +899,7 @@ struct FftRole {
   const ss::ColsArgs* cols = nullptr;
   const ss::Rows1024Args* rows1024 = nullptr;  // 2^20 points in two passes: the ROW tiles (the column half is a launch of its own)
   const ss::Rows256Args* rows256 = nullptr;    // 65536 points with tile culling: the ROW tiles (the column half is a launch of its own)
+  const ss::Dif8Front* dif = nullptr;          // 65536 points, the radix-8 fold: n = 8 x frames residues; `frames` carries the transform's tables and the rows' place
   int n = 0;  // frames / column tiles
   const void* halo_iq = nullptr;  // deep pipelining: n_halo frames of the previous call go through the FFT again, into halo_psd
   float* halo_psd = nullptr;
@@ -900,7 +916,11 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
 #endif
   ss::StepArgs a{};
   a.emit_per_wg = (!c->use_fft8192 && (c->diag.emit_wide || c->two_pass) && c->n / 32 >= 2048) ? 1 : 8;
-  if (fft && fft->frames) {
+  if (fft && fft->dif) {
+    a.fft = *fft->frames;
+    a.dif = *fft->dif;
+    a.n_fft = fft->n;
+  } else if (fft && fft->frames) {
     const int n_fft = fft->n + fft->n_halo;
     a.fft = *fft->frames;
     a.n_fft = n_fft;
@@ -931,7 +951,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
       a.plan_first = c->diag.plan_first * ss::step_plan_wgs(a);  // (the first pairs of every list on detect workgroups of their own: scan_step.h)
       a.plan_by_fft = a.n_fft > 0 && a.n_fft + a.plan_first >= ss::step_plan_consumers(a) ? 1 : 0;  // (consumer p serves list p mod S)
       if (!a.plan_by_fft) a.plan_first = 0;
-    } else if (det->tile_list && fft && (fft->cols || fft->rows1024 || fft->rows256)) {
+    } else if (det->tile_list && fft && (fft->cols || fft->rows1024 || fft->rows256 || fft->dif)) {
       a.list_by_fft = 1;  // long transforms, planned stage: FFT workgroup p takes pair list_first + p of the list after its own tile (scan_step.h)
       a.list_first = c->diag.list_first;  // (the first pairs on detect workgroups of their own, ahead of the FFT role: no tail)
       a.n_det = 2 * (a.list_first + std::max(0, (n_det_tiles + 1) / 2 - a.list_first - fft->n));  // detect workgroups for the first pairs and for the pairs beyond
@@ -1345,7 +1365,8 @@ RingPlace place_ring(ss_ctx* c, int nframes) {
   constexpr int H = kHistRows;
   // (the decision is ring_place.h's — a function of five integers that tests/host/ring_check.cpp runs on the CPU; here its consequences)
   const ss::RingPrev prevs[2] = {c->hist_prev, c->hist_prev2};
-  const ss::RingDecision d = ss::ring_place_decide(c->hist_start, prevs, c->merge ? 2 : 1, c->hist_rows, nframes, H, c->cull_long);
+  // (the fold writes a call's rows in the launch that carries the detect stage of two calls before, and the stage of the call before still waits)
+  const ss::RingDecision d = ss::ring_place_decide(c->hist_start, prevs, (c->merge || c->dif8) ? 2 : 1, c->hist_rows, nframes, H, c->cull_long);
   if (d.shift_first) {  // (stream order: a deferred detect stage that still reads or writes this window goes first)
     flush_stages(c);
     if (c->hist_start != 0)
@@ -1727,6 +1748,26 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   return SS_OK;
 }
 
+// 65536 points, the radix-8 fold (fft65536_dif8.h): the noise ceiling in the order of the fold's rows lives behind the ceiling and its
+// per-column minima (get_noise), rewritten by every learning call
+float* thr_perm8(const ss_ctx* c, const NoiseState* z) { return z->d_thr + (size_t)c->n + (size_t)std::max(32, c->n / 256); }
+
+// ... and the averager ring's rows are in residue-major order while calls go through the fold, in bin order while they take the
+// four-step form: a call of the other kind has what waits drained (those stages read the rows as they are), the window's 35 rows
+// rewritten at the front of the buffer, and no tile tested whose rows reach back across the change (the run maxima of the frames
+// before are in the other form's layout).
+void set_ring_form(ss_ctx* c, bool perm8) {
+  if (!c->dif8 || c->ring_perm8 == perm8) return;
+  flush_stages(c);
+  const size_t cnt = (size_t)kHistRows * (size_t)c->n;
+  hipLaunchKernelGGL(ss::k_rows_perm8, dim3(1024), dim3(256), 0, c->stream, (const float*)(c->d_hist + (size_t)c->hist_start * c->n), c->d_perm_tmp, kHistRows, perm8 ? 1 : 0);
+  hipLaunchKernelGGL(ss::k_copy_rows, dim3(grid_for(cnt / 4, 256)), dim3(256), 0, c->stream, (const float*)c->d_perm_tmp, c->d_hist, cnt / 4);
+  c->hist_start = 0;
+  c->hist_prev = c->hist_prev2 = ss::RingPrev{0, -1, 0};
+  c->clean_abs = c->abs_frames;
+  c->ring_perm8 = perm8;
+}
+
 // The chain for one batch, everything on c->stream, nothing synchronised.
 // n_learn = leading frames that belong to the noise-learning phase (decided by the caller).
 // 8192 points with the fused back end (c->step_path): the call's FFT stage is launched together with the deferred detect
@@ -1773,6 +1814,11 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     }
     // Tile culling for long transforms: the rows kernel leaves the run maxima of every frame and, in a call without learning
     // frames, writes the ring rows of the batch itself (placed now: moving the ring window drains the deferred stages).
+    // 65536 points, int8 IQ: a call that keeps no plane goes through the radix-8 fold (KIND 8) — decided before the ring is placed,
+    // because a change of form rewrites the window
+    const bool dif_call = c->dif8 && allow_overlap && c->cull_long && c->diag.pipeline && n_learn == 0 && !d_psd_out && !d_rel_out && !d_avg_out && !spec &&
+                          !(c->cfg.flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN | SS_FLAG_KEEP_PLANES));
+    set_ring_form(c, dif_call);
     ss::RowsExtra rx{};
     bool ring_by_rows = false, ring_only = false;
     const float* ring_rows = nullptr;
@@ -1823,7 +1869,28 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     // this way and have two rounds of workgroups per launch anyway, profiles/r04/s34_summary.txt)
     const bool merged_call = c->merge && c->rows256_step && overlap && ring_only && !spec && nframes <= c->diag.merge_max_frames;
     if (c->merge && !merged_call && (c->have_rows || c->have_plan2 || c->have_det3)) flush_stages(c);
-    if (merged_call) {
+    if (dif_call) {
+      if (!ring_only || !rx.hist_out) return fail(c, SS_ERR_INVALID, "internal: a fold call without a place for its rows");
+      ss::Fft8192Args gf{};
+      gf.tabs = ss::Fft8192V2Tables{c->d_tw8v2, c->d_tw8v2 + 256, c->d_tw8v2 + 256 + 384, nullptr, nullptr};
+      gf.db_off = c->db_off;
+      gf.scale = c->cfg.int_scale;
+      gf.psd = rx.hist_out;  // row f - first_hist of this region is frame f's (RowsExtra, fft256_kernels.h)
+      gf.rel_thr = thr_perm8(c, z);
+      ss::Dif8Front df = ss::dif8_front_of(d_iq, item_stride, c->d_dif8_tab);
+      df.smax = rx.smax;
+      df.smax_mask = rx.smax_mask;
+      df.abs0 = rx.abs0;
+      df.first_hist = rx.first_hist;
+      df.nframes = nframes;
+      df.zero_word = rx.zero_word;
+      FftRole drole;
+      drole.frames = &gf;
+      drole.dif = &df;
+      drole.n = 8 * nframes;
+      // the plan of the call before, the planned detect stage (of the call before that) and the emit stage behind it ride on the launch
+      launch_step(c, &drole, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr, nullptr, true);
+    } else if (merged_call) {
       ss::ColsArgs gcm = gc;
       gcm.work = c->work_cur ? c->d_work2 : c->d_work;
       FftRole crole;
@@ -1918,6 +1985,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     if (n_learn > 0) {
       hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
       if (c->cull || c->cull_long) hipLaunchKernelGGL(ss::k_thr_tilemin, dim3(c->n / 256), dim3(64), 0, c->stream, (const float*)z->d_thr, c->n, z->d_thr + c->n);
+      if (c->dif8) hipLaunchKernelGGL(ss::k_rows_perm8, dim3(256), dim3(256), 0, c->stream, (const float*)z->d_thr, thr_perm8(c, z), 1, 1);  // the ceiling in the order of the fold's rows
     }
     // (det_lag2: this call's detect stage waits for its plan, behind the planned one — which, if there is one, rode on this call's column launch)
     ss::DetectArgs& nd = merged_call ? c->pend_det3 : c->det_lag2 ? c->pend_det2 : c->pend_det;
@@ -1958,7 +2026,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         pl.cols = plan_cols;
         pl.logn = c->logn;
         pl.list = list;
-        pl.layout = c->two_pass ? 1 : 0;
+        pl.layout = c->two_pass ? 1 : dif_call ? 2 : 0;
         if (merged_call) {  // (not ready before this call's row half has run: one launch from now)
           c->have_plan2 = true;
           c->pend_plan2 = pl;
@@ -2007,6 +2075,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     c->last_psd = nullptr;
     c->last_rel_rows = ring_only_rows;
   }
+  c->last_rows_perm8 = c->ring_perm8;  // (the order last_hist and last_rel_rows are in: ss_read_window)
   c->last_n = nframes;
   return SS_OK;
 }
@@ -2033,7 +2102,7 @@ int get_noise(ss_ctx* c, NoiseState** out) {
   if (!z) {
     NoiseState nz;
     nz.center = center;
-    const size_t extra = (size_t)std::max(32, c->n / 256);  // + the per-tile-column minima (tile culling)
+    const size_t extra = (size_t)std::max(32, c->n / 256) + (c->dif8 ? (size_t)c->n : 0);  // + the per-tile-column minima (tile culling) + the ceiling in residue-major order (the fold's rows: thr_perm8)
     SS_HIP(c, hipMalloc(&nz.d_thr, sizeof(float) * ((size_t)c->n + extra)));
     hipLaunchKernelGGL(ss::k_fill, dim3(grid_for((size_t)c->n + extra, 256)), dim3(256), 0, c->stream, nz.d_thr, (size_t)c->n + extra, -FLT_MAX);
     c->noise.push_back(nz);
@@ -2081,6 +2150,8 @@ void free_ctx(ss_ctx* c) {
   (void)hipFree(c->d_pass);
   (void)hipFree(c->d_rel);
   (void)hipFree(c->d_tw8v2);
+  (void)hipFree(c->d_dif8_tab);
+  (void)hipFree(c->d_perm_tmp);
   (void)hipFree(c->diag.d_stamps);
   for (auto& t : c->order_tables) (void)hipFree(t.d);
   (void)hipFree(c->d_hist);
@@ -2269,6 +2340,11 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   c->det_lag2 = !c->deep && c->step_path && n == 65536 && !c->diag.fft_generic && c->diag.cull_65536 && c->diag.cull && !(cfg->flags & SS_FLAG_NO_CULL) &&
                 c->diag.rows256_step && c->diag.step_long && c->diag.det_lag2 && c->fused;
   c->merge = c->det_lag2 && c->diag.merge_65536 && c->diag.emit_wide;  // (one launch per call: scan_step.h KIND 7, whose emit role is the wide one)
+  // ... and with int8 IQ and the default window no work buffer at all: the radix-8 fold (scan_step.h KIND 8). It takes every call the
+  // one-launch form above would take — and longer ones — so that form is off then.
+  c->dif8 = c->det_lag2 && c->diag.dif8 && c->diag.emit_wide && c->diag.ring_only && (cfg->in_format == SS_FMT_CS8 || cfg->in_format == SS_FMT_CU8) && !cfg->window &&
+            !(cfg->flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN | SS_FLAG_KEEP_PLANES | SS_FLAG_SPECTROGRAM));
+  if (c->dif8) c->merge = false;
   c->lag = c->deep ? c->nq : (c->det_lag2 ? 2 : 1);
   c->ncnt = c->deep ? 3 * c->nq : (c->merge ? 8 : c->det_lag2 ? 6 : 3);
   c->nbuf = c->deep ? 2 * c->nq : (c->merge ? 6 : c->det_lag2 ? 4 : (c->step_path ? 2 : 1));
@@ -2286,7 +2362,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       // (long transforms, whose rows kernel may write ALL of a batch's rows into this buffer: three batches and the averager's reach,
       // so that a batch can go back to the front of the buffer while the one before it is still to be read — ring_place.h)
       if (n >= 65536 && c->step_path && rows < 3ll * cfg->max_batch + 3 * kHistRows) rows = 3ll * cfg->max_batch + 3 * kHistRows;
-      if (c->merge && rows < 4ll * (cfg->max_batch + kHistRows)) rows = 4ll * (cfg->max_batch + kHistRows);  // (two spans to protect: ring_place.h)
+      if ((c->merge || c->dif8) && rows < 4ll * (cfg->max_batch + kHistRows)) rows = 4ll * (cfg->max_batch + kHistRows);  // (two spans to protect: ring_place.h)
       c->hist_rows = (int)rows;
       CREATE_HIP(hipMalloc(&c->d_hist, sizeof(float) * (size_t)n * (size_t)rows));
       CREATE_HIP(hipMemsetAsync(c->d_hist, 0, sizeof(float) * (size_t)n * (size_t)kHistRows, c->stream));  // Averager ctor, averager.cpp:7-12
@@ -2492,6 +2568,18 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       ss::fft65536_window_rotation_table(wt.data());
       CREATE_HIP(hipMalloc(&c->d_wtab1024, sizeof(float2) * wt.size()));
       CREATE_HIP(hipMemcpy(c->d_wtab1024, wt.data(), sizeof(float2) * wt.size(), hipMemcpyHostToDevice));
+    }
+    if (c->dif8) {  // the radix-8 fold: its own tables and the 8192-point transform's
+      const double scale = (double)c->cfg.int_scale;  // (what load_iq multiplies with in the other front ends)
+      std::vector<float2> dt((size_t)ss::kDif8TableFloat2);
+      ss::dif8_host_tables(dt.data(), scale);
+      CREATE_HIP(hipMalloc(&c->d_dif8_tab, sizeof(float2) * dt.size()));
+      CREATE_HIP(hipMemcpy(c->d_dif8_tab, dt.data(), sizeof(float2) * dt.size(), hipMemcpyHostToDevice));
+      std::vector<float2> v2((size_t)(256 + 384 + 96));
+      ss::fft8192_v2_host_tables(v2.data(), v2.data() + 256, v2.data() + 256 + 384);
+      CREATE_HIP(hipMalloc(&c->d_tw8v2, sizeof(float2) * v2.size()));
+      CREATE_HIP(hipMemcpy(c->d_tw8v2, v2.data(), sizeof(float2) * v2.size(), hipMemcpyHostToDevice));
+      CREATE_HIP(hipMalloc(&c->d_perm_tmp, sizeof(float) * (size_t)n * (size_t)kHistRows));
     }
   }
   // Tile culling for long transforms: the sizes whose rows go through k_fft_rows256_psd (N2 = 256, or the radix-A step in front)
@@ -2827,6 +2915,15 @@ int ss_reset_noise(ss_ctx* c) {
   return SS_OK;
 }
 
+// bins [lo, lo + cnt) of a residue-major row of 65536 floats (fft65536_dif8.h): the row comes over whole, the host picks
+static int read_perm8_row(ss_ctx* c, const float* row, int lo, size_t cnt, float* out) {
+  std::vector<float> h((size_t)c->n);
+  SS_HIP(c, hipMemcpyAsync(h.data(), row, sizeof(float) * h.size(), hipMemcpyDeviceToHost, c->stream));
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  for (size_t k = 0; k < cnt; ++k) out[k] = h[(size_t)ss::dif8_bin_offset(lo + (int)k)];
+  return SS_OK;
+}
+
 int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t hi, float* out) {
   if (!c || !out) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
@@ -2840,6 +2937,7 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
     // the last batch kept no dB plane (a 2^20-point device call that handed out no plane: its rows went straight to the averager
     // ring as noise-relative values): the rel rows are there, bit for bit; a dB window needs a call with d_psd_db
     if (plane == SS_PLANE_REL && frame >= 0) {
+      if (c->last_rows_perm8) return read_perm8_row(c, c->last_rel_rows + (size_t)frame * n, lo, cnt, out);
       SS_HIP(c, hipMemcpyAsync(out, c->last_rel_rows + (size_t)frame * n + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
       SS_HIP(c, hipStreamSynchronize(c->stream));
       return SS_OK;
@@ -2873,6 +2971,7 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
     src = c->fused ? c->last_hist + (size_t)(kHistRows + frame) * n : c->d_rel + (size_t)(G - 1 + frame) * n;
   }
   if (!src) return fail(c, SS_ERR_INVALID, "bad plane/frame");
+  if (frame < 0 && c->fused && c->last_rows_perm8) return read_perm8_row(c, src, lo, cnt, out);  // (ring rows the radix-8 fold left)
   SS_HIP(c, hipMemcpyAsync(out, src + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
   SS_HIP(c, hipStreamSynchronize(c->stream));
   return SS_OK;

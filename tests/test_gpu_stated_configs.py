@@ -191,6 +191,54 @@ def test_config3_device_calls_against_the_reference(ref_mod, chunk, ncalls):
     assert len(b) > 10_000 and len(a ^ b) <= dont_care_limit(len(b))
 
 
+@pytest.mark.parametrize("chunk,ncalls", [(128, 10), (64, 12), (16, 30), (256, 4)])
+def test_config3_steady_state_of_the_shipped_form_against_the_reference(ref_mod, chunk, ncalls):
+    """Config 3 at depth on the PRODUCT library, against the reference's own code: the learning frames as a call of their own (which
+    takes the four-step form and leaves its rows in bin order), then `ncalls` int8 detect-mode ss_process_device calls with nothing in
+    between — the form bench.py times: one launch per call, every launch carrying the fold of its own call, the plan of the call
+    before, the listed tiles of the call before that and the candidate lists of a fourth (csrc/scan_step.h KIND 8), so from the fourth
+    call on every launch is a steady-state one. ss_get_stats shows that tiles were culled and that nothing drained the pipeline between
+    the first of those calls and the last (reference chain: transmission.cpp:57-68,88-96, averager.cpp:14-25,52-61, utils.cpp:31-53)."""
+    import torch
+    n, fs, learn = 65536, 20_000_000, 41
+    total = learn + chunk * ncalls
+    band = pkg.synth.SyntheticBand(n, seed=45, on_frame=learn + 30, off_frame=total - 40, period=total)
+    iq8 = band.frames_cs8(total)
+    iq = (iq8[..., 0].astype(np.float32) / np.float32(128.0) + 1j * (iq8[..., 1].astype(np.float32) / np.float32(128.0))).astype(np.complex64)
+    t = (10_000 + 50 * np.arange(total)).astype(np.int64)  # learning ends after 41 frames
+    ref_mod.ref().orc_set_fft_backend(0)
+    ref = _ref_result(ref_mod.RefChain(n, fs, CENTER - fs // 2, CENTER + fs // 2).process(iq, t))
+    del ref["psd"], ref["rel"]
+    eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, in_format=pkg.abi.SS_FMT_CS8, max_batch=max(chunk, learn), learn_frames=learn)
+    dev = torch.device("cuda", 0)
+    cuts = [(0, learn)] + [(learn + k * chunk, learn + (k + 1) * chunk) for k in range(ncalls)]
+    d_iq = [torch.from_numpy(iq8[a:b]).to(dev) for a, b in cuts]
+    outs = [dict(off=torch.zeros(b - a + 1, dtype=torch.int32, device=dev), idx=torch.empty((b - a) * 1024, dtype=torch.int32, device=dev)) for a, b in cuts]
+    torch.cuda.synchronize()
+    eng.process_device(d_iq[0], learn, cand_off=outs[0]["off"], cand_idx=outs[0]["idx"])
+    eng.process_device(d_iq[1], chunk, cand_off=outs[1]["off"], cand_idx=outs[1]["idx"])  # (the change of form drains the learning call's stages: counted before the run)
+    drains_before = eng.stats()["drains"]
+    for d, o in zip(d_iq[2:], outs[2:]):
+        eng.process_device(d, chunk, cand_off=o["off"], cand_idx=o["idx"])
+    drains_after = eng.stats()["drains"]
+    eng.sync()
+    st = eng.stats()
+    offs = [o["off"].cpu().numpy() for o in outs]
+    got_off = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(x) for x in offs]))]).astype(np.int32)
+    got_idx = np.concatenate([o["idx"].cpu().numpy()[:x[-1]] for o, x in zip(outs, offs)])
+    a, b = cand_set(got_off, got_idx), cand_set(ref["cand_off"], ref["cand_idx"])
+    near = np.abs(ref["avg"] - np.float32(8.0)) < BAND
+    outside = [(f, i) for (f, i) in a ^ b if not near[f, i]]
+    assert not outside, sorted(outside)[:10]
+    print(f"\n[config 3 at depth, product library: learning call + {ncalls} x {chunk} frames of 65536 points, CS8] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band; "
+          f"tiles {st['tiles_total']}, tested {st['tiles_tested']}, culled {st['tiles_culled']}; drains during the run {drains_after - drains_before}")
+    # (calls shorter than the averager's window slide it along the ring's buffer and bring it back to the front when the end is reached —
+    # a drain once in a few dozen calls, csrc/ring_place.h; calls of a window and more go round the buffer without one)
+    assert drains_after - drains_before <= (0 if chunk >= 35 else 1 + ncalls // 20), (drains_before, drains_after)
+    assert st["culling"] and st["tiles_culled"] > 0 and st["tiles_culled"] <= st["tiles_tested"] <= st["tiles_total"], st
+    assert len(b) > 10_000 and len(a ^ b) <= dont_care_limit(len(b))
+
+
 @pytest.mark.parametrize("chunk,ncalls", [(16, 8), (40, 3)])
 def test_config5_device_calls_against_the_reference(ref_mod, chunk, ncalls):
     """Config 5 as it ships and as bench.py times it: 2^20-point CF32 frames in 16-frame ss_process_device calls, detect mode (no
