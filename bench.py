@@ -177,19 +177,22 @@ def cpu_baseline(n: int, fs: int, budget_s: float = 12.0, stages: bool = False):
     return out
 
 
-def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False):
+def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False, call_frames: int | None = None):
     """A small parity check beside the numbers (the checker leg, like cpu_baseline), against the reference's own code (oracle/_ref;
     the C restatement where that is absent), same contract as tests/parity.py:
       host path    frames through ss_process with every plane handed out: achieved error quantiles per plane (dB and relative on
                    linear power), the bins outside the bare tolerance measured against an fp64 chain, candidate lists
       timed path   the same frames once more the way the timed region runs them — ss_process_device calls without a synchronisation
                    in between, the planes this configuration hands out and no others (detect mode: none), tile culling as the
-                   library does it at this size — candidate lists against the reference, and what ss_get_stats says was culled."""
+                   library does it at this size — candidate lists against the reference, and what ss_get_stats says was culled.
+                   call_frames: the timed region's own call size (long transforms: the form of a call depends on it) — the timed path then
+                   runs a stream of its own: the learning frames as one call, then calls of that many frames, enough of them for
+                   steady-state launches (a launch carries stages of up to five calls)."""
     import numpy as np
     import rtl_sdr_scanner_cpp_amd as pkg
     from oracle import oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from parity import BAND, cand_set, check_all, dont_care_limit, error_quantiles, excess_vs_fp64, excess_vs_fp64_rel, linear_power_error, strict_excess
+    from parity import BAND, all_bins_vs_fp64, cand_set, check_all, dont_care_limit, error_quantiles, excess_vs_fp64, excess_vs_fp64_rel, linear_power_error, strict_excess
     chunk = 48 if n <= 16384 else (32 if n <= 65536 else 16)
     nframes = 2 * chunk if n <= 65536 else 5 * chunk  # (2^20 points: 80 frames, so that whole 16-frame tiles lie behind learning + warm-up and can be culled)
     n_learn = 21
@@ -235,10 +238,41 @@ def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False):
            # bins the bare 1e-4 * max(1, |ref|) does not cover (held by the fp32-FFT floor allowance), and on those bins the distance of
            # the engine and of the reference to an fp64 chain on the same windowed frames (engine <= 1.5 x reference asserted)
            "outside_bare_1e-4": {k: {"n": v["n"], "frac": float(f"{v['frac']:.3g}"), "worst_dB": float(f"{v['worst']:.3g}")} for k, v in strict_excess(got, ref).items()},
-           "outside_bins_vs_fp64_fft_dB": {"psd": fmt3(vs64), "rel": fmt3(vs64_rel)}}
+           "outside_bins_vs_fp64_fft_dB": {"psd": fmt3(vs64), "rel": fmt3(vs64_rel)},
+           # ... and over ALL ordinary bins of a sample of rows: |dB - fp64| of the engine and of the reference's fp32 FFT, and the ratio of their rms
+           "all_bins_vs_fp64_fft_dB": (lambda v: None if v is None else {"rows": v["rows"], "bins": v["bins"], "engine": fmt3(v["engine"]), "reference": fmt3(v["reference"]),
+                                                                         "engine_over_reference_rms": float(f"{v['engine_over_reference_rms']:.3g}")})(all_bins_vs_fp64(iq_c, got["psd"], ref["psd"], fs))}
     # ---- the timed path: device calls, nothing synchronised in between ----
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
+    if call_frames and call_frames != chunk and n >= 65536:
+        # the timed region's call size: a stream of its own (the learning frames, then whole calls), the reference's code over all of it
+        chunk = call_frames
+        ncalls = 5 if n * call_frames <= (1 << 23) else (4 if n * call_frames <= (1 << 24) else 2)
+        nframes = n_learn + ncalls * chunk
+        band = pkg.synth.SyntheticBand(n, seed=78, on_frame=n_learn + 25, off_frame=nframes - 20)
+        raw = band.frames_cs8(nframes) if fmt == "cs8" else (band.frames_cu8(nframes) if fmt == "cu8" else band.frames_cf32(nframes))
+        if fmt == "cf32":
+            iq_c = raw
+        elif fmt == "cs8":
+            iq_c = (raw[..., 0].astype(np.float32) / np.float32(128.0) + 1j * (raw[..., 1].astype(np.float32) / np.float32(128.0))).astype(np.complex64)
+        else:
+            iq_c = ((raw[..., 0].astype(np.float32) - np.float32(127.5)) / np.float32(127.5) + 1j * ((raw[..., 1].astype(np.float32) - np.float32(127.5)) / np.float32(127.5))).astype(np.complex64)
+        t = (1_000 + 100 * np.arange(nframes)).astype(np.int64)
+        if O.have_ref() and fmt != "cu8":
+            O.ref().orc_set_fft_backend(2)  # (MKL's FFTW3 interface where it is there — candidates only are compared on this stream, and it is a hundred megasamples)
+            r = O.RefChain(n, fs, center - fs // 2, center + fs // 2).process(iq_c, t)
+            off = np.zeros(nframes + 1, np.int32)
+            off[1:] = np.cumsum([len(c) for c in r["cands"]])
+            ref = {"avg": r["avg"], "cand_off": off, "cand_idx": np.concatenate(r["cands"]).astype(np.int32)}
+            del r
+        else:
+            ch = O.oracle_chain(fs, center, fft_size=n, decim=1, in_format=in_format, max_batch=chunk)
+            cutsr = [(0, n_learn)] + [(a, a + chunk) for a in range(n_learn, nframes, chunk)]
+            routs = [ch.process(raw[a:b], t_ms=t[a:b]) for a, b in cutsr]
+            ref = {k: np.concatenate([o[k] for o in routs]) for k in ("avg", "cand_idx")}
+            ref["cand_off"] = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(o["cand_off"]) for o in routs]))]).astype(np.int32)
+        del iq_c
     eng = pkg.SpectrumEngine(fs, center, fft_size=n, decim=1, in_format=in_format, max_batch=max(chunk, n_learn), learn_frames=n_learn, flags=flags, device_id=dev.index)
     d_iq, d_out = [], []
     cuts = [(0, n_learn)] + [(a, min(a + chunk, nframes)) for a in range(n_learn, nframes, chunk)]  # (the learning frames as a call of their own: the calls behind it overlap)
@@ -344,9 +378,10 @@ def is_preset(args) -> bool:
             and not args.sync_every_step and not (args.diag_lib or args.lib) and args.start_level == 8.0)
 
 
-def chain_kernels(n: int, fmt: str, nb: int | None = None):
+def chain_kernels(n: int, fmt: str, nb: int | None = None, detect_mode: bool = False):
     """The launches one call of the chain takes, as the library's timing slots name them (include/specscan.h SS_KSLOT_*), with
-    what each must move per sample given the decomposition (its inputs once + its outputs once)."""
+    what each must move per sample given the decomposition (its inputs once + its outputs once). detect_mode: the
+    call hands out no plane (candidates only)."""
     in_b = 8.0 if fmt == "cf32" else 2.0
     if n == 8192:
         return [("step", "k_scan_step", "k_scan_step: load+window+FFT+dB of call k, carrying the 21x21 mean + threshold of call k-2 and the candidate lists "
@@ -360,6 +395,13 @@ def chain_kernels(n: int, fmt: str, nb: int | None = None):
                 ("rows", "k_scan_step", "k_scan_step with the ROW half as its FFT role (fft_rows1024_tile: 1024-point FFTs -> dB -> noise-relative rows straight into the averager "
                  "ring's buffer, no dB plane in detect mode, + run maxima for the tile culling), carrying the listed averaging tiles of call k-1 and the candidate lists of call k-2", 12.0),
                 ("plan", "k_plan_long", "k_plan_long as a launch of its own (SS_PLAN_FUSED=0 of the diagnostics build; the product runs the plan at the front of the next column launch)", 0.0)]
+    if n == 65536 and fmt != "cf32" and detect_mode and os.environ.get("SS_DIF8") != "0" and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0":
+        # 65536 points, int8 IQ, calls that keep no plane (round 5): the radix-8 fold — no work buffer, one launch per call whatever its length
+        return [("step", "k_scan_step", "k_scan_step (KIND 8), one launch per call: the radix-8 decimation-in-frequency fold in the load stage of the 8192-point transform "
+                 "(csrc/fft65536_dif8.h) — four workgroups per frame, each folding the whole int8 frame (LDS-DMA pieces, Hamming taps formed, W_8 rotations) into the 8192 points of "
+                 "residues r and r + 4 and running the 8192-point transform on both -> dB -> noise-relative rows in residue-major order straight into the averager ring's buffer "
+                 "(no work buffer, no dB plane) + run maxima for the tile culling —, carrying the plan of call k-1 (which averaging tiles can hold a candidate), the listed tiles of "
+                 "call k-2 (21x21 mean + threshold on residue-major rows) and the candidate lists of call k-3", in_b + 4.0)]
     if n == 65536 and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0" and os.environ.get("SS_MERGE_65536") != "0" and (nb is None or nb <= 128):
         # 65536 points, detect-mode calls of up to 128 frames as the product runs them since session 36 of round 4: ONE launch per call
         return [("step", "k_scan_step", "k_scan_step (KIND 7), one launch per call: the column half of the four-step FFT of call k (load, Hamming taps formed from one table entry per "
@@ -382,6 +424,40 @@ def chain_kernels(n: int, fmt: str, nb: int | None = None):
     ks.append(("rows", "k_fft_rows", "row half: 256-point FFTs -> dB rows (+ run maxima and the averager ring rows for the tile culling)", 12.0))
     ks.append(("plan", "k_plan_long", "k_plan_long: which averaging tiles of the call can hold a candidate, from the run maxima the rows kernel left (one list per call)", 0.0))
     return ks
+
+
+def kernel_tally(chain, slots, n: int, nb: int, peak_gbs: float = HBM_PEAK_GBS):
+    """roofline.kernels from the library's tally of the sampled launches — slots = {slot: (total ms, launches, frames those launches
+    covered)} (ss_kernel_timing_read_frames). Everything is per LAUNCH: a call the library takes through in chunks (2^20 points beyond
+    16 frames, the four-step form of 65536 points beyond 256) has several launches per slot, each over its chunk's frames, and its
+    bytes are those of the chunk — dividing a call's bytes by a launch's duration (round 4) gave fractions of peak above 1."""
+    kernels = []
+    for slot, match, what, bps in chain:
+        ms_k, cnt_k, fr_k = slots.get(slot, (0.0, 0, 0))
+        if not cnt_k:
+            continue
+        us = ms_k / cnt_k * 1e3
+        frames_per_launch = fr_k / cnt_k if fr_k else float(nb)
+        kb = bps * frames_per_launch * n
+        kernels.append({"slot": slot, "match": match, "what": what, "us": round(us, 2), "launches_timed": cnt_k, "frames_per_launch": round(frames_per_launch, 2),
+                        "launches_per_call": round(nb / frames_per_launch, 2) if frames_per_launch else None,
+                        "bytes_per_launch_it_must_move": kb, "gbs": round(kb / us / 1e3, 1) if us else None,
+                        "frac_of_peak": round(kb / us / 1e3 / peak_gbs, 4) if us else None})
+    return kernels
+
+
+def rank_plan(rank: int, local_rank: int, world: int, ndev: int, args, n: int) -> dict:
+    """Which device a rank takes and which of the side legs of the line it runs. One process per GPU: rank r of a node works on device
+    LOCAL_RANK (modulo the device count only where a box has fewer GPUs than ranks — ranks then share devices over gloo and the line
+    says so). The legs beside the timed region — CPU baseline, live PMC passes, the `also` runs, the parity sample — are rank 0's, at
+    N = 1 only: at N > 1 the timed region is all a rank does (tests/test_dist_gloo.py pins this on the CPU)."""
+    single = world == 1 and rank == 0
+    default2 = (args.config or 2) == 2 and n == 8192
+    return {"device_index": local_rank % max(ndev, 1), "shares_device": world > max(ndev, 1),
+            "cpu_baseline": single and not args.no_cpu_baseline,
+            "live_pmc": single and not args.sub and not args.no_live_pmc and is_preset(args) and default2,
+            "also": single and not args.sub and not args.no_also and default2 and not (args.diag_lib or args.lib),
+            "parity": single and not args.no_parity and (not args.no_cpu_baseline or args.sub)}
 
 
 def free_port() -> int:
@@ -463,8 +539,12 @@ def also_lines():
     kernel of the chain with its own duration and rate, what the library says it culled (ss_get_stats), and — except the last — a
     parity sample of its own against the reference (host path with every plane, and the timed device path in the entry's own mode)."""
     res = []
-    runs = ((2, 40, ["--no-cull"], "no_cull"), (3, 200, [], None), (3, 100, ["--frames", "256", "--no-parity"], None), (5, 100, [], None),
-            (5, 40, ["--frames", "64", "--no-parity"], None))  # (config 3 also in 256-frame calls — two rounds of workgroups per launch instead of one —, config 5 also in 64-frame calls: four chunks of 16)
+    runs = ((2, 40, ["--no-cull"], "no_cull"), (3, 200, [], None), (3, 100, ["--frames", "256"], None), (5, 100, [], None),
+            (5, 40, ["--frames", "64"], None),
+            # the sizes the reference itself would run these two signals at (getFft, utils/radio_utils.cpp:98-104: the first power of two
+            # whose bins are at most 250 Hz wide): 131072 points at 20 MS/s, 262144 at 61.44 MS/s — 8.4 MS per call like configs 3 and 5
+            (3, 60, ["--fft", "131072", "--frames", "64"], "getFft_131072"), (5, 60, ["--fft", "262144", "--frames", "32"], "getFft_262144"))
+    # (config 3 also in 256-frame calls — two rounds of workgroups per launch instead of one —, config 5 also in 64-frame calls: four chunks of 16; each with a parity sample at its own call size)
     for cfg_no, steps, extra, variant in runs:
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg_no), "--gpus", "1", "--steps", str(steps), "--warmup", "5",
                "--preheat-ms", "150", "--no-cpu-baseline", "--sub", *extra]
@@ -524,7 +604,8 @@ def run(args):
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs an MI355X: the spectral-scan engine has no CPU path")
-    device_index = local_rank % ndev
+    plan = rank_plan(rank, local_rank, world, ndev, args, n)
+    device_index = plan["device_index"]
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -624,8 +705,8 @@ def run(args):
     eng.sync()  # (settles the library's own bookkeeping; nothing left to wait for)
     kern_ms, launches, slots = 0.0, 0, {}
     if every:
-        slots = eng.kernel_timing_read_slots()
-        kern_ms, launches = slots["step"]
+        slots = eng.kernel_timing_read_frames()  # {slot: (ms, launches, frames those launches covered)}
+        kern_ms, launches, _ = slots["step"]
         eng.kernel_timing(0)
     elapsed = dist.max_over_ranks(t1 - t0, device=coll_dev)
     ncand = int(outs[(counter[0] - 1) % nout]["off"][-1].item())
@@ -637,19 +718,17 @@ def run(args):
         kern_avg_s = kern_ms / max(launches, 1) / 1e3
         step_s = elapsed / args.steps
         # every launch of the chain, kernel by kernel (start/stop events on the launches of the sampled calls)
-        kernels = []
-        for slot, match, what, bps in chain_kernels(n, args.fmt, nb):
-            ms_k, cnt_k = slots.get(slot, (0.0, 0))
-            if not cnt_k:
-                continue
-            us = ms_k / cnt_k * 1e3
-            per_call = cnt_k / max(launches, 1)  # launches of this kernel per sampled call
-            kb = bps * nb * n / per_call if per_call else 0.0
+        kernels = kernel_tally(chain_kernels(n, args.fmt, nb, args.no_psd_out and not args.planes), slots, n, nb)
+        for k in kernels:
+            slot, match = k["slot"], k.pop("match")
             # launches of the steady-state shape only. 8192 points: 1024 + 20 FFT, 128 emit and 4 plan workgroups of 512 threads; long
             # transforms: the column tiles + one emit workgroup per frame (the listed tiles ride on the column workgroups)
             two_pass = n == 1 << 20 and os.environ.get("SS_FFT_TWOPASS") != "0"
+            fold = n == 65536 and args.fmt != "cf32" and args.no_psd_out and not args.planes and os.environ.get("SS_DIF8") != "0"
             if n == 8192:
                 shape = (nb + 20 + nb // 8 + 4) * 512
+            elif fold:
+                shape = None  # (one launch per call whatever its length: every launch of the kernel in the committed pass is one)
             elif two_pass:  # column half: 64 workgroups of 1024 threads per frame behind the 128 that run the plan of the call before; row half: 128 of 512 per frame + one emit workgroup per frame
                 shape = {"step": (nb * 64 + 128) * 1024, "rows": (nb * 128 + nb + 64) * 512}.get(slot)  # (+ 64 detect workgroups for the first listed pairs)
             elif n == 65536 and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0" and os.environ.get("SS_MERGE_65536") != "0" and nb <= 128:
@@ -661,20 +740,19 @@ def run(args):
             else:
                 shape = (nb * (n // 8192) + (nb if n >= 65536 else -(-nb // 8))) * 512 if slot == "step" and n >= 16384 else None
             tp = traffic_from_profiles(args.config or 2, match, shape) if is_preset(args) else None
-            kernels.append({"slot": slot, "what": what, "us": round(us, 2), "launches_timed": cnt_k, "launches_per_call": round(per_call, 2),
-                            "bytes_per_launch_it_must_move": kb, "gbs": round(kb / us / 1e3, 1) if us else None,
-                            "frac_of_peak": round(kb / us / 1e3 / HBM_PEAK_GBS, 4) if us else None,
-                            "pmc_bytes_per_launch_from_profiles": tp["bytes_per_launch"] if tp else None})
+            k["pmc_bytes_per_launch_from_profiles"] = tp["bytes_per_launch"] if tp else None
         dom = max(kernels, key=lambda k: k["us"] * k["launches_per_call"]) if kernels else None
         abps = algo_bytes_per_sample(args.fmt, True)  # the FFT kernel always writes its dB row
-        literal = abps * nb * n / kern_avg_s / 1e9 if (launches and n == 8192) else (dom["gbs"] if dom else None)  # bytes per launch / mean launch duration
+        chain_bps = algo_bytes_per_sample(args.fmt, not args.no_psd_out) + (8.0 if args.planes else 0.0)
+        # ALGORITHMIC bytes per launch / mean launch duration; for the long transforms the dominant kernel of the chain
+        # (its share of what the DESIGN moves — work buffers included — is roofline.kernels[].gbs, not this)
+        literal = abps * nb * n / kern_avg_s / 1e9 if (launches and n == 8192) else (chain_bps * dom["frames_per_launch"] * n / dom["us"] / 1e3 if dom and dom["us"] else None)
         # Consecutive launches of k_scan_step overlap on two hardware queues (deep pipelining): a launch lasts about
         # twice as long as the GPU spends per launch. in_flight = mean launch duration / wall time per launch; the kernel's
         # achieved rate is its bytes over duration / in_flight (= the literal figure when launches do not overlap).
         # (Other sizes: launches in order on one stream, nothing overlaps.)
         in_flight = max(1.0, kern_avg_s / step_s) if (launches and n == 8192) else 1.0
         achieved = literal * in_flight if literal is not None else None
-        chain_bps = algo_bytes_per_sample(args.fmt, not args.no_psd_out) + (8.0 if args.planes else 0.0)
         chain_gbs = chain_bps * nb * n / step_s / 1e9  # per GPU
         pmc_chain = [k["pmc_bytes_per_launch_from_profiles"] * k["launches_per_call"] for k in kernels if k["pmc_bytes_per_launch_from_profiles"]]
         out = {
@@ -705,7 +783,11 @@ def run(args):
                          "kernel_us": dom["us"] if dom else None, "launches": dom["launches_timed"] if dom else 0,
                          "launches_in_flight": round(in_flight, 2) if dom else None,
                          "achieved_if_launches_did_not_overlap": None if literal is None else round(literal, 1),
-                         "algorithmic_bytes_per_launch": abps * nb * n if n == 8192 else (dom["bytes_per_launch_it_must_move"] if dom else None),
+                         # SURVEY.md 8d's figure — IQ in (+ the dB row in power mode) — times the samples one launch of the dominant kernel covers; and,
+                         # for the long transforms, what the DESIGN makes that kernel move (its inputs once + its outputs once: work buffers included)
+                         "algorithmic_bytes_per_launch": abps * nb * n if n == 8192 else chain_bps * (dom["frames_per_launch"] if dom else nb) * n,
+                         "design_bytes_per_launch": dom["bytes_per_launch_it_must_move"] if dom else None,
+                         "achieved_on_design_bytes": dom["gbs"] if dom else None,
                          "traffic": None,  # (filled in below by two short rocprofv3 --pmc passes of this command line on this box: live_pmc_traffic) ...
                          # ... the committed passes of the same command line (for 8192 points: launches of the steady-state shape, 1024 + 20 FFT, 128 emit and 4 plan workgroups of 512 threads)
                          "traffic_from_profiles": ({"bytes_per_launch": dom["pmc_bytes_per_launch_from_profiles"]} if dom and dom["pmc_bytes_per_launch_from_profiles"] else None),
@@ -715,7 +797,7 @@ def run(args):
                                "frac": round(chain_gbs / HBM_PEAK_GBS, 4),
                                "pmc_bytes_per_sample_from_profiles": round(sum(pmc_chain) / (nb * n), 2) if pmc_chain else None},
         }
-        if world == 1 and not args.sub and not args.no_live_pmc and is_preset(args) and (args.config or 2) == 2 and n == 8192 and dom:
+        if plan["live_pmc"] and dom:
             sub_argv = ["--gpus", "1", "--steps", "30", "--warmup", "5", "--preheat-ms", "0", "--no-cpu-baseline", "--no-also", "--no-parity", "--no-live-pmc", "--sub"]
             try:
                 live, why = live_pmc_traffic(sub_argv, "k_scan_step", (nb + 20 + nb // 8 + 4) * 512)
@@ -729,15 +811,15 @@ def run(args):
                 # launch takes (= ms_per_step: one launch per step) — beside `achieved`, which counts the algorithmic bytes only
                 out["roofline"]["traffic_gbs"] = round(live["bytes_per_launch"] / step_s / 1e9, 1)
                 out["roofline"]["traffic_frac_of_peak"] = round(live["bytes_per_launch"] / step_s / 1e9 / HBM_PEAK_GBS, 4)
-        if world == 1 and not args.sub and not args.no_also and (args.config or 2) == 2 and n == 8192 and not (args.diag_lib or args.lib):
+        if plan["also"]:
             out["also"] = also_lines()
-        if not args.no_cpu_baseline and world == 1:
+        if plan["cpu_baseline"]:
             out["cpu_baseline"] = cpu_baseline(n, fs, args.cpu_seconds)
         elif world == 1:
             out["cpu_baseline"] = None
-        if world == 1 and not args.no_parity and (not args.no_cpu_baseline or args.sub):  # (the `also` runs drop the CPU timing, not the parity sample)
+        if plan["parity"]:  # (the `also` runs drop the CPU timing, not the parity sample)
             try:
-                out["parity"] = parity_sample(n, fs, args.fmt, args.no_cull)
+                out["parity"] = parity_sample(n, fs, args.fmt, args.no_cull, nb)
             except AssertionError as e:
                 out["parity"] = {"failed": str(e)[:300]}
         print(json.dumps(out), flush=True)

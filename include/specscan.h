@@ -160,7 +160,11 @@ int ss_process(ss_ctx* ctx, const void* iq, int32_t nframes, const int64_t* t_ms
  * blocks each work on a different frame at any moment (sdr_device.cpp:161-171), consecutive calls overlap on the device —
  * a launch carries the FFT + dB stage of one call and the averaging / threshold and candidate-list stages of earlier calls
  * (csrc/scan_step.h); for 8192-point frames up to five calls are in flight, on two hardware queues of the library's own
- * (ss_ctx::deep in csrc/specscan.hip). The results of a call are therefore complete only after ss_sync, or after ss_flush
+ * (ss_ctx::deep in csrc/specscan.hip). 65536-point frames: the launch of call k carries the plan of call k - 1 (which of its
+ * averaging tiles can hold a candidate), the averaging / threshold stage of call k - 2 and the candidate lists of call k - 3 — the
+ * lists of a call exist three calls later, or after ss_flush / ss_sync —, mask / counter / list sets rotate over four to six, and
+ * the averager ring's buffer holds four batches (csrc/ring_place.h). 2^20-point frames: two launches per call, the stages of
+ * the two calls before riding on them. The results of a call are therefore complete only after ss_sync, or after ss_flush
  * followed by any synchronisation of ss_stream; every buffer passed to a call (d_iq included) must stay valid and
  * untouched until then — d_iq in particular: the next call's launch reads the call's last frames once more. A streaming
  * producer that cannot afford ss_sync learns when an input buffer is dead from ss_input_wait (below). (As a courtesy, a caller
@@ -231,6 +235,10 @@ enum { SS_KSLOT_STEP = 0, SS_KSLOT_ROWS = 1, SS_KSLOT_SUB = 2, SS_KSLOT_PLAN = 3
  * it. 65536-point frames: SS_KSLOT_STEP the column half with the plan, detect and emit stages of earlier calls, SS_KSLOT_ROWS the row
  * half. SS_KSLOT_PLAN: the plan as a launch of its own — drains only.) */
 int ss_kernel_timing_read_slots(ss_ctx* ctx, double* ms_by_slot, int32_t* launches_by_slot);
+/* ... and with the frames the timed launches covered, slot by slot (frames_by_slot: SS_KSLOT_COUNT entries): a call the library
+ * takes through in chunks — 2^20 points beyond 16 frames, the four-step form of 65536 points beyond 256 — has several launches per
+ * slot, each over its chunk's frames; bytes per launch follow from frames / launches, not from the call's size. */
+int ss_kernel_timing_read_frames(ss_ctx* ctx, double* ms_by_slot, int32_t* launches_by_slot, int64_t* frames_by_slot);
 
 /* Device self-test of arithmetic shortcuts used by the kernels (which = 0: the 3-instruction division by
  * 21 equals the IEEE division for every float). Returns the number of mismatches (0 = pass) or < 0. */
@@ -248,8 +256,11 @@ int ss_reset_noise(ss_ctx* ctx);
  * negative down to -(grouping_y-1) for SS_PLANE_REL, addressing the averager ring rows that
  * Transmission::getBestIndex walks (transmission.cpp:132-154). SS_PLANE_REL is always there. SS_PLANE_AVG needs
  * SS_FLAG_KEEP_PLANES. SS_PLANE_PSD is there after ss_process and after ss_process_device calls that were given d_psd_db; a
- * 2^20-point ss_process_device call in detect mode (no plane handed out) writes no dB plane at all — its rows go straight to the
- * averager ring's buffer as noise-relative values — and SS_PLANE_PSD then fails with SS_ERR_INVALID. */
+ * 65536-point or 2^20-point ss_process_device call in detect mode (no plane handed out, no SS_FLAG_KEEP_PLANES) writes no dB
+ * plane at all — its rows go straight to the averager ring's buffer as noise-relative values (65536 points, int8 IQ: in the
+ * residue-major order the radix-8 fold leaves them in, csrc/fft65536_dif8.h; this call hands bins back in bin order all the
+ * same) — and SS_PLANE_PSD / SS_PLANE_AVG then fail with SS_ERR_INVALID: pass d_psd_db, or SS_FLAG_KEEP_PLANES at ss_create,
+ * to a caller that wants them. */
 int ss_read_window(ss_ctx* ctx, int32_t plane, int32_t frame, int32_t lo, int32_t hi, float* out);
 
 /* Spectrogram side branch (needs SS_FLAG_SPECTROGRAM). ss_spectrogram_size: number of output bins,

@@ -675,10 +675,116 @@ __device__ __forceinline__ void plan_long_run(const PlanLongDet& a, const PlanLo
   if (live) p.list[1 + *list_base_p + base + __popcll(mask & ((1ull << lane) - 1ull))] = block;
 }
 
+// The plan for the radix-8 fold's rows (layout 2): one block = 32 consecutive tile columns x ONE frame tile, 256 threads. What
+// plan_long_run does for this layout — a block per tile column with all its frame tiles — fetched every 128-byte line of the run
+// maxima thirty-two times over (a column's eight values per frame sit in eight different lines, each shared with 31 other columns:
+// 143 MB of L1 fills per 512-frame call) and left all but a few dozen of its threads idle through 336 serial LDS reads; as the first
+// 128 workgroups of the fold's launch it cost a 128-frame call 8 us and a 512-frame call 12-16 (profiles/r05/s8_summary.txt). Here:
+//   1  R[colx][row] = max over the eight residues of the run maxima of column colx (34 of them: the block's 32 and one either side)
+//      and frame row (36: the tile's 16 frames and the 20 before) — lanes along the columns, so a wave's load is one line;
+//   2  M = max(R[col - 1], R[col], R[col + 1]) formed on the fly, S[col][j] = the 21-frame window sum that ends at frame j of the tile
+//      (thread per (col, j): 21 x 3 LDS reads);
+//   3  thread per tile: the largest of its window sums -> the same test, the same list, the same statistics as plan_long_run's.
+// Block b: column group b mod 8 (32 columns: the eight groups of a frame tile are consecutive blocks, one per XCD), frame tile b / 8 in
+// dispatch order (plan_long_run's ft_seq). `lds`: kPlanDif8Floats floats + kPlanLongInts ints behind them.
+constexpr int kPlanDif8Floats = 34 * 37 + 32 * 16;
+__host__ __device__ inline int plan_dif8_blocks(int nframes, int shift) { return 8 * ((nframes + shift + 15) / 16); }
+template <int G, int GX, int TF, int TB_ = 256>
+__device__ __forceinline__ void plan_dif8_run(const PlanLongDet& a, const PlanLongArgs& p, int block_no, int tid, float* __restrict__ lds, int* __restrict__ book) {
+  static_assert(TB_ == 256 && TF == 16 && G == 21, "the fold's rows: 256 tile columns of 256 bins, tiles of 16 frames");
+  constexpr int ROWS = TF + G - 1, RP = ROWS + 1;  // 36 frame rows per tile, LDS pitch 37
+  float* R = lds;              // [34][RP]
+  float* S = lds + 34 * RP;    // [32][TF]
+  int* wave_cnt = book;        // [4]
+  int* stat_cnt = book + 4;    // [4][2]
+  int* list_base_p = book + 12;
+  const int nframes = a.nframes, tiles_per_row = 256;
+  const int nft = (nframes + a.shift + TF - 1) / TF;
+  const int cg = block_no & 7, ft_seq = block_no >> 3;
+  const bool in_range = ft_seq < nft;  // (a workgroup's second block may lie past the end: it keeps the barriers company)
+  const int ft = in_range ? (ft_seq + nft - 1) % nft : 0;
+  const int f0 = ft * TF - a.shift;  // batch-relative frame of the tile's first row of outputs
+  const int c0 = 32 * cg;
+  if (in_range) {
+    for (int e = tid; e < 34 * ROWS; e += 256) {
+      const int colx = e % 34, r = e / 34;
+      const int col = min(max(c0 - 1 + colx, 0), tiles_per_row - 1);  // (the band's edges: the edge column once more)
+      const float* row = p.smax + ((size_t)((p.abs0 + f0 - (G - 1) + r) & p.smax_mask) << 11);
+      float m = -__builtin_inff();
+#pragma unroll
+      for (int g = 0; g < 8; ++g) m = fmaxf(m, row[256 * g + col]);  // (the fold's maxima hold no NaN: fft8192_v2.h takes them with fmaxf)
+      R[colx * RP + r] = m;
+    }
+  }
+  __syncthreads();
+  if (in_range) {
+    for (int e = tid; e < 32 * TF; e += 256) {
+      const int cl = e >> 4, j = e & 15;
+      const float *r0 = R + cl * RP + j, *r1 = r0 + RP, *r2 = r1 + RP;
+      float sum = 0.0f;
+#pragma unroll
+      for (int k = 0; k < G; ++k) sum += fmaxf(fmaxf(r0[k], r1[k]), r2[k]);  // M of frame f0 - 20 + j + k
+      S[e] = sum;
+    }
+  }
+  __syncthreads();
+  bool live = false, tested = false;
+  int block = 0;
+  if (in_range && tid < 32) {
+    const int col = c0 + tid;
+    block = ft_seq * tiles_per_row + col;
+    live = true;
+    if (a.n_learn == 0 && f0 - (G - 1) >= p.clean_rel && !a.planes_out) {
+      tested = true;
+      float best = -__builtin_inff();
+      bool unsure = false;
+#pragma unroll
+      for (int j = 0; j < TF; ++j) {
+        const float sum = S[tid * TF + j];
+        if (f0 + j >= 0 && f0 + j < nframes) {  // the frames of this batch the tile answers for
+          unsure = unsure || (sum != sum);
+          best = fmaxf(best, sum);
+        }
+      }
+      const float bound = best * (1.0f / (float)G) - a.thr_tilemin[col];
+      live = unsure || !(bound < a.start_level - kCullMargin);  // (a NaN difference: live)
+    }
+  }
+  // this block's share of the list, in thread order (as plan_long_run)
+  const int lane = tid & 63, w = tid >> 6;
+  const unsigned long long mask = __ballot(live);
+  if (lane == 0) wave_cnt[w] = __popcll(mask);
+  if (a.stats) {
+    const int n_tested = __popcll(__ballot(tested)), n_culled = __popcll(__ballot(tested && !live));
+    if (lane == 0) {
+      stat_cnt[2 * w] = n_tested;
+      stat_cnt[2 * w + 1] = n_culled;
+    }
+  }
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    base += k < w ? wave_cnt[k] : 0;
+    total += wave_cnt[k];
+  }
+  if (tid == 0) *list_base_p = total ? atomicAdd(&p.list[0], total) : 0;
+  if (tid == 1 && a.stats) {
+    const int nt = stat_cnt[0] + stat_cnt[2] + stat_cnt[4] + stat_cnt[6], nc = stat_cnt[1] + stat_cnt[3] + stat_cnt[5] + stat_cnt[7];
+    if (nt) {
+      atomicAdd(stat_word(a.stats, kStatTested), (unsigned long long)nt);
+      atomicAdd(stat_word(a.stats, kStatCulled), (unsigned long long)nc);
+    }
+  }
+  __syncthreads();
+  if (live) p.list[1 + *list_base_p + base + __popcll(mask & ((1ull << lane) - 1ull))] = block;
+}
+
 template <int G, int GX, int TF, int TB_ = 256>
 __global__ __launch_bounds__(256) void k_plan_long(PlanLongDet a, PlanLongArgs p) {
   __shared__ float mrow[kPlanLongFloats];
   __shared__ int book[kPlanLongInts];
+  if (p.layout == 2) return plan_dif8_run<G, GX, TF, TB_>(a, p, (int)blockIdx.x, (int)threadIdx.x, mrow, book);
   plan_long_run<G, GX, TF, TB_>(a, p, (int)blockIdx.x, (int)threadIdx.x, mrow, book);
 }
 

@@ -61,19 +61,22 @@ struct Dif8Front {
   int nframes;             // frames of the launch (the workgroup -> (frame, residue) map, dif8_item)
   int* zero_word;          // set to zero by the first workgroup: the count of the list the plan behind this launch appends to (or null)
 };
-// Which (frame, residue) the j-th of a launch's 8 nframes fold workgroups takes. Workgroups go round the eight XCDs in dispatch
-// order, so — as long as the launch's fold workgroups are consecutive blocks — the eight residues of a frame are given 64
-// consecutive numbers of ONE residue class mod 8: one XCD, one L2, and the frame crosses the fabric once (measured,
-// scripts/ubench/dif8_lab: 19 MB of fetches per 128-frame launch against 135 MB with a frame's residues on eight XCDs).
+// Which (frame, residue) the j-th of a launch's fold workgroups takes — W = 8 of them per frame (one residue each), or W = 4 (residues
+// r and r + 4 each, dif8_front2). Workgroups go round the eight XCDs in dispatch order, so — as long as the launch's fold workgroups
+// are consecutive blocks — the W workgroups of a frame are given 8 W consecutive numbers of ONE residue class mod 8: one XCD, one L2,
+// and the frame crosses the fabric once (measured, scripts/ubench/dif8_lab: 19 MB of fetches per 128-frame launch against 135 MB with
+// a frame's residues on eight XCDs).
+template <int W>
 __host__ __device__ inline void dif8_item(int j, int nframes, int* frame, int* residue) {
+  static_assert(W == 4 || W == 8, "workgroups per frame");
   const int full = nframes >> 3;
-  if (j < 64 * full) {
-    *residue = (j >> 3) & 7;
-    *frame = ((j >> 6) << 3) + (j & 7);
+  if (j < 8 * W * full) {
+    *residue = (j >> 3) & (W - 1);
+    *frame = ((j / (8 * W)) << 3) + (j & 7);
   } else {  // the frames beyond the last whole group of eight: in turn
-    const int jj = j - 64 * full;
-    *residue = jj & 7;
-    *frame = 8 * full + (jj >> 3);
+    const int jj = j - 8 * W * full;
+    *residue = jj & (W - 1);
+    *frame = 8 * full + jj / W;
   }
 }
 
@@ -282,6 +285,86 @@ __device__ __forceinline__ void dif8_front(const Dif8Front& d, size_t frame_in, 
   const float2 wt = d.wt[residue * 512 + t];
 #pragma unroll
   for (int rho = 0; rho < 16; ++rho) a[rho] = cmul(a[rho], cmul(wt, make_float2(crho[2 * rho], crho[2 * rho + 1])));
+}
+
+// Two residues by one workgroup: r (< 4) and r + 4 share a frame's conversions, taps and pair sums — W_8^(q (r + 4)) = (-1)^q W_8^(q r)
+// — so the fold costs twenty vector instructions per pair of samples for BOTH residues instead of sixteen for each; the price is
+// a second set of sixteen accumulators (and of points, kept in registers while the first residue goes through the transform):
+// 128 registers, four waves per SIMD, two workgroups per CU. LDS-DMA pieces as above. a = y_r, a2 = y_(r + 4).
+template <int FMT, class F>
+__device__ __forceinline__ void dif8_front2(const Dif8Front& d, size_t frame_in, int residue, unsigned char* __restrict__ smem_raw, int t, float2 (&a)[16],
+                                            float2 (&a2)[16], F&& after_first_issue) {
+  static_assert(FMT == FMT_CS8 || FMT == FMT_CU8, "two-byte samples");
+  const char* fb = reinterpret_cast<const char*>(d.iq) + frame_in * (size_t)d.item_stride * 2;
+  const __amdgpu_buffer_rsrc_t rin = buffer_of(fb, 65536 * 2);
+  const dif8_const_fp cq = (dif8_const_fp)(uintptr_t)d.wq;
+  const dif8_const_fp c8 = (dif8_const_fp)(uintptr_t)(d.w8 + residue * 8);
+  const dif8_const_fp crho = (dif8_const_fp)(uintptr_t)(d.wrho + residue * 16), crho2 = (dif8_const_fp)(uintptr_t)(d.wrho + (residue + 4) * 16);
+  const float sg = (residue & 1) ? -1.0f : 1.0f;
+#pragma unroll
+  for (int rho = 0; rho < 16; ++rho) a[rho] = a2[rho] = make_float2(0.f, 0.f);
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63;
+  const auto issue = [&](int q, int half) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem_raw + half * 16384 + (2 * w + j) * 1024), 16, lane * 16,
+                                               1024 * (8 * half + w) + 65536 * j + 16384 * q, 0, SS_AUX_DIF_IQ);
+  };
+  issue(0, 0);
+  issue(0, 1);
+  after_first_issue();
+  const float2 th = d.wthe[t];
+  const unsigned short* mine = reinterpret_cast<const unsigned short*>(smem_raw) + t;
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    const Dif8Trip x = dif8_trip(th, cq, c8, q, sg);
+    const float sq = (q & 1) ? -1.0f : 1.0f;  // W_8^(q (r + 4)) = (-1)^q W_8^(q r)
+    const float w8c2 = x.w8c * sq, w8s2 = x.w8s * sq;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (!(q == 0 && half == 0) && !(q == 3 && half == 1)) {
+        if (half == 0) issue(q, 1);
+        else issue(q + 1, 0);
+      }
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        unsigned raw1[4], raw2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          raw1[i] = mine[half * 8192 + 1024 * (4 * sub + i)];
+          raw2[i] = mine[half * 8192 + 1024 * (4 * sub + i) + 512];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int rho = 8 * half + 4 * sub + i;
+          float re1, im1, re2, im2;
+          dif8_convert<FMT>(raw1[i], re1, im1);
+          dif8_convert<FMT>(raw2[i], re2, im2);
+          const float t1 = fmaf(x.c1, kDif8P[rho], fmaf(x.s1, kDif8Q[rho], 0.54f));
+          const float t2 = fmaf(x.c2, kDif8P[rho], fmaf(x.s2, kDif8Q[rho], x.k2));
+          const float ur = fmaf(t2, re2, t1 * re1), ui = fmaf(t2, im2, t1 * im1);
+          float2 &acc = a[rho], &acc2 = a2[rho];
+          acc.x = fmaf(ur, x.w8c, fmaf(-ui, x.w8s, acc.x));
+          acc.y = fmaf(ur, x.w8s, fmaf(ui, x.w8c, acc.y));
+          acc2.x = fmaf(ur, w8c2, fmaf(-ui, w8s2, acc2.x));
+          acc2.y = fmaf(ur, w8s2, fmaf(ui, w8c2, acc2.y));
+          asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc2.x), "+v"(acc2.y));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __syncthreads();  // the plane goes back to the transform
+  const float2 wt = d.wt[residue * 512 + t], wt2 = d.wt[(residue + 4) * 512 + t];
+#pragma unroll
+  for (int rho = 0; rho < 16; ++rho) {
+    a[rho] = cmul(a[rho], cmul(wt, make_float2(crho[2 * rho], crho[2 * rho + 1])));
+    a2[rho] = cmul(a2[rho], cmul(wt2, make_float2(crho2[2 * rho], crho2[2 * rho + 1])));
+  }
 }
 
 }  // namespace ss

@@ -130,78 +130,18 @@ __device__ __forceinline__ void halfwave_max4_hi16(float& a, float& b, float& c,
 #undef SS_DPP4
 }
 
-// TW: 0 = every table from global memory (first generation), 1 = pass-2 table in LDS, 2 = all tables in LDS / SGPRs,
-//     3 = no tables at all (timing bound only: the output is meaningless).
-// SWZ: exchange 1 as four 16-byte LDS stores per plane into an unpadded, quad-rotated image instead of sixteen 4-byte
-//      stores into the 17-word pitch.
-// One frame by one workgroup of 512 threads; `smem_raw` = kFft8192V2LdsBytes of LDS, `t` = threadIdx.x.
-// FRONT: 0 = an 8192-point frame of its own; 1, 2 = residue `residue` of the 65536-point frame `frame_in` of `dif` (fft65536_dif8.h,
-//        LOADV = FRONT - 1: the load stage is the radix-8 fold, g.iq / g.win / g.item_stride are not read), `frame` = the row
-//        of 8192 floats the residue's bins go to (8 frame_in + residue in a plane of residue-major rows).
-template <int FMT, int TW, bool SWZ = false, bool NOWIN = false, int FRONT = 0>
-__device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t frame, unsigned char* __restrict__ smem_raw, int t, int* hdr,
-                                                 const Dif8Front* dif = nullptr, size_t frame_in = 0, int residue = 0) {
+// Everything behind the load stage: the three register passes on a[16] (the thread's y[t + 512 r], r < 16), dB, the row's stores and
+// what the frame leaves for the detect stage. `a` is consumed.
+template <int FMT, int TW, bool SWZ, int FRONT>
+__device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Args& g, size_t frame, unsigned char* __restrict__ smem_raw, int t, int* hdr,
+                                                const Dif8Front* dif, size_t frame_in, int residue) {
   float* s = reinterpret_cast<float*>(smem_raw);
   float2* tw2_l = reinterpret_cast<float2*>(smem_raw + kFft8192V2PlaneBytes);
   float2* lane_l = tw2_l + 256;
   const Fft8192V2Tables& tabs = g.tabs;
-  const void* iq = g.iq;
-  const float* win = g.win;
-  const float db_off = g.db_off, scale = g.scale;
+  const float db_off = g.db_off;
   float* psd = g.psd;
   float* segsum = g.segsum;
-  const size_t in_base = frame * (size_t)g.item_stride;
-
-  // ---- tables first: these loads are ahead of the frame's own in the vector-memory queue ----
-  float2 tf0 = make_float2(0.f, 0.f), tf1 = make_float2(0.f, 0.f);
-  if constexpr (FRONT != 0) {
-    static_assert(TW == 2, "the fold keeps the transform's tables in LDS");
-  } else if constexpr (TW == 1) {
-    if (t < 256) tf0 = tabs.tw2[t];
-  } else if constexpr (TW == 2) {
-    tf0 = t < 256 ? tabs.tw2[t] : tabs.lane[t - 256];
-    if (t < 128) tf1 = tabs.lane[256 + t];
-  }
-
-  // ---------------- pass 1: radix 16, Ns = 1, butterfly j = t ----------------
-  float2 a[16];
-  if constexpr (FRONT != 0) {
-    // (the tables go to LDS at once — their place behind the exchange plane is free — instead of through registers that would
-    // have to live through the fold)
-    dif8_front<FMT, FRONT - 1>(*dif, frame_in, residue, smem_raw, t, a, [&]() {
-      tw2_l[t] = t < 256 ? tabs.tw2[t] : tabs.lane[t - 256];
-      if (t < 128) lane_l[256 + t] = tabs.lane[256 + t];
-    });
-  } else {
-    constexpr int kSample = FMT == FMT_CF32 ? 8 : 2;  // bytes per IQ sample
-    const __amdgpu_buffer_rsrc_t rin = buffer_of(reinterpret_cast<const char*>(iq) + in_base * kSample, 8192 * kSample);
-    const __amdgpu_buffer_rsrc_t rwin = buffer_of(win, 8192 * 4);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float2 x;
-      if constexpr (FMT == FMT_CF32) {
-        x = buffer_load_f2<SS_AUX_IQ>(rin, t * 8, 4096 * r);
-      } else {
-        const unsigned short raw = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rin, t * 2, 1024 * r, SS_AUX_IQ);
-        if constexpr (FMT == FMT_CS8) x = make_float2((float)(signed char)(raw & 0xff) * scale, (float)(signed char)(raw >> 8) * scale);
-        else x = make_float2(((float)(raw & 0xff) - 127.5f) * scale, ((float)(raw >> 8) - 127.5f) * scale);
-      }
-      if constexpr (NOWIN) {
-        a[r] = x;
-      } else {
-        const float w = buffer_load_f1(rwin, t * 4, 2048 * r);
-        a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
-      }
-    }
-  }
-  if constexpr (FRONT != 0) {
-    // (written by the fold's prologue)
-  } else if constexpr (TW == 1) {
-    if (t < 256) tw2_l[t] = tf0;
-  } else if constexpr (TW == 2) {
-    tw2_l[t] = tf0;  // tw2_l and lane_l are contiguous: entries 0..511
-    if (t < 128) lane_l[256 + t] = tf1;
-  }
   dft16(a);
   float2 c[16];
   if constexpr (SWZ) {
@@ -511,6 +451,100 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
     *hdr = __builtin_amdgcn_readfirstlane(__float_as_int(*hint_slot));
   }
 #endif
+}
+
+
+// TW: 0 = every table from global memory (first generation), 1 = pass-2 table in LDS, 2 = all tables in LDS / SGPRs,
+//     3 = no tables at all (timing bound only: the output is meaningless).
+// SWZ: exchange 1 as four 16-byte LDS stores per plane into an unpadded, quad-rotated image instead of sixteen 4-byte
+//      stores into the 17-word pitch.
+// One frame by one workgroup of 512 threads; `smem_raw` = kFft8192V2LdsBytes of LDS, `t` = threadIdx.x.
+// FRONT: 0 = an 8192-point frame of its own; 1, 2 = residue `residue` of the 65536-point frame `frame_in` of `dif` (fft65536_dif8.h,
+//        LOADV = FRONT - 1: the load stage is the radix-8 fold, g.iq / g.win / g.item_stride are not read), `frame` = the row
+//        of 8192 floats the residue's bins go to (8 frame_in + residue in a plane of residue-major rows); 3 = residues `residue` (< 4)
+//        AND residue + 4 by the same workgroup, one fold for both, rows `frame` and `frame` + 4 (twice the registers: four waves per SIMD).
+template <int FMT, int TW, bool SWZ = false, bool NOWIN = false, int FRONT = 0>
+__device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t frame, unsigned char* __restrict__ smem_raw, int t, int* hdr,
+                                                 const Dif8Front* dif = nullptr, size_t frame_in = 0, int residue = 0) {
+  float2* tw2_l = reinterpret_cast<float2*>(smem_raw + kFft8192V2PlaneBytes);
+  float2* lane_l = tw2_l + 256;
+  const Fft8192V2Tables& tabs = g.tabs;
+  const void* iq = g.iq;
+  const float* win = g.win;
+  const float scale = g.scale;
+  const size_t in_base = frame * (size_t)g.item_stride;
+
+  // ---- tables first: these loads are ahead of the frame's own in the vector-memory queue ----
+  float2 tf0 = make_float2(0.f, 0.f), tf1 = make_float2(0.f, 0.f);
+  if constexpr (FRONT != 0) {
+    static_assert(TW == 2, "the fold keeps the transform's tables in LDS");
+  } else if constexpr (TW == 1) {
+    if (t < 256) tf0 = tabs.tw2[t];
+  } else if constexpr (TW == 2) {
+    tf0 = t < 256 ? tabs.tw2[t] : tabs.lane[t - 256];
+    if (t < 128) tf1 = tabs.lane[256 + t];
+  }
+
+  // ---------------- pass 1: radix 16, Ns = 1, butterfly j = t ----------------
+  float2 a[16];
+  [[maybe_unused]] float2 a2[16];  // FRONT = 3: the second residue's points
+  if constexpr (FRONT != 0) {
+    // (the tables go to LDS at once — their place behind the exchange plane is free — instead of through registers that would
+    // have to live through the fold)
+    const auto tables_to_lds = [&]() {
+      tw2_l[t] = t < 256 ? tabs.tw2[t] : tabs.lane[t - 256];
+      if (t < 128) lane_l[256 + t] = tabs.lane[256 + t];
+    };
+    if constexpr (FRONT == 3) dif8_front2<FMT>(*dif, frame_in, residue, smem_raw, t, a, a2, tables_to_lds);
+    else dif8_front<FMT, FRONT - 1>(*dif, frame_in, residue, smem_raw, t, a, tables_to_lds);
+    (void)iq;
+    (void)win;
+    (void)scale;
+    (void)in_base;
+  } else {
+    constexpr int kSample = FMT == FMT_CF32 ? 8 : 2;  // bytes per IQ sample
+    const __amdgpu_buffer_rsrc_t rin = buffer_of(reinterpret_cast<const char*>(iq) + in_base * kSample, 8192 * kSample);
+    const __amdgpu_buffer_rsrc_t rwin = buffer_of(win, 8192 * 4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float2 x;
+      if constexpr (FMT == FMT_CF32) {
+        x = buffer_load_f2<SS_AUX_IQ>(rin, t * 8, 4096 * r);
+      } else {
+        const unsigned short raw = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rin, t * 2, 1024 * r, SS_AUX_IQ);
+        if constexpr (FMT == FMT_CS8) x = make_float2((float)(signed char)(raw & 0xff) * scale, (float)(signed char)(raw >> 8) * scale);
+        else x = make_float2(((float)(raw & 0xff) - 127.5f) * scale, ((float)(raw >> 8) - 127.5f) * scale);
+      }
+      if constexpr (NOWIN) {
+        a[r] = x;
+      } else {
+        const float w = buffer_load_f1(rwin, t * 4, 2048 * r);
+        a[r] = make_float2(x.x * w, x.y * w);  // volk_32fc_32f_multiply_32fc
+      }
+    }
+  }
+  if constexpr (FRONT != 0) {
+    // (written by the fold's prologue)
+  } else if constexpr (TW == 1) {
+    if (t < 256) tw2_l[t] = tf0;
+  } else if constexpr (TW == 2) {
+    tw2_l[t] = tf0;  // tw2_l and lane_l are contiguous: entries 0..511
+    if (t < 128) lane_l[256 + t] = tf1;
+  }
+  if constexpr (FRONT == 3) {
+    // two residues by one workgroup (fft65536_dif8.h, dif8_front2): r's transform, then (r + 4)'s from the registers that kept it
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass) {
+        __syncthreads();  // the first residue's last reads of the plane are done
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = a2[r];
+      }
+      fft8192_v2_core<FMT, TW, SWZ, FRONT>(a, g, frame + 4 * pass, smem_raw, t, hdr, dif, frame_in, residue + 4 * pass);
+    }
+  } else {
+    fft8192_v2_core<FMT, TW, SWZ, FRONT>(a, g, frame, smem_raw, t, hdr, dif, frame_in, residue);
+  }
 }
 
 }  // namespace ss

@@ -25,6 +25,10 @@
 // Exact for NaN and -inf — the values degenerate input produces (zeros, NaN samples). +inf (|X|^2 overflowing: samples beyond
 // 1e19) is handled through the same first-bin summary, which leaves out one contrived case: infinities of both signs at the SAME
 // bin within 21 frames where that bin is not the first infinite bin of both rows.
+// Not covered either: a +inf dB value in a LEARNING frame (|X|^2 overflowing while the ceiling is learned). The reference's ceiling
+// then is +inf at that bin (std::max, noise_learner.cpp:18-26), every later rel value there -inf and the Averager's sums NaN after
+// 21 frames, while the dB rows this scan looks at stay finite: the engine reports -inf averages where the reference has NaN (no
+// candidates either way: neither passes `start_level <= avg`).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -52,6 +52,13 @@
 #include "fft256_kernels.h"
 #include "fft8192_v2.h"
 
+// KIND 8 (65536 points, the radix-8 fold): workgroups per frame — 4: two residues each (one fold for both, 128 registers, four waves per
+// SIMD); 8: one residue each (64 registers, eight waves per SIMD). Build-time so that the two can be timed against each other
+// (scripts/build_ab.py).
+#ifndef SS_DIF8_W
+#define SS_DIF8_W 4
+#endif
+
 namespace ss {
 
 struct StepArgs {
@@ -107,8 +114,9 @@ struct StepArgs {
   // beside the ROW tiles of call k - 1 (ROLE_ROWS: rows256, n_rows of them, reading the other of two work buffers), the plan of call
   // k - 2, detect(k - 3) and emit(k - 4). 0: no such role.
   int n_rows;
-  // KIND 8 — 65536 points, int8 IQ, NO work buffer: the FFT role is a residue of a frame — the radix-8 fold in the load stage of the
-  // 8192-point transform (fft65536_dif8.h), eight workgroups per frame, n_fft = 8 x frames, item j -> dif8_item — whose rows (noise-
+  // KIND 8 — 65536 points, int8 IQ, NO work buffer: the FFT role is TWO residues of a frame, r and r + 4 — the radix-8 fold in the load
+  // stage of the 8192-point transform, once for both, then the transform twice (fft65536_dif8.h: dif8_front2; 128 registers, so this
+  // instantiation runs four waves per SIMD) —, four workgroups per frame, n_fft = 4 x frames, item j -> dif8_item<4> — whose rows (noise-
   // relative, residue-major: `fft.psd` is the ring's buffer, `fft.rel_thr` the ceiling in the same order) and run maxima the detect
   // stage of two calls later reads; the plan of call k - 1, detect(k - 2) (PERM8 tiles) and emit(k - 3) ride on the launch as they ride
   // on the column launch of the four-step form (KIND 2). `fft` carries the transform's tables and the rows' place, `dif` the fold's.
@@ -140,6 +148,7 @@ static_assert((8 * kEmitList + 9) * 4 <= kFft8192V2LdsBytes, "eight emit lists p
 static_assert(kFft256ColsLdsBytes <= kFft8192V2LdsBytes && kFft1024ColsLdsBytes <= kFft8192V2LdsBytes && kFft1024RowsLdsBytes <= kFft8192V2LdsBytes && kFft256RowsPsdLdsBytes <= kFft8192V2LdsBytes, "a column / row tile");
 static_assert((kPlanLdsFloats + 64) * 4 <= kFft8192V2LdsBytes, "a plan workgroup's staging area");
 static_assert(2 * (kPlanFusedFloats + kPlanLongInts) * 4 <= kFft8192V2LdsBytes, "two blocks of a long transform's plan");
+static_assert(kPlanDif8Floats <= kPlanFusedFloats && kPlanDif8Floats <= kPlanLongFloats, "a block of the fold's plan in a plan block's LDS");
 __host__ __device__ inline int step_fft_wgs(const StepArgs& a) { return a.n_fft; }
 __host__ __device__ inline int step_emit_wgs(const StepArgs& a) { return a.emit_per_wg == 1 ? a.n_emit : (a.n_emit + 7) / 8; }
 __host__ __device__ inline int step_plan_wgs(const StepArgs& a) { return a.n_plan ? 32 / a.plan_cols : a.n_plan_long; }
@@ -219,7 +228,8 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     if constexpr (KIND == 1 || KIND == 2 || KIND == 7 || KIND == 8) {  // a long transform's plan: two blocks of k_plan_long's numbering
       const int sub = tid >> 8;
       float* mrow = reinterpret_cast<float*>(smem_raw) + sub * (kPlanFusedFloats + kPlanLongInts);
-      plan_long_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));
+      if constexpr (KIND == 8) plan_dif8_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));  // (the fold's rows: layout 2)
+      else plan_long_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));
       return;
     }
     if constexpr (KIND == 0) plan_seg = item;
@@ -232,8 +242,8 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     else if constexpr (KIND == 8) {  // a residue of a 65536-point frame: fold + 8192-point transform + dB -> the ring's rows
       if constexpr (FMT != FMT_CF32) {
         int f, r, hdr;
-        dif8_item(item, a.dif.nframes, &f, &r);
-        fft8192_v2_frame<FMT, 2, true, false, 2>(a.fft, (size_t)(8 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
+        dif8_item<SS_DIF8_W>(item, a.dif.nframes, &f, &r);  // (W = 4: residues r and r + 4 by this workgroup)
+        fft8192_v2_frame<FMT, 2, true, false, SS_DIF8_W == 4 ? 3 : 2>(a.fft, (size_t)(8 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
       }
     }
     else if constexpr (KIND == 6) fft_rows256_tile(a.rows256, item, smem_raw, tid);  // (the ROW half of call k: its column half ran as its own launch right before)
@@ -342,7 +352,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
 }
 
 template <int FMT, bool SPEC, int TW = 2, bool SWZ = true, bool PRIO = false, int KIND = 0>
-__global__ __launch_bounds__(kStepThreads, 8) void k_scan_step(StepArgs a_by_value) {
+__global__ __launch_bounds__(kStepThreads, (KIND == 8 && SS_DIF8_W == 4) ? 4 : 8) void k_scan_step(StepArgs a_by_value) {
   // The arguments are read where they are used, straight from the kernel-argument segment (scalar loads from constant
   // memory): taken from the by-value parameter they are all loaded at the top of the kernel and kept alive through every
   // role — hundreds of scalar registers spilled into vector registers the 64-VGPR budget does not have.

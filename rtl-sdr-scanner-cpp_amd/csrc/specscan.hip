@@ -153,6 +153,13 @@ struct ss_ctx {
     // workgroups whose phases overlap. In turn (R1,F1) they took 45.7 us per 128-frame call against 41.0-41.7 in two runs, 26.2 against
     // 24.0 per 64-frame call (rows first: 41.0 / 26.7): profiles/r04/s35_summary.txt
     std::string step_order_merged = "E*|D*,F*,R*";
+    // ... of the radix-8 fold's launch (KIND 8; the plan's few dozen workgroups always first): the fold workgroups, then the candidate
+    // lists, then the listed tiles' detect workgroups. A detect workgroup lives 10-20 us, and every one dispatched ahead of the fold
+    // workgroups holds up one of the launch's last round by as much: detect first (the long transforms' order above) 52.8 us per
+    // 128-frame call, this order 40.3; passengers spread between the fold workgroups (F8,E2,D1 and the like) 47-52
+    // (profiles/r05/s5_summary.txt, s6_summary.txt); emit ahead of the fold workgroups: 71.7 / 129.5 us per 256- / 512-frame call against
+    // 69.8 / 126.5 (s9_summary.txt)
+    std::string step_order_fold = "F*,E*,D*";
 #ifdef SS_DIAG
     void read() {
       const auto is = [](const char* name, const char* value) {
@@ -207,7 +214,7 @@ struct ss_ctx {
       no_order_table = tri("SS_ORDER_TABLE") == 0;
       if (tri("SS_PLAN_NOZERO") == 1) d_cull_stats = reinterpret_cast<unsigned*>(1);
       else if (tri("SS_CULL_STATS") == 1 && hipMalloc(&d_cull_stats, 3 * sizeof(unsigned)) == hipSuccess) (void)hipMemset(d_cull_stats, 0, 3 * sizeof(unsigned));
-      if (const char* v = getenv("SS_STEP_ORDER")) step_order = step_order_long = v;
+      if (const char* v = getenv("SS_STEP_ORDER")) step_order = step_order_long = step_order_fold = v;
       if (const char* v = getenv("SS_STEP_ORDER_MERGED")) step_order_merged = v;
     }
 #else
@@ -487,6 +494,8 @@ struct ss_ctx {
   unsigned prof_seen = 0;
   std::vector<hipEvent_t> prof_events;  // pairs
   std::vector<int> prof_slots;          // which kernel of the chain each pair timed (SS_KSLOT_*)
+  std::vector<int> prof_frames;         // ... and how many frames that launch covered (a call taken through in chunks: the chunk's)
+  int prof_launch_frames = 0;           // frames of the launches being enqueued now (run_batch, its chunk loops)
   size_t prof_used = 0;
   bool prof_call = false;   // the current call is a sampled one: its other kernels (rows, radix-A step, plan) carry events too
   // ss_get_stats: host-side counters, and the device-side ones (detect_fused.h kStat*: tiles tested / culled, wait fallbacks)
@@ -592,10 +601,12 @@ bool prof_take(ss_ctx* c, int slot, hipEvent_t* a, hipEvent_t* b) {
     c->prof_events.push_back(e0);
     c->prof_events.push_back(e1);
     c->prof_slots.push_back(0);
+    c->prof_frames.push_back(0);
   }
   *a = c->prof_events[c->prof_used];
   *b = c->prof_events[c->prof_used + 1];
   c->prof_slots[c->prof_used / 2] = slot;
+  c->prof_frames[c->prof_used / 2] = c->prof_launch_frames;
   c->prof_used += 2;
   return true;
 }
@@ -789,7 +800,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
   std::vector<Seg> prefix, cycle;
   {
     std::vector<Seg>* into = &prefix;
-    const std::string& sp = wg_rows ? c->diag.step_order_merged : c->use_fft8192 ? c->diag.step_order : c->diag.step_order_long;
+    const std::string& sp = wg_rows ? c->diag.step_order_merged : c->use_fft8192 ? c->diag.step_order : a.dif.iq ? c->diag.step_order_fold : c->diag.step_order_long;
     for (size_t i = 0; i < sp.size();) {
       const char ch = sp[i];
       if (ch == '|') {
@@ -879,6 +890,9 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
   if (c->two_pass && a.list_loop) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 5>);
   if (c->two_pass) return c->diag.cols1024_wide ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 4>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 3>);
   if constexpr (FMT != ss::FMT_CF32 && !SPEC) {  // (the fold's launches, and the drains of the stages that wait behind them: their tiles read residue-major rows)
+#ifdef SS_DIAG
+    if (!c->use_fft8192 && c->ring_perm8 && (c->diag.prio_fft || c->diag.prio_other)) return go(ss::k_scan_step<FMT, SPEC, 2, true, true, 8>);
+#endif
     if (!c->use_fft8192 && c->ring_perm8) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 8>);
   }
   if (!c->use_fft8192 && a.n_fft && a.rows256.work && !a.n_rows) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 6>);  // (65536 points: the row tiles as the FFT role; rows of 2048 mask words: the wide emit role)
@@ -899,7 +913,7 @@ struct FftRole {
   const ss::ColsArgs* cols = nullptr;
   const ss::Rows1024Args* rows1024 = nullptr;  // 2^20 points in two passes: the ROW tiles (the column half is a launch of its own)
   const ss::Rows256Args* rows256 = nullptr;    // 65536 points with tile culling: the ROW tiles (the column half is a launch of its own)
-  const ss::Dif8Front* dif = nullptr;          // 65536 points, the radix-8 fold: n = 8 x frames residues; `frames` carries the transform's tables and the rows' place
+  const ss::Dif8Front* dif = nullptr;          // 65536 points, the radix-8 fold: n = 4 x frames workgroups (two residues each); `frames` carries the transform's tables and the rows' place
   int n = 0;  // frames / column tiles
   const void* halo_iq = nullptr;  // deep pipelining: n_halo frames of the previous call go through the FFT again, into halo_psd
   float* halo_psd = nullptr;
@@ -973,7 +987,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   if (with_long_plan && c->have_plan) {  // 65536 points: the plan of the call before as a role of this (column) launch
     a.plan_det = c->pend_plan_det;
     a.plan_long = c->pend_plan;
-    a.n_plan_long = (ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n) + 1) / 2;
+    a.n_plan_long = ((c->pend_plan.layout == 2 ? ss::plan_dif8_blocks(c->pend_plan_det.nframes, c->pend_plan_det.shift) : ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n)) + 1) / 2;
     c->have_plan = false;
   }
   if (ss::step_items(a) == 0) return;
@@ -1144,7 +1158,8 @@ void launch_nan_stage(ss_ctx* c, const NanStage& g) {
 // The plan of the last call as a launch of its own (it would have ridden on the next call's column launch, ss_ctx::have_plan).
 void launch_pending_plan(ss_ctx* c) {
   if (!c->have_plan) return;
-  const int plan_wgs = ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n);  // (groups past the band's end find no column)
+  const int plan_wgs = c->pend_plan.layout == 2 ? ss::plan_dif8_blocks(c->pend_plan_det.nframes, c->pend_plan_det.shift)
+                                                : ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n);  // (groups past the band's end find no column)
   hipLaunchKernelGGL((ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, c->stream, c->pend_plan_det, c->pend_plan);
   c->have_plan = false;
 }
@@ -1788,6 +1803,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
   float* d_psd = d_psd_out ? d_psd_out : c->d_psd2[c->psd_cur];
   if (!d_psd_out) c->psd_cur = (c->psd_cur + 1) % c->npsd;
   c->prof_call = false;
+  c->prof_launch_frames = nframes;
   int st = SS_OK;
   const float* ring_only_rows = nullptr;  // set by a call that writes no dB plane (2^20 points, detect mode, shorter than the ring)
   SpecState* spec = nullptr;
@@ -1887,7 +1903,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       FftRole drole;
       drole.frames = &gf;
       drole.dif = &df;
-      drole.n = 8 * nframes;
+      drole.n = SS_DIF8_W * nframes;  // (4: two residues per workgroup)
       // the plan of the call before, the planned detect stage (of the call before that) and the emit stage behind it ride on the launch
       launch_step(c, &drole, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr, nullptr, true);
     } else if (merged_call) {
@@ -1921,6 +1937,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       for (int f0 = 0; f0 < nframes; f0 += chunk) {
         const int nf = std::min(chunk, nframes - f0);
         const bool first = f0 == 0;
+        c->prof_launch_frames = nf;
         ss::ColsArgs gcc = gc;
         gcc.iq = static_cast<const char*>(d_iq) + (size_t)f0 * (size_t)item_stride * sample;
         FftRole crole;
@@ -1950,6 +1967,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       const int chunk = (c->diag.chunk_long > 0 && nframes > c->diag.chunk_long) ? c->diag.chunk_long : nframes;
       for (int f0 = 0; f0 < nframes; f0 += chunk) {
         const int nf = std::min(chunk, nframes - f0);
+        c->prof_launch_frames = nf;
         launch_cols1024(c, d_iq, item_stride, nf, f0);
         ss::RowsExtra rxc = rx;
         rxc.abs0 += f0;
@@ -2036,7 +2054,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
           c->pend_plan = pl;
           c->pend_plan_det = ss::plan_long_det(nd);
         } else {
-          const int plan_wgs = ss::plan_long_blocks(pl.layout, plan_cols, c->n);  // (groups past the band's end find no column)
+          const int plan_wgs = pl.layout == 2 ? ss::plan_dif8_blocks(nframes, nd.shift) : ss::plan_long_blocks(pl.layout, plan_cols, c->n);  // (groups past the band's end find no column)
           SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, ss::plan_long_det(nd), pl);
         }
         nd.tile_list = list;
@@ -2443,7 +2461,8 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     }
   }
   if (c->logn > 13) CREATE_HIP(hipMalloc(&c->d_work, sizeof(float2) * (size_t)n * (size_t)cfg->max_batch));
-  if (c->merge) CREATE_HIP(hipMalloc(&c->d_work2, sizeof(float2) * (size_t)n * (size_t)cfg->max_batch));
+  // (the one-launch form only takes calls of up to merge_max_frames: the second work buffer need not hold more)
+  if (c->merge) CREATE_HIP(hipMalloc(&c->d_work2, sizeof(float2) * (size_t)n * (size_t)std::min(cfg->max_batch, std::max(1, c->diag.merge_max_frames))));
 
   // window: caller's taps or gr::fft::window::hamming(N) (sdr_device.cpp:164; GNU Radio's definition:
   // 0.54 - 0.46*cos(2*pi*n/(N-1)) in double, stored as float). Twiddles W_N^k from double.
@@ -2747,7 +2766,9 @@ int ss_kernel_timing(ss_ctx* c, int enable) {
   return SS_OK;
 }
 
-int ss_kernel_timing_read_slots(ss_ctx* c, double* ms_by_slot, int32_t* launches_by_slot) {
+int ss_kernel_timing_read_slots(ss_ctx* c, double* ms_by_slot, int32_t* launches_by_slot) { return ss_kernel_timing_read_frames(c, ms_by_slot, launches_by_slot, nullptr); }
+
+int ss_kernel_timing_read_frames(ss_ctx* c, double* ms_by_slot, int32_t* launches_by_slot, int64_t* frames_by_slot) {
   if (!c || !ms_by_slot || !launches_by_slot) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
@@ -2756,6 +2777,7 @@ int ss_kernel_timing_read_slots(ss_ctx* c, double* ms_by_slot, int32_t* launches
   for (int k = 0; k < SS_KSLOT_COUNT; ++k) {
     ms_by_slot[k] = 0.0;
     launches_by_slot[k] = 0;
+    if (frames_by_slot) frames_by_slot[k] = 0;
   }
   for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
     float ms = 0.f;
@@ -2763,6 +2785,7 @@ int ss_kernel_timing_read_slots(ss_ctx* c, double* ms_by_slot, int32_t* launches
     const int slot = c->prof_slots[i / 2];
     ms_by_slot[slot] += ms;
     ++launches_by_slot[slot];
+    if (frames_by_slot) frames_by_slot[slot] += c->prof_frames[i / 2];
   }
   c->prof_used = 0;
   c->prof_call = false;

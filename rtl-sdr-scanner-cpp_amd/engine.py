@@ -58,6 +58,8 @@ def load_library(diag: bool | None = None) -> C.CDLL:
         lib.ss_kernel_timing_read.restype = C.c_int
         lib.ss_kernel_timing_read_slots.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
         lib.ss_kernel_timing_read_slots.restype = C.c_int
+        lib.ss_kernel_timing_read_frames.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        lib.ss_kernel_timing_read_frames.restype = C.c_int
         lib.ss_spectrogram_size.argtypes = [C.c_void_p]
         lib.ss_spectrogram_size.restype = C.c_int
         lib.ss_spectrogram_read.argtypes = [C.c_void_p, C.POINTER(C.c_int8), C.POINTER(C.c_float)]
@@ -84,7 +86,7 @@ def load_library(diag: bool | None = None) -> C.CDLL:
 
 EXPORTS = ("ss_default_config", "ss_device_count", "ss_create", "ss_destroy", "ss_last_error", "ss_process",
            "ss_process_device", "ss_flush", "ss_sync", "ss_stream", "ss_input_wait", "ss_get_stats", "ss_set_frequency_range", "ss_reset", "ss_reset_noise",
-           "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read", "ss_kernel_timing_read_slots", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read",
+           "ss_read_window", "ss_read_noise", "ss_kernel_timing", "ss_kernel_timing_read", "ss_kernel_timing_read_slots", "ss_kernel_timing_read_frames", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read",
            "ss_spectrogram_payload", "ss_feed_create", "ss_feed_destroy", "ss_feed_acquire", "ss_feed_submit", "ss_feed_collect", "ss_feed_pending")
 
 
@@ -179,6 +181,13 @@ class SpectrumEngine(abi.Chain):
         ms, cnt = (C.c_double * 4)(), (C.c_int32 * 4)()
         self._check(self._lib.ss_kernel_timing_read_slots(self._h, ms, cnt))
         return {name: (ms[k], cnt[k]) for k, name in enumerate(self.KERNEL_SLOTS)}
+
+    def kernel_timing_read_frames(self):
+        """{slot: (total device ms, launches, frames those launches covered)} of the sampled launches since the last read — a call
+        the library takes through in chunks has several launches per slot, each over its chunk's frames."""
+        ms, cnt, fr = (C.c_double * 4)(), (C.c_int32 * 4)(), (C.c_int64 * 4)()
+        self._check(self._lib.ss_kernel_timing_read_frames(self._h, ms, cnt, fr))
+        return {name: (ms[k], cnt[k], fr[k]) for k, name in enumerate(self.KERNEL_SLOTS)}
 
     def feed(self, depth: int = 3, cand_cap: int = 1 << 20, want_psd: bool = False) -> "Feed":
         """Pipelined host feeding (ss_feed_*): pinned staging slots, H2D overlapped with the chain."""

@@ -31,12 +31,14 @@
 // XMAP 1: block b -> XCD b mod 8 (round-robin dispatch); the eight residues of frame f are blocks 64 (f / 8) + 8 r + (f mod 8): one XCD,
 // 64 consecutive block numbers. XMAP 0: b = 8 f + r — a frame's residues on eight different XCDs.
 template <int FMT, int FRONT, int XMAP>
-__global__ __launch_bounds__(512, 8) void k_dif8_lab(ss::Fft8192Args g, ss::Dif8Front d) {
+__global__ __launch_bounds__(512, FRONT == 3 ? 4 : 8) void k_dif8_lab(ss::Fft8192Args g, ss::Dif8Front d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int b = (int)blockIdx.x;
   int f, r;
-  if (XMAP) {
-    ss::dif8_item(b, d.nframes, &f, &r);
+  if (FRONT == 3) {  // four workgroups per frame (residues r and r + 4 each)
+    ss::dif8_item<4>(b, d.nframes, &f, &r);
+  } else if (XMAP) {
+    ss::dif8_item<8>(b, d.nframes, &f, &r);
   } else {
     r = b & 7;
     f = b >> 3;
@@ -146,7 +148,9 @@ int main(int argc, char** argv) {
       {"LDS-DMA pieces, a frame's residues on ONE XCD", 2, 1},
       {"two-byte loads, residues over eight XCDs", 1, 0},
       {"LDS-DMA pieces, residues over eight XCDs", 2, 0},
+      {"LDS-DMA pieces, TWO residues per workgroup (128 VGPRs), ONE XCD", 3, 1},
   };
+  const int nvariants = 5;
   const auto launch = [&](const Variant& v, int set, int frames, hipEvent_t e0, hipEvent_t e1) {
     ss::Fft8192Args g{};
     g.tabs = tabs;
@@ -158,9 +162,10 @@ int main(int argc, char** argv) {
     d.smax = d_seg[set];
     d.smax_mask = 1023;
     d.nframes = frames;
-    const dim3 grid(8 * frames), block(512);
+    const dim3 grid((v.front == 3 ? 4 : 8) * frames), block(512);
 #define GO(FRONT, XMAP) hipExtLaunchKernelGGL((k_dif8_lab<ss::FMT_CS8, FRONT, XMAP>), grid, block, ss::kFft8192V2LdsBytes, st, e0, e1, 0, g, d)
-    if (v.front == 1 && v.xmap == 1) GO(1, 1);
+    if (v.front == 3) GO(3, 1);
+    else if (v.front == 1 && v.xmap == 1) GO(1, 1);
     else if (v.front == 2 && v.xmap == 1) GO(2, 1);
     else if (v.front == 1 && v.xmap == 0) GO(1, 0);
     else GO(2, 0);
@@ -182,7 +187,7 @@ int main(int argc, char** argv) {
       for (int i = 0; i < N; ++i) db[i] = 10.0 * log10(std::norm(x[(i + N / 2) % N]) / fs);
       ref.push_back(db);
     }
-    for (int vi = 0; vi < 4; ++vi) {
+    for (int vi = 0; vi < nvariants; ++vi) {
       if (only >= 0 && vi != only) continue;
       CK(hipMemset(d_out[0], 0xff, out_bytes));
       launch(variants[vi], 0, max_frames, nullptr, nullptr);
@@ -211,7 +216,7 @@ int main(int argc, char** argv) {
   std::vector<hipEvent_t> ev(2 * iters);
   for (auto& e : ev) CK(hipEventCreate(&e));
   for (int frames : frame_counts) {
-    for (int vi = 0; vi < 4; ++vi) {
+    for (int vi = 0; vi < nvariants; ++vi) {
       if (only >= 0 && vi != only) continue;
       for (int k = 0; k < 12; ++k) launch(variants[vi], k % nsets, frames, nullptr, nullptr);
       CK(hipStreamSynchronize(st));

@@ -37,10 +37,13 @@ def test_chain_kernels_and_their_bytes():
     b = _bench()
     assert [k[0] for k in b.chain_kernels(8192, "cf32")] == ["step"] and b.chain_kernels(8192, "cf32")[0][3] == 12.0
     assert b.chain_kernels(8192, "cs8")[0][3] == 6.0
-    k3 = {k[0]: k[3] for k in b.chain_kernels(65536, "cs8")}
+    for nb in (None, 128, 512):  # config 3 as it ships (int8 IQ, detect mode): the radix-8 fold, one launch per call whatever its length, int8 in + rel rows out
+        assert {k[0]: k[3] for k in b.chain_kernels(65536, "cs8", nb, True)} == {"step": 6.0}
+    k3 = {k[0]: k[3] for k in b.chain_kernels(65536, "cs8")}  # ... a call that keeps a plane: the four-step form
     assert k3 == {"step": 22.0}  # one launch per call: columns (int8 in + work buffer out) and rows (work in + dB out)
     k3 = {k[0]: k[3] for k in b.chain_kernels(65536, "cs8", 256)}
     assert k3 == {"step": 10.0, "rows": 12.0, "plan": 0.0}  # calls of more than 128 frames: two launches
+    assert {k[0]: k[3] for k in b.chain_kernels(65536, "cf32", 128, True)} == {"step": 28.0}  # CF32 IQ: the four-step form in detect mode too
     k5 = {k[0]: k[3] for k in b.chain_kernels(1 << 20, "cf32")}
     assert k5 == {"step": 16.0, "rows": 12.0, "plan": 0.0}  # 2^20 points in two passes: column half (a launch of its own), row half (k_scan_step's FFT role), plan
     os.environ["SS_FFT_TWOPASS"] = "0"  # (a switch of the diagnostics build: round 3's three passes)
@@ -49,6 +52,47 @@ def test_chain_kernels_and_their_bytes():
     finally:
         del os.environ["SS_FFT_TWOPASS"]
     assert b.algo_bytes_per_sample("cf32", True) == 12.0 and b.algo_bytes_per_sample("cs8", False) == 2.0
+
+
+def test_ranks_take_their_own_device_and_only_rank_zero_of_one_runs_the_side_legs():
+    """bench.py at N > 1 (the driver's 2 / 4 / 8-GPU runs, which no round could try on hardware): rank r works on device LOCAL_RANK,
+    and the legs beside the timed region — CPU baseline, live PMC passes, `also`, the parity sample — run at N = 1 only."""
+    b = _bench()
+    args = b.parse_args([])
+    for world in (2, 4, 8):
+        seen = set()
+        for r in range(world):
+            p = b.rank_plan(r, r, world, 8, args, 8192)
+            seen.add(p["device_index"])
+            assert p["device_index"] == r and not p["shares_device"]
+            assert not (p["cpu_baseline"] or p["live_pmc"] or p["also"] or p["parity"]), (world, r, p)
+        assert seen == set(range(world))
+    p = b.rank_plan(0, 0, 1, 1, args, 8192)
+    assert p["device_index"] == 0 and p["cpu_baseline"] and p["live_pmc"] and p["also"] and p["parity"]
+    p = b.rank_plan(3, 3, 4, 1, args, 8192)  # a one-GPU box asked for four ranks (gloo, functional only): they share device 0 and say so
+    assert p["device_index"] == 0 and p["shares_device"]
+    sub = b.parse_args(["--config", "3", "--gpus", "1", "--sub", "--no-cpu-baseline"])
+    p = b.rank_plan(0, 0, 1, 1, sub, 65536)
+    assert p["parity"] and not (p["cpu_baseline"] or p["live_pmc"] or p["also"])  # an `also` run: its own parity sample, nothing else
+
+
+def test_kernel_tally_is_per_launch():
+    """A call the library takes through in chunks has several launches per slot: bytes per launch are those of the chunk's frames
+    (round 4 divided a 64-frame call's bytes by one 16-frame launch's duration and printed 2.07 of peak)."""
+    b = _bench()
+    n, nb = 1 << 20, 64
+    chain = b.chain_kernels(n, "cf32", nb, True)
+    # twenty sampled launches per slot, each over a 16-frame chunk: 64.8 and 57.6 us per launch (BENCH_r04's figures)
+    slots = {"step": (20 * 64.78e-3, 20, 20 * 16), "rows": (20 * 57.61e-3, 20, 20 * 16), "sub": (0.0, 0, 0), "plan": (0.0, 0, 0)}
+    ks = {k["slot"]: k for k in b.kernel_tally(chain, slots, n, nb)}
+    assert set(ks) == {"step", "rows"}
+    for k in ks.values():
+        assert k["frames_per_launch"] == 16 and k["launches_per_call"] == 4.0, k
+        assert 0.3 < k["frac_of_peak"] <= 1.0, k
+    assert abs(ks["step"]["bytes_per_launch_it_must_move"] - 16.0 * 16 * n) < 1 and abs(ks["step"]["gbs"] - 16.0 * 16 * n / 64.78e-6 / 1e9) < 1.0
+    # a tally without frame counts (an older library): the call's frames per launch, as before
+    ks = b.kernel_tally(b.chain_kernels(8192, "cf32"), {"step": (8 * 44e-3, 8, 0)}, 8192, 1024)
+    assert ks[0]["frames_per_launch"] == 1024 and ks[0]["launches_per_call"] == 1.0 and ks[0]["frac_of_peak"] <= 1.0
 
 
 def test_traffic_from_the_committed_pmc_passes():

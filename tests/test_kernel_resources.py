@@ -1,5 +1,6 @@
 """The register budget of the step kernel, checked without a GPU: tests/host/step_kernel_resources.hip instantiates the two
-instantiations that matter (8192 points CF32 — what bench.py times — and the long transforms' int8 column launch), hipcc compiles
+instantiations that matter (8192 points CF32 — what bench.py times —, the long transforms' int8 column launch, 2^20 points' row
+launch, and both one-launch forms of 65536 points: KIND 7, four-step, and KIND 8, the radix-8 fold config 3 ships with), hipcc compiles
 them for gfx950 with the product's code-generation flags and reports what the kernels use. 512 threads at <= 64 VGPRs are eight
 waves per SIMD = four workgroups per CU whatever their roles; the spill figures are the ones the measured
 numbers were taken with — one careless loop in a role cost eleven more spilled registers and 12 % of the step in round 3."""
@@ -29,8 +30,13 @@ def test_step_kernel_keeps_its_registers(tmp_path):
             continue
         get = lambda key: int(re.search(key + r": (\d+)", block).group(1))  # noqa: E731
         seen[name] = dict(vgprs=get("VGPRs"), spill=get("VGPRs Spill"), scratch=get(r"ScratchSize \[bytes/lane\]"), occupancy=get(r"Occupancy \[waves/SIMD\]"))
-    assert len(seen) == 3, seen
+    assert len(seen) == 5, seen
     for name, r in seen.items():
+        if name.endswith("Li8EEEvNS_8StepArgsE"):
+            # KIND 8, the radix-8 fold with two residues per workgroup: two sets of sixteen accumulators and the second residue's points
+            # live through the first one's transform — 128 registers by design, four waves per SIMD, and NOTHING spilled
+            assert r["vgprs"] <= 128 and r["occupancy"] == 4 and r["spill"] == 0 and r["scratch"] == 0, (name, r)
+            continue
         assert r["vgprs"] <= 64 and r["occupancy"] == 8, (name, r)
         # What the numbers of DESIGN.md were measured with. WHERE the spilled registers are used matters more than how many there
         # are: test_the_fft_role_of_the_step_kernel_touches_no_scratch below pins that the frame path — the part that is on the
