@@ -302,8 +302,8 @@ def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False, call_frames:
 
 # ---------------------------------------------------------------------------------------------- launcher
 PMC_FILES = {"fetch": "pmc_fetch.csv", "write": "pmc_write.csv"}  # under profiles/<PMC_SET>/, one counter per rocprofv3 pass
-# the committed passes of each configuration's command line on the final tree of round 4 (scripts/r04/s8.sh)
-PMC_SET = {2: "r04/s8_cfg2", 3: "r04/s38_cfg3", 5: "r04/s38_cfg5"}  # (config 2's kernel has not changed its traffic since; its default line measures it live: live_pmc_traffic)
+# the committed passes of each configuration's command line (config 2: round 4, scripts/r04/s8.sh; configs 3 and 5: round 5, scripts/r05/s12.sh)
+PMC_SET = {2: "r04/s8_cfg2", 3: "r05/s12_cfg3", 5: "r05/s12_cfg5"}  # (config 2's kernel has not changed its traffic since; its default line measures it live: live_pmc_traffic)
 
 
 def traffic_from_profiles(config: int, kernel_match: str, threads_per_launch: int | None = None):
@@ -397,7 +397,7 @@ def chain_kernels(n: int, fmt: str, nb: int | None = None, detect_mode: bool = F
                 ("plan", "k_plan_long", "k_plan_long as a launch of its own (SS_PLAN_FUSED=0 of the diagnostics build; the product runs the plan at the front of the next column launch)", 0.0)]
     if n == 65536 and fmt != "cf32" and detect_mode and os.environ.get("SS_DIF8") != "0" and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0":
         # 65536 points, int8 IQ, calls that keep no plane (round 5): the radix-8 fold — no work buffer, one launch per call whatever its length
-        return [("step", "k_scan_step", "k_scan_step (KIND 8), one launch per call: the radix-8 decimation-in-frequency fold in the load stage of the 8192-point transform "
+        return [("step", "true, false, 8>", "k_scan_step (KIND 8), one launch per call: the radix-8 decimation-in-frequency fold in the load stage of the 8192-point transform "
                  "(csrc/fft65536_dif8.h) — four workgroups per frame, each folding the whole int8 frame (LDS-DMA pieces, Hamming taps formed, W_8 rotations) into the 8192 points of "
                  "residues r and r + 4 and running the 8192-point transform on both -> dB -> noise-relative rows in residue-major order straight into the averager ring's buffer "
                  "(no work buffer, no dB plane) + run maxima for the tile culling —, carrying the plan of call k-1 (which averaging tiles can hold a candidate), the listed tiles of "
@@ -530,6 +530,67 @@ def parse_args(argv):
     if args.sample_rate is None:
         args.sample_rate = 2_048_000 * (args.fft // 8192 if args.fft >= 8192 else 1)
     return args
+
+
+PCIE_GBS = 63.0  # PCIe Gen5 x16 (MI355X_MICROARCH.md): the bound of every path that takes HOST buffers
+
+
+def drop_in_lines():
+    """The drop-in path's rate at the long transforms (what a GNU Radio block sees: host buffers in, results back, PCIe inclusive) —
+    never the headline `value` (its inputs are not resident in HBM), but the number a maintainer gets after INTEGRATION.md's diff:
+      ss_process   one work() call on pageable host buffers, every stage drained before it returns (include/specscan.h), candidates only
+      ss_feed_*    the pipelined form for a source that owns its buffers: pinned staging, H2D of batch k + 1 beside the chain of batch k
+    for BASELINE config 3 (65536 points, int8 IQ, 128-frame calls) and config 5 (2^20 points, CF32, 16-frame calls), each beside its
+    PCIe bound (input bytes per sample over 63 GB/s)."""
+    import numpy as np
+    import rtl_sdr_scanner_cpp_amd as pkg
+    res = []
+    for cfg_no, n, fs, fmt, nb in ((3, 65536, 20_000_000, "cs8", 128), (5, 1 << 20, 61_440_000, "cf32", 16)):
+        try:
+            in_format = {"cf32": 0, "cs8": 1}[fmt]
+            band = pkg.synth.SyntheticBand(n, seed=9, on_frame=40, off_frame=10_000)
+            learn = band.frames_cs8(32) if fmt == "cs8" else band.frames_cf32(32)
+            batch = band.frames_cs8(nb) if fmt == "cs8" else band.frames_cf32(nb)
+            kw = dict(fft_size=n, decim=1, in_format=in_format, learn_frames=32, max_batch=max(nb, 32))
+            eng = pkg.SpectrumEngine(fs, 145_000_000, **kw)
+            eng.process(learn, want=())
+            for _ in range(2):
+                eng.process(batch, want=())
+            reps = 6
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.process(batch, want=())
+            dt_proc = (time.perf_counter() - t0) / reps
+            eng.close()
+            eng = pkg.SpectrumEngine(fs, 145_000_000, **kw)
+            eng.process(learn, want=())
+            feed = eng.feed(depth=3, cand_cap=1 << 20)
+            for _ in range(3):
+                feed.acquire()[:nb] = batch
+                feed.submit(nb)
+            for _ in range(3):
+                feed.collect()
+            reps, sub, done = 12, 0, 0
+            t0 = time.perf_counter()
+            while done < reps:
+                while sub < reps and feed.pending < 3:
+                    feed.acquire()  # (a source that writes into the pinned slot itself: nothing copied on the host)
+                    feed.submit(nb)
+                    sub += 1
+                feed.collect()
+                done += 1
+            dt_feed = (time.perf_counter() - t0) / reps
+            feed.close()
+            eng.close()
+            in_b = 2.0 if fmt == "cs8" else 8.0
+            res.append({"baseline_config": cfg_no, "variant": "drop_in_path", "fft_size": n, "frames_per_call": nb, "fmt": fmt,
+                        "ss_process_MSps": round(nb * n / dt_proc / 1e6, 1), "ss_feed_MSps": round(nb * n / dt_feed / 1e6, 1),
+                        "pcie_bound_MSps": round(PCIE_GBS * 1e9 / in_b / 1e6, 1),
+                        "what": "host buffers in, candidate lists back, PCIe inclusive: ss_process (pageable buffers, drained every call) and ss_feed_* (pinned "
+                                "staging, depth 3, copy of batch k + 1 beside the chain of batch k); bound = 63 GB/s over the input's bytes per sample"})
+        except Exception as e:  # the default line must not depend on these
+            res.append({"baseline_config": cfg_no, "variant": "drop_in_path", "error": f"{type(e).__name__}: {str(e)[:200]}"})
+    return res
 
 
 def also_lines():
@@ -813,6 +874,8 @@ def run(args):
                 out["roofline"]["traffic_frac_of_peak"] = round(live["bytes_per_launch"] / step_s / 1e9 / HBM_PEAK_GBS, 4)
         if plan["also"]:
             out["also"] = also_lines()
+            eng.close()  # (the drop-in lines below make contexts of their own; this one's memory goes back first)
+            out["also"] += drop_in_lines()
         if plan["cpu_baseline"]:
             out["cpu_baseline"] = cpu_baseline(n, fs, args.cpu_seconds)
         elif world == 1:

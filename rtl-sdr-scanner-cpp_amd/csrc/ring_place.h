@@ -75,4 +75,29 @@ inline RingDecision ring_place_decide(int start, const RingPrev& prev, int rows,
   return ring_place_decide(start, &prev, 1, rows, nframes, H, whole);
 }
 
+// HOW MANY earlier calls' spans a call must keep clear of follows from where the chain's launches put the stages (scan_step.h): with
+// L launches per call, the rows of call k written by launch L k + rows_at and the detect stage of call k riding on launch
+// L (k + detect_call_lag) + detect_at, the detect stage of call k - j has not finished before rows(k) are written exactly when
+// L (k - j + detect_call_lag) + detect_at >= L k + rows_at (the same launch counts: its roles run side by side). The chains:
+//   ROWS_THEN_DETECT  two launches per call — column half, row half; rows(k) by the row launch, detect(k - 1) riding on it (2^20 points;
+//                     65536 points with SS_DET_LAG2=0)                                                                       -> 1
+//   DET_LAG2          the same two launches, detect(k - 2) on the COLUMN launch of call k (65536 points, calls the fold does not take)  -> 1
+//   MERGED            one launch per call, the row half of call k - 1 beside the column half of call k, detect(k - 3) riding (KIND 7)    -> 2
+//   FOLD              one launch per call that writes the call's own rows, detect(k - 2) riding (KIND 8)                       -> 2
+// tests/host/ring_check.cpp plays random streams through each chain's launch timeline with this many spans protected (and, to show
+// that the check can fail, with one fewer).
+enum RingChain { RING_ROWS_THEN_DETECT = 0, RING_DET_LAG2 = 1, RING_MERGED = 2, RING_FOLD = 3 };
+struct RingSchedule {
+  int launches_per_call, rows_at, detect_call_lag, detect_at;
+};
+constexpr RingSchedule ring_schedule(RingChain c) {
+  return c == RING_ROWS_THEN_DETECT ? RingSchedule{2, 1, 1, 1} : c == RING_DET_LAG2 ? RingSchedule{2, 1, 2, 0} : c == RING_MERGED ? RingSchedule{1, 1, 3, 0} : RingSchedule{1, 0, 2, 0};
+}
+constexpr int ring_spans_to_protect(RingSchedule s) {
+  int n = 0;
+  for (int j = 1; j <= 8; ++j)
+    if (s.launches_per_call * (s.detect_call_lag - j) + s.detect_at >= s.rows_at) ++n;
+  return n;
+}
+
 }  // namespace ss

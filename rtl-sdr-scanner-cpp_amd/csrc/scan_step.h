@@ -370,7 +370,23 @@ __global__ __launch_bounds__(kStepThreads, (KIND == 8 && SS_DIF8_W == 4) ? 4 : 8
     // has nothing to interleave and does without.)
     int b = (int)blockIdx.x;
     const int np = step_plan_wgs(a), ne = step_emit_wgs(a), nd = step_det_wgs(a);
-    if (b < np) {
+#ifndef SS_ORDER_FFT_FIRST  // (A/B builds, scripts/build_ab.py: 1 = plan, FFT, emit, detect, rows — the frames ahead of the candidate lists)
+#define SS_ORDER_FFT_FIRST 0
+#endif
+    if (SS_ORDER_FFT_FIRST && KIND == 0) {
+      if (b < np) {
+        role = ROLE_PLAN;
+      } else if ((b -= np) < a.n_fft) {
+        role = ROLE_FFT;
+      } else if ((b -= a.n_fft) < ne) {
+        role = ROLE_EMIT;
+      } else if ((b -= ne) < nd) {
+        role = ROLE_DET;
+      } else {
+        role = ROLE_ROWS;
+        b -= nd;
+      }
+    } else if (b < np) {
       role = ROLE_PLAN;
     } else if ((b -= np) < ne) {
       role = ROLE_EMIT;

@@ -1380,8 +1380,10 @@ RingPlace place_ring(ss_ctx* c, int nframes) {
   constexpr int H = kHistRows;
   // (the decision is ring_place.h's — a function of five integers that tests/host/ring_check.cpp runs on the CPU; here its consequences)
   const ss::RingPrev prevs[2] = {c->hist_prev, c->hist_prev2};
-  // (the fold writes a call's rows in the launch that carries the detect stage of two calls before, and the stage of the call before still waits)
-  const ss::RingDecision d = ss::ring_place_decide(c->hist_start, prevs, (c->merge || c->dif8) ? 2 : 1, c->hist_rows, nframes, H, c->cull_long);
+  // how many earlier calls' spans to keep clear of: from the chain's launch schedule (ring_place.h; a context that runs the fold also runs
+  // two-launch calls — learning frames, planes handed out — and protects what the deeper of its chains needs)
+  const ss::RingChain chain = c->dif8 ? ss::RING_FOLD : c->merge ? ss::RING_MERGED : c->det_lag2 ? ss::RING_DET_LAG2 : ss::RING_ROWS_THEN_DETECT;
+  const ss::RingDecision d = ss::ring_place_decide(c->hist_start, prevs, ss::ring_spans_to_protect(ss::ring_schedule(chain)), c->hist_rows, nframes, H, c->cull_long);
   if (d.shift_first) {  // (stream order: a deferred detect stage that still reads or writes this window goes first)
     flush_stages(c);
     if (c->hist_start != 0)

@@ -32,6 +32,7 @@ VARIANTS = {
     "rowsstag2": ["SS_ROWS_STAGGER=2"],
     "bothstag2": ["SS_COLS_STAGGER=2", "SS_ROWS_STAGGER=1"],
     "segdpp": ["SS_SEGMAX_LDS=0"],   # 8192 points: the per-column maxima for the tile culling in registers (v_max_f32_dpp), as until session 15 of round 4
+    "ordfe": ["SS_ORDER_FFT_FIRST=1"],   # 8192 points, launches without an order table: the frames dispatched ahead of the candidate lists
     "dif8w8": ["SS_DIF8_W=8"],   # 65536 points, the radix-8 fold: one residue per workgroup (64 registers, eight waves per SIMD)
     "dif8w4": ["SS_DIF8_W=4"],   # ... two residues per workgroup (128 registers, four waves per SIMD)
     "colsnone": ["SS_COLS_TW6=0", "SS_COLS_ABL=3"],   # ... without either  # 8192 points, deep pipelining: ring rows written by three frame tiles of every call

@@ -11,6 +11,7 @@
 // for long transforms a stream of largest batches goes round the buffer without draining.
 #include <cstdio>
 #include <random>
+#include <vector>
 
 #include "../../rtl-sdr-scanner-cpp_amd/csrc/ring_place.h"
 
@@ -77,6 +78,70 @@ int main() {
         ++bad;
       }
     }
-  printf("%lld calls, %lld drains, %lld returns to the front; bad %d\n", calls, shifts, wraps, bad);
+  // The launch schedule itself (ring_place.h: ring_schedule): every chain's calls on its launch timeline — rows(k) written by launch
+  // W(k), detect(k) riding on launch D(k) — with as many earlier spans protected as ring_spans_to_protect derives from the schedule.
+  // Whatever a call writes must not touch what ANY earlier call's detect stage still has to read (D(k') >= W(k), no drain in between).
+  // One span fewer must fail somewhere: the check is not vacuous.
+  long long sched_calls = 0;
+  for (int chain_no = 0; chain_no < 4; ++chain_no) {
+    const ss::RingSchedule sc = ss::ring_schedule((ss::RingChain)chain_no);
+    const int need = ss::ring_spans_to_protect(sc);
+    const int expect[4] = {1, 1, 2, 2};
+    if (need != expect[chain_no]) {
+      printf("chain %d: %d spans derived, %d expected\n", chain_no, need, expect[chain_no]);
+      ++bad;
+    }
+    for (int short_by = 0; short_by < 2; ++short_by) {
+      const int nprev = need - short_by;
+      if (nprev < 1) continue;
+      int collisions = 0;
+      std::mt19937 r2(777 + chain_no);
+      for (int trial = 0; trial < 1500; ++trial) {
+        const int max_batch = 1 + (int)(r2() % 300);
+        // (buffers from the smallest that holds a window and a batch to the size ss_create allocates: the rule must hold whatever the size)
+        const int rows_full = (2 + need) * (max_batch + H);
+        const int rows = (r2() & 1) ? rows_full + (int)(r2() % (4 * H)) : 3 * H + (int)(r2() % (unsigned)(rows_full - 3 * H + 1));
+        const int fixed = (r2() % 3) ? 0 : 1 + (int)(r2() % max_batch);
+        struct Past {
+          int start, batch, n;
+          long detect_launch;
+        };
+        std::vector<Past> past;  // calls whose detect stage may still have to run
+        int start = 0;
+        ss::RingPrev prev[2] = {{0, -1, 0}, {0, -1, 0}};
+        long k0 = 0;  // call index of the first call after the last drain (the drain completed everything before it)
+        for (long k = 0; k < 120; ++k) {
+          const int nframes = fixed ? fixed : 1 + (int)(r2() % max_batch);
+          const ss::RingDecision d = ss::ring_place_decide(start, prev, nprev, rows, nframes, H, true);
+          ++sched_calls;
+          if (d.shift_first) {
+            past.clear();
+            prev[0] = prev[1] = ss::RingPrev{0, -1, 0};
+            k0 = k;
+          }
+          const long w = sc.launches_per_call * k + sc.rows_at;
+          for (const Past& q : past)
+            if (q.detect_launch >= w && q.n > 0 &&
+                (overlap(d.write_lo, d.write_hi, q.start, q.start + H) || (q.batch >= 0 && overlap(d.write_lo, d.write_hi, q.batch, q.batch + q.n))))
+              ++collisions;
+          past.push_back(Past{d.in, d.batch, nframes, sc.launches_per_call * (k + sc.detect_call_lag) + sc.detect_at});
+          if (past.size() > 8) past.erase(past.begin());
+          prev[1] = prev[0];
+          prev[0] = ss::RingPrev{d.in, d.batch, nframes};
+          start = d.next_start;
+          (void)k0;
+        }
+      }
+      if (short_by == 0 && collisions) {
+        printf("chain %d with %d spans protected: %d collisions\n", chain_no, nprev, collisions);
+        ++bad;
+      }
+      if (short_by == 1 && !collisions) {
+        printf("chain %d with only %d spans protected: no collision found — the schedule check cannot fail\n", chain_no, nprev);
+        ++bad;
+      }
+    }
+  }
+  printf("%lld calls, %lld drains, %lld returns to the front; %lld calls on the chains' launch timelines; bad %d\n", calls, shifts, wraps, sched_calls, bad);
   return bad ? 1 : 0;
 }

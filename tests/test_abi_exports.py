@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_oracle_exports_the_same_set(oracle_mod):
     L = oracle_mod.lib()
     for name in pkg.engine.EXPORTS:
-        if name in ("ss_device_count", "ss_process_device", "ss_flush", "ss_sync", "ss_stream", "ss_input_wait", "ss_get_stats", "ss_kernel_timing", "ss_kernel_timing_read", "ss_kernel_timing_read_slots", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read") or name.startswith("ss_feed_"):  # (the oracle has its own orc_spectrogram_* object)
+        if name in ("ss_device_count", "ss_process_device", "ss_flush", "ss_sync", "ss_stream", "ss_input_wait", "ss_get_stats", "ss_kernel_timing", "ss_kernel_timing_read", "ss_kernel_timing_read_slots", "ss_kernel_timing_read_frames", "ss_selftest", "ss_spectrogram_size", "ss_spectrogram_read") or name.startswith("ss_feed_"):  # (the oracle has its own orc_spectrogram_* object)
             continue  # device-only entry points (streams, pinned staging, PCIe pipelining)
         assert hasattr(L, "orc_" + name[3:]), name
 
