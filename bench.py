@@ -395,12 +395,13 @@ def chain_kernels(n: int, fmt: str, nb: int | None = None, detect_mode: bool = F
                 ("rows", "k_scan_step", "k_scan_step with the ROW half as its FFT role (fft_rows1024_tile: 1024-point FFTs -> dB -> noise-relative rows straight into the averager "
                  "ring's buffer, no dB plane in detect mode, + run maxima for the tile culling), carrying the listed averaging tiles of call k-1 and the candidate lists of call k-2", 12.0),
                 ("plan", "k_plan_long", "k_plan_long as a launch of its own (SS_PLAN_FUSED=0 of the diagnostics build; the product runs the plan at the front of the next column launch)", 0.0)]
-    if n == 65536 and fmt != "cf32" and detect_mode and os.environ.get("SS_DIF8") != "0" and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0":
-        # 65536 points, int8 IQ, calls that keep no plane (round 5): the radix-8 fold — no work buffer, one launch per call whatever its length
-        return [("step", "true, false, 8>", "k_scan_step (KIND 8), one launch per call: the radix-8 decimation-in-frequency fold in the load stage of the 8192-point transform "
-                 "(csrc/fft65536_dif8.h) — four workgroups per frame, each folding the whole int8 frame (LDS-DMA pieces, Hamming taps formed, W_8 rotations) into the 8192 points of "
-                 "residues r and r + 4 and running the 8192-point transform on both -> dB -> noise-relative rows in residue-major order straight into the averager ring's buffer "
-                 "(no work buffer, no dB plane) + run maxima for the tile culling —, carrying the plan of call k-1 (which averaging tiles can hold a candidate), the listed tiles of "
+    if n in (65536, 131072) and fmt != "cf32" and detect_mode and os.environ.get("SS_DIF8") != "0" and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0":
+        # 65536 / 131072 points, int8 IQ, calls that keep no plane (round 5): the radix-8 / radix-16 fold — no work buffer, one launch per call whatever its length
+        q = n // 8192
+        return [("step", f"true, false, {8 if q == 8 else 9}>", f"k_scan_step (KIND {8 if q == 8 else 9}), one launch per call: the radix-{q} decimation-in-frequency fold in the load stage of the "
+                 f"8192-point transform (csrc/fft65536_dif8.h) — {q // 2} workgroups per frame, each folding the whole int8 frame (LDS-DMA pieces, Hamming taps formed, W_{q} rotations) into the "
+                 f"8192 points of residues r and r + {q // 2} and running the 8192-point transform on both -> dB -> noise-relative rows in residue-major order straight into the averager ring's "
+                 "buffer (no work buffer, no dB plane) + run maxima for the tile culling —, carrying the plan of call k-1 (which averaging tiles can hold a candidate), the listed tiles of "
                  "call k-2 (21x21 mean + threshold on residue-major rows) and the candidate lists of call k-3", in_b + 4.0)]
     if n == 65536 and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0" and os.environ.get("SS_MERGE_65536") != "0" and (nb is None or nb <= 128):
         # 65536 points, detect-mode calls of up to 128 frames as the product runs them since session 36 of round 4: ONE launch per call
@@ -785,7 +786,7 @@ def run(args):
             # launches of the steady-state shape only. 8192 points: 1024 + 20 FFT, 128 emit and 4 plan workgroups of 512 threads; long
             # transforms: the column tiles + one emit workgroup per frame (the listed tiles ride on the column workgroups)
             two_pass = n == 1 << 20 and os.environ.get("SS_FFT_TWOPASS") != "0"
-            fold = n == 65536 and args.fmt != "cf32" and args.no_psd_out and not args.planes and os.environ.get("SS_DIF8") != "0"
+            fold = n in (65536, 131072) and args.fmt != "cf32" and args.no_psd_out and not args.planes and os.environ.get("SS_DIF8") != "0"
             if n == 8192:
                 shape = (nb + 20 + nb // 8 + 4) * 512
             elif fold:

@@ -687,20 +687,23 @@ __device__ __forceinline__ void plan_long_run(const PlanLongDet& a, const PlanLo
 //   3  thread per tile: the largest of its window sums -> the same test, the same list, the same statistics as plan_long_run's.
 // Block b: column group b mod 8 (32 columns: the eight groups of a frame tile are consecutive blocks, one per XCD), frame tile b / 8 in
 // dispatch order (plan_long_run's ft_seq). `lds`: kPlanDif8Floats floats + kPlanLongInts ints behind them.
+// Radix Q = 1 << logq (logq = p.logn - 13: 3 or 4): 32 Q tile columns, Q column groups per frame tile; a run of a residue's row (32 of
+// its bins) spans Q / 8 tile columns.
 constexpr int kPlanDif8Floats = 34 * 37 + 32 * 16;
-__host__ __device__ inline int plan_dif8_blocks(int nframes, int shift) { return 8 * ((nframes + shift + 15) / 16); }
+__host__ __device__ inline int plan_dif8_blocks(int nframes, int shift, int logq = 3) { return ((nframes + shift + 15) / 16) << logq; }
 template <int G, int GX, int TF, int TB_ = 256>
 __device__ __forceinline__ void plan_dif8_run(const PlanLongDet& a, const PlanLongArgs& p, int block_no, int tid, float* __restrict__ lds, int* __restrict__ book) {
-  static_assert(TB_ == 256 && TF == 16 && G == 21, "the fold's rows: 256 tile columns of 256 bins, tiles of 16 frames");
+  static_assert(TB_ == 256 && TF == 16 && G == 21, "the fold's rows: tile columns of 256 bins, tiles of 16 frames");
   constexpr int ROWS = TF + G - 1, RP = ROWS + 1;  // 36 frame rows per tile, LDS pitch 37
   float* R = lds;              // [34][RP]
   float* S = lds + 34 * RP;    // [32][TF]
   int* wave_cnt = book;        // [4]
   int* stat_cnt = book + 4;    // [4][2]
   int* list_base_p = book + 12;
-  const int nframes = a.nframes, tiles_per_row = 256;
+  const int logq = p.logn - 13, nres = 1 << logq;
+  const int nframes = a.nframes, tiles_per_row = 32 << logq;
   const int nft = (nframes + a.shift + TF - 1) / TF;
-  const int cg = block_no & 7, ft_seq = block_no >> 3;
+  const int cg = block_no & (nres - 1), ft_seq = block_no >> logq;
   const bool in_range = ft_seq < nft;  // (a workgroup's second block may lie past the end: it keeps the barriers company)
   const int ft = in_range ? (ft_seq + nft - 1) % nft : 0;
   const int f0 = ft * TF - a.shift;  // batch-relative frame of the tile's first row of outputs
@@ -709,10 +712,10 @@ __device__ __forceinline__ void plan_dif8_run(const PlanLongDet& a, const PlanLo
     for (int e = tid; e < 34 * ROWS; e += 256) {
       const int colx = e % 34, r = e / 34;
       const int col = min(max(c0 - 1 + colx, 0), tiles_per_row - 1);  // (the band's edges: the edge column once more)
-      const float* row = p.smax + ((size_t)((p.abs0 + f0 - (G - 1) + r) & p.smax_mask) << 11);
+      const float* row = p.smax + ((size_t)((p.abs0 + f0 - (G - 1) + r) & p.smax_mask) << (8 + logq));
+      const int run = col >> (logq - 3);  // (radix 16: a run of a residue's row covers two tile columns)
       float m = -__builtin_inff();
-#pragma unroll
-      for (int g = 0; g < 8; ++g) m = fmaxf(m, row[256 * g + col]);  // (the fold's maxima hold no NaN: fft8192_v2.h takes them with fmaxf)
+      for (int g = 0; g < nres; ++g) m = fmaxf(m, row[256 * g + run]);  // (the fold's maxima hold no NaN: fft8192_v2.h takes them with fmaxf)
       R[colx * RP + r] = m;
     }
   }
@@ -821,11 +824,11 @@ __host__ __device__ inline int plan_fused_wgs(int plan_blocks) { return (((plan_
 // `tile` / `cnt` = this tile's LDS (TF * P floats, TF ints). `valid` = false: the caller has no tile for these threads (odd
 // tile count in a two-tile workgroup) — they only keep the workgroup's barriers company. Every __syncthreads() below is
 // reached by all threads of the workgroup whatever `valid`, `steady` or `interior` are.
-// PERM8: the rows the tile reads (a.psd, the ring) and writes (the ring) are RESIDUE-MAJOR rows of 65536 bins — bin i at
-// (i & 7) * 8192 + (i >> 3), fft65536_dif8.h: the rows the radix-8 fold leaves; calls that hand out no plane only (no rel_out). A lane's
-// 36 row loads then sit in eight runs of 32 bytes per wave instead of one of 256; everything else — the noise ceiling, the pass mask,
-// mask bits, sparse averages — stays in bin order.
-template <int G, int GX, int TF, int TB_ = 256, bool SPEC = false, bool PERM8 = false>
+// PERM8 (0, or log2 of the fold's radix: 3, 4): the rows the tile reads (a.psd, the ring) and writes (the ring) are RESIDUE-MAJOR rows of
+// 8192 Q bins — bin i at (i mod Q) * 8192 + i / Q, fft65536_dif8.h: the rows the radix-Q fold leaves; calls that hand out no plane only
+// (no rel_out). A lane's 36 row loads then sit in Q runs of 256 / Q bytes per wave instead of one of 256; everything else — the noise
+// ceiling, the pass mask, mask bits, sparse averages — stays in bin order.
+template <int G, int GX, int TF, int TB_ = 256, bool SPEC = false, int PERM8 = 0>
 __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int tid, float* __restrict__ tile, int* __restrict__ cnt, bool valid) {
   using T = DetectTile<G, GX, TF, TB_>;
   constexpr int A = T::A, TB = T::TB, P = T::P, ROWS = T::ROWS, H = T::H, SEGW = T::SEGW, NSEG = T::NSEG, YW = T::YW;
@@ -869,7 +872,7 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
         const float t = a.thr[colc];
         // block-uniform row base (scalar registers) + one 32-bit per-thread byte offset
         const char* p = reinterpret_cast<const char*>(a.psd + (size_t)(f0 - (G - 1)) * n);
-        const uint32_t coff = (uint32_t)(PERM8 ? dif8_bin_offset(colc) : colc) * 4u;
+        const uint32_t coff = (uint32_t)(PERM8 ? dif_bin_offset(colc, PERM8) : colc) * 4u;
         float x[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) x[r] = load_row_value(p + (size_t)r * n * 4 + coff) - t;
@@ -911,7 +914,7 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
         // all loads first, unconditional, on always-legal addresses: independent and in flight together; a
         // branch around each load would serialise them on s_waitcnt. The row pointer is block-uniform:
         // frames before the batch come from the ring (row H + frame), frames past its end are clamped.
-        const uint32_t coff = (uint32_t)(PERM8 ? dif8_bin_offset(col) : col) * 4u;
+        const uint32_t coff = (uint32_t)(PERM8 ? dif_bin_offset(col, PERM8) : col) * 4u;
         float x[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {

@@ -57,6 +57,7 @@ struct Dif8Front {
   //          (detect_fused.h PlanLongArgs::layout). Null: no maxima.
   float* smax;
   int smax_mask, abs0;
+  int smax_pitch;          // floats per frame of the ring of maxima: 256 Q
   int first_hist;          // frame f's row is row f - first_hist of Fft8192Args::psd (RowsExtra::first_hist; <= 0 here: every frame has a row)
   int nframes;             // frames of the launch (the workgroup -> (frame, residue) map, dif8_item)
   int* zero_word;          // set to zero by the first workgroup: the count of the list the plan behind this launch appends to (or null)
@@ -68,7 +69,7 @@ struct Dif8Front {
 // a frame's residues on eight XCDs).
 template <int W>
 __host__ __device__ inline void dif8_item(int j, int nframes, int* frame, int* residue) {
-  static_assert(W == 4 || W == 8, "workgroups per frame");
+  static_assert(W == 4 || W == 8 || W == 16, "workgroups per frame");
   const int full = nframes >> 3;
   if (j < 8 * W * full) {
     *residue = (j >> 3) & (W - 1);
@@ -88,60 +89,86 @@ __device__ constexpr float kDif8Q[16] = {0.0f, 0.022571474313735962f, 0.04508857
                                          0.13353292644023895f, 0.15497159957885742f, 0.17603692412376404f, 0.19667814671993256f, 0.2168455421924591f, 0.23649051785469055f,
                                          0.25556573271751404f, 0.2740252912044525f, 0.2918246388435364f, 0.3089209496974945f};
 
-constexpr int kDif8TableFloat2 = 8 * 512 + 8 * 16 + 8 * 8 + 512 + 8;
-// Host side: the five tables in one block (wt, wrho, w8, wthe, wq in this order), double precision rounded once; `scale` is what
-// load_iq multiplies the format's integers with.
-inline void dif8_host_tables(float2* tab, double scale) {
+// ... and for N = 131072 (the radix-16 fold: sixteen residues of 8192 points, Phi_rho = 2 pi 512 rho / 131071)
+__device__ constexpr float kDif16P[16] = {-0.46000000834465027f, -0.4598614573478699f, -0.45944589376449585f, -0.4587535858154297f, -0.4577849507331848f, -0.4565405249595642f,
+                                          -0.45502111315727234f, -0.45322760939598083f, -0.45116108655929565f, -0.4488227963447571f, -0.4462141692638397f, -0.44333672523498535f,
+                                          -0.44019225239753723f, -0.4367825984954834f, -0.433109849691391f, -0.4291762113571167f};
+__device__ constexpr float kDif16Q[16] = {0.0f, 0.011289050802588463f, 0.022571302950382233f, 0.03383995592594147f, 0.04508822783827782f, 0.05630933865904808f,
+                                          0.06749653071165085f, 0.0786430612206459f, 0.08974222093820572f, 0.10078732669353485f, 0.11177171766757965f, 0.12268878519535065f,
+                                          0.13353194296360016f, 0.14429466426372528f, 0.1549704670906067f, 0.16555292904376984f};
+template <int Q>
+__device__ __forceinline__ constexpr float dif_tap_p(int rho) { return Q == 16 ? kDif16P[rho] : kDif8P[rho]; }
+template <int Q>
+__device__ __forceinline__ constexpr float dif_tap_q(int rho) { return Q == 16 ? kDif16Q[rho] : kDif8Q[rho]; }
+
+// The fold generalises from radix 8 (N = 65536) to radix Q = 16 (N = 131072 — what getFft picks at 20 MS/s, utils/radio_utils.cpp:98-104):
+// Q residues of 8192 points per frame, X[Q k' + r], the same transform behind a fold of Q samples per point; tables below take Q.
+constexpr int dif_table_float2(int q) { return q * 512 + q * 16 + q * q + 512 + q; }
+constexpr int kDif8TableFloat2 = dif_table_float2(8);
+// Host side: the five tables in one block (wt [Q][512], wrho [Q][16], w8 [Q][Q], wthe [512], wq [Q] in this order), double precision
+// rounded once; `scale` is what load_iq multiplies the format's integers with; N = 8192 Q.
+inline void dif8_host_tables(float2* tab, double scale, int Q = 8) {
   const double two_pi = 2.0 * 3.14159265358979323846;
-  float2 *wt = tab, *wrho = wt + 8 * 512, *w8 = wrho + 8 * 16, *wthe = w8 + 8 * 8, *wq = wthe + 512;
-  for (int r = 0; r < 8; ++r) {
+  const int N = 8192 * Q;
+  float2 *wt = tab, *wrho = wt + Q * 512, *w8 = wrho + Q * 16, *wthe = w8 + Q * Q, *wq = wthe + 512;
+  for (int r = 0; r < Q; ++r) {
     for (int t = 0; t < 512; ++t) {
-      const double ang = -two_pi * (double)(t * r) / 65536.0;
+      const double ang = -two_pi * (double)(t * r) / (double)N;
       wt[r * 512 + t] = make_float2((float)(scale * cos(ang)), (float)(scale * sin(ang)));
     }
-    for (int rho = 0; rho < 16; ++rho) {
-      const double ang = -two_pi * (double)((rho * r) & 127) / 128.0;
+    for (int rho = 0; rho < 16; ++rho) {  // W_N^(512 rho r) = W_(16 Q)^(rho r)
+      const double ang = -two_pi * (double)((rho * r) % (16 * Q)) / (double)(16 * Q);
       wrho[r * 16 + rho] = make_float2((float)cos(ang), (float)sin(ang));
     }
-    for (int q = 0; q < 8; ++q) {
-      // exact values for the multiples of a right angle, 0.70710678 for the others
-      const int k = (q * r) & 7;
-      const double ang = -two_pi * (double)k / 8.0;
-      const double c = (k & 1) ? cos(ang) : (k == 0 ? 1.0 : k == 4 ? -1.0 : 0.0), s_ = (k & 1) ? sin(ang) : (k == 2 ? -1.0 : k == 6 ? 1.0 : 0.0);
-      w8[r * 8 + q] = make_float2((float)c, (float)s_);
+    for (int q = 0; q < Q; ++q) {
+      // W_Q^(q r): exact values for the multiples of a right angle
+      const int k = (q * r) % Q;
+      const double ang = -two_pi * (double)k / (double)Q;
+      double c = cos(ang), s_ = sin(ang);
+      if ((4 * k) % Q == 0) {
+        const int quarter = 4 * k / Q;
+        c = quarter == 0 ? 1.0 : quarter == 2 ? -1.0 : 0.0;
+        s_ = quarter == 1 ? -1.0 : quarter == 3 ? 1.0 : 0.0;
+      }
+      w8[r * Q + q] = make_float2((float)c, (float)s_);
     }
   }
   for (int t = 0; t < 512; ++t) {
-    const double th = two_pi * (double)t / 65535.0;
+    const double th = two_pi * (double)t / (double)(N - 1);
     wthe[t] = make_float2((float)cos(th), (float)sin(th));
   }
-  for (int q = 0; q < 8; ++q) {
-    const double ph = two_pi * 8192.0 * (double)q / 65535.0;
+  for (int q = 0; q < Q; ++q) {
+    const double ph = two_pi * 8192.0 * (double)q / (double)(N - 1);
     wq[q] = make_float2((float)cos(ph), (float)sin(ph));
   }
 }
-inline Dif8Front dif8_front_of(const void* iq, long long item_stride, const float2* tab) {
+inline Dif8Front dif8_front_of(const void* iq, long long item_stride, const float2* tab, int Q = 8) {
   Dif8Front d{};
   d.iq = iq;
   d.item_stride = item_stride;
   d.wt = tab;
-  d.wrho = tab + 8 * 512;
-  d.w8 = d.wrho + 8 * 16;
-  d.wthe = d.w8 + 8 * 8;
+  d.wrho = tab + Q * 512;
+  d.w8 = d.wrho + Q * 16;
+  d.wthe = d.w8 + Q * Q;
   d.wq = d.wthe + 512;
+  d.smax_pitch = 256 * Q;
   return d;
 }
 
 // bin i of a 65536-bin row (DC at 32768) in a residue-major row
 __host__ __device__ inline int dif8_bin_offset(int i) { return ((i & 7) << 13) + (i >> 3); }
+// ... of a row of 8192 Q bins, Q = 1 << logq residues
+__host__ __device__ inline int dif_bin_offset(int i, int logq) { return ((i & ((1 << logq) - 1)) << 13) + (i >> logq); }
 
-// `rows` rows of 65536 floats from bin order to residue-major order (to_perm8 != 0) or back; in and out are different memory.
-// (The averager ring's window when a context changes between the fold and the four-step form, the noise ceiling once per learning call.)
-__global__ void k_rows_perm8(const float* __restrict__ in, float* __restrict__ out, int rows, int to_perm8) {
-  const size_t total = (size_t)rows << 16;
+// `rows` rows of 8192 Q floats (Q = 1 << logq) from bin order to residue-major order (to_perm8 != 0) or back; in and out are different
+// memory. (The averager ring's window when a context changes between the fold and the four-step form, the noise ceiling once per
+// learning call.)
+__global__ void k_rows_perm8(const float* __restrict__ in, float* __restrict__ out, int rows, int to_perm8, int logq) {
+  const int logn = 13 + logq;
+  const size_t total = (size_t)rows << logn;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    // i walks the residue-major side (whole lines there, 32-byte pieces on the other): position r * 8192 + k' holds bin 8 k' + r
-    const size_t bin_order = ((i >> 16) << 16) | (size_t)(((int)(i & 8191) << 3) | (int)((i >> 13) & 7));
+    // i walks the residue-major side (whole lines there, short pieces on the other): position r * 8192 + k' holds bin Q k' + r
+    const size_t bin_order = ((i >> logn) << logn) | (size_t)(((int)(i & 8191) << logq) | (int)((i >> 13) & ((1 << logq) - 1)));
     if (to_perm8) out[i] = in[bin_order];
     else out[bin_order] = in[i];
   }
@@ -168,9 +195,9 @@ struct Dif8Trip {
   float c1, s1, c2, s2, k2;  // k2 = 0.54 sg
   float w8c, w8s;            // W_8^(q r)
 };
-__device__ __forceinline__ Dif8Trip dif8_trip(float2 th, dif8_const_fp cq, dif8_const_fp c8, int q, float sg) {
+__device__ __forceinline__ Dif8Trip dif8_trip(float2 th, dif8_const_fp cq, dif8_const_fp c8, int q, float sg, int half_q = 4) {
   Dif8Trip x;
-  const float qc1 = cq[2 * q], qs1 = cq[2 * q + 1], qc2 = cq[2 * q + 8] * sg, qs2 = cq[2 * q + 9] * sg;
+  const float qc1 = cq[2 * q], qs1 = cq[2 * q + 1], qc2 = cq[2 * (q + half_q)] * sg, qs2 = cq[2 * (q + half_q) + 1] * sg;
   x.c1 = fmaf(th.x, qc1, -(th.y * qs1));
   x.s1 = fmaf(th.y, qc1, th.x * qs1);
   x.c2 = fmaf(th.x, qc2, -(th.y * qs2));
@@ -291,25 +318,32 @@ __device__ __forceinline__ void dif8_front(const Dif8Front& d, size_t frame_in, 
 // — so the fold costs twenty vector instructions per pair of samples for BOTH residues instead of sixteen for each; the price is
 // a second set of sixteen accumulators (and of points, kept in registers while the first residue goes through the transform):
 // 128 registers, four waves per SIMD, two workgroups per CU. LDS-DMA pieces as above. a = y_r, a2 = y_(r + 4).
-template <int FMT, class F>
+// Q = 16 (N = 131072): residues r (< 8) and r + 8, eight trips over q and q + 8, W_16 in the place of W_8 — the same code.
+template <int FMT, int Q, class F>
 __device__ __forceinline__ void dif8_front2(const Dif8Front& d, size_t frame_in, int residue, unsigned char* __restrict__ smem_raw, int t, float2 (&a)[16],
                                             float2 (&a2)[16], F&& after_first_issue) {
   static_assert(FMT == FMT_CS8 || FMT == FMT_CU8, "two-byte samples");
+  static_assert(Q == 8 || Q == 16, "radix of the fold");
+  constexpr int HQ = Q / 2;
   const char* fb = reinterpret_cast<const char*>(d.iq) + frame_in * (size_t)d.item_stride * 2;
-  const __amdgpu_buffer_rsrc_t rin = buffer_of(fb, 65536 * 2);
+  const __amdgpu_buffer_rsrc_t rin = buffer_of(fb, 8192 * Q * 2);
   const dif8_const_fp cq = (dif8_const_fp)(uintptr_t)d.wq;
-  const dif8_const_fp c8 = (dif8_const_fp)(uintptr_t)(d.w8 + residue * 8);
-  const dif8_const_fp crho = (dif8_const_fp)(uintptr_t)(d.wrho + residue * 16), crho2 = (dif8_const_fp)(uintptr_t)(d.wrho + (residue + 4) * 16);
+  const dif8_const_fp c8 = (dif8_const_fp)(uintptr_t)(d.w8 + residue * Q);
+  const dif8_const_fp crho = (dif8_const_fp)(uintptr_t)(d.wrho + residue * 16), crho2 = (dif8_const_fp)(uintptr_t)(d.wrho + (residue + HQ) * 16);
   const float sg = (residue & 1) ? -1.0f : 1.0f;
 #pragma unroll
   for (int rho = 0; rho < 16; ++rho) a[rho] = a2[rho] = make_float2(0.f, 0.f);
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lane = t & 63;
+#ifndef SS_DIF_NODMA  // (lab builds: 1 = no fetches and no waits for them — garbage results, the fold's own arithmetic and barriers alone)
+#define SS_DIF_NODMA 0
+#endif
   const auto issue = [&](int q, int half) {
+    if (SS_DIF_NODMA) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem_raw + half * 16384 + (2 * w + j) * 1024), 16, lane * 16,
-                                               1024 * (8 * half + w) + 65536 * j + 16384 * q, 0, SS_AUX_DIF_IQ);
+                                               1024 * (8 * half + w) + (8192 * Q) * j + 16384 * q, 0, SS_AUX_DIF_IQ);
   };
   issue(0, 0);
   issue(0, 1);
@@ -317,16 +351,16 @@ __device__ __forceinline__ void dif8_front2(const Dif8Front& d, size_t frame_in,
   const float2 th = d.wthe[t];
   const unsigned short* mine = reinterpret_cast<const unsigned short*>(smem_raw) + t;
 #pragma unroll 1
-  for (int q = 0; q < 4; ++q) {
-    const Dif8Trip x = dif8_trip(th, cq, c8, q, sg);
-    const float sq = (q & 1) ? -1.0f : 1.0f;  // W_8^(q (r + 4)) = (-1)^q W_8^(q r)
+  for (int q = 0; q < HQ; ++q) {
+    const Dif8Trip x = dif8_trip(th, cq, c8, q, sg, HQ);
+    const float sq = (q & 1) ? -1.0f : 1.0f;  // W_Q^(q (r + Q/2)) = (-1)^q W_Q^(q r)
     const float w8c2 = x.w8c * sq, w8s2 = x.w8s * sq;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!SS_DIF_NODMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (!(q == 0 && half == 0) && !(q == 3 && half == 1)) {
+      if (!(q == 0 && half == 0) && !(q == HQ - 1 && half == 1)) {
         if (half == 0) issue(q, 1);
         else issue(q + 1, 0);
       }
@@ -344,8 +378,8 @@ __device__ __forceinline__ void dif8_front2(const Dif8Front& d, size_t frame_in,
           float re1, im1, re2, im2;
           dif8_convert<FMT>(raw1[i], re1, im1);
           dif8_convert<FMT>(raw2[i], re2, im2);
-          const float t1 = fmaf(x.c1, kDif8P[rho], fmaf(x.s1, kDif8Q[rho], 0.54f));
-          const float t2 = fmaf(x.c2, kDif8P[rho], fmaf(x.s2, kDif8Q[rho], x.k2));
+          const float t1 = fmaf(x.c1, dif_tap_p<Q>(rho), fmaf(x.s1, dif_tap_q<Q>(rho), 0.54f));
+          const float t2 = fmaf(x.c2, dif_tap_p<Q>(rho), fmaf(x.s2, dif_tap_q<Q>(rho), x.k2));
           const float ur = fmaf(t2, re2, t1 * re1), ui = fmaf(t2, im2, t1 * im1);
           float2 &acc = a[rho], &acc2 = a2[rho];
           acc.x = fmaf(ur, x.w8c, fmaf(-ui, x.w8s, acc.x));
@@ -359,7 +393,7 @@ __device__ __forceinline__ void dif8_front2(const Dif8Front& d, size_t frame_in,
     }
   }
   __syncthreads();  // the plane goes back to the transform
-  const float2 wt = d.wt[residue * 512 + t], wt2 = d.wt[(residue + 4) * 512 + t];
+  const float2 wt = d.wt[residue * 512 + t], wt2 = d.wt[(residue + HQ) * 512 + t];
 #pragma unroll
   for (int rho = 0; rho < 16; ++rho) {
     a[rho] = cmul(a[rho], cmul(wt, make_float2(crho[2 * rho], crho[2 * rho + 1])));

@@ -380,7 +380,7 @@ __device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Ar
                    "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
                    : "+v"(m));
       if ((tt & 1) == 0) {
-        const __amdgpu_buffer_rsrc_t rs = buffer_of(dif->smax + ((size_t)((dif->abs0 + (int)frame_in) & dif->smax_mask) << 11), 2048 * 4);
+        const __amdgpu_buffer_rsrc_t rs = buffer_of(dif->smax + (size_t)((dif->abs0 + (int)frame_in) & dif->smax_mask) * (size_t)dif->smax_pitch, dif->smax_pitch * 4);
         buffer_store_f1(rs, run * 4, residue * 1024, m);
       }
     }
@@ -462,7 +462,8 @@ __device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Ar
 // FRONT: 0 = an 8192-point frame of its own; 1, 2 = residue `residue` of the 65536-point frame `frame_in` of `dif` (fft65536_dif8.h,
 //        LOADV = FRONT - 1: the load stage is the radix-8 fold, g.iq / g.win / g.item_stride are not read), `frame` = the row
 //        of 8192 floats the residue's bins go to (8 frame_in + residue in a plane of residue-major rows); 3 = residues `residue` (< 4)
-//        AND residue + 4 by the same workgroup, one fold for both, rows `frame` and `frame` + 4 (twice the registers: four waves per SIMD).
+//        AND residue + 4 by the same workgroup, one fold for both, rows `frame` and `frame` + 4 (twice the registers: four waves per SIMD);
+//        4 = the same for a 131072-point frame: radix 16, residues `residue` (< 8) and residue + 8, rows `frame` and `frame` + 8.
 template <int FMT, int TW, bool SWZ = false, bool NOWIN = false, int FRONT = 0>
 __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t frame, unsigned char* __restrict__ smem_raw, int t, int* hdr,
                                                  const Dif8Front* dif = nullptr, size_t frame_in = 0, int residue = 0) {
@@ -495,7 +496,8 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
       tw2_l[t] = t < 256 ? tabs.tw2[t] : tabs.lane[t - 256];
       if (t < 128) lane_l[256 + t] = tabs.lane[256 + t];
     };
-    if constexpr (FRONT == 3) dif8_front2<FMT>(*dif, frame_in, residue, smem_raw, t, a, a2, tables_to_lds);
+    if constexpr (FRONT == 3) dif8_front2<FMT, 8>(*dif, frame_in, residue, smem_raw, t, a, a2, tables_to_lds);
+    else if constexpr (FRONT == 4) dif8_front2<FMT, 16>(*dif, frame_in, residue, smem_raw, t, a, a2, tables_to_lds);
     else dif8_front<FMT, FRONT - 1>(*dif, frame_in, residue, smem_raw, t, a, tables_to_lds);
     (void)iq;
     (void)win;
@@ -531,8 +533,9 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
     tw2_l[t] = tf0;  // tw2_l and lane_l are contiguous: entries 0..511
     if (t < 128) lane_l[256 + t] = tf1;
   }
-  if constexpr (FRONT == 3) {
-    // two residues by one workgroup (fft65536_dif8.h, dif8_front2): r's transform, then (r + 4)'s from the registers that kept it
+  if constexpr (FRONT == 3 || FRONT == 4) {
+    // two residues by one workgroup (fft65536_dif8.h, dif8_front2): r's transform, then (r + Q/2)'s from the registers that kept it
+    constexpr int HQ = FRONT == 4 ? 8 : 4;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       if (pass) {
@@ -540,7 +543,7 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = a2[r];
       }
-      fft8192_v2_core<FMT, TW, SWZ, FRONT>(a, g, frame + 4 * pass, smem_raw, t, hdr, dif, frame_in, residue + 4 * pass);
+      fft8192_v2_core<FMT, TW, SWZ, FRONT>(a, g, frame + HQ * pass, smem_raw, t, hdr, dif, frame_in, residue + HQ * pass);
     }
   } else {
     fft8192_v2_core<FMT, TW, SWZ, FRONT>(a, g, frame, smem_raw, t, hdr, dif, frame_in, residue);

@@ -120,6 +120,7 @@ struct StepArgs {
   // relative, residue-major: `fft.psd` is the ring's buffer, `fft.rel_thr` the ceiling in the same order) and run maxima the detect
   // stage of two calls later reads; the plan of call k - 1, detect(k - 2) (PERM8 tiles) and emit(k - 3) ride on the launch as they ride
   // on the column launch of the four-step form (KIND 2). `fft` carries the transform's tables and the rows' place, `dif` the fold's.
+  // KIND 9 — the same for 131072-point frames (what getFft picks at 20 MS/s): radix 16, residues r and r + 8 per workgroup, n_fft = 8 x frames.
   Dif8Front dif;
   int n_emit;  // frames of the emit role
   int emit_per_wg;  // 8: one wave per frame; 1 (KIND 2): rows of 2048 mask words and more, the eight waves share one frame
@@ -225,10 +226,10 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;
     }
   } else if (role == ROLE_PLAN) {
-    if constexpr (KIND == 1 || KIND == 2 || KIND == 7 || KIND == 8) {  // a long transform's plan: two blocks of k_plan_long's numbering
+    if constexpr (KIND == 1 || KIND == 2 || KIND == 7 || KIND == 8 || KIND == 9) {  // a long transform's plan: two blocks of k_plan_long's numbering
       const int sub = tid >> 8;
       float* mrow = reinterpret_cast<float*>(smem_raw) + sub * (kPlanFusedFloats + kPlanLongInts);
-      if constexpr (KIND == 8) plan_dif8_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));  // (the fold's rows: layout 2)
+      if constexpr (KIND == 8 || KIND == 9) plan_dif8_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));  // (the fold's rows: layout 2)
       else plan_long_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));
       return;
     }
@@ -244,6 +245,13 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
         int f, r, hdr;
         dif8_item<SS_DIF8_W>(item, a.dif.nframes, &f, &r);  // (W = 4: residues r and r + 4 by this workgroup)
         fft8192_v2_frame<FMT, 2, true, false, SS_DIF8_W == 4 ? 3 : 2>(a.fft, (size_t)(8 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
+      }
+    }
+    else if constexpr (KIND == 9) {  // 131072 points, radix 16: residues r (< 8) and r + 8 of a frame, eight workgroups per frame
+      if constexpr (FMT != FMT_CF32) {
+        int f, r, hdr;
+        dif8_item<8>(item, a.dif.nframes, &f, &r);
+        fft8192_v2_frame<FMT, 2, true, false, 4>(a.fft, (size_t)(16 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
       }
     }
     else if constexpr (KIND == 6) fft_rows256_tile(a.rows256, item, smem_raw, tid);  // (the ROW half of call k: its column half ran as its own launch right before)
@@ -347,12 +355,12 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     float* tile = reinterpret_cast<float*>(smem_raw) + half * (16 * T::P + 16);
     int* cnt = reinterpret_cast<int*>(tile + 16 * T::P);
     const int mine = half ? tile_b : tile_a;
-    detect_tile<21, 21, 16, 256, SPEC, KIND == 8>(a.det, mine < 0 ? tile_a : mine, tid & 255, tile, cnt, mine >= 0);
+    detect_tile<21, 21, 16, 256, SPEC, KIND == 8 ? 3 : KIND == 9 ? 4 : 0>(a.det, mine < 0 ? tile_a : mine, tid & 255, tile, cnt, mine >= 0);
   }
 }
 
 template <int FMT, bool SPEC, int TW = 2, bool SWZ = true, bool PRIO = false, int KIND = 0>
-__global__ __launch_bounds__(kStepThreads, (KIND == 8 && SS_DIF8_W == 4) ? 4 : 8) void k_scan_step(StepArgs a_by_value) {
+__global__ __launch_bounds__(kStepThreads, ((KIND == 8 && SS_DIF8_W == 4) || KIND == 9) ? 4 : 8) void k_scan_step(StepArgs a_by_value) {
   // The arguments are read where they are used, straight from the kernel-argument segment (scalar loads from constant
   // memory): taken from the by-value parameter they are all loaded at the top of the kernel and kept alive through every
   // role — hundreds of scalar registers spilled into vector registers the 64-VGPR budget does not have.

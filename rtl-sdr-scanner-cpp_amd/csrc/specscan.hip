@@ -310,6 +310,8 @@ struct ss_ctx {
   // are in bin order. ring_perm8 says which order the ring's window and the stages that wait are in; a call of the other kind
   // drains what waits and has the window's 35 rows rewritten first (set_ring_form).
   bool dif8 = false;
+  int dif_logq = 3;               // log2 of the fold's radix: 3 (65536 points) or 4 (131072 points: sixteen residues, KIND 9)
+  bool cull_fold_only = false;    // 131072 points: the culling machinery (run maxima, plan, ring rows by the FFT stage) serves the fold's calls only — the four-step form of that size has no such epilogue
   bool ring_perm8 = false;
   bool last_rows_perm8 = false;   // ... and the rows ss_read_window serves (last_hist, last_rel_rows)
   float2* d_dif8_tab = nullptr;   // the fold's tables (dif8_host_tables)
@@ -891,9 +893,9 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
   if (c->two_pass) return c->diag.cols1024_wide ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 4>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 3>);
   if constexpr (FMT != ss::FMT_CF32 && !SPEC) {  // (the fold's launches, and the drains of the stages that wait behind them: their tiles read residue-major rows)
 #ifdef SS_DIAG
-    if (!c->use_fft8192 && c->ring_perm8 && (c->diag.prio_fft || c->diag.prio_other)) return go(ss::k_scan_step<FMT, SPEC, 2, true, true, 8>);
+    if (!c->use_fft8192 && c->ring_perm8 && c->dif_logq == 3 && (c->diag.prio_fft || c->diag.prio_other)) return go(ss::k_scan_step<FMT, SPEC, 2, true, true, 8>);
 #endif
-    if (!c->use_fft8192 && c->ring_perm8) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 8>);
+    if (!c->use_fft8192 && c->ring_perm8) return c->dif_logq == 4 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 9>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 8>);
   }
   if (!c->use_fft8192 && a.n_fft && a.rows256.work && !a.n_rows) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 6>);  // (65536 points: the row tiles as the FFT role; rows of 2048 mask words: the wide emit role)
   if (!c->use_fft8192 && c->merge) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 7>);  // (one launch per call: KIND 2's roles and the row tiles as one more; its drains too)
@@ -987,7 +989,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   if (with_long_plan && c->have_plan) {  // 65536 points: the plan of the call before as a role of this (column) launch
     a.plan_det = c->pend_plan_det;
     a.plan_long = c->pend_plan;
-    a.n_plan_long = ((c->pend_plan.layout == 2 ? ss::plan_dif8_blocks(c->pend_plan_det.nframes, c->pend_plan_det.shift) : ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n)) + 1) / 2;
+    a.n_plan_long = ((c->pend_plan.layout == 2 ? ss::plan_dif8_blocks(c->pend_plan_det.nframes, c->pend_plan_det.shift, c->dif_logq) : ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n)) + 1) / 2;
     c->have_plan = false;
   }
   if (ss::step_items(a) == 0) return;
@@ -1158,7 +1160,7 @@ void launch_nan_stage(ss_ctx* c, const NanStage& g) {
 // The plan of the last call as a launch of its own (it would have ridden on the next call's column launch, ss_ctx::have_plan).
 void launch_pending_plan(ss_ctx* c) {
   if (!c->have_plan) return;
-  const int plan_wgs = c->pend_plan.layout == 2 ? ss::plan_dif8_blocks(c->pend_plan_det.nframes, c->pend_plan_det.shift)
+  const int plan_wgs = c->pend_plan.layout == 2 ? ss::plan_dif8_blocks(c->pend_plan_det.nframes, c->pend_plan_det.shift, c->dif_logq)
                                                 : ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n);  // (groups past the band's end find no column)
   hipLaunchKernelGGL((ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, c->stream, c->pend_plan_det, c->pend_plan);
   c->have_plan = false;
@@ -1777,7 +1779,7 @@ void set_ring_form(ss_ctx* c, bool perm8) {
   if (!c->dif8 || c->ring_perm8 == perm8) return;
   flush_stages(c);
   const size_t cnt = (size_t)kHistRows * (size_t)c->n;
-  hipLaunchKernelGGL(ss::k_rows_perm8, dim3(1024), dim3(256), 0, c->stream, (const float*)(c->d_hist + (size_t)c->hist_start * c->n), c->d_perm_tmp, kHistRows, perm8 ? 1 : 0);
+  hipLaunchKernelGGL(ss::k_rows_perm8, dim3(1024), dim3(256), 0, c->stream, (const float*)(c->d_hist + (size_t)c->hist_start * c->n), c->d_perm_tmp, kHistRows, perm8 ? 1 : 0, c->dif_logq);
   hipLaunchKernelGGL(ss::k_copy_rows, dim3(grid_for(cnt / 4, 256)), dim3(256), 0, c->stream, (const float*)c->d_perm_tmp, c->d_hist, cnt / 4);
   c->hist_start = 0;
   c->hist_prev = c->hist_prev2 = ss::RingPrev{0, -1, 0};
@@ -1840,7 +1842,8 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     ss::RowsExtra rx{};
     bool ring_by_rows = false, ring_only = false;
     const float* ring_rows = nullptr;
-    if (c->cull_long) {
+    const bool cull_call = c->cull_long && (!c->cull_fold_only || dif_call);  // (131072 points: only the fold's calls leave run maxima and write the ring themselves)
+    if (cull_call) {
       rx.smax = c->d_smax;
       rx.smax_mask = c->smax_rows - 1;
       rx.abs0 = (int)(c->abs_frames & 0x3fffffff);
@@ -1895,7 +1898,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       gf.scale = c->cfg.int_scale;
       gf.psd = rx.hist_out;  // row f - first_hist of this region is frame f's (RowsExtra, fft256_kernels.h)
       gf.rel_thr = thr_perm8(c, z);
-      ss::Dif8Front df = ss::dif8_front_of(d_iq, item_stride, c->d_dif8_tab);
+      ss::Dif8Front df = ss::dif8_front_of(d_iq, item_stride, c->d_dif8_tab, 1 << c->dif_logq);
       df.smax = rx.smax;
       df.smax_mask = rx.smax_mask;
       df.abs0 = rx.abs0;
@@ -1905,7 +1908,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       FftRole drole;
       drole.frames = &gf;
       drole.dif = &df;
-      drole.n = SS_DIF8_W * nframes;  // (4: two residues per workgroup)
+      drole.n = (c->dif_logq == 4 ? 8 : SS_DIF8_W) * nframes;  // (two residues per workgroup: four per frame at radix 8, eight at radix 16)
       // the plan of the call before, the planned detect stage (of the call before that) and the emit stage behind it ride on the launch
       launch_step(c, &drole, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr, nullptr, true);
     } else if (merged_call) {
@@ -1993,7 +1996,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       c->have_rows = true;
       c->work_cur ^= 1;
     }
-    if (!c->use_fft8192 && !rows_by_step) {
+    if (!c->use_fft8192 && !rows_by_step && !dif_call) {
       st = launch_fft_rows(c, nframes, ring_only ? nullptr : d_psd, rx);
       if (st != SS_OK) return st;
     }
@@ -2005,7 +2008,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     if (n_learn > 0) {
       hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
       if (c->cull || c->cull_long) hipLaunchKernelGGL(ss::k_thr_tilemin, dim3(c->n / 256), dim3(64), 0, c->stream, (const float*)z->d_thr, c->n, z->d_thr + c->n);
-      if (c->dif8) hipLaunchKernelGGL(ss::k_rows_perm8, dim3(256), dim3(256), 0, c->stream, (const float*)z->d_thr, thr_perm8(c, z), 1, 1);  // the ceiling in the order of the fold's rows
+      if (c->dif8) hipLaunchKernelGGL(ss::k_rows_perm8, dim3(256), dim3(256), 0, c->stream, (const float*)z->d_thr, thr_perm8(c, z), 1, 1, c->dif_logq);  // the ceiling in the order of the fold's rows
     }
     // (det_lag2: this call's detect stage waits for its plan, behind the planned one — which, if there is one, rode on this call's column launch)
     ss::DetectArgs& nd = merged_call ? c->pend_det3 : c->det_lag2 ? c->pend_det2 : c->pend_det;
@@ -2023,7 +2026,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       c->have_det = true;
       c->pend_det_spec = c->spec_in_detect && spec != nullptr;
     }
-    if (c->cull_long) {
+    if (cull_call) {
       nd.hist_by_fft = ring_by_rows ? 1 : 0;
       nd.tile_list = nullptr;
       if (ring_only) {
@@ -2034,7 +2037,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       // the plan: which tiles of this call can hold a candidate at all (k_plan_long) — behind the rows kernel, ahead of the
       // launch that carries the detect stage. Only a stage whose sole products are mask bits and counts is planned.
       // (the plan of call k rides at the front of call k + 1's column launch: four plan blocks share a column tile's LDS)
-      const bool plan_fused = rows_by_step && c->diag.plan_fused && overlap;
+      const bool plan_fused = (rows_by_step || dif_call) && c->diag.plan_fused && overlap;
       const int plan_cols = ss::plan_long_cols(nframes, nd.shift, c->n / 256, 8, plan_fused ? ss::kPlanFusedFloats : ss::kPlanLongFloats);  // (32 columns per workgroup — whole lines of the two-pass layout — halved the fetches and doubled the time: 128 workgroups are too few, profiles/r04/s6_summary.txt)
       if (ring_by_rows && !spec && !nd.rel_out && !nd.avg_out && plan_cols > 0) {
         int* list = c->d_tlist[(c->buf_cur + c->nbuf - 1) % c->nbuf];  // (run_backend_fused has moved buf_cur on: the set this call's mask bits go to)
@@ -2056,7 +2059,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
           c->pend_plan = pl;
           c->pend_plan_det = ss::plan_long_det(nd);
         } else {
-          const int plan_wgs = pl.layout == 2 ? ss::plan_dif8_blocks(nframes, nd.shift) : ss::plan_long_blocks(pl.layout, plan_cols, c->n);  // (groups past the band's end find no column)
+          const int plan_wgs = pl.layout == 2 ? ss::plan_dif8_blocks(nframes, nd.shift, c->dif_logq) : ss::plan_long_blocks(pl.layout, plan_cols, c->n);  // (groups past the band's end find no column)
           SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, ss::plan_long_det(nd), pl);
         }
         nd.tile_list = list;
@@ -2357,13 +2360,17 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   c->nq = c->deep ? std::min(std::max(c->diag.queues, 2), kMaxQueues) : 1;
   // 65536 points with tile culling: a call's detect stage rides two calls later (ss_ctx::det_lag2) — decided here, where the rotating
   // buffers are sized: two more sets than launches in order need
-  c->det_lag2 = !c->deep && c->step_path && n == 65536 && !c->diag.fft_generic && c->diag.cull_65536 && c->diag.cull && !(cfg->flags & SS_FLAG_NO_CULL) &&
+  // (131072 points — what getFft picks at 20 MS/s — have the pipeline of 65536 points where the fold can run at all: int8 IQ, default window)
+  const bool fold_ok = c->diag.dif8 && c->diag.emit_wide && c->diag.ring_only && (cfg->in_format == SS_FMT_CS8 || cfg->in_format == SS_FMT_CU8) && !cfg->window &&
+                       !(cfg->flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN | SS_FLAG_KEEP_PLANES | SS_FLAG_SPECTROGRAM));
+  c->det_lag2 = !c->deep && c->step_path && (n == 65536 || (n == 131072 && fold_ok)) && !c->diag.fft_generic && c->diag.cull_65536 && c->diag.cull && !(cfg->flags & SS_FLAG_NO_CULL) &&
                 c->diag.rows256_step && c->diag.step_long && c->diag.det_lag2 && c->fused;
-  c->merge = c->det_lag2 && c->diag.merge_65536 && c->diag.emit_wide;  // (one launch per call: scan_step.h KIND 7, whose emit role is the wide one)
+  c->merge = c->det_lag2 && n == 65536 && c->diag.merge_65536 && c->diag.emit_wide;  // (one launch per call: scan_step.h KIND 7, whose emit role is the wide one)
   // ... and with int8 IQ and the default window no work buffer at all: the radix-8 fold (scan_step.h KIND 8). It takes every call the
   // one-launch form above would take — and longer ones — so that form is off then.
-  c->dif8 = c->det_lag2 && c->diag.dif8 && c->diag.emit_wide && c->diag.ring_only && (cfg->in_format == SS_FMT_CS8 || cfg->in_format == SS_FMT_CU8) && !cfg->window &&
-            !(cfg->flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN | SS_FLAG_KEEP_PLANES | SS_FLAG_SPECTROGRAM));
+  c->dif8 = c->det_lag2 && fold_ok;
+  c->dif_logq = n == 131072 ? 4 : 3;
+  c->cull_fold_only = c->dif8 && n == 131072;
   if (c->dif8) c->merge = false;
   c->lag = c->deep ? c->nq : (c->det_lag2 ? 2 : 1);
   c->ncnt = c->deep ? 3 * c->nq : (c->merge ? 8 : c->det_lag2 ? 6 : 3);
@@ -2592,8 +2599,8 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     }
     if (c->dif8) {  // the radix-8 fold: its own tables and the 8192-point transform's
       const double scale = (double)c->cfg.int_scale;  // (what load_iq multiplies with in the other front ends)
-      std::vector<float2> dt((size_t)ss::kDif8TableFloat2);
-      ss::dif8_host_tables(dt.data(), scale);
+      std::vector<float2> dt((size_t)ss::dif_table_float2(1 << c->dif_logq));
+      ss::dif8_host_tables(dt.data(), scale, 1 << c->dif_logq);
       CREATE_HIP(hipMalloc(&c->d_dif8_tab, sizeof(float2) * dt.size()));
       CREATE_HIP(hipMemcpy(c->d_dif8_tab, dt.data(), sizeof(float2) * dt.size(), hipMemcpyHostToDevice));
       std::vector<float2> v2((size_t)(256 + 384 + 96));
@@ -2609,12 +2616,13 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   // (57.4 against 56.9 us per 128-frame call now that detect-mode calls write no dB plane, run_batch: ring_only; 57.1 against
   // 53.4 before; 38 against 29 us per 16-frame call either way: profiles/r04/s11_summary.txt, profiles/r03/s53_summary.txt).
   // There only the diagnostics build switches it on (SS_CULL_65536=1; tests/test_gpu_cull.py keeps it honest).
-  c->cull_long = c->step_path && c->use_fft256 && ((n == 65536 && c->diag.cull_65536) || (n > 65536 && c->d_tw_sub && !c->d_tw_rowsR) || c->two_pass) &&
+  c->cull_long = c->step_path && c->use_fft256 && ((n == 65536 && c->diag.cull_65536) || (n > 65536 && c->d_tw_sub && !c->d_tw_rowsR) || c->two_pass || c->cull_fold_only) &&
                  !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
   // 65536 points: with the plan of call k at the front of call k + 1's column launch — which therefore is a launch of its own, the
   // row tiles taking the FFT role of k_scan_step in its place (KIND 6) — the culling pays there too (session 17 of round 4).
   c->rows256_step = c->cull_long && !c->two_pass && c->logn == 16 && c->diag.rows256_step && c->diag.step_long;  // (no emit stage ever rides on the row launch — KIND 6, whose emit role is the wide one — but under SS_EMIT_ON_ROWS)
-  if (!c->rows256_step) c->det_lag2 = false;  // (never: the two are decided from the same switches; the rotating buffers sized for it do no harm)
+  if (!c->rows256_step && !c->cull_fold_only) c->det_lag2 = false;  // (never: the two are decided from the same switches; the rotating buffers sized for it do no harm)
+  if (c->dif8 && !c->cull_long) c->dif8 = c->cull_fold_only = false;
   if (c->cull_long) {
     CREATE_HIP(hipMalloc(&c->d_zero_row, sizeof(float) * (size_t)n));  // (what a ring-only call's detect stage subtracts from rows that are noise-relative already)
     CREATE_HIP(hipMemset(c->d_zero_row, 0, sizeof(float) * (size_t)n));
@@ -2945,7 +2953,7 @@ static int read_perm8_row(ss_ctx* c, const float* row, int lo, size_t cnt, float
   std::vector<float> h((size_t)c->n);
   SS_HIP(c, hipMemcpyAsync(h.data(), row, sizeof(float) * h.size(), hipMemcpyDeviceToHost, c->stream));
   SS_HIP(c, hipStreamSynchronize(c->stream));
-  for (size_t k = 0; k < cnt; ++k) out[k] = h[(size_t)ss::dif8_bin_offset(lo + (int)k)];
+  for (size_t k = 0; k < cnt; ++k) out[k] = h[(size_t)ss::dif_bin_offset(lo + (int)k, c->dif_logq)];
   return SS_OK;
 }
 

@@ -31,10 +31,16 @@
 // XMAP 1: block b -> XCD b mod 8 (round-robin dispatch); the eight residues of frame f are blocks 64 (f / 8) + 8 r + (f mod 8): one XCD,
 // 64 consecutive block numbers. XMAP 0: b = 8 f + r — a frame's residues on eight different XCDs.
 template <int FMT, int FRONT, int XMAP>
-__global__ __launch_bounds__(512, FRONT == 3 ? 4 : 8) void k_dif8_lab(ss::Fft8192Args g, ss::Dif8Front d) {
+__global__ __launch_bounds__(512, FRONT >= 3 ? 4 : 8) void k_dif8_lab(ss::Fft8192Args g, ss::Dif8Front d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int b = (int)blockIdx.x;
   int f, r;
+  if (FRONT == 4) {  // 131072 points, radix 16: eight workgroups per frame (residues r and r + 8 each)
+    ss::dif8_item<8>(b, d.nframes, &f, &r);
+    int hdr;
+    ss::fft8192_v2_frame<FMT, 2, true, false, FRONT>(g, (size_t)(16 * f + r), smem_raw, (int)threadIdx.x, &hdr, &d, (size_t)f, r);
+    return;
+  }
   if (FRONT == 3) {  // four workgroups per frame (residues r and r + 4 each)
     ss::dif8_item<4>(b, d.nframes, &f, &r);
   } else if (XMAP) {
@@ -88,11 +94,12 @@ int main(int argc, char** argv) {
   CK(hipGetDeviceProperties(&prop, 0));
   printf("# device %s, %d CUs; SS_DIF_NOTHR=%d SS_AUX_DIF_IQ=%d\n", prop.name, prop.multiProcessorCount, SS_DIF_NOTHR, SS_AUX_DIF_IQ);
 
-  const int N = 65536;
+  const int Q = getenv("DIF_Q") ? atoi(getenv("DIF_Q")) : 8, logq = Q == 16 ? 4 : 3;  // DIF_Q=16: 131072-point frames, radix 16 (the two-residue form only)
+  const int N = 8192 * Q;
   const double fs = 20e6, scale = 1.0 / 128.0;
-  std::vector<float2> tw2(256), lane(384), wave(96), dt(ss::kDif8TableFloat2);
+  std::vector<float2> tw2(256), lane(384), wave(96), dt(ss::dif_table_float2(Q));
   ss::fft8192_v2_host_tables(tw2.data(), lane.data(), wave.data());
-  ss::dif8_host_tables(dt.data(), scale);
+  ss::dif8_host_tables(dt.data(), scale, Q);
   float2 *d_tw2, *d_lane, *d_wave, *d_dt;
   CK(hipMalloc(&d_tw2, 256 * 8));
   CK(hipMalloc(&d_lane, 384 * 8));
@@ -108,14 +115,14 @@ int main(int argc, char** argv) {
   // noise ceiling, residue-major like the rows
   std::vector<float> thr(N), thr_perm(N);
   for (int i = 0; i < N; ++i) thr[i] = -70.0f + 3.0f * (float)sin(0.001 * i);
-  for (int i = 0; i < N; ++i) thr_perm[ss::dif8_bin_offset(i)] = thr[i];
+  for (int i = 0; i < N; ++i) thr_perm[ss::dif_bin_offset(i, logq)] = thr[i];
   float* d_thr;
   CK(hipMalloc(&d_thr, N * 4));
   CK(hipMemcpy(d_thr, thr_perm.data(), N * 4, hipMemcpyHostToDevice));
 
   // input: int8 noise + tones; 12 sets
   const int nsets = 12;
-  const size_t in_bytes = (size_t)max_frames * N * 2, out_bytes = (size_t)max_frames * N * 4, seg_floats = (size_t)2048 * 1024;
+  const size_t in_bytes = (size_t)max_frames * N * 2, out_bytes = (size_t)max_frames * N * 4, seg_floats = (size_t)4096 * 1024;
   std::vector<signed char> h_in(in_bytes);
   {
     unsigned x = 12345u;
@@ -125,7 +132,7 @@ int main(int argc, char** argv) {
     };
     for (int f = 0; f < max_frames; ++f)
       for (int n = 0; n < N; ++n) {
-        const double ph1 = 2.0 * M_PI * (double)(12345 + 7 * f) * n / N, ph2 = 2.0 * M_PI * (double)(40001) * n / N;
+        const double ph1 = 2.0 * M_PI * (double)(12345 + 7 * f) * n / 65536.0, ph2 = 2.0 * M_PI * (double)(40001) * n / 65536.0;
         double re = 20.0 * cos(ph1) + 9.0 * cos(ph2) + 0.12 * (rnd() + rnd() + rnd() + rnd()) * 0.25;
         double im = 20.0 * sin(ph1) + 9.0 * sin(ph2) + 0.12 * (rnd() + rnd() + rnd() + rnd()) * 0.25;
         h_in[((size_t)f * N + n) * 2] = (signed char)lrint(re);
@@ -149,8 +156,9 @@ int main(int argc, char** argv) {
       {"two-byte loads, residues over eight XCDs", 1, 0},
       {"LDS-DMA pieces, residues over eight XCDs", 2, 0},
       {"LDS-DMA pieces, TWO residues per workgroup (128 VGPRs), ONE XCD", 3, 1},
+      {"131072 points, radix 16, TWO residues per workgroup, ONE XCD", 4, 1},
   };
-  const int nvariants = 5;
+  const int nvariants = 6;
   const auto launch = [&](const Variant& v, int set, int frames, hipEvent_t e0, hipEvent_t e1) {
     ss::Fft8192Args g{};
     g.tabs = tabs;
@@ -158,13 +166,14 @@ int main(int argc, char** argv) {
     g.scale = (float)scale;
     g.psd = d_out[set];
     g.rel_thr = d_thr;
-    ss::Dif8Front d = ss::dif8_front_of(d_in[set], (long long)N, d_dt);
+    ss::Dif8Front d = ss::dif8_front_of(d_in[set], (long long)N, d_dt, Q);
     d.smax = d_seg[set];
     d.smax_mask = 1023;
     d.nframes = frames;
-    const dim3 grid((v.front == 3 ? 4 : 8) * frames), block(512);
+    const dim3 grid((v.front == 3 ? 4 : 8) * frames), block(512);  // (radix 16, two residues each: eight per frame too)
 #define GO(FRONT, XMAP) hipExtLaunchKernelGGL((k_dif8_lab<ss::FMT_CS8, FRONT, XMAP>), grid, block, ss::kFft8192V2LdsBytes, st, e0, e1, 0, g, d)
-    if (v.front == 3) GO(3, 1);
+    if (v.front == 4) GO(4, 1);
+    else if (v.front == 3) GO(3, 1);
     else if (v.front == 1 && v.xmap == 1) GO(1, 1);
     else if (v.front == 2 && v.xmap == 1) GO(2, 1);
     else if (v.front == 1 && v.xmap == 0) GO(1, 0);
@@ -189,6 +198,7 @@ int main(int argc, char** argv) {
     }
     for (int vi = 0; vi < nvariants; ++vi) {
       if (only >= 0 && vi != only) continue;
+      if ((Q == 16) != (variants[vi].front == 4)) continue;
       CK(hipMemset(d_out[0], 0xff, out_bytes));
       launch(variants[vi], 0, max_frames, nullptr, nullptr);
       CK(hipStreamSynchronize(st));
@@ -200,7 +210,7 @@ int main(int argc, char** argv) {
         mean /= N;
         int worst_i = 0;
         for (int i = 0; i < N; ++i) {
-          const double got = (double)row[ss::dif8_bin_offset(i)] + (SS_DIF_NOTHR ? 0.0 : (double)thr[i]);
+          const double got = (double)row[ss::dif_bin_offset(i, logq)] + (SS_DIF_NOTHR ? 0.0 : (double)thr[i]);
           const double e = fabs(got - ref[c][i]);
           if (e > worst) worst = e, worst_i = i;
           if (ref[c][i] > mean - 10.0 && e > worst_strong) worst_strong = e;
@@ -218,6 +228,7 @@ int main(int argc, char** argv) {
   for (int frames : frame_counts) {
     for (int vi = 0; vi < nvariants; ++vi) {
       if (only >= 0 && vi != only) continue;
+      if ((Q == 16) != (variants[vi].front == 4)) continue;
       for (int k = 0; k < 12; ++k) launch(variants[vi], k % nsets, frames, nullptr, nullptr);
       CK(hipStreamSynchronize(st));
       hipEvent_t w0, w1;

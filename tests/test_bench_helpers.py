@@ -40,6 +40,7 @@ def test_chain_kernels_and_their_bytes():
     for nb in (None, 128, 512):  # config 3 as it ships (int8 IQ, detect mode): the radix-8 fold, one launch per call whatever its length, int8 in + rel rows out
         assert {k[0]: k[3] for k in b.chain_kernels(65536, "cs8", nb, True)} == {"step": 6.0}
         assert b.traffic_from_profiles(3, b.chain_kernels(65536, "cs8", nb, True)[0][1]) is not None  # (the kernel name the committed pass is searched for)
+    assert {k[0]: k[3] for k in b.chain_kernels(131072, "cs8", 64, True)} == {"step": 6.0}  # what getFft picks at 20 MS/s: the same fold with radix 16
     k3 = {k[0]: k[3] for k in b.chain_kernels(65536, "cs8")}  # ... a call that keeps a plane: the four-step form
     assert k3 == {"step": 22.0}  # one launch per call: columns (int8 in + work buffer out) and rows (work in + dB out)
     k3 = {k[0]: k[3] for k in b.chain_kernels(65536, "cs8", 256)}

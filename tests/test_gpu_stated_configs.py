@@ -196,8 +196,8 @@ def test_config3_device_calls_against_the_reference(ref_mod, chunk, ncalls):
     assert len(b) > 10_000 and len(a ^ b) <= dont_care_limit(len(b))
 
 
-@pytest.mark.parametrize("chunk,ncalls", [(128, 10), (64, 12), (16, 30), (256, 4)])
-def test_config3_steady_state_of_the_shipped_form_against_the_reference(ref_mod, chunk, ncalls):
+@pytest.mark.parametrize("n,chunk,ncalls", [(65536, 128, 10), (65536, 64, 12), (65536, 16, 30), (65536, 256, 4), (131072, 64, 8), (131072, 24, 12)])
+def test_config3_steady_state_of_the_shipped_form_against_the_reference(ref_mod, n, chunk, ncalls):
     """Config 3 at depth on the PRODUCT library, against the reference's own code: the learning frames as a call of their own (which
     takes the four-step form and leaves its rows in bin order), then `ncalls` int8 detect-mode ss_process_device calls with nothing in
     between — the form bench.py times: one launch per call, every launch carrying the fold of its own call, the plan of the call
@@ -205,7 +205,7 @@ def test_config3_steady_state_of_the_shipped_form_against_the_reference(ref_mod,
     call on every launch is a steady-state one. ss_get_stats shows that tiles were culled and that nothing drained the pipeline between
     the first of those calls and the last (reference chain: transmission.cpp:57-68,88-96, averager.cpp:14-25,52-61, utils.cpp:31-53)."""
     import torch
-    n, fs, learn = 65536, 20_000_000, 41
+    fs, learn = 20_000_000, 41  # (131072 points: the size getFft picks for this signal — the same fold with radix 16, KIND 9)
     total = learn + chunk * ncalls
     band = pkg.synth.SyntheticBand(n, seed=45, on_frame=learn + 30, off_frame=total - 40, period=total)
     iq8 = band.frames_cs8(total)
@@ -235,13 +235,14 @@ def test_config3_steady_state_of_the_shipped_form_against_the_reference(ref_mod,
     near = np.abs(ref["avg"] - np.float32(8.0)) < BAND
     outside = [(f, i) for (f, i) in a ^ b if not near[f, i]]
     assert not outside, sorted(outside)[:10]
-    print(f"\n[config 3 at depth, product library: learning call + {ncalls} x {chunk} frames of 65536 points, CS8] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band; "
+    print(f"\n[config 3 at depth, product library: learning call + {ncalls} x {chunk} frames of {n} points, CS8] {len(b)} reference candidates, {len(a ^ b)} inside the {BAND} dB band; "
           f"tiles {st['tiles_total']}, tested {st['tiles_tested']}, culled {st['tiles_culled']}; drains during the run {drains_after - drains_before}")
     # (calls shorter than the averager's window slide it along the ring's buffer and bring it back to the front when the end is reached —
     # a drain once in a few dozen calls, csrc/ring_place.h; calls of a window and more go round the buffer without one)
     assert drains_after - drains_before <= (0 if chunk >= 35 else 1 + ncalls // 20), (drains_before, drains_after)
     assert st["culling"] and st["tiles_culled"] > 0 and st["tiles_culled"] <= st["tiles_tested"] <= st["tiles_total"], st
     assert len(b) > 10_000 and len(a ^ b) <= dont_care_limit(len(b))
+    assert st["tiles_culled"] > 0.5 * st["tiles_tested"], st  # (the band leaves a few per cent of the tiles to evaluate)
 
 
 @pytest.mark.parametrize("n,fs,fmt,chunk,ncalls", [(1 << 17, 20_000_000, "cs8", 32, 4), (1 << 18, 61_440_000, "cf32", 16, 5)])
