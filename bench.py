@@ -601,7 +601,7 @@ def also_lines():
     kernel of the chain with its own duration and rate, what the library says it culled (ss_get_stats), and — except the last — a
     parity sample of its own against the reference (host path with every plane, and the timed device path in the entry's own mode)."""
     res = []
-    runs = ((2, 40, ["--no-cull"], "no_cull"), (3, 200, [], None), (3, 100, ["--frames", "256"], None), (5, 100, [], None),
+    runs = ((2, 40, ["--no-cull"], "no_cull"), (3, 200, [], None), (3, 100, ["--frames", "256"], None), (3, 60, ["--frames", "512", "--no-parity"], None), (5, 100, [], None),
             (5, 40, ["--frames", "64"], None),
             # the sizes the reference itself would run these two signals at (getFft, utils/radio_utils.cpp:98-104: the first power of two
             # whose bins are at most 250 Hz wide): 131072 points at 20 MS/s, 262144 at 61.44 MS/s — 8.4 MS per call like configs 3 and 5
@@ -770,6 +770,19 @@ def run(args):
         slots = eng.kernel_timing_read_frames()  # {slot: (ms, launches, frames those launches covered)}
         kern_ms, launches, _ = slots["step"]
         eng.kernel_timing(0)
+    # A run of up to 32 steps times ONE launch inside the timed region (each timed launch costs its queue ~13 us: two of them were 5 % of
+    # a 20-step run). One sample is a poor estimate of a launch's duration: right behind the timed region — same clocks, same working
+    # set, nothing of it inside the timed region — 32 more steps with every 4th launch timed give eight more.
+    kern_after = None
+    if every and args.steps <= 32 and world == 1 and n == 8192:
+        eng.kernel_timing(4)
+        for _ in range(32):
+            step()
+        eng.sync()
+        ms_a, cnt_a, _ = eng.kernel_timing_read_frames()["step"]
+        eng.kernel_timing(0)
+        if cnt_a:
+            kern_after = {"us": round(ms_a / cnt_a * 1e3, 2), "launches": cnt_a, "what": "32 more steps right behind the timed region, every 4th launch timed"}
     elapsed = dist.max_over_ranks(t1 - t0, device=coll_dev)
     ncand = int(outs[(counter[0] - 1) % nout]["off"][-1].item())
     lib_stats = eng.stats()  # what the library says it did (counters from creation: learning, preheat, warm-up and the timed steps)
@@ -843,6 +856,7 @@ def run(args):
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                          "kernel_us": dom["us"] if dom else None, "launches": dom["launches_timed"] if dom else 0,
+                         "kernel_us_behind_the_timed_region": kern_after,
                          "launches_in_flight": round(in_flight, 2) if dom else None,
                          "achieved_if_launches_did_not_overlap": None if literal is None else round(literal, 1),
                          # SURVEY.md 8d's figure — IQ in (+ the dB row in power mode) — times the samples one launch of the dominant kernel covers; and,

@@ -123,6 +123,12 @@ struct DetectArgs {
   // calls without learning frames; halo_rows = frames of that plane (>= H).
   const float* halo_psd;
   int halo_rows;
+  // Ring rows that hold dB values, not noise-relative ones (round 5): the FFT stage of a long transform's detect-mode call leaves its
+  // rows in the ring's buffer as dB values — the ceiling loads cost its launch 7-9 % — and the tiles that are evaluated subtract the
+  // ceiling, the same fp32 subtraction on the same values (noise_learner.cpp:55). Rows of the window from batch-relative frame
+  // ring_db_from (<= 0) on are such rows, the ones before it are noise-relative (learning frames' -100, rows a call with planes wrote);
+  // 0: none. The host settles the window (subtracts the ceiling in place) before anything else writes to it or the ceiling changes.
+  int ring_db_from;
   int n, nframes, n_learn, pushed_before;
   int shift;  // (frames since reset, before this batch) mod TF: tile t covers batch frames [t*TF - shift, t*TF - shift + TF)
   float start_level;
@@ -927,7 +933,7 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
         for (int r = 0; r < ROWS; ++r) {
           const int fr = f0 - (G - 1) + r;
           const float v = fr < a.n_learn ? kNoData : x[r] - t;  // noise_learner.cpp:49 / :55
-          x[r] = fr < 0 ? x[r] - t_before : (fr < nframes ? v : 0.0f);
+          x[r] = fr < 0 ? x[r] - (fr >= a.ring_db_from ? t : t_before) : (fr < nframes ? v : 0.0f);  // (ring rows from ring_db_from on hold dB values)
         }
         if (main_col) {
 #pragma unroll

@@ -340,11 +340,19 @@ __device__ __forceinline__ void fft_rows1024_tile(const Rows1024Args& g, int blo
     // load, subtract, store per output — and since nothing tells the compiler that the ceiling and the ring are different memory it
     // kept that order: every store waited for its own load AND, vmcnt counting both, for the store before it: sixteen memory round
     // trips one after the other at the end of every workgroup, ~20 of its ~25 us.)
-    float th[16];
+    // (round 5: detect-mode calls hand in no ceiling — x.thr null, workgroup-uniform — and the rows leave as dB values: the sixteen ceiling
+    // loads per thread, 4 B/sample through L2, cost the launch 4-5 of its 45 us, profiles/r05/s18_summary.txt; the tiles that are
+    // evaluated subtract the ceiling, DetectArgs::ring_db_from)
+    if (!x.thr) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) th[i] = x.thr[bin0 ^ (i << 16)];
+      for (int i = 0; i < 16; ++i) hrow[bin0 ^ (i << 16)] = s[(kb + 64 * i) * 9 + rr];
+    } else {
+      float th[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) hrow[bin0 ^ (i << 16)] = s[(kb + 64 * i) * 9 + rr] - th[i];  // noise_learner.cpp:55, as detect_tile forms it
+      for (int i = 0; i < 16; ++i) th[i] = x.thr[bin0 ^ (i << 16)];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hrow[bin0 ^ (i << 16)] = s[(kb + 64 * i) * 9 + rr] - th[i];  // noise_learner.cpp:55, as detect_tile forms it
+    }
   }
 }
 

@@ -204,7 +204,7 @@ struct RowsExtra {
   float* smax;       // null: no maxima
   int smax_mask;     // ring rows - 1 (a power of two)
   int abs0;          // frames since the last reset before this batch
-  const float* thr;  // the noise ceiling (hist_out != null)
+  const float* thr;  // the noise ceiling (hist_out != null): the rows are written noise-relative; null: as dB values (DetectArgs::ring_db_from)
   float* hist_out;   // null: the detect stage writes the ring
   int first_hist;    // batch frames >= first_hist become ring rows [frame - first_hist]
   int* zero_word;    // set to zero by the first workgroup: the count of the list k_plan_long appends to right behind this launch (or null)
@@ -297,11 +297,16 @@ __device__ __forceinline__ void fft_rows256_tile(const Rows256Args& g, int block
     // the ceiling values first, all in flight together, then the stores: load, subtract, store per output is what the compiler keeps
     // when written that way (it cannot know that ceiling and ring are different memory), and then every store waits for its own
     // load and for the store before it (fft1024_kernels.h: fft_rows1024_tile)
-    float th[16];
+    if (!x.thr) {  // (workgroup-uniform) the rows leave as dB values: the tiles that are evaluated subtract the ceiling (DetectArgs::ring_db_from)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) th[i] = x.thr[bin_of(i)];
+      for (int i = 0; i < 16; ++i) hrow[bin_of(i)] = s[(kb + 16 * i) * 33 + rr];
+    } else {
+      float th[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) hrow[bin_of(i)] = s[(kb + 16 * i) * 33 + rr] - th[i];  // noise_learner.cpp:55, as detect_tile forms it
+      for (int i = 0; i < 16; ++i) th[i] = x.thr[bin_of(i)];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) hrow[bin_of(i)] = s[(kb + 16 * i) * 33 + rr] - th[i];  // noise_learner.cpp:55, as detect_tile forms it
+    }
   }
 }
 __global__ __launch_bounds__(512, 8) void k_fft_rows256_psd(const float2* __restrict__ work, const float2* __restrict__ tw256, float db_off,

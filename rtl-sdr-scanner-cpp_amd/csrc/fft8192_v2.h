@@ -99,10 +99,9 @@ struct Fft8192Args {
   // rides on the launch (scan_step.h). It is asked for before the frame's own loads and handed back in `hdr` when they have
   // landed: the answer costs the workgroup nothing.
   const int* live_hint;
-  // FRONT != 0 (a residue of a 65536-point frame): the rows take NOISE-RELATIVE values, dB - rel_thr[residue * 8192 + k'] (the noise
-  // ceiling in the rows' own residue-major order; noise_learner.cpp:55) — the averager ring's rows, written by the transform itself
-  // as the row half of the four-step form does (fft256_kernels.h, RowsExtra::hist_out). The maxima for the tile culling stay dB values.
-  const float* rel_thr;
+  // (FRONT != 0 — a residue of a 65536- / 131072-point frame: `psd` is the averager ring's buffer and the rows are dB values in
+  // residue-major order; the tiles that are evaluated subtract the noise ceiling, DetectArgs::ring_db_from. Until session 18 of round 5
+  // the transform subtracted it itself, from a copy of the ceiling in the rows' order: 32 loads per thread, 8-9 % of the launch.)
 #ifdef SS_DIAG
   int hint_nowait;  // timing ablation: do not wait for the header word (garbage result)
 #endif
@@ -294,10 +293,6 @@ __device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Ar
   float* out = psd + frame * 8192;
   const __amdgpu_buffer_rsrc_t rout = buffer_of(out, 8192 * 4);
   const int voff = (j + 2048 * h) * 4;
-#ifndef SS_DIF_NOTHR  // (lab builds: the residue rows keep their dB values — what the ceiling loads cost)
-#define SS_DIF_NOTHR 0
-#endif
-  const __amdgpu_buffer_rsrc_t rthr = buffer_of(FRONT != 0 && !SS_DIF_NOTHR ? g.rel_thr + residue * 8192 : nullptr, 8192 * 4);
   // Per-segment maxima for the detect stage's tile culling: the 32 lanes of a half-wave hold, for every (k, s), the 32
   // consecutive bins of segment w + 8 k + 64 h + 128 s; lane 16 + i of each half keeps the maximum of value i = 2 k + s.
   // The 256 segment maxima of the frame meet in LDS (the 512 floats behind the exchange plane, idle since exchange 1) and the
@@ -333,14 +328,8 @@ __device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Ar
       // X[kk] to bin0 + 4096 and X[kk + 16] to bin0
       pv[2 * i + 1] = psd_db(cadd(e, o), db_off);
       pv[2 * i] = psd_db(csub(e, o), db_off);
-      if constexpr (FRONT != 0 && !SS_DIF_NOTHR) {
-        const float t1 = buffer_load_f1(rthr, voff, 1024 * k + 16384), t0 = buffer_load_f1(rthr, voff, 1024 * k);
-        buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k + 16384, pv[2 * i + 1] - t1);
-        buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k, pv[2 * i] - t0);
-      } else {
-        buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k + 16384, pv[2 * i + 1]);
-        buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k, pv[2 * i]);
-      }
+      buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k + 16384, pv[2 * i + 1]);
+      buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k, pv[2 * i]);
 #if SS_SEGMAX_LDS
       // (whether or not the frame leaves a summary: a branch here costs the dB stores their interleaving and the kernel registers)
       dbrow[256 * k + 4096] = pv[2 * i + 1];

@@ -314,6 +314,14 @@ struct ss_ctx {
   bool cull_fold_only = false;    // 131072 points: the culling machinery (run maxima, plan, ring rows by the FFT stage) serves the fold's calls only — the four-step form of that size has no such epilogue
   bool ring_perm8 = false;
   bool last_rows_perm8 = false;   // ... and the rows ss_read_window serves (last_hist, last_rel_rows)
+  // Long transforms, detect-mode calls (ring-only): the FFT stage leaves its rows in the ring's buffer as dB values and the tiles that
+  // are evaluated subtract the ceiling (DetectArgs::ring_db_from) — the ceiling loads cost such a launch 7-9 %. ring_db_rows: how
+  // many of the window's newest rows are such rows, formed under the ceiling ring_db_thr; settle_ring_db subtracts it from them in
+  // place before a call of another kind writes to the window, before the ceiling changes and before another centre frequency's is used.
+  int ring_db_rows = 0;
+  const float* ring_db_thr = nullptr;
+  int last_db_from = 0;           // ss_read_window: rows of the last call from this batch-relative frame on (<= 0; frames >= 0 all) are dB values ... 
+  bool last_rows_db = false;      // ... when the last call left such rows at all
   float2* d_dif8_tab = nullptr;   // the fold's tables (dif8_host_tables)
   float* d_perm_tmp = nullptr;    // 35 rows: the window on its way from one order to the other
   bool have_det2 = false;
@@ -1767,9 +1775,29 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   return SS_OK;
 }
 
-// 65536 points, the radix-8 fold (fft65536_dif8.h): the noise ceiling in the order of the fold's rows lives behind the ceiling and its
-// per-column minima (get_noise), rewritten by every learning call
-float* thr_perm8(const ss_ctx* c, const NoiseState* z) { return z->d_thr + (size_t)c->n + (size_t)std::max(32, c->n / 256); }
+// The window's newest ring_db_rows rows hold dB values (the FFT stage of the detect-mode calls before left them so): subtract the ceiling
+// they were formed under, in place — rel = dB - ceiling, the fp32 subtraction the rows kernel or a detect tile would have made on the
+// same values (noise_learner.cpp:55) — after which every row of the window is noise-relative again. What waits is drained first (its
+// tiles read the rows as they are).
+__global__ void k_rows_sub_thr(float* __restrict__ rows, const float* __restrict__ thr, int n, int nrows, int logq) {
+  const size_t total = (size_t)nrows * (size_t)n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int pos = (int)(i % (size_t)n);
+    const int bin = logq ? (((pos & 8191) << logq) | (pos >> 13)) : pos;  // (residue-major rows: position r * 8192 + k' holds bin Q k' + r)
+    rows[i] -= thr[bin];
+  }
+}
+void settle_ring_db(ss_ctx* c) {
+  if (c->ring_db_rows <= 0 || !c->ring_db_thr) {
+    c->ring_db_rows = 0;
+    return;
+  }
+  flush_stages(c);
+  float* first = c->d_hist + (size_t)(c->hist_start + kHistRows - c->ring_db_rows) * (size_t)c->n;
+  hipLaunchKernelGGL(k_rows_sub_thr, dim3(1024), dim3(256), 0, c->stream, first, c->ring_db_thr, c->n, c->ring_db_rows, c->ring_perm8 ? c->dif_logq : 0);
+  c->ring_db_rows = 0;
+  c->ring_db_thr = nullptr;
+}
 
 // ... and the averager ring's rows are in residue-major order while calls go through the fold, in bin order while they take the
 // four-step form: a call of the other kind has what waits drained (those stages read the rows as they are), the window's 35 rows
@@ -1838,6 +1866,11 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     // because a change of form rewrites the window
     const bool dif_call = c->dif8 && allow_overlap && c->cull_long && c->diag.pipeline && n_learn == 0 && !d_psd_out && !d_rel_out && !d_avg_out && !spec &&
                           !(c->cfg.flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN | SS_FLAG_KEEP_PLANES));
+    // ... and the rows the FFT stage of a detect-mode call leaves in the ring are dB values (ring_db_rows): a call of any other kind, and
+    // a call under another ceiling, has them turned into noise-relative rows first
+    const bool db_call = c->cull_long && (!c->cull_fold_only || dif_call) && n_learn == 0 && allow_overlap && !d_psd_out && !d_rel_out && !d_avg_out && !spec && !c->ref_nan &&
+                         !(c->cfg.flags & SS_FLAG_KEEP_PLANES) && c->diag.ring_only;  // (what ring_only below comes to, but for the room in the ring's buffer)
+    if (c->ring_db_rows > 0 && (!db_call || c->ring_db_thr != z->d_thr)) settle_ring_db(c);
     set_ring_form(c, dif_call);
     ss::RowsExtra rx{};
     bool ring_by_rows = false, ring_only = false;
@@ -1859,13 +1892,15 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
                     !(c->cfg.flags & SS_FLAG_KEEP_PLANES) && c->diag.ring_only;
         if (ring_only && nframes < kHistRows) {
           ring_rows = rp.in + (size_t)kHistRows * c->n;  // batch frame f = row H + f of the window being read: right behind it (place_ring)
-        } else if (ring_only) {  // every frame of the batch as a rel row of the region place_ring reserved; its last H rows are the next call's ring
+        } else if (ring_only) {  // every frame of the batch as a row of the region place_ring reserved; its last H rows are the next call's ring
           rx.hist_out = rp.batch;
           rx.first_hist = 0;
           ring_rows = rp.batch;
         }
+        if (ring_only) rx.thr = nullptr;  // ... as dB values: the tiles that are evaluated subtract the ceiling (ring_db_rows)
       }
     }
+    if (!ring_only && c->ring_db_rows > 0) settle_ring_db(c);  // (a call that was to keep no plane and found no room for its rows in the ring's buffer)
     // (SS_FLAG_STREAM_ORDERED / SS_FLAG_REFERENCE_NAN: every stage of the call before the call returns, in order on the public stream)
     const bool overlap = c->diag.pipeline && n_learn == 0 && !(c->cfg.flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN));
     ++c->stats.calls_in_order;
@@ -1897,7 +1932,6 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       gf.db_off = c->db_off;
       gf.scale = c->cfg.int_scale;
       gf.psd = rx.hist_out;  // row f - first_hist of this region is frame f's (RowsExtra, fft256_kernels.h)
-      gf.rel_thr = thr_perm8(c, z);
       ss::Dif8Front df = ss::dif8_front_of(d_iq, item_stride, c->d_dif8_tab, 1 << c->dif_logq);
       df.smax = rx.smax;
       df.smax_mask = rx.smax_mask;
@@ -2008,7 +2042,6 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     if (n_learn > 0) {
       hipLaunchKernelGGL(ss::k_noise_learn, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, (const float*)d_psd, c->n, n_learn, z->d_thr);
       if (c->cull || c->cull_long) hipLaunchKernelGGL(ss::k_thr_tilemin, dim3(c->n / 256), dim3(64), 0, c->stream, (const float*)z->d_thr, c->n, z->d_thr + c->n);
-      if (c->dif8) hipLaunchKernelGGL(ss::k_rows_perm8, dim3(256), dim3(256), 0, c->stream, (const float*)z->d_thr, thr_perm8(c, z), 1, 1, c->dif_logq);  // the ceiling in the order of the fold's rows
     }
     // (det_lag2: this call's detect stage waits for its plan, behind the planned one — which, if there is one, rode on this call's column launch)
     ss::DetectArgs& nd = merged_call ? c->pend_det3 : c->det_lag2 ? c->pend_det2 : c->pend_det;
@@ -2029,10 +2062,14 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     if (cull_call) {
       nd.hist_by_fft = ring_by_rows ? 1 : 0;
       nd.tile_list = nullptr;
-      if (ring_only) {
+      if (ring_only) {  // the batch's rows are in the ring's buffer, as dB values — and so are the newest ring_db_rows rows of the window before them
         nd.psd = ring_rows;
-        nd.thr = c->d_zero_row;
+        nd.thr = z->d_thr;
+        nd.ring_db_from = -c->ring_db_rows;
         ring_only_rows = ring_rows;
+        c->last_db_from = nd.ring_db_from;
+        c->ring_db_rows = std::min(kHistRows, c->ring_db_rows + nframes);
+        c->ring_db_thr = z->d_thr;
       }
       // the plan: which tiles of this call can hold a candidate at all (k_plan_long) — behind the rows kernel, ahead of the
       // launch that carries the detect stage. Only a stage whose sole products are mask bits and counts is planned.
@@ -2099,6 +2136,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     c->last_rel_rows = ring_only_rows;
   }
   c->last_rows_perm8 = c->ring_perm8;  // (the order last_hist and last_rel_rows are in: ss_read_window)
+  c->last_rows_db = ring_only_rows != nullptr;  // (... and whether they hold dB values, from frame last_db_from on)
   c->last_n = nframes;
   return SS_OK;
 }
@@ -2125,7 +2163,7 @@ int get_noise(ss_ctx* c, NoiseState** out) {
   if (!z) {
     NoiseState nz;
     nz.center = center;
-    const size_t extra = (size_t)std::max(32, c->n / 256) + (c->dif8 ? (size_t)c->n : 0);  // + the per-tile-column minima (tile culling) + the ceiling in residue-major order (the fold's rows: thr_perm8)
+    const size_t extra = (size_t)std::max(32, c->n / 256);  // + the per-tile-column minima (tile culling)
     SS_HIP(c, hipMalloc(&nz.d_thr, sizeof(float) * ((size_t)c->n + extra)));
     hipLaunchKernelGGL(ss::k_fill, dim3(grid_for((size_t)c->n + extra, 256)), dim3(256), 0, c->stream, nz.d_thr, (size_t)c->n + extra, -FLT_MAX);
     c->noise.push_back(nz);
@@ -2904,6 +2942,7 @@ int ss_set_frequency_range(ss_ctx* c, int32_t lo_hz, int32_t hi_hz) {
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
   flush_stages(c);  // deferred stages belong to the old range (pass mask, noise ceiling)
+  settle_ring_db(c);  // (ring rows left as dB values belong to the old centre frequency's ceiling)
   c->range_lo = lo_hz;
   c->range_hi = hi_hz;
   c->pass_dirty = true;
@@ -2916,6 +2955,8 @@ int ss_reset(ss_ctx* c) {  // Transmission::resetBuffers -> Averager::reset: row
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
   flush_stages(c);  // deferred stages still read and write the ring
+  c->ring_db_rows = 0;
+  c->ring_db_thr = nullptr;
   const int G = c->cfg.grouping_y;
   if (c->fused) {
     c->hist_start = 0;
@@ -2939,6 +2980,7 @@ int ss_reset_noise(ss_ctx* c) {
   std::lock_guard<std::mutex> lock(c->mtx);
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
   flush_stages(c);
+  settle_ring_db(c);  // (ring rows left as dB values: the ceiling they belong to goes away)
   SS_HIP(c, hipStreamSynchronize(c->stream));
   for (auto& z : c->noise) (void)hipFree(z.d_thr);
   c->noise.clear();
@@ -2957,6 +2999,16 @@ static int read_perm8_row(ss_ctx* c, const float* row, int lo, size_t cnt, float
   return SS_OK;
 }
 
+// out[k] -= ceiling[lo + k]: a window of a row that holds dB values, as the noise-relative values the reference's chain has (noise_learner.cpp:55)
+static int sub_thr_window(ss_ctx* c, int lo, size_t cnt, float* out) {
+  if (!c->last_thr) return fail(c, SS_ERR_INVALID, "no noise ceiling to subtract");
+  std::vector<float> thr(cnt);
+  SS_HIP(c, hipMemcpyAsync(thr.data(), c->last_thr + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
+  SS_HIP(c, hipStreamSynchronize(c->stream));
+  for (size_t k = 0; k < cnt; ++k) out[k] = out[k] - thr[k];
+  return SS_OK;
+}
+
 int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t hi, float* out) {
   if (!c || !out) return SS_ERR_INVALID;
   std::lock_guard<std::mutex> lock(c->mtx);
@@ -2970,10 +3022,14 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
     // the last batch kept no dB plane (a 2^20-point device call that handed out no plane: its rows went straight to the averager
     // ring as noise-relative values): the rel rows are there, bit for bit; a dB window needs a call with d_psd_db
     if (plane == SS_PLANE_REL && frame >= 0) {
-      if (c->last_rows_perm8) return read_perm8_row(c, c->last_rel_rows + (size_t)frame * n, lo, cnt, out);
-      SS_HIP(c, hipMemcpyAsync(out, c->last_rel_rows + (size_t)frame * n + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
-      SS_HIP(c, hipStreamSynchronize(c->stream));
-      return SS_OK;
+      if (c->last_rows_perm8) {
+        const int st = read_perm8_row(c, c->last_rel_rows + (size_t)frame * n, lo, cnt, out);
+        if (st != SS_OK) return st;
+      } else {
+        SS_HIP(c, hipMemcpyAsync(out, c->last_rel_rows + (size_t)frame * n + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
+        SS_HIP(c, hipStreamSynchronize(c->stream));
+      }
+      return c->last_rows_db ? sub_thr_window(c, lo, cnt, out) : SS_OK;  // (the rows are dB values: rel = dB - ceiling, noise_learner.cpp:55)
     }
     if (frame >= 0) return fail(c, SS_ERR_INVALID, "the last ss_process_device call kept no dB / avg plane (detect mode): pass d_psd_db, or SS_FLAG_KEEP_PLANES at ss_create");
   }
@@ -3004,10 +3060,15 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
     src = c->fused ? c->last_hist + (size_t)(kHistRows + frame) * n : c->d_rel + (size_t)(G - 1 + frame) * n;
   }
   if (!src) return fail(c, SS_ERR_INVALID, "bad plane/frame");
-  if (frame < 0 && c->fused && c->last_rows_perm8) return read_perm8_row(c, src, lo, cnt, out);  // (ring rows the radix-8 fold left)
+  const bool ring_row_db = frame < 0 && c->fused && plane == SS_PLANE_REL && c->last_rows_db && frame >= c->last_db_from;  // (a ring row an earlier detect-mode call left as dB values)
+  if (frame < 0 && c->fused && c->last_rows_perm8) {  // (ring rows the fold left)
+    const int st = read_perm8_row(c, src, lo, cnt, out);
+    if (st != SS_OK) return st;
+    return ring_row_db ? sub_thr_window(c, lo, cnt, out) : SS_OK;
+  }
   SS_HIP(c, hipMemcpyAsync(out, src + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
   SS_HIP(c, hipStreamSynchronize(c->stream));
-  return SS_OK;
+  return ring_row_db ? sub_thr_window(c, lo, cnt, out) : SS_OK;
 }
 
 int ss_spectrogram_size(const ss_ctx* c) { return c ? c->spec_n : 0; }

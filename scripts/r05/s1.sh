@@ -7,7 +7,7 @@ R=/root/repo
 cd $R
 export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
 timeout 300 scripts/ubench/dif8_lab > $OUT/dif8_lab.txt 2>&1
-timeout 200 scripts/ubench/dif8_lab_nothr 128 256 > $OUT/dif8_lab_nothr.txt 2>&1
+# (dif8_lab_nothr: the variant without the ceiling subtraction — since session 18 the kernel never subtracts)
 cd /tmp
 for v in 0 1; do
   DIF8_ONLY=$v timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof$v -- $R/scripts/ubench/dif8_lab 128 > $R/$OUT/prof$v.log 2>&1

@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
   const int only = only_s ? atoi(only_s) : -1;
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
-  printf("# device %s, %d CUs; SS_DIF_NOTHR=%d SS_AUX_DIF_IQ=%d\n", prop.name, prop.multiProcessorCount, SS_DIF_NOTHR, SS_AUX_DIF_IQ);
+  printf("# device %s, %d CUs; SS_AUX_DIF_IQ=%d (the rows leave as dB values)\n", prop.name, prop.multiProcessorCount, SS_AUX_DIF_IQ);
 
   const int Q = getenv("DIF_Q") ? atoi(getenv("DIF_Q")) : 8, logq = Q == 16 ? 4 : 3;  // DIF_Q=16: 131072-point frames, radix 16 (the two-residue form only)
   const int N = 8192 * Q;
@@ -165,7 +165,6 @@ int main(int argc, char** argv) {
     g.db_off = db_off;
     g.scale = (float)scale;
     g.psd = d_out[set];
-    g.rel_thr = d_thr;
     ss::Dif8Front d = ss::dif8_front_of(d_in[set], (long long)N, d_dt, Q);
     d.smax = d_seg[set];
     d.smax_mask = 1023;
@@ -210,7 +209,7 @@ int main(int argc, char** argv) {
         mean /= N;
         int worst_i = 0;
         for (int i = 0; i < N; ++i) {
-          const double got = (double)row[ss::dif_bin_offset(i, logq)] + (SS_DIF_NOTHR ? 0.0 : (double)thr[i]);
+          const double got = (double)row[ss::dif_bin_offset(i, logq)] ;
           const double e = fabs(got - ref[c][i]);
           if (e > worst) worst = e, worst_i = i;
           if (ref[c][i] > mean - 10.0 && e > worst_strong) worst_strong = e;
