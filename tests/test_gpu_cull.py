@@ -280,10 +280,14 @@ def _device_calls_culled_equal_unculled(n, fs, nb, ncalls, min_candidates=5_000)
 def _cull_scenario(seed):
     rng = np.random.default_rng(7000 + seed)
     n = [8192, 65536, 8192, 65536, 1 << 20][seed % 5] if seed % 10 != 9 else 16384  # (16384: a long transform without culling support)
-    fs = {8192: 2_048_000, 16384: 4_096_000, 65536: 20_000_000, 1 << 20: 61_440_000}[n]
-    nframes = {8192: int(rng.integers(300, 700)), 16384: 200, 65536: int(rng.integers(120, 260)), 1 << 20: 72}[n]
-    max_batch = {8192: int(rng.choice([64, 200, 512])), 16384: 64, 65536: int(rng.choice([16, 48, 128])), 1 << 20: 16}[n]
+    if seed % 10 == 7:
+        n = 131072  # (round 5: the size getFft picks at 20 MS/s — int8 sessions go through the radix-16 fold, CF32 sessions through round 2's path)
+    fs = {8192: 2_048_000, 16384: 4_096_000, 65536: 20_000_000, 131072: 20_000_000, 1 << 20: 61_440_000}[n]
+    nframes = {8192: int(rng.integers(300, 700)), 16384: 200, 65536: int(rng.integers(120, 260)), 131072: int(rng.integers(100, 180)), 1 << 20: 72}[n]
+    max_batch = {8192: int(rng.choice([64, 200, 512])), 16384: 64, 65536: int(rng.choice([16, 48, 128])), 131072: int(rng.choice([16, 40, 64])), 1 << 20: 16}[n]
     fmt = str(rng.choice(["cf32", "cs8"])) if n < (1 << 20) else "cs8"
+    if n == 131072 and seed % 20 == 7:
+        fmt = "cs8"
     learn = int(rng.integers(5, 50)) if n < (1 << 20) else 6
     return rng, n, fs, nframes, max_batch, fmt, learn
 
