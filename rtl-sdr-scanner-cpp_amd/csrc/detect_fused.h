@@ -165,7 +165,7 @@ struct DetectArgs {
   // [2] workgroups that stopped waiting for a launch's plan and made it themselves (kStat*). Null: not counted.
   unsigned long long* stats;
 #ifdef SS_DIAG
-  long long* stamp_mid;  // measurement builds: wall clock after phase 1 (loads + time means) and after phase 2, per tile
+  long long* stamp_mid;  // measurement builds, four per tile: wall clock at the tile's start, after the first pass of phase 1 (thread 0's 36 rows have landed), after phase 1 and after phase 2
   unsigned* cull_stats;  // measurement builds: {tiles, tiles on the culling path, tiles culled}
 #endif
 };
@@ -715,14 +715,35 @@ __device__ __forceinline__ void plan_dif8_run(const PlanLongDet& a, const PlanLo
   const int f0 = ft * TF - a.shift;  // batch-relative frame of the tile's first row of outputs
   const int c0 = 32 * cg;
   if (in_range) {
-    for (int e = tid; e < 34 * ROWS; e += 256) {
+    // (a thread's five entries, eight residues each: forty loads in flight at once. One entry after the other, a residue after the
+    // other, this was forty round trips to L2 beside workgroups that keep the memory system busy — a plan workgroup held its slot for
+    // 14 us of a 128-frame launch and the 32 fold workgroups that had to wait for those slots ended it 7 us late, profiles/r05/s24_*)
+    constexpr int NE = (34 * ROWS + 255) / 256;
+    const float* src[NE];
+    float m[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = min(tid + 256 * i, 34 * ROWS - 1);
       const int colx = e % 34, r = e / 34;
       const int col = min(max(c0 - 1 + colx, 0), tiles_per_row - 1);  // (the band's edges: the edge column once more)
-      const float* row = p.smax + ((size_t)((p.abs0 + f0 - (G - 1) + r) & p.smax_mask) << (8 + logq));
-      const int run = col >> (logq - 3);  // (radix 16: a run of a residue's row covers two tile columns)
-      float m = -__builtin_inff();
-      for (int g = 0; g < nres; ++g) m = fmaxf(m, row[256 * g + run]);  // (the fold's maxima hold no NaN: fft8192_v2.h takes them with fmaxf)
-      R[colx * RP + r] = m;
+      src[i] = p.smax + ((size_t)((p.abs0 + f0 - (G - 1) + r) & p.smax_mask) << (8 + logq)) + (col >> (logq - 3));  // (radix 16: a run of a residue's row covers two tile columns)
+      m[i] = -__builtin_inff();
+    }
+    for (int g0 = 0; g0 < nres; g0 += 8) {
+      float v[NE][8];
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v[i][g] = src[i][256 * (g0 + g)];
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) m[i] = fmaxf(m[i], v[i][g]);  // (the fold's maxima hold no NaN: fft8192_v2.h takes them with fmaxf)
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + 256 * i;
+      if (e < 34 * ROWS) R[(e % 34) * RP + e / 34] = m[i];
     }
   }
   __syncthreads();
@@ -826,6 +847,23 @@ __host__ __device__ inline int plan_fused_wgs(int plan_blocks) { return (((plan_
 
 // min of the noise ceiling over bins [256 c - 32, 256 c + 288) is k_thr_tilemin above, one wave per tile column.
 
+// Which of the tile's 276 columns (256 + 10 either side, in bin order) a thread takes in phase 1. Rows in bin order: thread = column
+// (256, then 20 more). The fold's rows (PERM8 = log2 Q, fft65536_dif8.h): a tile's own 256 bins are one block of the row (Q = 8) or
+// half of one (Q = 16) with the residues' runs side by side, consecutive BINS 128 bytes apart — so the first 256 threads take the
+// tile's own columns in the block's order, thread g * (256 / Q) + j the bin Q j + g: a wave's load is 256 contiguous bytes (four
+// runs of 64) instead of sixteen lanes on eight lines — and the 20 columns either side go to the second pass. The tile in LDS stays
+// in bin order.
+template <int PERM8, int A, int TB>
+__device__ __forceinline__ int tile_column_of(int pass_c, int tid) {
+  if constexpr (PERM8 == 0) {
+    return pass_c * TB + tid;
+  } else {
+    constexpr int RUN = TB >> PERM8;  // bins of a residue in the tile
+    if (pass_c == 0) return A + ((tid & (RUN - 1)) << PERM8) + tid / RUN;
+    return tid < A ? tid : TB + tid;  // (tid < 2 A)
+  }
+}
+
 // One tile of the fused back end. `block` = tile number (what blockIdx.x is for the stand-alone kernel), `tid` = 0..TB-1,
 // `tile` / `cnt` = this tile's LDS (TF * P floats, TF ints). `valid` = false: the caller has no tile for these threads (odd
 // tile count in a two-tile workgroup) — they only keep the workgroup's barriers company. Every __syncthreads() below is
@@ -851,6 +889,9 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
   const int f0 = ft * TF - a.shift;  // batch-relative frame of the tile's first row of outputs; may be negative
   const int b0 = bt * TB;
   if (tid < TF) cnt[tid] = 0;
+#ifdef SS_DIAG
+  if (a.stamp_mid && valid && tid == 0) a.stamp_mid[4 * (size_t)block] = wall_clock64();
+#endif
   if constexpr (SPEC) {
     if (valid && a.spec_prev_partial && ft_seq == 0) spectrogram_fold<TB>(a, tid, b0);  // the first-dispatched tile of each bin column
   }
@@ -863,14 +904,92 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
   const bool writes_hist = f0 + TF > first_hist;
 
   // ---------------- phase 1: time means, thread = column ----------------
-  if (!valid) {
+  if constexpr (PERM8 != 0) {
+    // The fold's rows (KIND 8 / 9 of k_scan_step: 128 registers per thread). A pair of tiles holds a workgroup slot that a residue's
+    // transform is waiting for, or ends the launch: what counts is how long ONE wave takes, and a wave issues an instruction every
+    // four or five cycles — 1000 instructions are 2 us. Measured per tile, alone on the chip (profiles/r05/s29_*): first pass
+    // 1.7 us, the second pass — twenty columns, the same 36 loads and the same latency over again — 1.5, and for the tiles that read
+    // rows from before the batch 5-8 + 4-7 us: twenty scalar instructions per row and pass to pick the row's address. So here
+    //   * a thread of the first twenty takes its second column's 36 rows in the same flight as its first;
+    //   * rows that lie one after the other in memory — a steady tile's, and with the batch's rows right behind the ring's window
+    //     (ring_place.h) every tile's but a ragged last one — are addressed as the steady path addresses them.
+    // The arithmetic per value is the other paths' own.
+    if (valid) {
+      const bool two = tid < 2 * A;
+      const int c0 = tile_column_of<PERM8, A, TB>(0, tid), c1 = tile_column_of<PERM8, A, TB>(1, tid);
+      const int col0 = b0 - A + c0;  // one of the tile's own 256 columns: inside the band
+      const int col1 = b0 - A + c1, col1c = min(max(col1, 0), n - 1);
+      const bool in1 = col1 == col1c;
+      const uint32_t off0 = (uint32_t)dif_bin_offset(col0, PERM8) * 4u, off1 = (uint32_t)dif_bin_offset(two ? col1c : col0, PERM8) * 4u;
+      const float t0 = a.thr[col0], t1 = a.thr[two ? col1c : col0];
+      const bool in_line = steady || (!a.halo_psd && a.psd == a.hist_in + (size_t)H * n && f0 + TF <= nframes);  // (f0 - 20 >= -H: shift < TF)
+      float x[ROWS], y[ROWS];
+      if (in_line) {
+        const char* p = reinterpret_cast<const char*>(a.psd) + (ptrdiff_t)(f0 - (G - 1)) * (ptrdiff_t)n * 4;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) x[r] = load_row_value(p + (size_t)r * n * 4 + off0);
+        if (two) {
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) y[r] = load_row_value(p + (size_t)r * n * 4 + off1);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          const int fr = f0 - (G - 1) + r;
+          const float* src = fr < 0 ? before_base + (size_t)max(before_rows + fr, 0) * n : a.psd + (size_t)min(fr, nframes - 1) * n;
+          x[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + off0);
+          y[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + off1);  // (every thread: a branch per row would cost more than the loads)
+        }
+      }
+      // rel = value - ceiling; learning frames, rows of the ring, frames past a ragged end as the general path below has them
+      const auto settle = [&](float (&v)[ROWS], float t) {
+        if (steady) {
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) v[r] -= t;
+        } else {
+          const float t_before = a.halo_psd ? t : 0.0f;
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) {
+            const int fr = f0 - (G - 1) + r;
+            const float w = fr < a.n_learn ? kNoData : v[r] - t;  // noise_learner.cpp:49 / :55
+            v[r] = fr < 0 ? v[r] - (fr >= a.ring_db_from ? t : t_before) : (fr < nframes ? w : 0.0f);
+          }
+        }
+      };
+      settle(x, t0);
+      if (two) settle(y, t1);
+#pragma unroll
+      for (int j = 0; j < TF; ++j) {
+        const int fr = f0 + j;
+        if (fr >= 0 && fr < nframes) {
+          if (a.rel_out) store_row(a.rel_out, fr, n, off0, x[G - 1 + j]);
+          if (fr >= first_hist) store_row(a.hist_out, fr - first_hist, n, off0, x[G - 1 + j]);
+        }
+      }
+      if (steady) time_means_to_tile<G, TF, P, false>(x, &tile[c0], 0);
+      else time_means_to_tile<G, TF, P, true>(x, &tile[c0], a.pushed_before + f0 + 1);
+      if (two) {
+        if (!in1) {
+#pragma unroll
+          for (int j = 0; j < TF; ++j) tile[j * P + c1] = 0.0f;  // outside the band: contributes exactly nothing to the clipped window sums
+        } else if (steady) {
+          time_means_to_tile<G, TF, P, false>(y, &tile[c1], 0);
+        } else {
+          time_means_to_tile<G, TF, P, true>(y, &tile[c1], a.pushed_before + f0 + 1);
+        }
+      }
+    }
+  } else if (!valid) {
     // nothing
   } else if (steady) {
     // straight line: ROWS independent, unconditional loads per column; 276 columns over 256 threads.
     // Columns outside the band (first / last tile of a row) read a clamped address and contribute 0.0f.
 #pragma unroll
     for (int pass_c = 0; pass_c < 2; ++pass_c) {
-      const int c = pass_c * TB + tid;
+#ifdef SS_DIAG
+      if (pass_c == 1 && a.stamp_mid && tid == 0) a.stamp_mid[4 * (size_t)block + 1] = wall_clock64();
+#endif
+      const int c = tile_column_of<PERM8, A, TB>(pass_c, tid);
       if (pass_c == 0 || tid < 2 * A) {
         const int col = b0 - A + c;
         const int colc = min(max(col, 0), n - 1);
@@ -907,7 +1026,10 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
     // pointers out of it and spill scalar registers)
 #pragma unroll
     for (int pass_c = 0; pass_c < 2; ++pass_c) {
-      const int c = pass_c * TB + tid;
+#ifdef SS_DIAG
+      if (pass_c == 1 && a.stamp_mid && tid == 0) a.stamp_mid[4 * (size_t)block + 1] = wall_clock64();
+#endif
+      const int c = tile_column_of<PERM8, A, TB>(pass_c, tid);
       const int col = b0 - A + c;
       if (pass_c == 1 && tid >= 2 * A) {
         // nothing: 276 columns over 256 threads
@@ -951,7 +1073,7 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
   }
   __syncthreads();
 #ifdef SS_DIAG
-  if (a.stamp_mid && valid && tid == 0) a.stamp_mid[2 * (size_t)block] = wall_clock64();
+  if (a.stamp_mid && valid && tid == 0) a.stamp_mid[4 * (size_t)block + 2] = wall_clock64();
 #endif
 
   // ---------------- phase 2: frequency means + threshold, thread = (frame, 16-bin segment) ----------------
@@ -1028,7 +1150,7 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
   }
   __syncthreads();
 #ifdef SS_DIAG
-  if (a.stamp_mid && valid && tid == 0) a.stamp_mid[2 * (size_t)block + 1] = wall_clock64();
+  if (a.stamp_mid && valid && tid == 0) a.stamp_mid[4 * (size_t)block + 3] = wall_clock64();
 #endif
   if (valid && tid < TF && cnt[tid] != 0) atomicAdd(&a.counts[f0 + tid], cnt[tid]);
   if constexpr (SPEC) {

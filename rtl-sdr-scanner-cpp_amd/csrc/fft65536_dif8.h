@@ -155,20 +155,31 @@ inline Dif8Front dif8_front_of(const void* iq, long long item_stride, const floa
   return d;
 }
 
-// bin i of a 65536-bin row (DC at 32768) in a residue-major row
-__host__ __device__ inline int dif8_bin_offset(int i) { return ((i & 7) << 13) + (i >> 3); }
-// ... of a row of 8192 Q bins, Q = 1 << logq residues
-__host__ __device__ inline int dif_bin_offset(int i, int logq) { return ((i & ((1 << logq) - 1)) << 13) + (i >> logq); }
+// The fold's rows (the averager ring while calls go through the fold): a row of 8192 Q bins (Q = 1 << logq residues, DC in the middle)
+// in blocks of 32 Q bins — the 32 consecutive k' of every residue side by side: bin Q k' + g at (k' / 32) * 32 Q + 32 g + k' % 32. A
+// residue's workgroup writes whole 128-byte lines (32 of its outputs); a detect tile's 256 bins are one run of 1 KB (Q = 8) or half of
+// a run of 2 KB (Q = 16). (Until session 28 of round 5 the rows were residue-major — bin Q k' + g at 8192 g + k': a tile column's
+// lines, one per row and residue, were 32 KB and 256 KB apart, all of them on one memory channel, and a pair of tiles held its
+// workgroup for 7-15 us, alone on the chip or not: profiles/r05/s25_*, s27_*.)
+__host__ __device__ inline int dif_bin_offset(int i, int logq) {
+  const int g = i & ((1 << logq) - 1), k = i >> logq;
+  return ((k >> 5) << (5 + logq)) + (g << 5) + (k & 31);
+}
+// ... and the bin at position `pos` of such a row
+__host__ __device__ inline int dif_offset_bin(int pos, int logq) {
+  const int k = ((pos >> (5 + logq)) << 5) + (pos & 31), g = (pos >> 5) & ((1 << logq) - 1);
+  return (k << logq) | g;
+}
+__host__ __device__ inline int dif8_bin_offset(int i) { return dif_bin_offset(i, 3); }
 
-// `rows` rows of 8192 Q floats (Q = 1 << logq) from bin order to residue-major order (to_perm8 != 0) or back; in and out are different
-// memory. (The averager ring's window when a context changes between the fold and the four-step form, the noise ceiling once per
-// learning call.)
+// `rows` rows of 8192 Q floats (Q = 1 << logq) from bin order to the fold's order (to_perm8 != 0) or back; in and out are different
+// memory. (The averager ring's window when a context changes between the fold and the four-step form.)
 __global__ void k_rows_perm8(const float* __restrict__ in, float* __restrict__ out, int rows, int to_perm8, int logq) {
   const int logn = 13 + logq;
   const size_t total = (size_t)rows << logn;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    // i walks the residue-major side (whole lines there, short pieces on the other): position r * 8192 + k' holds bin Q k' + r
-    const size_t bin_order = ((i >> logn) << logn) | (size_t)(((int)(i & 8191) << logq) | (int)((i >> 13) & ((1 << logq) - 1)));
+    // i walks the fold's side (whole lines there, short pieces on the other)
+    const size_t bin_order = ((i >> logn) << logn) | (size_t)dif_offset_bin((int)(i & ((1u << logn) - 1)), logq);
     if (to_perm8) out[i] = in[bin_order];
     else out[bin_order] = in[i];
   }

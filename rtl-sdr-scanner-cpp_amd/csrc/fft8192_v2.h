@@ -290,9 +290,13 @@ __device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Ar
   u[13] = mulw32_if<13>(a[slot16(13)], odd);
   u[14] = mulw32_if<14>(a[slot16(14)], odd);
   u[15] = mulw32_if<15>(a[slot16(15)], odd);
-  float* out = psd + frame * 8192;
-  const __amdgpu_buffer_rsrc_t rout = buffer_of(out, 8192 * 4);
+  // FRONT != 0: `frame` = Q * (row of the ring) + residue, and the row is in the fold's layout (fft65536_dif8.h: blocks of 32 Q bins,
+  // 32 outputs of every residue side by side) — this thread's output k' = j + 2048 h + 256 kk (+ 4096) at block k' / 32, place j % 32
+  constexpr int LOGQ = FRONT == 4 ? 4 : 3;
+  float* out = FRONT != 0 ? psd + (((frame >> LOGQ) << LOGQ) * 8192 + (frame & ((1 << LOGQ) - 1)) * 32) : psd + frame * 8192;
+  const __amdgpu_buffer_rsrc_t rout = buffer_of(out, FRONT != 0 ? ((8192 << LOGQ) - 32 * (int)(frame & ((1 << LOGQ) - 1))) * 4 : 8192 * 4);
   const int voff = (j + 2048 * h) * 4;
+  constexpr int kOutStep = FRONT != 0 ? (256 << LOGQ) * 4 : 1024;  // bytes between outputs 256 apart: eight blocks / 256 floats
   // Per-segment maxima for the detect stage's tile culling: the 32 lanes of a half-wave hold, for every (k, s), the 32
   // consecutive bins of segment w + 8 k + 64 h + 128 s; lane 16 + i of each half keeps the maximum of value i = 2 k + s.
   // The 256 segment maxima of the frame meet in LDS (the 512 floats behind the exchange plane, idle since exchange 1) and the
@@ -311,6 +315,10 @@ __device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Ar
 #if SS_SEGMAX_LDS
   float* dbrow = reinterpret_cast<float*>(smem_raw + voff);  // the frame's dB values at their bin numbers (the exchange plane is idle since pass 3 began)
 #endif
+  // the stores' per-thread offset: voff itself, or for the fold's rows block (j + 2048 h) / 32, place j % 32 — (j + 2048 h) * 4 has
+  // j % 32 in bits 2-6, j / 32 in bits 7-9 and h in bit 13
+  int gvoff = voff;
+  if constexpr (FRONT != 0) gvoff = (voff & 0x7c) | ((voff & 0x2380) << LOGQ);
 #pragma unroll
   for (int k2 = 0; k2 < 4; ++k2) {
     float pv[4];  // pv[2 i + s]: the dB value of bin j + 2048 h + 256 (2 k2 + i) + 4096 s
@@ -328,8 +336,8 @@ __device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Ar
       // X[kk] to bin0 + 4096 and X[kk + 16] to bin0
       pv[2 * i + 1] = psd_db(cadd(e, o), db_off);
       pv[2 * i] = psd_db(csub(e, o), db_off);
-      buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k + 16384, pv[2 * i + 1]);
-      buffer_store_f1<SS_AUX_PSD>(rout, voff, 1024 * k, pv[2 * i]);
+      buffer_store_f1<SS_AUX_PSD>(rout, gvoff, kOutStep * k + 16 * kOutStep, pv[2 * i + 1]);
+      buffer_store_f1<SS_AUX_PSD>(rout, gvoff, kOutStep * k, pv[2 * i]);
 #if SS_SEGMAX_LDS
       // (whether or not the frame leaves a summary: a branch here costs the dB stores their interleaving and the kernel registers)
       dbrow[256 * k + 4096] = pv[2 * i + 1];

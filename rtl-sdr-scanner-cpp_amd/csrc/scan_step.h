@@ -135,7 +135,7 @@ struct StepArgs {
   int wait_limit;
   int prio_fft, prio_other;  // s_setprio of the roles' waves (0..3)
 #ifdef SS_DIAG
-  int hint_mode;      // timing ablations of the list hand-over (garbage results): 1 = FFT workgroups ignore the lists, 2 = they do not wait for their header word; 3 (a test, correct results) = the plan workgroups never publish
+  int hint_mode;      // timing ablations of the list hand-over (garbage results): 1 = FFT workgroups ignore the lists, 2 = they do not wait for their header word; 3 (a test, correct results) = the plan workgroups never publish; 4 = the radix-8 fold's workgroups skip their transforms
   long long* stamps;  // measurement builds only: {start, end (100 MHz wall clock), role << 32 | item, XCC_ID << 32 | HW_ID} per workgroup
 #endif
 };
@@ -244,6 +244,9 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       if constexpr (FMT != FMT_CF32) {
         int f, r, hdr;
         dif8_item<SS_DIF8_W>(item, a.dif.nframes, &f, &r);  // (W = 4: residues r and r + 4 by this workgroup)
+#ifdef SS_DIAG
+        if (a.hint_mode != 4)  // (timing ablation, garbage results: the passengers of the launch by themselves)
+#endif
         fft8192_v2_frame<FMT, 2, true, false, SS_DIF8_W == 4 ? 3 : 2>(a.fft, (size_t)(8 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
       }
     }
@@ -337,11 +340,15 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
   if constexpr (KIND >= 1) {
     if (list_pair_no >= 0) {
       // (a tile number that is none must not become an address; the slot behind an odd count is not an entry)
+      // (count and entries asked for together, the entries at an always-legal place — the list holds n_tiles + 2 words: one round trip
+      // to memory instead of two in a chain of five that a pair's workgroup spends most of its time waiting in)
       const int n_tiles = (a.det.n / 256) * plan_frame_tiles(a.det.nframes, a.det.shift);
-      const int cnt = min(a.det.tile_list[0], n_tiles);
+      const int at = min(1 + 2 * list_pair_no, n_tiles);
+      const int listed = a.det.tile_list[0], entry_a = a.det.tile_list[at], entry_b = a.det.tile_list[at + 1];
+      const int cnt = min(listed, n_tiles);
       if (2 * list_pair_no < cnt) {
-        tile_a = a.det.tile_list[1 + 2 * list_pair_no];
-        tile_b = 2 * list_pair_no + 1 < cnt ? a.det.tile_list[2 + 2 * list_pair_no] : -1;
+        tile_a = entry_a;
+        tile_b = 2 * list_pair_no + 1 < cnt ? entry_b : -1;
         if ((unsigned)tile_a >= (unsigned)n_tiles) tile_a = tile_b = -1;
         if ((unsigned)tile_b >= (unsigned)n_tiles) tile_b = -1;
         if (tile_a >= 0 && role == ROLE_FFT) __syncthreads();  // the column tile's last LDS reads are done

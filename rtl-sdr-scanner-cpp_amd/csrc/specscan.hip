@@ -136,6 +136,7 @@ struct ss_ctx {
     int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
     int chunk_65536 = 256;         // 65536 points with tile culling: calls of more frames go through in chunks of this many (SS_CHUNK_65536=0: in one piece)
     int chunk_long = 16;           // 2^20 points in two passes: calls of more frames go through in chunks of this many (SS_CHUNK_LONG=0: in one piece)
+    int list_first_fold = -1;      // ... in the fold's launches: -1 = by the launch's size (launch_step), k > 0 = k - 1 pairs
     int list_first = 64;           // long transforms with tile culling: the first pairs of the plan's list go to detect workgroups of their own, dispatched ahead of the launch's FFT role (SS_LIST_FIRST=0: every pair behind an FFT workgroup's tile, as until session 19 of round 4)
     bool plan_fused = true;        // 2^20 points in two passes: the plan of call k at the front of call k + 1's column launch (SS_PLAN_FUSED=0: a launch of its own behind call k's rows, as until session 14 of round 4)
     int ablate_roles = 0;          // SS_DIAG timing ablation (garbage results): 1 = launches carry no detect role, 2 = no emit role
@@ -159,7 +160,7 @@ struct ss_ctx {
     // 128-frame call, this order 40.3; passengers spread between the fold workgroups (F8,E2,D1 and the like) 47-52
     // (profiles/r05/s5_summary.txt, s6_summary.txt); emit ahead of the fold workgroups: 71.7 / 129.5 us per 256- / 512-frame call against
     // 69.8 / 126.5 (s9_summary.txt)
-    std::string step_order_fold = "F*,E*,D*";
+    std::string step_order_fold = "F*,P*,E*,D*";
 #ifdef SS_DIAG
     void read() {
       const auto is = [](const char* name, const char* value) {
@@ -198,6 +199,7 @@ struct ss_ctx {
       rows256_step = tri("SS_ROWS256_STEP") != 0;
       plan_fused = tri("SS_PLAN_FUSED") != 0;
       list_first = num("SS_LIST_FIRST", list_first);
+      list_first_fold = getenv("SS_LIST_FIRST") ? list_first + 1 : num("SS_LIST_FIRST_FOLD", list_first_fold);
       chunk_long = num("SS_CHUNK_LONG", chunk_long);
       chunk_65536 = num("SS_CHUNK_65536", chunk_65536);
       plan_first = num("SS_PLAN_FIRST", plan_first);
@@ -808,9 +810,9 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
     int role, count;
   };
   std::vector<Seg> prefix, cycle;
+  const std::string& sp = wg_rows ? c->diag.step_order_merged : c->use_fft8192 ? c->diag.step_order : a.dif.iq ? c->diag.step_order_fold : c->diag.step_order_long;
   {
     std::vector<Seg>* into = &prefix;
-    const std::string& sp = wg_rows ? c->diag.step_order_merged : c->use_fft8192 ? c->diag.step_order : a.dif.iq ? c->diag.step_order_fold : c->diag.step_order_long;
     for (size_t i = 0; i < sp.size();) {
       const char ch = sp[i];
       if (ch == '|') {
@@ -818,7 +820,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
         ++i;
         continue;
       }
-      const int role = ch == 'F' ? ss::ROLE_FFT : ch == 'D' ? ss::ROLE_DET : ch == 'E' ? ss::ROLE_EMIT : ch == 'R' ? ss::ROLE_ROWS : ss::ROLE_NONE;
+      const int role = ch == 'F' ? ss::ROLE_FFT : ch == 'D' ? ss::ROLE_DET : ch == 'E' ? ss::ROLE_EMIT : ch == 'R' ? ss::ROLE_ROWS : ch == 'P' ? ss::ROLE_PLAN : ss::ROLE_NONE;
       ++i;
       int count = 0;
       if (i < sp.size() && sp[i] == '*') {
@@ -835,7 +837,11 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
   int next[6] = {0, 0, 0, 0, 0, 0};
   std::vector<uint32_t> out;
   out.clear();
-  for (int k = 0; k < wg_plan; ++k) out.push_back((uint32_t)ss::ROLE_PLAN << 24 | (uint32_t)k);  // the few plan workgroups first: the launch's other workgroups wait for their list, never the other way round
+  // the few plan workgroups first: the launch's other workgroups wait for their list, never the other way round — unless the pattern
+  // places them itself ('P': a long transform's plan, which nothing in its own launch waits for)
+  const bool plan_placed = sp.find('P') != std::string::npos && !c->use_fft8192;
+  if (!plan_placed)
+    for (int k = 0; k < wg_plan; ++k) out.push_back((uint32_t)ss::ROLE_PLAN << 24 | (uint32_t)k);
   const auto place = [&](const Seg& sg) {
     for (int k = 0; k < sg.count && next[sg.role] < total[sg.role]; ++k) out.push_back((uint32_t)sg.role << 24 | (uint32_t)next[sg.role]++);
   };
@@ -849,6 +855,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
       place(Seg{ss::ROLE_ROWS, 1 << 27});
       place(Seg{ss::ROLE_DET, 1 << 27});
       place(Seg{ss::ROLE_EMIT, 1 << 27});
+      place(Seg{ss::ROLE_PLAN, 1 << 27});
     }
   }
   // A new shape: one of the tables allocated at ss_create, filled by a copy on the launch's own stream (the table's host
@@ -978,6 +985,12 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
     } else if (det->tile_list && fft && (fft->cols || fft->rows1024 || fft->rows256 || fft->dif)) {
       a.list_by_fft = 1;  // long transforms, planned stage: FFT workgroup p takes pair list_first + p of the list after its own tile (scan_step.h)
       a.list_first = c->diag.list_first;  // (the first pairs on detect workgroups of their own, ahead of the FFT role: no tail)
+      // The fold's launches dispatch their own workgroups first (step_order_fold). With more of them than the chip has CUs, the ones
+      // dispatched first — one per CU, the older waves there — are through after 20 us, the second on each CU after 30: a pair of tiles
+      // behind one of the first costs the launch nothing, on a detect workgroup it waits for a slot first (128-frame calls 34.8 -> 31.9 us,
+      // profiles/r05/s30_*). With at most one per CU there are free slots from the start, and a pair behind a transform only makes
+      // that workgroup late (64-frame calls 20.4 against 30.1 us).
+      if (fft->dif && c->diag.list_first_fold != 0) a.list_first = c->diag.list_first_fold > 0 ? c->diag.list_first_fold - 1 : (fft->n > c->n_cus ? 0 : c->diag.list_first);
       a.n_det = 2 * (a.list_first + std::max(0, (n_det_tiles + 1) / 2 - a.list_first - fft->n));  // detect workgroups for the first pairs and for the pairs beyond
     } else if (det->tile_list && c->two_pass && !fft) {
       a.list_loop = 1;  // 2^20 points in two passes: 128 detect workgroups share the list out in a loop (scan_step.h)
@@ -1011,7 +1024,8 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
     if (!c->diag.d_stamps) (void)hipMalloc(&c->diag.d_stamps, sizeof(long long) * 4 * 8192);
     if (c->diag.d_stamps && ++c->diag.stamp_launches == 40) {
       a.stamps = c->diag.d_stamps;
-      a.det.stamp_mid = c->diag.d_stamps + 4 * 4096;  // (2 per tile, behind the per-workgroup stamps)
+      a.det.stamp_mid = c->diag.d_stamps + 4 * 4096;  // (4 per tile, behind the per-workgroup stamps)
+      (void)hipMemsetAsync(a.det.stamp_mid, 0, sizeof(long long) * 4 * 4096, stream);
       dump_stamps = true;
     }
   }
@@ -1038,10 +1052,11 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
       for (int b = 0; b < wgs; ++b)
         fprintf(fp, "%d %lld %lld %lld %lld %lld %lld\n", b, h[4 * b], h[4 * b + 1], h[4 * b + 2] >> 32, h[4 * b + 2] & 0xffffffff, h[4 * b + 3] >> 32, h[4 * b + 3] & 0xffffffff);
       fclose(fp);
-      std::vector<long long> m((size_t)2 * a.n_det);
+      const int n_tiles = std::min(4096, (a.det.n / 256) * ss::plan_frame_tiles(a.det.nframes, a.det.shift));
+      std::vector<long long> m((size_t)4 * n_tiles);
       (void)hipMemcpy(m.data(), c->diag.d_stamps + 4 * 4096, sizeof(long long) * m.size(), hipMemcpyDeviceToHost);
       if (FILE* fm = fopen((c->diag.stamp_path + ".det").c_str(), "w")) {
-        for (int t = 0; t < a.n_det; ++t) fprintf(fm, "%d %lld %lld\n", t, m[2 * t], m[2 * t + 1]);
+        for (int t = 0; t < n_tiles; ++t) fprintf(fm, "%d %lld %lld %lld %lld\n", t, m[4 * t], m[4 * t + 1], m[4 * t + 2], m[4 * t + 3]);
         fclose(fm);
       }
     }
@@ -1783,7 +1798,7 @@ __global__ void k_rows_sub_thr(float* __restrict__ rows, const float* __restrict
   const size_t total = (size_t)nrows * (size_t)n;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int pos = (int)(i % (size_t)n);
-    const int bin = logq ? (((pos & 8191) << logq) | (pos >> 13)) : pos;  // (residue-major rows: position r * 8192 + k' holds bin Q k' + r)
+    const int bin = logq ? ss::dif_offset_bin(pos, logq) : pos;  // (the fold's rows: fft65536_dif8.h)
     rows[i] -= thr[bin];
   }
 }

@@ -232,16 +232,22 @@ def test_long_rows_device_calls_without_sync_culled_equal_unculled(cull_65536, n
     _device_calls_culled_equal_unculled(65536, 20_000_000, nb, ncalls)
 
 
-# the forms the 65536- and 2^20-point chains went through in round 4 (switches of the diagnostics build): each of
-# them in detect mode with calls in flight, culled == unculled
+# the forms the 65536- and 2^20-point chains went through in round 4 (switches of the diagnostics build; SS_DIF8=0:
+# int8 input through the four-step chain, as CF32 input still goes): each of them in detect mode with calls in flight, culled == unculled
 @pytest.mark.parametrize("env,n,fs,nb,ncalls", [
-    ({"SS_MERGE_65536": "0"}, 65536, 20_000_000, 128, 7),   # two launches per call (session 20's form; still what calls of more than 128 frames and calls that keep a plane take)
-    ({"SS_MERGE_65536": "0"}, 65536, 20_000_000, 48, 9),
-    ({"SS_DET_LAG2": "0"}, 65536, 20_000_000, 128, 7),
-    ({"SS_ROWS256_STEP": "0"}, 65536, 20_000_000, 128, 7),
-    ({"SS_LIST_FIRST": "0", "SS_EMIT_ON_ROWS": "1"}, 65536, 20_000_000, 48, 9),
-    ({"SS_PLAN_FUSED": "0", "SS_WIN_CALC": "0"}, 65536, 20_000_000, 64, 6),
+    ({"SS_DIF8": "0", "SS_MERGE_65536": "0"}, 65536, 20_000_000, 128, 7),   # two launches per call (session 20's form; still what calls of more than 128 frames and calls that keep a plane take)
+    ({"SS_DIF8": "0", "SS_MERGE_65536": "0"}, 65536, 20_000_000, 48, 9),
+    ({"SS_DIF8": "0", "SS_DET_LAG2": "0"}, 65536, 20_000_000, 128, 7),
+    ({"SS_DIF8": "0", "SS_ROWS256_STEP": "0"}, 65536, 20_000_000, 128, 7),
+    ({"SS_DIF8": "0", "SS_LIST_FIRST": "0", "SS_EMIT_ON_ROWS": "1"}, 65536, 20_000_000, 48, 9),
+    ({"SS_DIF8": "0", "SS_PLAN_FUSED": "0", "SS_WIN_CALC": "0"}, 65536, 20_000_000, 64, 6),
+    ({"SS_DIF8": "0"}, 65536, 20_000_000, 128, 7),   # round 4's one-launch form (KIND 7) on int8 input: what int8 calls took before the fold
     ({"SS_PLAN_FUSED": "0", "SS_WIN_CALC": "0", "SS_LIST_FIRST": "0"}, 1 << 20, 61_440_000, 16, 7),
+    # the radix-8 fold's launches (round 5): the listed pairs on detect workgroups of their own where the shipped form puts them behind the
+    # fold's workgroups (more workgroups than CUs) and the other way round, the dispatch order of sessions 9-29
+    ({"SS_LIST_FIRST_FOLD": "65"}, 65536, 20_000_000, 128, 7),
+    ({"SS_LIST_FIRST_FOLD": "1", "SS_STEP_ORDER": "F*,E*,D*"}, 65536, 20_000_000, 48, 9),
+    ({"SS_STEP_ORDER": "D64,F*,E*,P*,D*"}, 65536, 20_000_000, 128, 7),
 ], ids=lambda v: "-".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
 def test_long_rows_intermediate_forms_culled_equal_unculled(cull_65536, monkeypatch, env, n, fs, nb, ncalls):
     for k, v in env.items():
