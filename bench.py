@@ -302,8 +302,8 @@ def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False, call_frames:
 
 # ---------------------------------------------------------------------------------------------- launcher
 PMC_FILES = {"fetch": "pmc_fetch.csv", "write": "pmc_write.csv"}  # under profiles/<PMC_SET>/, one counter per rocprofv3 pass
-# the committed passes of each configuration's command line (config 2: round 4, scripts/r04/s8.sh; configs 3 and 5: round 5, scripts/r05/s12.sh)
-PMC_SET = {2: "r04/s8_cfg2", 3: "r05/s12_cfg3", 5: "r05/s12_cfg5"}  # (config 2's kernel has not changed its traffic since; its default line measures it live: live_pmc_traffic)
+# the committed passes of each configuration's command line (config 2: round 4, scripts/r04/s8.sh; configs 3 and 5: round 5, scripts/r05/s35.sh)
+PMC_SET = {2: "r04/s8_cfg2", 3: "r05/s35_cfg3", 5: "r05/s35_cfg5"}  # (config 2's kernel has not changed its traffic since; its default line measures it live: live_pmc_traffic)
 
 
 def traffic_from_profiles(config: int, kernel_match: str, threads_per_launch: int | None = None):
@@ -400,9 +400,9 @@ def chain_kernels(n: int, fmt: str, nb: int | None = None, detect_mode: bool = F
         q = n // 8192
         return [("step", f"true, false, {8 if q == 8 else 9}>", f"k_scan_step (KIND {8 if q == 8 else 9}), one launch per call: the radix-{q} decimation-in-frequency fold in the load stage of the "
                  f"8192-point transform (csrc/fft65536_dif8.h) — {q // 2} workgroups per frame, each folding the whole int8 frame (LDS-DMA pieces, Hamming taps formed, W_{q} rotations) into the "
-                 f"8192 points of residues r and r + {q // 2} and running the 8192-point transform on both -> dB -> noise-relative rows in residue-major order straight into the averager ring's "
+                 f"8192 points of residues r and r + {q // 2} and running the 8192-point transform on both -> dB -> dB rows, in blocks of 32 Q bins, straight into the averager ring's "
                  "buffer (no work buffer, no dB plane) + run maxima for the tile culling —, carrying the plan of call k-1 (which averaging tiles can hold a candidate), the listed tiles of "
-                 "call k-2 (21x21 mean + threshold on residue-major rows) and the candidate lists of call k-3", in_b + 4.0)]
+                 "call k-2 (21x21 mean + threshold on those rows) and the candidate lists of call k-3", in_b + 4.0)]
     if n == 65536 and os.environ.get("SS_CULL_65536") != "0" and os.environ.get("SS_ROWS256_STEP") != "0" and os.environ.get("SS_MERGE_65536") != "0" and (nb is None or nb <= 128):
         # 65536 points, detect-mode calls of up to 128 frames as the product runs them since session 36 of round 4: ONE launch per call
         return [("step", "k_scan_step", "k_scan_step (KIND 7), one launch per call: the column half of the four-step FFT of call k (load, Hamming taps formed from one table entry per "

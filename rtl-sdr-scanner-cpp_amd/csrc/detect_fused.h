@@ -847,6 +847,100 @@ __host__ __device__ inline int plan_fused_wgs(int plan_blocks) { return (((plan_
 
 // min of the noise ceiling over bins [256 c - 32, 256 c + 288) is k_thr_tilemin above, one wave per tile column.
 
+// The general path's per-row work, written for the instruction count: a tile that takes this path is evaluated by a workgroup whose
+// end the launch waits for, its waves share their SIMDs with six or seven others, and an instruction of theirs is issued every ~5 ns —
+// the two passes cost such a tile 8.4 us each against 1.8 us for a steady tile's (profiles/r05/s32_*: 20 scalar instructions per row for
+// its address and ~30, branches included, for its value). Both are block-uniform decisions on the row's frame number:
+//   general_row_address   row fr < 0 at `before_end` + fr rows (clamped to the rows there are), fr >= 0 at psd + min(fr, nframes - 1) rows
+//   general_row_value     fr < 0: x - (ceiling or 0.0f);  learning frame: kNoData;  frame of the batch: x - ceiling;  past its end: 0.0f
+//                         — as masks on the operands (x - 0.0f is x bit for bit), no branch
+#ifndef SS_GENERAL_ROW_OLD  // (A/B builds, scripts/build_ab.py: 1 = the expressions as they were until session 33 of round 5)
+#define SS_GENERAL_ROW_OLD 0
+#endif
+__device__ __forceinline__ const char* general_row_address(const char* psd, const char* before_end, int before_rows, int nframes, ptrdiff_t row_bytes, int fr) {
+#if SS_GENERAL_ROW_OLD
+  const char* before_base = before_end - (ptrdiff_t)before_rows * row_bytes;
+  return fr < 0 ? before_base + (size_t)max(before_rows + fr, 0) * (size_t)row_bytes : psd + (size_t)min(fr, nframes - 1) * (size_t)row_bytes;
+#else
+  const int idx = min(max(fr, -before_rows), nframes - 1);
+  return (fr < 0 ? before_end : psd) + (ptrdiff_t)idx * row_bytes;  // (tried: a 32 x 32 -> 64-bit product by hand — the compiler expands __mulhi on scalars into the same six instructions)
+#endif
+}
+__device__ __forceinline__ float general_row_value(float x, float t, int fr, int nframes, int n_learn, int ring_db_from, bool before_are_psd) {
+#if SS_GENERAL_ROW_OLD
+  const float t_before = before_are_psd ? t : 0.0f;
+  const float w = fr < n_learn ? kNoData : x - t;
+  return fr < 0 ? x - (fr >= ring_db_from ? t : t_before) : (fr < nframes ? w : 0.0f);
+#endif
+  const bool kept = fr < 0 || (fr < nframes && fr >= n_learn);                       // the value is x - (t or 0.0f)
+  const bool with_t = fr >= 0 || fr >= ring_db_from || before_are_psd;                 // ... t: rows of the batch, dB rows of the ring, plane rows
+  const uint32_t other = fr < nframes ? __float_as_uint(kNoData) : 0u;                 // not kept: a learning frame (noise_learner.cpp:49), or past the batch's end
+  const uint32_t tm = with_t ? 0xffffffffu : 0u, km = kept ? 0xffffffffu : 0u;
+  const float v = x - __uint_as_float(__float_as_uint(t) & tm);                       // noise_learner.cpp:55
+  return __uint_as_float((__float_as_uint(v) & km) | (other & ~km));
+}
+
+// ... and both for the 36 rows at once: lane l of a wave works out row l's address and masks with a dozen VECTOR instructions, the
+// wave then picks them up row by row with v_readlane (uniform again: the loads keep their scalar base) — three instructions per row
+// for the address and load, six for the value, where the scalar unit spent 21 + 12 in turn (each behind the one before).
+#ifndef SS_GENERAL_ROW_LANES  // (A/B builds: 0 = row by row on the scalar unit, as sessions 33's first form)
+#define SS_GENERAL_ROW_LANES 1
+#endif
+struct GeneralRowsOfLane {
+  unsigned lo, hi, tm, km, other;
+};
+__device__ __forceinline__ GeneralRowsOfLane general_rows_of_lane(const char* psd, const char* before_end, int before_rows, int nframes, ptrdiff_t row_bytes, int fr0, int lane,
+                                                                   int n_learn, int ring_db_from, bool before_are_psd) {
+  const int fr = fr0 + lane;  // (lanes beyond the 36th: a clamped, legal address nobody asks for)
+  const unsigned long long at = (unsigned long long)(uintptr_t)general_row_address(psd, before_end, before_rows, nframes, row_bytes, fr);
+  GeneralRowsOfLane g;
+  g.lo = (unsigned)at;
+  g.hi = (unsigned)(at >> 32);
+  const bool kept = fr < 0 || (fr < nframes && fr >= n_learn);
+  const bool with_t = fr >= 0 || fr >= ring_db_from || before_are_psd;
+  g.other = fr < nframes ? __float_as_uint(kNoData) : 0u;
+  g.tm = with_t ? 0xffffffffu : 0u;
+  g.km = kept ? 0xffffffffu : 0u;
+  return g;
+}
+typedef const __attribute__((address_space(1))) char* global_bytes;  // (global memory, said so: the loads keep a scalar base and a 32-bit lane offset)
+template <int R>
+__device__ __forceinline__ global_bytes general_row_address_at(const GeneralRowsOfLane& g) {
+  // (v_readlane's result is an int: through unsigned, or the low word's sign bit floods the high one)
+  const unsigned long long at = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(g.hi, R) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane(g.lo, R);
+  return (global_bytes)at;
+}
+template <int R>
+__device__ __forceinline__ float general_row_value_at(const GeneralRowsOfLane& g, float x, float t) {
+  const unsigned tm = __builtin_amdgcn_readlane(g.tm, R), km = __builtin_amdgcn_readlane(g.km, R), other = __builtin_amdgcn_readlane(g.other, R);
+  const float v = x - __uint_as_float(__float_as_uint(t) & tm);
+  return __uint_as_float((__float_as_uint(v) & km) | (other & ~km));
+}
+// x[r] = the row's value at byte offset `coff`, r = 0 .. ROWS - 1 (compile-time recursion: v_readlane takes its lane as an immediate)
+template <int R, int ROWS>
+__device__ __forceinline__ void general_rows_load(const GeneralRowsOfLane& g, uint32_t coff, float (&x)[ROWS]) {
+  if constexpr (R < ROWS) {
+    x[R] = *(const __attribute__((address_space(1))) float*)(general_row_address_at<R>(g) + coff);
+    general_rows_load<R + 1, ROWS>(g, coff, x);
+  }
+}
+template <int R, int ROWS>
+__device__ __forceinline__ void general_rows_load2(const GeneralRowsOfLane& g, uint32_t coff0, uint32_t coff1, float (&x)[ROWS], float (&y)[ROWS]) {
+  if constexpr (R < ROWS) {
+    const global_bytes src = general_row_address_at<R>(g);
+    x[R] = *(const __attribute__((address_space(1))) float*)(src + coff0);
+    y[R] = *(const __attribute__((address_space(1))) float*)(src + coff1);
+    general_rows_load2<R + 1, ROWS>(g, coff0, coff1, x, y);
+  }
+}
+template <int R, int ROWS>
+__device__ __forceinline__ void general_rows_settle(const GeneralRowsOfLane& g, float t, float (&x)[ROWS]) {
+  if constexpr (R < ROWS) {
+    x[R] = general_row_value_at<R>(g, x[R], t);
+    general_rows_settle<R + 1, ROWS>(g, t, x);
+  }
+}
+
 // Which of the tile's 276 columns (256 + 10 either side, in bin order) a thread takes in phase 1. Rows in bin order: thread = column
 // (256, then 20 more). The fold's rows (PERM8 = log2 Q, fft65536_dif8.h): a tile's own 256 bins are one block of the row (Q = 8) or
 // half of one (Q = 16) with the residues' runs side by side, consecutive BINS 128 bytes apart — so the first 256 threads take the
@@ -924,22 +1018,38 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
       const float t0 = a.thr[col0], t1 = a.thr[two ? col1c : col0];
       const bool in_line = steady || (!a.halo_psd && a.psd == a.hist_in + (size_t)H * n && f0 + TF <= nframes);  // (f0 - 20 >= -H: shift < TF)
       float x[ROWS], y[ROWS];
+      // (a non-steady tile's 36 rows on 36 lanes, general_rows_of_lane: every lane of the wave is active here, and the lanes stay together
+      // wherever the result is read lane by lane — the second column is the whole first wave's business up to its stores, see the general
+      // path below)
+      const bool wave0 = tid < 64;
+      [[maybe_unused]] GeneralRowsOfLane rows_l{};
+#if SS_GENERAL_ROW_LANES
+      if (!steady) {
+        rows_l = general_rows_of_lane(reinterpret_cast<const char*>(a.psd), reinterpret_cast<const char*>(before_base) + (ptrdiff_t)before_rows * (ptrdiff_t)n * 4, before_rows, nframes,
+                                      (ptrdiff_t)n * 4, f0 - (G - 1), tid & 63, a.n_learn, a.ring_db_from, a.halo_psd != nullptr);
+        asm volatile("" : "+v"(rows_l.lo), "+v"(rows_l.hi), "+v"(rows_l.tm), "+v"(rows_l.km), "+v"(rows_l.other));
+      }
+#endif
       if (in_line) {
         const char* p = reinterpret_cast<const char*>(a.psd) + (ptrdiff_t)(f0 - (G - 1)) * (ptrdiff_t)n * 4;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) x[r] = load_row_value(p + (size_t)r * n * 4 + off0);
-        if (two) {
+        if (wave0) {
 #pragma unroll
           for (int r = 0; r < ROWS; ++r) y[r] = load_row_value(p + (size_t)r * n * 4 + off1);
         }
       } else {
+#if SS_GENERAL_ROW_LANES
+        general_rows_load2<0, ROWS>(rows_l, off0, off1, x, y);  // (the second column by every thread: a branch per row would cost more than the loads)
+#else
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-          const int fr = f0 - (G - 1) + r;
-          const float* src = fr < 0 ? before_base + (size_t)max(before_rows + fr, 0) * n : a.psd + (size_t)min(fr, nframes - 1) * n;
-          x[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + off0);
-          y[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + off1);  // (every thread: a branch per row would cost more than the loads)
+          const char* src = general_row_address(reinterpret_cast<const char*>(a.psd), reinterpret_cast<const char*>(before_base) + (ptrdiff_t)before_rows * (ptrdiff_t)n * 4,
+                                                before_rows, nframes, (ptrdiff_t)n * 4, f0 - (G - 1) + r);
+          x[r] = *reinterpret_cast<const float*>(src + off0);
+          y[r] = *reinterpret_cast<const float*>(src + off1);
         }
+#endif
       }
       // rel = value - ceiling; learning frames, rows of the ring, frames past a ragged end as the general path below has them
       const auto settle = [&](float (&v)[ROWS], float t) {
@@ -947,17 +1057,16 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
 #pragma unroll
           for (int r = 0; r < ROWS; ++r) v[r] -= t;
         } else {
-          const float t_before = a.halo_psd ? t : 0.0f;
+#if SS_GENERAL_ROW_LANES
+          general_rows_settle<0, ROWS>(rows_l, t, v);
+#else
 #pragma unroll
-          for (int r = 0; r < ROWS; ++r) {
-            const int fr = f0 - (G - 1) + r;
-            const float w = fr < a.n_learn ? kNoData : v[r] - t;  // noise_learner.cpp:49 / :55
-            v[r] = fr < 0 ? v[r] - (fr >= a.ring_db_from ? t : t_before) : (fr < nframes ? w : 0.0f);
-          }
+          for (int r = 0; r < ROWS; ++r) v[r] = general_row_value(v[r], t, f0 - (G - 1) + r, nframes, a.n_learn, a.ring_db_from, a.halo_psd != nullptr);
+#endif
         }
       };
       settle(x, t0);
-      if (two) settle(y, t1);
+      if (wave0) settle(y, t1);
 #pragma unroll
       for (int j = 0; j < TF; ++j) {
         const int fr = f0 + j;
@@ -1029,6 +1138,47 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
 #ifdef SS_DIAG
       if (pass_c == 1 && a.stamp_mid && tid == 0) a.stamp_mid[4 * (size_t)block + 1] = wall_clock64();
 #endif
+#if SS_GENERAL_ROW_LANES
+      // The 36 rows' addresses and masks on 36 lanes (general_rows_of_lane), read back lane by lane. A lane's registers are only safe from
+      // the register allocator while the lane runs the same code as its readers (a lane that has branched off "needs them no more" and may
+      // find them reused there): so a wave takes part in a pass as a whole or not at all — the second pass is the tile's first wave, its
+      // lanes without a column and the lanes outside the band go through the loads on a legal column of their own and part only at the
+      // stores.
+      if (pass_c == 0 || tid < 64) {
+        GeneralRowsOfLane rows_l = general_rows_of_lane(reinterpret_cast<const char*>(a.psd), reinterpret_cast<const char*>(before_base) + (ptrdiff_t)before_rows * (ptrdiff_t)n * 4,
+                                                        before_rows, nframes, (ptrdiff_t)n * 4, f0 - (G - 1), tid & 63, a.n_learn, a.ring_db_from, a.halo_psd != nullptr);
+        asm volatile("" : "+v"(rows_l.lo), "+v"(rows_l.hi), "+v"(rows_l.tm), "+v"(rows_l.km), "+v"(rows_l.other));
+        const bool has_column = pass_c == 0 || tid < 2 * A;  // 276 columns over 256 threads
+        const int c = tile_column_of<PERM8, A, TB>(pass_c, has_column ? tid : 0);
+        const int col = b0 - A + c, colc = min(max(col, 0), n - 1);
+        const bool in_band = col == colc;
+        const float t = a.thr[colc];
+        const uint32_t coff = (uint32_t)(PERM8 ? dif_bin_offset(colc, PERM8) : colc) * 4u;
+        float x[ROWS];
+        // all loads first, unconditional, on always-legal addresses: independent and in flight together. Ring rows hold rel values — or dB
+        // values, from ring_db_from on —, plane rows (the halo frames) are PSD
+        general_rows_load<0, ROWS>(rows_l, coff, x);
+        general_rows_settle<0, ROWS>(rows_l, t, x);
+        if (has_column) {
+          if (!in_band) {
+#pragma unroll
+            for (int j = 0; j < TF; ++j) tile[j * P + c] = 0.0f;  // outside the band: contributes exactly nothing to the clipped window sums
+          } else {
+            if (c >= A && c < A + TB) {
+#pragma unroll
+              for (int j = 0; j < TF; ++j) {
+                const int fr = f0 + j;
+                if (fr >= 0 && fr < nframes) {
+                  if (a.rel_out) store_row(a.rel_out, fr, n, coff, x[G - 1 + j]);
+                  if (fr >= first_hist) store_row(a.hist_out, fr - first_hist, n, coff, x[G - 1 + j]);
+                }
+              }
+            }
+            time_means_to_tile<G, TF, P, true>(x, &tile[c], a.pushed_before + f0 + 1);
+          }
+        }
+      }
+#else
       const int c = tile_column_of<PERM8, A, TB>(pass_c, tid);
       const int col = b0 - A + c;
       if (pass_c == 1 && tid >= 2 * A) {
@@ -1044,19 +1194,13 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
         // frames before the batch come from the ring (row H + frame), frames past its end are clamped.
         const uint32_t coff = (uint32_t)(PERM8 ? dif_bin_offset(col, PERM8) : col) * 4u;
         float x[ROWS];
+        const char* before_end = reinterpret_cast<const char*>(before_base) + (ptrdiff_t)before_rows * (ptrdiff_t)n * 4;
+        // ring rows hold rel values — or dB values, from ring_db_from on —, plane rows (the halo frames) are PSD
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          const int fr = f0 - (G - 1) + r;
-          const float* src = fr < 0 ? before_base + (size_t)max(before_rows + fr, 0) * n : a.psd + (size_t)min(fr, nframes - 1) * n;
-          x[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + coff);
-        }
-        const float t_before = a.halo_psd ? t : 0.0f;  // ring rows already hold rel values (x - 0.0f is x, bit for bit); plane rows are PSD
+        for (int r = 0; r < ROWS; ++r)
+          x[r] = *reinterpret_cast<const float*>(general_row_address(reinterpret_cast<const char*>(a.psd), before_end, before_rows, nframes, (ptrdiff_t)n * 4, f0 - (G - 1) + r) + coff);
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-          const int fr = f0 - (G - 1) + r;
-          const float v = fr < a.n_learn ? kNoData : x[r] - t;  // noise_learner.cpp:49 / :55
-          x[r] = fr < 0 ? x[r] - (fr >= a.ring_db_from ? t : t_before) : (fr < nframes ? v : 0.0f);  // (ring rows from ring_db_from on hold dB values)
-        }
+        for (int r = 0; r < ROWS; ++r) x[r] = general_row_value(x[r], t, f0 - (G - 1) + r, nframes, a.n_learn, a.ring_db_from, a.halo_psd != nullptr);
         if (main_col) {
 #pragma unroll
           for (int j = 0; j < TF; ++j) {
@@ -1069,6 +1213,7 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
         }
         time_means_to_tile<G, TF, P, true>(x, &tile[c], a.pushed_before + f0 + 1);
       }
+#endif
     }
   }
   __syncthreads();

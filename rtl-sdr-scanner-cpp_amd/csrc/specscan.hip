@@ -1020,12 +1020,12 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
 #ifdef SS_DIAG
   a.hint_mode = c->diag.hint_mode;
   bool dump_stamps = false;
-  if (!c->diag.stamp_path.empty() && fft && det && emit && ss::step_items(a) <= 4096 && a.n_det <= 4096) {
-    if (!c->diag.d_stamps) (void)hipMalloc(&c->diag.d_stamps, sizeof(long long) * 4 * 8192);
+  if (!c->diag.stamp_path.empty() && fft && det && emit && ss::step_items(a) <= 8192) {
+    if (!c->diag.d_stamps) (void)hipMalloc(&c->diag.d_stamps, sizeof(long long) * 4 * (8192 + 16384));  // (per workgroup, then per tile)
     if (c->diag.d_stamps && ++c->diag.stamp_launches == 40) {
       a.stamps = c->diag.d_stamps;
-      a.det.stamp_mid = c->diag.d_stamps + 4 * 4096;  // (4 per tile, behind the per-workgroup stamps)
-      (void)hipMemsetAsync(a.det.stamp_mid, 0, sizeof(long long) * 4 * 4096, stream);
+      a.det.stamp_mid = c->diag.d_stamps + 4 * 8192;  // (4 per tile, behind the per-workgroup stamps)
+      (void)hipMemsetAsync(a.det.stamp_mid, 0, sizeof(long long) * 4 * 16384, stream);
       dump_stamps = true;
     }
   }
@@ -1045,16 +1045,16 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
 #ifdef SS_DIAG
   if (dump_stamps) {
     const int wgs = ss::step_items(a);
-    std::vector<long long> h((size_t)4 * wgs);  // (wgs <= 4096 here)
+    std::vector<long long> h((size_t)4 * wgs);  // (wgs <= 8192 here)
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpy(h.data(), c->diag.d_stamps, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
     if (FILE* fp = fopen(c->diag.stamp_path.c_str(), "w")) {
       for (int b = 0; b < wgs; ++b)
         fprintf(fp, "%d %lld %lld %lld %lld %lld %lld\n", b, h[4 * b], h[4 * b + 1], h[4 * b + 2] >> 32, h[4 * b + 2] & 0xffffffff, h[4 * b + 3] >> 32, h[4 * b + 3] & 0xffffffff);
       fclose(fp);
-      const int n_tiles = std::min(4096, (a.det.n / 256) * ss::plan_frame_tiles(a.det.nframes, a.det.shift));
+      const int n_tiles = std::min(16384, (a.det.n / 256) * ss::plan_frame_tiles(a.det.nframes, a.det.shift));
       std::vector<long long> m((size_t)4 * n_tiles);
-      (void)hipMemcpy(m.data(), c->diag.d_stamps + 4 * 4096, sizeof(long long) * m.size(), hipMemcpyDeviceToHost);
+      (void)hipMemcpy(m.data(), c->diag.d_stamps + 4 * 8192, sizeof(long long) * m.size(), hipMemcpyDeviceToHost);
       if (FILE* fm = fopen((c->diag.stamp_path + ".det").c_str(), "w")) {
         for (int t = 0; t < n_tiles; ++t) fprintf(fm, "%d %lld %lld %lld %lld\n", t, m[4 * t], m[4 * t + 1], m[4 * t + 2], m[4 * t + 3]);
         fclose(fm);

@@ -35,6 +35,8 @@ VARIANTS = {
     "ordfe": ["SS_ORDER_FFT_FIRST=1"],   # 8192 points, launches without an order table: the frames dispatched ahead of the candidate lists
     "dif8w8": ["SS_DIF8_W=8"],   # 65536 points, the radix-8 fold: one residue per workgroup (64 registers, eight waves per SIMD)
     "dif8w4": ["SS_DIF8_W=4"],   # ... two residues per workgroup (128 registers, four waves per SIMD)
+    "genrows": ["SS_GENERAL_ROW_LANES=0"],   # ... row by row on the scalar unit with session 33's expressions (the shipped form works the 36 rows out on 36 lanes)
+    "genold": ["SS_GENERAL_ROW_OLD=1", "SS_GENERAL_ROW_LANES=0"],   # the averaging tiles' general path with its per-row address and value expressions as they were until session 33 of round 5
     "colsnone": ["SS_COLS_TW6=0", "SS_COLS_ABL=3"],   # ... without either  # 8192 points, deep pipelining: ring rows written by three frame tiles of every call
 }
 
