@@ -257,8 +257,8 @@ int ss_reset_noise(ss_ctx* ctx);
  * Transmission::getBestIndex walks (transmission.cpp:132-154). SS_PLANE_REL is always there. SS_PLANE_AVG needs
  * SS_FLAG_KEEP_PLANES. SS_PLANE_PSD is there after ss_process and after ss_process_device calls that were given d_psd_db; a
  * 65536-point or 2^20-point ss_process_device call in detect mode (no plane handed out, no SS_FLAG_KEEP_PLANES) writes no dB
- * plane at all — its rows go straight to the averager ring's buffer as noise-relative values (65536 points, int8 IQ: in the
- * residue-major order the radix-8 fold leaves them in, csrc/fft65536_dif8.h; this call hands bins back in bin order all the
+ * plane at all — its rows go straight to the averager ring's buffer (65536 / 131072 points, int8 IQ: as dB values, in the blocked
+ * order the fold leaves them in, csrc/fft65536_dif8.h; this call hands noise-relative values back in bin order all the
  * same) — and SS_PLANE_PSD / SS_PLANE_AVG then fail with SS_ERR_INVALID: pass d_psd_db, or SS_FLAG_KEEP_PLANES at ss_create,
  * to a caller that wants them. */
 int ss_read_window(ss_ctx* ctx, int32_t plane, int32_t frame, int32_t lo, int32_t hi, float* out);

@@ -100,7 +100,7 @@ struct Fft8192Args {
   // landed: the answer costs the workgroup nothing.
   const int* live_hint;
   // (FRONT != 0 — a residue of a 65536- / 131072-point frame: `psd` is the averager ring's buffer and the rows are dB values in
-  // residue-major order; the tiles that are evaluated subtract the noise ceiling, DetectArgs::ring_db_from. Until session 18 of round 5
+  // the fold's order (blocks of 32 Q bins, fft65536_dif8.h); the tiles that are evaluated subtract the noise ceiling, DetectArgs::ring_db_from. Until session 18 of round 5
   // the transform subtracted it itself, from a copy of the ceiling in the rows' order: 32 loads per thread, 8-9 % of the launch.)
 #ifdef SS_DIAG
   int hint_nowait;  // timing ablation: do not wait for the header word (garbage result)
@@ -458,7 +458,7 @@ __device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Ar
 // One frame by one workgroup of 512 threads; `smem_raw` = kFft8192V2LdsBytes of LDS, `t` = threadIdx.x.
 // FRONT: 0 = an 8192-point frame of its own; 1, 2 = residue `residue` of the 65536-point frame `frame_in` of `dif` (fft65536_dif8.h,
 //        LOADV = FRONT - 1: the load stage is the radix-8 fold, g.iq / g.win / g.item_stride are not read), `frame` = the row
-//        of 8192 floats the residue's bins go to (8 frame_in + residue in a plane of residue-major rows); 3 = residues `residue` (< 4)
+//        the residue's bins go to, as 8 x (the ring's row) + residue (the bins land in that row's blocks, fft65536_dif8.h); 3 = residues `residue` (< 4)
 //        AND residue + 4 by the same workgroup, one fold for both, rows `frame` and `frame` + 4 (twice the registers: four waves per SIMD);
 //        4 = the same for a 131072-point frame: radix 16, residues `residue` (< 8) and residue + 8, rows `frame` and `frame` + 8.
 template <int FMT, int TW, bool SWZ = false, bool NOWIN = false, int FRONT = 0>

@@ -116,8 +116,8 @@ struct StepArgs {
   int n_rows;
   // KIND 8 — 65536 points, int8 IQ, NO work buffer: the FFT role is TWO residues of a frame, r and r + 4 — the radix-8 fold in the load
   // stage of the 8192-point transform, once for both, then the transform twice (fft65536_dif8.h: dif8_front2; 128 registers, so this
-  // instantiation runs four waves per SIMD) —, four workgroups per frame, n_fft = 4 x frames, item j -> dif8_item<4> — whose rows (noise-
-  // relative, residue-major: `fft.psd` is the ring's buffer, `fft.rel_thr` the ceiling in the same order) and run maxima the detect
+  // instantiation runs four waves per SIMD) —, four workgroups per frame, n_fft = 4 x frames, item j -> dif8_item<4> — whose rows (dB
+  // values in the fold's blocked order: `fft.psd` is the ring's buffer) and run maxima the detect
   // stage of two calls later reads; the plan of call k - 1, detect(k - 2) (PERM8 tiles) and emit(k - 3) ride on the launch as they ride
   // on the column launch of the four-step form (KIND 2). `fft` carries the transform's tables and the rows' place, `dif` the fold's.
   // KIND 9 — the same for 131072-point frames (what getFft picks at 20 MS/s): radix 16, residues r and r + 8 per workgroup, n_fft = 8 x frames.

@@ -906,7 +906,7 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
   // (KIND 5: a launch without an FFT role — the drain — whose detect workgroups share the plan's list out in a loop)
   if (c->two_pass && a.list_loop) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 5>);
   if (c->two_pass) return c->diag.cols1024_wide ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 4>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 3>);
-  if constexpr (FMT != ss::FMT_CF32 && !SPEC) {  // (the fold's launches, and the drains of the stages that wait behind them: their tiles read residue-major rows)
+  if constexpr (FMT != ss::FMT_CF32 && !SPEC) {  // (the fold's launches, and the drains of the stages that wait behind them: their tiles read the fold's rows)
 #ifdef SS_DIAG
     if (!c->use_fft8192 && c->ring_perm8 && c->dif_logq == 3 && (c->diag.prio_fft || c->diag.prio_other)) return go(ss::k_scan_step<FMT, SPEC, 2, true, true, 8>);
 #endif
@@ -1814,7 +1814,7 @@ void settle_ring_db(ss_ctx* c) {
   c->ring_db_thr = nullptr;
 }
 
-// ... and the averager ring's rows are in residue-major order while calls go through the fold, in bin order while they take the
+// ... and the averager ring's rows are in the fold's blocked order while calls go through the fold, in bin order while they take the
 // four-step form: a call of the other kind has what waits drained (those stages read the rows as they are), the window's 35 rows
 // rewritten at the front of the buffer, and no tile tested whose rows reach back across the change (the run maxima of the frames
 // before are in the other form's layout).
@@ -3005,7 +3005,7 @@ int ss_reset_noise(ss_ctx* c) {
   return SS_OK;
 }
 
-// bins [lo, lo + cnt) of a residue-major row of 65536 floats (fft65536_dif8.h): the row comes over whole, the host picks
+// bins [lo, lo + cnt) of a row in the fold's order (fft65536_dif8.h): the row comes over whole, the host picks
 static int read_perm8_row(ss_ctx* c, const float* row, int lo, size_t cnt, float* out) {
   std::vector<float> h((size_t)c->n);
   SS_HIP(c, hipMemcpyAsync(h.data(), row, sizeof(float) * h.size(), hipMemcpyDeviceToHost, c->stream));
