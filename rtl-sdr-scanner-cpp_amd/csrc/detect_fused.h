@@ -147,6 +147,9 @@ struct DetectArgs {
   // Tile culling (tile_is_culled, 8192 points): per-column maxima of this batch's PSD rows (Fft8192Args::segsum), or null
   const float* segsum;             // [32][seg_pitch]
   int seg_pitch;
+  // ... and of the halo_rows frames before the batch (deep pipelining: the frames the launch transformed once more into halo_psd left
+  // their maxima too, [32][kHaloSegPitch], frame -halo_rows + i at [c][i]); null: tiles that reach back before the batch are not tested
+  const float* halo_segsum;
   const float* thr_tilemin;        // [32] min of thr over bins [256 c - 32, 256 c + 288)
   // [s], s < 8: nonzero once list s has been written through; [16 + kLiveCap s ...] the tiles of plan workgroup s that must be
   // evaluated; [kLiveCounts + kLiveCopyStride k + s], k < kLiveCopies: kLiveReady | their number, published as soon as it is
@@ -282,8 +285,13 @@ constexpr int kPlanLdsFloats = 9600; // staging area of a plan workgroup (+ 64 i
 
 // Frame tiles of a batch, and how many tile columns one plan workgroup can take (0: the stage cannot be planned).
 __host__ __device__ inline int plan_frame_tiles(int nframes, int shift) { return (nframes + shift + 15) / 16; }
+// a column's maxima in a plan wave's LDS: frame f of the batch (f >= -kPlanBefore: the frames before it whose maxima the halo frames
+// left) at word F + F / 16, F = f + kPlanBefore (one pad word per frame tile)
+constexpr int kHaloSegPitch = 64;
+constexpr int kPlanBefore = 48;  // >= kHistRows = 35, a multiple of 16
+__host__ __device__ inline int plan_col_floats(int nframes) { return nframes + kPlanBefore + ((nframes + kPlanBefore) >> 4) + 1; }
 __host__ __device__ inline int plan_cols_per_wg(int nframes, int shift) {
-  const int per_col = nframes + (nframes >> 4) + 1, nft = plan_frame_tiles(nframes, shift);
+  const int per_col = plan_col_floats(nframes), nft = plan_frame_tiles(nframes, shift);
   for (int cols = 8; cols >= 4; cols >>= 1)
     if (cols * per_col <= kPlanLdsFloats && cols * nft <= kLiveCap && nft <= 192) return cols;
   return 0;
@@ -316,12 +324,30 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
   const int col = seg * cols + w;
   const bool has_col = w < cols && col < tiles_per_row;
   const bool plannable = a.segsum && !a.rel_out && !a.avg_out;
-  float* mine = lds + w * (nframes + (nframes >> 4) + 1);
+  float* mine = lds + w * plan_col_floats(nframes);
+  const auto at = [](int f) { return f + kPlanBefore + ((f + kPlanBefore) >> 4); };  // frame f's word in `mine`
+  // frames before the batch whose maxima are known (the halo frames' — until session 36 of round 5 they left none, and the 64 tiles of
+  // a batch's first two frame tiles were evaluated whatever they held: the last workgroups of every launch, profiles/r05/s32_*)
+  const int before = a.halo_segsum && a.halo_psd ? min(a.halo_rows, kPlanBefore) : 0;
   float tm = 0.0f;
   if (has_col && plannable) {
     const float* src = a.segsum + (size_t)col * a.seg_pitch;
     tm = a.thr_tilemin[col];
-    for (int f = lane; f < nframes; f += 64) mine[f + (f >> 4)] = src[f];
+    // (eight loads in flight per trip: one after the other — load, wait, store, sixteen times for a 1024-frame batch — the copy alone
+    // took the plan workgroups 8-13 us, and the launch's frame workgroups are through after 12: they wait for this list)
+    float hm = 0.0f;
+    if (lane < before) hm = a.halo_segsum[col * kHaloSegPitch + (a.halo_rows - before) + lane];
+    for (int fb = 0; fb < nframes; fb += 512) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[min(fb + 64 * u + lane, nframes - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = fb + 64 * u + lane;
+        if (f < nframes) mine[at(f)] = v[u];
+      }
+    }
+    if (lane < before) mine[at(lane - before)] = hm;
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's column is in LDS (nobody else reads it)
   unsigned long long live_mask[3] = {0ull, 0ull, 0ull}, dead_mask[3] = {0ull, 0ull, 0ull};
@@ -332,7 +358,8 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
       const bool exists = has_col && ft_seq < nft;
       const int ft = (ft_seq + nft - 1) % nft;
       const int f0 = ft * TF - a.shift;
-      const bool steady = (f0 - (G - 1) >= a.n_learn) && (f0 - (G - 1) >= 0) && (f0 + TF <= nframes);
+      // (its 36 frames' maxima are all there — the batch's, and before it the halo frames' —, none of them a learning frame, no ragged end)
+      const bool steady = (a.n_learn == 0 ? f0 - (G - 1) >= -before : f0 - (G - 1) >= a.n_learn) && (f0 + TF <= nframes);
       const bool writes_hist = !a.hist_by_fft && f0 + TF > nframes - H;
       bool culled = false;
       if (exists && plannable && steady && !writes_hist) {
@@ -343,13 +370,13 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
         const int b = f0 - (G - 1);
         float sum = 0.0f;
 #pragma unroll
-        for (int k = 0; k < G; ++k) sum += mine[b + k + ((b + k) >> 4)];
+        for (int k = 0; k < G; ++k) sum += mine[at(b + k)];
         float best = sum;
         bool unsure = sum != sum;
 #pragma unroll
         for (int j = 1; j < TF; ++j) {
-          sum -= mine[b + j - 1 + ((b + j - 1) >> 4)];
-          sum += mine[b + j + G - 1 + ((b + j + G - 1) >> 4)];
+          sum -= mine[at(b + j - 1)];
+          sum += mine[at(b + j + G - 1)];
           unsure = unsure || (sum != sum);
           best = fmaxf(best, sum);
         }

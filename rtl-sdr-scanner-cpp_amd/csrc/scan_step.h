@@ -67,6 +67,7 @@ struct StepArgs {
   // transformed again into a buffer of this launch's own, so that no stage has to read what the launch before wrote
   const void* halo_iq;  // first of those frames
   float* halo_psd;      // [n_halo][8192]
+  float* halo_segsum;   // [32][kHaloSegPitch]: the halo frames' per-column maxima (null: none wanted)
   int n_halo;
   Rows256Args rows256;  // KIND 6: 256-point ROW tiles of a long transform (fft256_kernels.h: fft_rows256_tile) — 65536 points with tile culling: the column half is a launch of its own right before, the plan of the call before at its front
   Rows1024Args rows;  // KIND 4: 1024-point ROW tiles of a 2^20-point frame (fft1024_kernels.h) — the column half, 1024 threads per tile, is a launch of its own right before
@@ -272,7 +273,8 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     Fft8192Args g = a.fft;
     g.iq = halo ? a.halo_iq : a.fft.iq;
     g.psd = halo ? a.halo_psd : a.fft.psd;
-    g.segsum = halo ? nullptr : a.fft.segsum;  // (the tiles that read halo rows are not culled)
+    g.segsum = halo ? a.halo_segsum : a.fft.segsum;  // (the halo frames leave their maxima too: the tiles that read their rows are tested like the others)
+    g.seg_pitch = halo ? kHaloSegPitch : a.fft.seg_pitch;
     g.live_hint = a.plan_by_fft ? a.det.live + live_count_word(a.plan_first + item, step_plan_wgs(a)) : nullptr;  // the list this workgroup serves for the detect stage that rides on the launch
 #ifdef SS_DIAG
     if (a.hint_mode == 1) g.live_hint = nullptr;

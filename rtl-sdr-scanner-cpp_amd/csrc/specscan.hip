@@ -136,6 +136,7 @@ struct ss_ctx {
     int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
     int chunk_65536 = 256;         // 65536 points with tile culling: calls of more frames go through in chunks of this many (SS_CHUNK_65536=0: in one piece)
     int chunk_long = 16;           // 2^20 points in two passes: calls of more frames go through in chunks of this many (SS_CHUNK_LONG=0: in one piece)
+    bool halo_maxima = true;       // 8192 points, deep pipelining: the re-transformed halo frames leave per-column maxima, so that the tiles of a batch's first two frame tiles are tested like the others (SS_HALO_MAXIMA=0: evaluated whatever they hold, as until session 36 of round 5)
     int list_first_fold = -1;      // ... in the fold's launches: -1 = by the launch's size (launch_step), k > 0 = k - 1 pairs
     int list_first = 64;           // long transforms with tile culling: the first pairs of the plan's list go to detect workgroups of their own, dispatched ahead of the launch's FFT role (SS_LIST_FIRST=0: every pair behind an FFT workgroup's tile, as until session 19 of round 4)
     bool plan_fused = true;        // 2^20 points in two passes: the plan of call k at the front of call k + 1's column launch (SS_PLAN_FUSED=0: a launch of its own behind call k's rows, as until session 14 of round 4)
@@ -199,6 +200,7 @@ struct ss_ctx {
       rows256_step = tri("SS_ROWS256_STEP") != 0;
       plan_fused = tri("SS_PLAN_FUSED") != 0;
       list_first = num("SS_LIST_FIRST", list_first);
+      halo_maxima = tri("SS_HALO_MAXIMA") != 0;
       list_first_fold = getenv("SS_LIST_FIRST") ? list_first + 1 : num("SS_LIST_FIRST_FOLD", list_first_fold);
       chunk_long = num("SS_CHUNK_LONG", chunk_long);
       chunk_65536 = num("SS_CHUNK_65536", chunk_65536);
@@ -925,6 +927,9 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
 }
 
 // The FFT role of a launch: 8192-point frames, or the column tiles of a long transform.
+// the per-column maxima of the halo frames a launch transforms once more: behind their rows in the launch's d_halo buffer
+inline float* halo_segsum_of(const ss_ctx* c, float* halo_psd) { return halo_psd + (size_t)c->n * (size_t)kHistRows; }
+
 struct FftRole {
   const ss::Fft8192Args* frames = nullptr;
   const ss::ColsArgs* cols = nullptr;
@@ -958,6 +963,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
     a.halo_iq = fft->halo_iq;
     a.halo_psd = fft->halo_psd;
     a.n_halo = fft->n_halo;
+    a.halo_segsum = (fft->halo_psd && c->cull && c->diag.halo_maxima) ? halo_segsum_of(c, fft->halo_psd) : nullptr;
   } else if (fft && fft->cols) {
     a.cols = *fft->cols;
     a.n_fft = fft->n;
@@ -1745,6 +1751,7 @@ int run_call_deep(ss_ctx* c, const void* d_iq, long long item_stride, int nframe
   if (role.n_halo) {
     mine_det.a.halo_psd = role.halo_psd;
     mine_det.a.halo_rows = role.n_halo;
+    mine_det.a.halo_segsum = (c->cull && c->diag.halo_maxima && mine_det.a.segsum) ? halo_segsum_of(c, role.halo_psd) : nullptr;  // (this launch's FFT role leaves them)
   }
 #ifndef SS_RING_AT_DRAIN  // (A/B builds, scripts/build_ab.py: 0 = the ring rows by the tiles of every call, as until round 3)
 #define SS_RING_AT_DRAIN 1
@@ -2484,7 +2491,8 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
 #endif
     c->deep_ring_safe = c->hist_rows / kHistRows >= kDeepSyncPhase + 8;
     for (int k = 0; k < c->nq; ++k) CREATE_HIP(hipStreamCreateWithFlags(&c->s_ab[k], hipStreamNonBlocking));
-    for (int k = 0; k < 2 * c->nq; ++k) CREATE_HIP(hipMalloc(&c->d_halo[k], sizeof(float) * (size_t)n * (size_t)kHistRows));
+    for (int k = 0; k < 2 * c->nq; ++k)  // (+ the halo frames' per-column maxima behind their rows: halo_segsum_of)
+      CREATE_HIP(hipMalloc(&c->d_halo[k], sizeof(float) * ((size_t)n * (size_t)kHistRows + 32 * (size_t)ss::kHaloSegPitch)));
     for (auto& e : c->ev_launch) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_in) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_join) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

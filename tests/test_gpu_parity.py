@@ -117,6 +117,7 @@ ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurem
     ({"SS_MERGE_65536": "0"}, 65536, 20_000_000, "cs8"),    # ... two launches per call also for detect-mode calls of up to 128 frames
     ({"SS_EMIT_ON_ROWS": "1", "SS_LIST_FIRST": "0"}, 65536, 20_000_000, "cf32"),
     ({"SS_PLAN_FIRST": "32"}, 8192, 2_048_000, "cf32"),     # 8192 points: the first pairs of every list on detect workgroups of their own
+    ({"SS_HALO_MAXIMA": "0"}, 8192, 2_048_000, "cf32"),     # 8192 points: the halo frames leave no maxima, the tiles at a batch's start are evaluated untested (until session 36 of round 5)
 ]
 
 
