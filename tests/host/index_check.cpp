@@ -7,7 +7,8 @@
 //   * 2^20 points in two passes (csrc/fft1024_kernels.h): the block decodes of the column tiles, the row tiles and the plan are
 //     bijections that put the workgroups sharing a 128-byte line on one XCD; rows1024_smax_index is where the row tiles write and
 //     the plan reads; the window in the column tiles' order is a permutation of the taps, element by element what the tile loads;
-//     the atomic maxima's keys keep the order of the floats.
+//     the atomic maxima's keys keep the order of the floats;
+//   * the fold's rows (csrc/fft65536_dif8.h): the layout's bijection, the epilogue's store address, a tile's loads (bottom of main).
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -206,6 +207,49 @@ int main() {
     if (ss::max_key(__builtin_nanf("")) != 0xffffffffu || ss::max_key(-__builtin_nanf("")) != 0xffffffffu || !(ss::max_key_value(0xffffffffu) != ss::max_key_value(0xffffffffu))) ++bad;
     if (!(ss::max_key_value(0u) == -__builtin_inff())) ++bad;
     printf("2^20 in two passes: bad %d\n", bad);
+  }
+  // ---- the fold's rows (csrc/fft65536_dif8.h: blocks of 32 Q bins, the 32 consecutive k' of every residue side by side) ----
+  //   * dif_bin_offset is a bijection of a row onto itself and dif_offset_bin its inverse;
+  //   * the place the transform's epilogue stores output k' of residue r (csrc/fft8192_v2.h, FRONT != 0: the per-thread offset
+  //     gvoff = (voff & 0x7c) | ((voff & 0x2380) << LOGQ) out of voff = (j + 2048 h) * 4, j = 32 w + lane % 32, the constants
+  //     kOutStep * kk and 16 * kOutStep for the upper half, the residue's 128 bytes in the row's base) is 4 * dif_bin_offset(Q k' + r);
+  //   * a detect tile's own 256 bins are ONE block (Q = 8: 1 KB) or half of one (Q = 16), and a wave of the tile's first pass — thread
+  //     g * (256 / Q) + j takes bin Q j + g (detect_fused.h: tile_column_of) — reads 64 consecutive floats (Q = 8) / four runs of 16.
+  for (int logq : {3, 4}) {
+    const int Q = 1 << logq, n = 8192 << logq;
+    std::vector<int> seen((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+      const int o = ss::dif_bin_offset(i, logq);
+      if (o < 0 || o >= n || seen[(size_t)o]++ || ss::dif_offset_bin(o, logq) != i) ++bad;
+    }
+    const int kOutStep = (256 << logq) * 4;
+    for (int r = 0; r < Q; ++r)
+      for (int t = 0; t < 512; ++t) {
+        const int w = t >> 6, lam = t & 31, h = (t >> 5) & 1;
+        const int j = 32 * w + lam, voff = (j + 2048 * h) * 4;
+        const int gvoff = (voff & 0x7c) | ((voff & 0x2380) << logq);
+        for (int kk = 0; kk < 8; ++kk)
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int kprime = j + 2048 * h + 256 * kk + 4096 * s2;
+            const long long bytes = (long long)r * 128 + gvoff + (long long)kOutStep * kk + (s2 ? 16ll * kOutStep : 0ll);
+            if (bytes != 4ll * ss::dif_bin_offset(Q * kprime + r, logq)) ++bad;
+          }
+      }
+    const int run = 256 >> logq;
+    for (int col = 0; col < n / 256; col += 37)
+      for (int wave = 0; wave < 4; ++wave) {
+        int lo = 1 << 30, hi = -1;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int tid = 64 * wave + lane, bin = 256 * col + ((tid & (run - 1)) << logq) + tid / run;
+          const int o = ss::dif_bin_offset(bin, logq);
+          lo = o < lo ? o : lo;
+          hi = o > hi ? o : hi;
+          if (o / (32 * Q) != (256 * col) / (32 * Q)) ++bad;  // inside the tile's block
+        }
+        if (logq == 3 && hi - lo != 63) ++bad;               // 256 contiguous bytes
+        if (logq == 4 && hi - lo != 3 * 32 + 15) ++bad;      // four runs of 16 floats, 32 apart
+      }
+    printf("the fold's rows, Q = %d: bad %d\n", Q, bad);
   }
   printf("bad %d\n", bad);
   return bad ? 1 : 0;

@@ -1,7 +1,9 @@
 """The index algebra of the long transforms' tile culling, checked on the CPU: tests/host/index_check.cpp includes the product's own
 headers (rows_smax_index, plan_long_cols, plan_cols_per_wg are __host__ __device__), is compiled with hipcc for the host and run
 here — no GPU, no HIP call. What the GPU tests can only show indirectly (culled == unculled) is pinned directly: the place the rows
-kernel writes a run's maximum is the place the plan reads it from, for every run of 65536- and 2^20-point rows."""
+kernel writes a run's maximum is the place the plan reads it from, for every run of 65536- and 2^20-point rows; and for the radix-8 /
+radix-16 fold's rows (round 5): the layout is a bijection, the transform's epilogue stores every output where the layout says, a
+detect tile reads its block in contiguous runs."""
 import os
 import shutil
 import subprocess
