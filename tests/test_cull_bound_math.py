@@ -7,7 +7,9 @@
 
 The oracle is the reference's arithmetic (running sums included; tests/test_oracle_vs_reference.py), so this pins the bound
 against what the reference would have found — for signals from well below to well above the threshold, int8 input, and with a
-fair share of the tiles really dropped (the check is not vacuous). The GPU tests (tests/test_gpu_cull.py) then show that the
+fair share of the tiles really dropped (the check is not vacuous). The stream here is one sequence of frames: where a caller's batches
+begin makes no difference to the bound — which is why the tiles at a batch's start may be tested with the maxima of the frames before it
+(8192 points, deep pipelining: the halo frames the launch transforms once more leave theirs, round 5). The GPU tests (tests/test_gpu_cull.py) then show that the
 kernels implement this decision: culled == unculled, list by list."""
 import numpy as np
 import pytest
