@@ -513,6 +513,7 @@ def parse_args(argv):
     ap.add_argument("--launch-check", action="store_true", help="exercise launcher, rendezvous, config broadcast and max-over-ranks timing only (no GPU work)")
     ap.add_argument("--sync-engine-first", action="store_true", help="end of the timed region as in round 2: ss_sync, then torch.cuda.synchronize() (A/B; the default lets the device-wide synchronisation do the waiting)")
     ap.add_argument("--no-also", action="store_true", help="default line only: do not append the short runs of BASELINE configs 3 and 5 (`also`)")
+    ap.add_argument("--also-all", action="store_true", help="`also` with two more call sizes (config 3 in 256-frame calls, config 5 in 64-frame calls)")
     ap.add_argument("--sub", action="store_true", help="(internal) this process is one of the `also` runs of another bench.py")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic stays null: do not run the two short rocprofv3 --pmc passes of this command line behind the timed region (default line of config 2 at N = 1 only)")
     ap.add_argument("--no-parity", action="store_true", help="no parity sample beside the numbers (the `also` runs carry one each unless told otherwise)")
@@ -562,6 +563,37 @@ def drop_in_lines():
             for _ in range(reps):
                 eng.process(batch, want=())
             dt_proc = (time.perf_counter() - t0) / reps
+            # ... and its pieces, each alone (the 2^20-point entry read 1.8 GS/s on round 5's driver box and 6.2 on the builder's):
+            # the same pageable buffer to the device through the runtime (what hipMemcpy2DAsync of ss_process does: the runtime
+            # pins the caller's pages for the copy — cheap on 2 MiB pages, a page-table walk per 4 KiB page otherwise), and the
+            # chain on resident frames, drained (ss_process_device + ss_sync)
+            import torch
+            dev = torch.device("cuda", torch.cuda.current_device())
+            host_t = torch.from_numpy(batch.view(np.float32) if batch.dtype == np.complex64 else batch)
+            d_t = torch.empty_like(host_t, device=dev)
+            d_off = torch.zeros(nb + 1, dtype=torch.int32, device=dev)
+            d_idx = torch.empty(1 << 20, dtype=torch.int32, device=dev)
+            d_t.copy_(host_t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                d_t.copy_(host_t)
+                torch.cuda.synchronize()
+            dt_h2d = (time.perf_counter() - t0) / reps
+            eng.process_device(d_t, nb, cand_off=d_off, cand_idx=d_idx)
+            eng.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.process_device(d_t, nb, cand_off=d_off, cand_idx=d_idx)
+                eng.sync()
+            dt_chain = (time.perf_counter() - t0) / reps
+            try:
+                thp = open("/sys/kernel/mm/transparent_hugepage/enabled").read().strip()
+            except OSError:
+                thp = None
+            pieces = {"total": round(dt_proc * 1e3, 2), "h2d_pageable_alone": round(dt_h2d * 1e3, 2), "chain_resident_drained": round(dt_chain * 1e3, 3),
+                      "h2d_gbs": round(batch.nbytes / dt_h2d / 1e9, 1), "transparent_hugepage": thp}
+            del d_t, d_off, d_idx
             eng.close()
             eng = pkg.SpectrumEngine(fs, 145_000_000, **kw)
             eng.process(learn, want=())
@@ -586,7 +618,7 @@ def drop_in_lines():
             in_b = 2.0 if fmt == "cs8" else 8.0
             res.append({"baseline_config": cfg_no, "variant": "drop_in_path", "fft_size": n, "frames_per_call": nb, "fmt": fmt,
                         "ss_process_MSps": round(nb * n / dt_proc / 1e6, 1), "ss_feed_MSps": round(nb * n / dt_feed / 1e6, 1),
-                        "pcie_bound_MSps": round(PCIE_GBS * 1e9 / in_b / 1e6, 1),
+                        "pcie_bound_MSps": round(PCIE_GBS * 1e9 / in_b / 1e6, 1), "ss_process_pieces_ms": pieces,
                         "what": "host buffers in, candidate lists back, PCIe inclusive: ss_process (pageable buffers, drained every call) and ss_feed_* (pinned "
                                 "staging, depth 3, copy of batch k + 1 beside the chain of batch k); bound = 63 GB/s over the input's bytes per sample"})
         except Exception as e:  # the default line must not depend on these
@@ -594,19 +626,20 @@ def drop_in_lines():
     return res
 
 
-def also_lines():
+def also_lines(all_sizes: bool = False):
     """Beside the default line, as short runs of this script in processes of their own: the default configuration once more with
     every averaging tile evaluated (`--no-cull`: the data-independent cost of the chain — the reference evaluates every bin of every
     frame, transmission.cpp:88-96), and BASELINE configs 3 and 5 (one GPU each). Every entry has ms_per_step, the chain's rate, every
     kernel of the chain with its own duration and rate, what the library says it culled (ss_get_stats), and — except the last — a
     parity sample of its own against the reference (host path with every plane, and the timed device path in the entry's own mode)."""
     res = []
-    runs = ((2, 40, ["--no-cull"], "no_cull"), (3, 200, [], None), (3, 100, ["--frames", "256"], None), (3, 60, ["--frames", "512", "--no-parity"], None), (5, 100, [], None),
-            (5, 40, ["--frames", "64"], None),
+    runs = [(2, 40, ["--no-cull"], "no_cull"), (3, 200, [], None), (3, 60, ["--frames", "512", "--no-parity"], None), (5, 100, [], None),
             # the sizes the reference itself would run these two signals at (getFft, utils/radio_utils.cpp:98-104: the first power of two
             # whose bins are at most 250 Hz wide): 131072 points at 20 MS/s, 262144 at 61.44 MS/s — 8.4 MS per call like configs 3 and 5
-            (3, 60, ["--fft", "131072", "--frames", "64"], "getFft_131072"), (5, 60, ["--fft", "262144", "--frames", "32"], "getFft_262144"))
-    # (config 3 also in 256-frame calls — two rounds of workgroups per launch instead of one —, config 5 also in 64-frame calls: four chunks of 16; each with a parity sample at its own call size)
+            (3, 60, ["--fft", "131072", "--frames", "64"], "getFft_131072"), (5, 60, ["--fft", "262144", "--frames", "32"], "getFft_262144")]
+    if all_sizes:  # (--also-all: config 3 also in 256-frame calls — two rounds of workgroups per launch instead of one —, config 5 also in 64-frame calls: four chunks of 16)
+        runs[3:3] = [(3, 100, ["--frames", "256"], None)]
+        runs.insert(5, (5, 40, ["--frames", "64"], None))
     for cfg_no, steps, extra, variant in runs:
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg_no), "--gpus", "1", "--steps", str(steps), "--warmup", "5",
                "--preheat-ms", "150", "--no-cpu-baseline", "--sub", *extra]
@@ -614,7 +647,7 @@ def also_lines():
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
             j = json.loads(line)
-            entry = {"baseline_config": cfg_no, "frames_per_batch": j["config"]["frames_per_batch"], "workload": j["config"]["workload"], "metric": j["metric"], "value": j["value"], "unit": j["unit"],
+            entry = {"baseline_config": cfg_no, "fft_size": j["config"]["fft_size"], "frames_per_batch": j["config"]["frames_per_batch"], "workload": j["config"]["workload"], "metric": j["metric"], "value": j["value"], "unit": j["unit"],
                      "steps": j["steps"], "ms_per_step": j["ms_per_step"], "psd_plane_out": j["config"]["psd_plane_out"], "tile_culling": j["config"]["tile_culling"],
                      "tiles": j["config"].get("tiles"), "candidates_per_batch": j["config"]["candidates_per_batch"],
                      "roofline_chain": j["roofline_chain"], "kernels": j["roofline"]["kernels"], "parity": j.get("parity")}
@@ -624,6 +657,110 @@ def also_lines():
         except Exception as e:  # the default line must not depend on these
             res.append({"baseline_config": cfg_no, **({"variant": variant} if variant else {}), "error": f"{type(e).__name__}: {str(e)[:200]}"})
     return res
+
+
+# ---------------------------------------------------------------------------------------------- the line the driver parses
+FULL_LINE_FILE = "bench_full.json"  # beside bench.py (and under gpurun_out/ when that exists): everything the run measured
+
+
+def _short(text, limit: int):
+    if text is None:
+        return None
+    text = str(text)
+    return text if len(text) <= limit else text[:limit - 3] + "..."
+
+
+def _compact_parity(p):
+    """A parity block in a few numbers: who it was checked against, how many reference candidates, how many of them inside the
+    1e-3 dB threshold band (counted, not compared), bins outside the bare 1e-4 per plane, the rms distance to an fp64 FFT over all
+    bins as a ratio engine / reference, and the timed path's own leg."""
+    if not p:
+        return None
+    if "failed" in p:
+        return {"failed": _short(p["failed"], 200)}
+    out = {"against": "oracle/_ref" if "_ref" in p.get("against", "") else "oracle/liboracle.so", "frames": p.get("frames"),
+           "reference_candidates": p.get("reference_candidates"), "inside_band": p.get("inside_1e-3_dB_band"),
+           "outside_bare_1e-4": {k: v["n"] for k, v in (p.get("outside_bare_1e-4") or {}).items()},
+           "worst_dB": max([v["worst_dB"] for v in (p.get("outside_bare_1e-4") or {}).values()] or [0.0]),
+           "rel_linear_p999": ((p.get("rel_linear") or {}).get("psd") or {}).get("p99.9"),
+           "engine_over_reference_rms": (p.get("all_bins_vs_fp64_fft_dB") or {}).get("engine_over_reference_rms")}
+    t = p.get("timed_path")
+    if t:
+        out["timed_path"] = {"calls": _short(t.get("what"), 60), "reference_candidates": t.get("reference_candidates"), "inside_band": t.get("inside_1e-3_dB_band"),
+                             "tiles_tested": t.get("tiles_tested"), "tiles_culled": t.get("tiles_culled"), "wait_fallbacks": t.get("wait_fallbacks")}
+    return out
+
+
+def _compact_also(e):
+    if "error" in e:
+        return {k: (_short(v, 160) if k == "error" else v) for k, v in e.items()}
+    if e.get("variant") == "drop_in_path":
+        return {k: e.get(k) for k in ("variant", "baseline_config", "fft_size", "frames_per_call", "fmt", "ss_process_MSps", "ss_feed_MSps", "pcie_bound_MSps", "ss_process_pieces_ms") if k in e}
+    par = e.get("parity")
+    out = {"config": e.get("baseline_config"), "fft_size": e.get("fft_size"), "frames_per_call": e.get("frames_per_batch"), "value": e.get("value"), "ms_per_step": e.get("ms_per_step"),
+           "chain_frac": (e.get("roofline_chain") or {}).get("frac"), "pmc_B_per_sample": (e.get("roofline_chain") or {}).get("pmc_bytes_per_sample_from_profiles"),
+           "tile_culling": e.get("tile_culling"), "evaluated_frac": (e.get("tiles") or {}).get("evaluated_frac"),
+           "kernels_us": [k.get("us") for k in (e.get("kernels") or [])],
+           "parity": None if not par else ("FAILED" if "failed" in par else
+                                          {"ok": True, "reference_candidates": (par.get("timed_path") or par).get("reference_candidates"),
+                                           "inside_band": (par.get("timed_path") or {}).get("inside_1e-3_dB_band", par.get("inside_1e-3_dB_band")),
+                                           "engine_over_reference_rms": (par.get("all_bins_vs_fp64_fft_dB") or {}).get("engine_over_reference_rms")})}
+    if e.get("variant"):
+        out = {"variant": e["variant"], **out}
+    return {k: v for k, v in out.items() if v is not None}
+
+
+def compact_line(full: dict) -> dict:
+    """The ONE line the driver parses (the last line of stdout): the contract's keys, `roofline` and `cpu_baseline` in a few numbers each,
+    the parity sample's verdict and one short record per `also` entry — a few KB whatever the run measured. Everything else (every kernel
+    of every chain with its description, the parity blocks' quantiles, the traffic passes' details) is the full form in bench_full.json;
+    round 5's single ~30 KB line was more than the driver parses. tests/test_bench_helpers.py holds this to < 6 KB."""
+    c = full.get("config") or {}
+    keep_c = ("workload", "baseline_config", "fft_size", "frames_per_batch", "bands", "shard", "psd_plane_out", "tile_culling", "tiles", "candidates_per_batch",
+              "input_sets", "working_set_mib", "dist_backend", "ranks_share_devices", "device_index_of_ranks", "candidates_last_batch_of_ranks", "host_enqueue_ms_per_step", "diag_lib", "file_fed")
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {k: (_short(c[k], 260) if k == "workload" else c[k]) for k in keep_c if k in c}
+    r = full.get("roofline")
+    if r:
+        keep_r = ("bound", "achieved", "peak", "unit", "frac", "kernel_us", "kernel_timing", "launches", "launches_in_flight", "achieved_if_launches_did_not_overlap",
+                  "algorithmic_bytes_per_launch", "traffic", "traffic_over_algorithmic", "traffic_gbs", "traffic_frac_of_peak")
+        out["roofline"] = {"kernel": _short(r.get("kernel"), 120), **{k: r[k] for k in keep_r if k in r}}
+        if r.get("traffic") is None and isinstance(r.get("traffic_live"), dict) and "unavailable" in r["traffic_live"]:
+            out["roofline"]["traffic_unavailable"] = _short(r["traffic_live"]["unavailable"], 120)
+        if len(r.get("kernels") or []) > 1:  # chains of several launches: each kernel's own duration and rate on the bytes the design makes it move
+            out["roofline"]["kernels"] = [{"slot": k["slot"], "us": k["us"], "frames_per_launch": k["frames_per_launch"], "frac_of_peak_on_design_bytes": k["frac_of_peak"]} for k in r["kernels"]]
+    else:
+        out["roofline"] = None
+    rc = full.get("roofline_chain")
+    if rc:
+        out["roofline_chain"] = {k: rc.get(k) for k in ("algorithmic_bytes_per_sample", "achieved", "peak", "unit", "frac")}
+    cb = full.get("cpu_baseline")
+    out["cpu_baseline"] = None if not cb else {**{k: cb.get(k) for k in ("value", "unit", "cores", "kind", "one_thread", "cpu_model")}, "sample": _short(cb.get("sample"), 200)}
+    if "parity" in full:
+        out["parity"] = _compact_parity(full["parity"])
+    if "also" in full:
+        out["also"] = [_compact_also(e) for e in full["also"]]
+    out["full"] = FULL_LINE_FILE
+    return out
+
+
+def emit_line(full: dict, sub: bool = False) -> None:
+    """Write the full form to bench_full.json (beside bench.py; a copy under gpurun_out/ where that directory is) and print the compact
+    line as the last line of stdout. An `also` run of another bench.py (--sub) hands its full form to its parent on stdout instead and
+    writes nothing."""
+    text = json.dumps(full)
+    if sub:
+        print(text, flush=True)
+        return
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, FULL_LINE_FILE), "w") as f:
+                    f.write(text + "\n")
+            except OSError:
+                pass
+    print(json.dumps(compact_line(full)), flush=True)
+
 
 
 # ---------------------------------------------------------------------------------------------- the measured job
@@ -744,11 +881,12 @@ def run(args):
         step()
     eng.sync()
     every = 0
-    if not args.no_kernel_timing:
+    short_run = args.steps <= 32
+    if not args.no_kernel_timing and not short_run:
         # each timed launch costs its queue ~13 us (the start packet ~7 us before it, the stop packet ~6 us before the queue's next
-        # launch: profiles/r03/s37_timeline_k20.txt): every 8th launch in a long run (25 samples in 200 steps), ONE launch — the
-        # (steps / 2)-th — in a run of up to 32 steps, where two of them were 5 % of the time measured
-        every = args.time_every or (8 if args.steps > 32 else max(1, args.steps))
+        # launch: profiles/r03/s37_timeline_k20.txt): every 8th launch in a long run (25 samples in 200 steps). A run of up to 32 steps
+        # (the driver's form) carries NO events inside its timed region: its launches are timed in 32 more steps right behind it.
+        every = args.time_every or 8
         eng.kernel_timing(every)
     dist.barrier()
     torch.cuda.synchronize()
@@ -770,20 +908,24 @@ def run(args):
         slots = eng.kernel_timing_read_frames()  # {slot: (ms, launches, frames those launches covered)}
         kern_ms, launches, _ = slots["step"]
         eng.kernel_timing(0)
-    # A run of up to 32 steps times ONE launch inside the timed region (each timed launch costs its queue ~13 us: two of them were 5 % of
-    # a 20-step run). One sample is a poor estimate of a launch's duration: right behind the timed region — same clocks, same working
-    # set, nothing of it inside the timed region — 32 more steps with every 4th launch timed give eight more.
+    # A run of up to 32 steps has no event-timed launch inside its timed region (each costs its queue ~13 us: one was 2.7 % of a 20-step
+    # run). Right behind the timed region — same clocks, same working set, nothing of it inside — 32 more steps with every 4th launch
+    # timed give eight samples per kernel of the chain; they are what roofline.kernel_us is made of in such a run.
     kern_after = None
-    if every and args.steps <= 32 and world == 1 and n == 8192:
+    if short_run and not args.no_kernel_timing:
         eng.kernel_timing(4)
         for _ in range(32):
             step()
         eng.sync()
-        ms_a, cnt_a, _ = eng.kernel_timing_read_frames()["step"]
+        slots = eng.kernel_timing_read_frames()
+        kern_ms, launches, _ = slots["step"]
         eng.kernel_timing(0)
-        if cnt_a:
-            kern_after = {"us": round(ms_a / cnt_a * 1e3, 2), "launches": cnt_a, "what": "32 more steps right behind the timed region, every 4th launch timed"}
+        every = 4
+        if launches:
+            kern_after = {"us": round(kern_ms / launches * 1e3, 2), "launches": launches, "what": "32 more steps right behind the timed region, every 4th launch timed"}
     elapsed = dist.max_over_ranks(t1 - t0, device=coll_dev)
+    devices_of_ranks = dist.ints_of_ranks(device_index, device=coll_dev)  # (rank r -> the device it worked on: LOCAL_RANK modulo the box's device count)
+    cands_of_ranks = dist.ints_of_ranks(int(outs[(counter[0] - 1) % nout]["off"][-1].item()), device=coll_dev)
     ncand = int(outs[(counter[0] - 1) % nout]["off"][-1].item())
     lib_stats = eng.stats()  # what the library says it did (counters from creation: learning, preheat, warm-up and the timed steps)
 
@@ -849,6 +991,7 @@ def run(args):
                        "calls": {"overlapped": lib_stats["calls_overlapped"], "in_order": lib_stats["calls_in_order"], "drains": lib_stats["drains"], "demotions": lib_stats["demotions"]},
                        "preheat_steps": preheat_steps, "input_sets": nsets, "output_sets": nout, "working_set_mib": round((nsets * in_bytes + nout * out_bytes) / 2**20, 1),
                        "dist_backend": backend if world > 1 else None, "ranks_share_devices": bool(world > ndev),
+                       "device_index_of_ranks": devices_of_ranks, "candidates_last_batch_of_ranks": cands_of_ranks,
                        "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4),
                        # where the end of the timed region goes: the chain's own drain + wait, then the contract's device-wide synchronisation and barrier
                        "tail_us": {"engine_sync": round((t_eng - t_enq) * 1e6, 1) if args.sync_engine_first else None, "device_synchronize": round((t_dev - t_eng) * 1e6, 1), "barrier": round((t1 - t_dev) * 1e6, 1)}},
@@ -856,7 +999,7 @@ def run(args):
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                          "kernel_us": dom["us"] if dom else None, "launches": dom["launches_timed"] if dom else 0,
-                         "kernel_us_behind_the_timed_region": kern_after,
+                         "kernel_timing": (kern_after["what"] if kern_after else f"start/stop events on every {every}th launch inside the timed region") if every else None,
                          "launches_in_flight": round(in_flight, 2) if dom else None,
                          "achieved_if_launches_did_not_overlap": None if literal is None else round(literal, 1),
                          # SURVEY.md 8d's figure — IQ in (+ the dB row in power mode) — times the samples one launch of the dominant kernel covers; and,
@@ -888,7 +1031,7 @@ def run(args):
                 out["roofline"]["traffic_gbs"] = round(live["bytes_per_launch"] / step_s / 1e9, 1)
                 out["roofline"]["traffic_frac_of_peak"] = round(live["bytes_per_launch"] / step_s / 1e9 / HBM_PEAK_GBS, 4)
         if plan["also"]:
-            out["also"] = also_lines()
+            out["also"] = also_lines(args.also_all)
             eng.close()  # (the drop-in lines below make contexts of their own; this one's memory goes back first)
             out["also"] += drop_in_lines()
         if plan["cpu_baseline"]:
@@ -900,7 +1043,7 @@ def run(args):
                 out["parity"] = parity_sample(n, fs, args.fmt, args.no_cull, nb)
             except AssertionError as e:
                 out["parity"] = {"failed": str(e)[:300]}
-        print(json.dumps(out), flush=True)
+        emit_line(out, sub=args.sub)
 
     if world > 1:
         import torch.distributed as td
@@ -969,7 +1112,7 @@ def run_cpu_only(args):
            "config": {"workload": f"synthetic {fs / 1e6:.3f} MS/s IQ file, {n}-pt FFT, single band, CPU reference path (no GPU), one chain on one thread", "baseline_config": 1,
                       "file_fed": fed},
            "roofline": None, "cpu_baseline": cb}
-    print(json.dumps(out), flush=True)
+    emit_line(out)
 
 
 def main():

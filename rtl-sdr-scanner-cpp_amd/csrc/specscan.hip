@@ -326,6 +326,8 @@ struct ss_ctx {
   const float* ring_db_thr = nullptr;
   int last_db_from = 0;           // ss_read_window: rows of the last call from this batch-relative frame on (<= 0; frames >= 0 all) are dB values ... 
   bool last_rows_db = false;      // ... when the last call left such rows at all
+  const float* last_settled_lo = nullptr;  // ... except the rows in [last_settled_lo, last_settled_hi): settle_ring_db has turned them into noise-relative
+  const float* last_settled_hi = nullptr;  //     rows since (a retune or ss_reset_noise after the call) — ss_read_window must not subtract the ceiling twice
   float2* d_dif8_tab = nullptr;   // the fold's tables (dif8_host_tables)
   float* d_perm_tmp = nullptr;    // 35 rows: the window on its way from one order to the other
   bool have_det2 = false;
@@ -438,7 +440,7 @@ struct ss_ctx {
   // k_scan_step's dispatch-order table for the current launch shape (rebuilt when the shape changes; two buffers so that a
   // launch still in flight keeps the table it was given)
   struct OrderTable {
-    int key[5];  // FFT / detect / emit / plan / row workgroups of the launch shape
+    int key[6];  // FFT / detect / emit / plan / row workgroups of the launch shape, and which order pattern it was built from
     uint32_t* d;
     unsigned long long used;       // 0: free
     std::vector<uint32_t> host;    // what was uploaded (kept alive: the copy is asynchronous)
@@ -802,8 +804,11 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
   a.prio_fft = c->diag.prio_fft;
   a.prio_other = c->diag.prio_other;
   if (n_fft == 0 || (wg_det == 0 && wg_rows == 0) || c->diag.no_order_table) return;  // nothing to interleave: the kernel takes the roles one after the other (plan, emit, detect, FFT)
+  // which pattern the table is built from is part of its key: a context's fold launches (4 workgroups per frame) and its four-step column
+  // launches (8 per frame) can have the same counts — any permutation is correct, but the measured order of each form must not be lost to the other's
+  const int pattern = wg_rows ? 1 : c->use_fft8192 ? 2 : a.dif.iq ? 3 : 4;
   for (auto& t : c->order_tables)
-    if (t.used && t.stream == stream && t.key[0] == n_fft && t.key[1] == wg_det && t.key[2] == wg_emit && t.key[3] == wg_plan && t.key[4] == wg_rows) {  // (uploaded on this stream: complete for this launch by stream order)
+    if (t.used && t.stream == stream && t.key[0] == n_fft && t.key[1] == wg_det && t.key[2] == wg_emit && t.key[3] == wg_plan && t.key[4] == wg_rows && t.key[5] == pattern) {  // (uploaded on this stream: complete for this launch by stream order)
       t.used = ++c->order_clock;
       a.order = t.d;
       return;
@@ -812,7 +817,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
     int role, count;
   };
   std::vector<Seg> prefix, cycle;
-  const std::string& sp = wg_rows ? c->diag.step_order_merged : c->use_fft8192 ? c->diag.step_order : a.dif.iq ? c->diag.step_order_fold : c->diag.step_order_long;
+  const std::string& sp = pattern == 1 ? c->diag.step_order_merged : pattern == 2 ? c->diag.step_order : pattern == 3 ? c->diag.step_order_fold : c->diag.step_order_long;
   {
     std::vector<Seg>* into = &prefix;
     for (size_t i = 0; i < sp.size();) {
@@ -892,6 +897,7 @@ void step_order(ss_ctx* c, ss::StepArgs& a, hipStream_t stream) {
   slot->key[2] = wg_emit;
   slot->key[3] = wg_plan;
   slot->key[4] = wg_rows;
+  slot->key[5] = pattern;
   slot->used = ++c->order_clock;
   a.order = slot->d;
 }
@@ -1817,6 +1823,8 @@ void settle_ring_db(ss_ctx* c) {
   flush_stages(c);
   float* first = c->d_hist + (size_t)(c->hist_start + kHistRows - c->ring_db_rows) * (size_t)c->n;
   hipLaunchKernelGGL(k_rows_sub_thr, dim3(1024), dim3(256), 0, c->stream, first, c->ring_db_thr, c->n, c->ring_db_rows, c->ring_perm8 ? c->dif_logq : 0);
+  c->last_settled_lo = first;  // (run_batch forgets this again: a new call's rows are what last_rows_db / last_db_from say)
+  c->last_settled_hi = first + (size_t)c->ring_db_rows * (size_t)c->n;
   c->ring_db_rows = 0;
   c->ring_db_thr = nullptr;
 }
@@ -2159,6 +2167,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
   }
   c->last_rows_perm8 = c->ring_perm8;  // (the order last_hist and last_rel_rows are in: ss_read_window)
   c->last_rows_db = ring_only_rows != nullptr;  // (... and whether they hold dB values, from frame last_db_from on)
+  c->last_settled_lo = c->last_settled_hi = nullptr;
   c->last_n = nframes;
   return SS_OK;
 }
@@ -3052,7 +3061,9 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
         SS_HIP(c, hipMemcpyAsync(out, c->last_rel_rows + (size_t)frame * n + lo, sizeof(float) * cnt, hipMemcpyDeviceToHost, c->stream));
         SS_HIP(c, hipStreamSynchronize(c->stream));
       }
-      return c->last_rows_db ? sub_thr_window(c, lo, cnt, out) : SS_OK;  // (the rows are dB values: rel = dB - ceiling, noise_learner.cpp:55)
+      const float* row = c->last_rel_rows + (size_t)frame * n;
+      const bool settled = c->last_settled_lo && row >= c->last_settled_lo && row < c->last_settled_hi;  // (a retune since: the window's rows are noise-relative already)
+      return c->last_rows_db && !settled ? sub_thr_window(c, lo, cnt, out) : SS_OK;  // (the rows are dB values: rel = dB - ceiling, noise_learner.cpp:55)
     }
     if (frame >= 0) return fail(c, SS_ERR_INVALID, "the last ss_process_device call kept no dB / avg plane (detect mode): pass d_psd_db, or SS_FLAG_KEEP_PLANES at ss_create");
   }
@@ -3083,7 +3094,8 @@ int ss_read_window(ss_ctx* c, int32_t plane, int32_t frame, int32_t lo, int32_t 
     src = c->fused ? c->last_hist + (size_t)(kHistRows + frame) * n : c->d_rel + (size_t)(G - 1 + frame) * n;
   }
   if (!src) return fail(c, SS_ERR_INVALID, "bad plane/frame");
-  const bool ring_row_db = frame < 0 && c->fused && plane == SS_PLANE_REL && c->last_rows_db && frame >= c->last_db_from;  // (a ring row an earlier detect-mode call left as dB values)
+  const bool ring_row_db = frame < 0 && c->fused && plane == SS_PLANE_REL && c->last_rows_db && frame >= c->last_db_from &&
+                          !(c->last_settled_lo && src >= c->last_settled_lo && src < c->last_settled_hi);  // (a ring row an earlier detect-mode call left as dB values, not settled since)
   if (frame < 0 && c->fused && c->last_rows_perm8) {  // (ring rows the fold left)
     const int st = read_perm8_row(c, src, lo, cnt, out);
     if (st != SS_OK) return st;

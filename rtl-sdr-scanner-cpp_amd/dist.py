@@ -65,6 +65,18 @@ def max_over_ranks(seconds: float, device="cpu") -> float:
     return float(t.item())
 
 
+def ints_of_ranks(value: int, device="cpu") -> list[int]:
+    """One integer per rank, known to every rank afterwards (a sum over one-hot vectors: a few bytes, outside any timed region)."""
+    import torch
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return [int(value)]
+    t = torch.zeros(td.get_world_size(), dtype=torch.int64, device=device)
+    t[td.get_rank()] = int(value)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return [int(v) for v in t.cpu().tolist()]
+
+
 def barrier():
     import torch.distributed as td
     if td.is_available() and td.is_initialized() and td.get_world_size() > 1:

@@ -109,3 +109,37 @@ def test_traffic_from_the_committed_pmc_passes():
              for m, s in (("k_fft_cols1024", (16 * 64 + 128) * 1024), ("k_scan_step", (16 * 128 + 16 + 64) * 512)))
     assert 5.0 < c3 / (128 * 65536) < 10.0 and 24.0 < c5 / (16 * (1 << 20)) < 31.0, (c3 / (128 * 65536), c5 / (16 * (1 << 20)))  # 7.0 and 30.3 B per sample (round 4: 25.9 and 30.3; the review's marks: <= 10 and <= 27)
     assert b.traffic_from_profiles(4, "k_scan_step") is None
+
+
+def test_the_line_the_driver_parses_is_a_few_kb_whatever_the_run_measured():
+    """Round 5's single ~30 KB JSON line was more than the driver parses (BENCH_r05.parsed: null). The last line of stdout is now
+    compact_line(full): the contract's keys, roofline and cpu_baseline, a parity verdict and one short record per `also` entry; the
+    full form goes to bench_full.json. Held here on round 5's own full line and on a line with absurdly long strings."""
+    import json
+    b = _bench()
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r05", "s38_bench_default_k20.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 25_000
+    line = b.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 6000, len(text)
+    back = json.loads(text)
+    assert back == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert back["value"] == full["value"] and back["ms_per_step"] == full["ms_per_step"] and back["config"]["workload"].startswith("8192-pt FFT")
+    r = back["roofline"]
+    assert r["bound"] == "hbm" and r["frac"] == full["roofline"]["frac"] and r["peak"] == 8000.0 and r["traffic"] == full["roofline"]["traffic"] and len(r["kernel"]) <= 120
+    assert back["cpu_baseline"]["kind"] == "reference" and back["cpu_baseline"]["cores"] == 16 and back["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    assert back["parity"]["inside_band"] == 0 and back["parity"]["engine_over_reference_rms"] == 1.24 and back["parity"]["timed_path"]["inside_band"] == 0
+    assert len(back["also"]) == len(full["also"]) and all(len(json.dumps(e)) < 420 for e in back["also"])
+    assert [e.get("variant") for e in back["also"]][-2:] == ["drop_in_path", "drop_in_path"]
+    # whatever a run puts into its strings and lists, the line stays small
+    fat = json.loads(json.dumps(full))
+    fat["config"]["workload"] = "w" * 5000
+    fat["roofline"]["kernel"] = "k" * 5000
+    fat["cpu_baseline"]["sample"] = "s" * 5000
+    fat["parity"] = {"failed": "f" * 5000}
+    fat["also"].append({"baseline_config": 3, "error": "e" * 5000})
+    assert len(json.dumps(b.compact_line(fat))) < 6500
+    # a CPU-only line (config 1) and a multi-rank line (no side legs) go through as well
+    assert b.compact_line({"metric": "m", "value": 1.0, "roofline": None, "cpu_baseline": None, "config": {"workload": "x"}})["roofline"] is None

@@ -344,3 +344,31 @@ def test_config5_calls_that_keep_no_db_plane_serve_the_tracker_all_the_same(chun
         np.testing.assert_array_equal(res[False][1][k], res[True][1][k])
         np.testing.assert_array_equal(res[False][2][k], res[True][2][k])
     assert sum(int(x[-1]) for x in res[True][1]) > 1000
+
+
+@pytest.mark.parametrize("n,fs,chunk,ncalls", [(65536, 20_000_000, 48, 3), (65536, 20_000_000, 20, 4), (1 << 20, 61_440_000, 40, 2)])
+def test_read_window_after_a_retune_does_not_subtract_the_ceiling_twice(n, fs, chunk, ncalls):
+    """ss_set_frequency_range settles the ring window's dB rows in place (settle_ring_db: the newest <= 35 rows of the last detect-mode
+    call become noise-relative). ss_read_window(SS_PLANE_REL) of that last call must give the same values before and after the retune:
+    rows the settle pass has rewritten are read as they are, the earlier frames of a call longer than the window still have the
+    ceiling subtracted on the way out (round 5's advisor: they were subtracted twice, with SS_OK)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    band = pkg.synth.SyntheticBand(n, seed=45, on_frame=chunk + 10, off_frame=chunk * ncalls + 100)
+    eng = pkg.SpectrumEngine(fs, CENTER, fft_size=n, decim=1, in_format=pkg.abi.SS_FMT_CS8, max_batch=chunk, learn_frames=chunk)
+    keep = []
+    for k in range(ncalls):
+        d = torch.from_numpy(band.frames_cs8(chunk)).to(dev)
+        o = dict(off=torch.zeros(chunk + 1, dtype=torch.int32, device=dev), idx=torch.empty(chunk * 1024, dtype=torch.int32, device=dev))
+        eng.process_device(d, chunk, cand_off=o["off"], cand_idx=o["idx"])
+        keep.append((d, o))
+    eng.sync()
+    frames = sorted({-20, -1, 0, 3, chunk - 36, chunk - 35, chunk - 34, chunk - 1} & set(range(-20, chunk)))
+    spots = [(f, lo) for f in frames for lo in (0, n // 2 - 150, n - 300)]
+    before = [eng.read_window(pkg.abi.SS_PLANE_REL, f, lo, lo + 300) for f, lo in spots]
+    eng.set_frequency_range(CENTER - fs // 4, CENTER + fs // 4)
+    after = [eng.read_window(pkg.abi.SS_PLANE_REL, f, lo, lo + 300) for f, lo in spots]
+    for (f, lo), a, b in zip(spots, before, after):
+        np.testing.assert_array_equal(a, b, err_msg=f"frame {f}, bins from {lo}")
+    assert max(float(np.abs(a).max()) for a in before) < 90.0  # (noise-relative values of a noisy band: nowhere near a ceiling subtracted twice)
+    eng.close()
