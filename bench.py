@@ -241,7 +241,9 @@ def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False, call_frames:
            "outside_bins_vs_fp64_fft_dB": {"psd": fmt3(vs64), "rel": fmt3(vs64_rel)},
            # ... and over ALL ordinary bins of a sample of rows: |dB - fp64| of the engine and of the reference's fp32 FFT, and the ratio of their rms
            "all_bins_vs_fp64_fft_dB": (lambda v: None if v is None else {"rows": v["rows"], "bins": v["bins"], "engine": fmt3(v["engine"]), "reference": fmt3(v["reference"]),
-                                                                         "engine_over_reference_rms": float(f"{v['engine_over_reference_rms']:.3g}")})(all_bins_vs_fp64(iq_c, got["psd"], ref["psd"], fs))}
+                                                                         "engine_over_reference_rms": float(f"{v['engine_over_reference_rms']:.3g}"),
+                                                                         "engine_over_reference_median": float(f"{v['engine_over_reference_median']:.3g}"),
+                                                                         "engine_over_reference_p99": float(f"{v['engine_over_reference_p99']:.3g}")})(all_bins_vs_fp64(iq_c, got["psd"], ref["psd"], fs))}
     # ---- the timed path: device calls, nothing synchronised in between ----
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -416,6 +418,13 @@ def chain_kernels(n: int, fmt: str, nb: int | None = None, detect_mode: bool = F
                  "the first 64 pairs on workgroups of their own) and the candidate lists of call k-3", in_b + 8.0),
                 ("rows", "k_scan_step", "k_scan_step (KIND 6): row half (256-point FFTs -> dB -> noise-relative rows straight into the averager ring's buffer, no dB plane in "
                  "detect mode, + run maxima for the tile culling); carries nothing", 12.0),
+                ("plan", "k_plan_long", "k_plan_long as a launch of its own (drains only: in a run of calls the plan is a role of the column launch)", 0.0)]
+    if n == 1 << 18 and os.environ.get("SS_ROWS1024X256") != "0" and os.environ.get("SS_CULL") != "0":
+        # 262144 points — the size getFft picks at 61.44 MS/s — as they ship since round 6: 256-point column tiles + the 1024-point row tile, culled
+        return [("step", "k_scan_step", "k_scan_step (KIND 2): column half of the four-step FFT of call k (load, window, 256-point FFTs, twiddle -> work buffer), carrying the plan of "
+                 "call k-1 (which averaging tiles can hold a candidate, from a maximum per 8 bins the row tiles left), the listed tiles of call k-2 and the candidate lists of call k-3", in_b + 8.0),
+                ("rows", "k_fft_rows1024_psd", "k_fft_rows1024_psd<8>: row half — 8 rows of 1024 points per workgroup (four interleaved 256-point FFTs and a radix-4 step) -> dB -> dB rows "
+                 "straight into the averager ring's buffer (no dB plane in detect mode) + the maxima for the tile culling; carries nothing", 12.0),
                 ("plan", "k_plan_long", "k_plan_long as a launch of its own (drains only: in a run of calls the plan is a role of the column launch)", 0.0)]
     n2 = n // 256
     ks = [("step", "k_scan_step", "k_scan_step: column half of the four-step FFT of call k (load, window, 256-point FFTs, twiddle -> work buffer), carrying the "
@@ -683,7 +692,9 @@ def _compact_parity(p):
            "outside_bare_1e-4": {k: v["n"] for k, v in (p.get("outside_bare_1e-4") or {}).items()},
            "worst_dB": max([v["worst_dB"] for v in (p.get("outside_bare_1e-4") or {}).values()] or [0.0]),
            "rel_linear_p999": ((p.get("rel_linear") or {}).get("psd") or {}).get("p99.9"),
-           "engine_over_reference_rms": (p.get("all_bins_vs_fp64_fft_dB") or {}).get("engine_over_reference_rms")}
+           "engine_over_reference_rms": (p.get("all_bins_vs_fp64_fft_dB") or {}).get("engine_over_reference_rms"),
+           "engine_over_reference_median": (p.get("all_bins_vs_fp64_fft_dB") or {}).get("engine_over_reference_median"),
+           "engine_over_reference_p99": (p.get("all_bins_vs_fp64_fft_dB") or {}).get("engine_over_reference_p99")}
     t = p.get("timed_path")
     if t:
         out["timed_path"] = {"calls": _short(t.get("what"), 60), "reference_candidates": t.get("reference_candidates"), "inside_band": t.get("inside_1e-3_dB_band"),

@@ -335,14 +335,20 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
     tm = a.thr_tilemin[col];
     // (eight loads in flight per trip: one after the other — load, wait, store, sixteen times for a 1024-frame batch — the copy alone
     // took the plan workgroups 8-13 us, and the launch's frame workgroups are through after 12: they wait for this list)
+    // (round 6: sixteen at a time — ONE round trip for a 1024-frame batch, the halo frames' maxima in the same flight: with two trips of
+    // eight the plan workgroups were through after 11-12 us, the frame workgroups ask for their list's count 9-11 us into the launch, most
+    // were told "not ready" and polled for it when their frame was done, profiles/r05/s37_summary.txt)
     float hm = 0.0f;
     if (lane < before) hm = a.halo_segsum[col * kHaloSegPitch + (a.halo_rows - before) + lane];
-    for (int fb = 0; fb < nframes; fb += 512) {
-      float v[8];
+#ifndef SS_PLAN_COPY_LOADS  // (A/B builds, scripts/build_ab.py: 8 = round 5's two trips)
+#define SS_PLAN_COPY_LOADS 16
+#endif
+    for (int fb = 0; fb < nframes; fb += 64 * SS_PLAN_COPY_LOADS) {
+      float v[SS_PLAN_COPY_LOADS];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[min(fb + 64 * u + lane, nframes - 1)];
+      for (int u = 0; u < SS_PLAN_COPY_LOADS; ++u) v[u] = src[min(fb + 64 * u + lane, nframes - 1)];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < SS_PLAN_COPY_LOADS; ++u) {
         const int f = fb + 64 * u + lane;
         if (f < nframes) mine[at(f)] = v[u];
       }
@@ -517,7 +523,10 @@ struct PlanLongArgs {
   // 0: the ring holds dB values where k_fft_rows256_psd puts them (rows_smax_index); 1: 2^20 points in two passes
   // (fft1024_kernels.h): max_key values at rows1024_smax_index(run) — [k1 group][k2], gathered by atomic maxima;
   // 2: 65536 points by the radix-8 fold (fft65536_dif8.h): value g of tile column c is the largest dB value among the column's bins
-  // of residue g, at [g][c] — a column's neighbours then count with all eight of their values, not with their nearest run
+  // of residue g, at [g][c] — a column's neighbours then count with all eight of their values, not with their nearest run;
+  // 3: 262144 points as 256 columns x 1024-point rows (round 6, fft1024_kernels.h: fft_rows1024_tile<8>): max_key values of the eight
+  // 32-bin runs of tile column c at [run][c] (rows1024x256_smax_index), gathered by atomic maxima like layout 1's — planned by
+  // plan_x256_run below (a block per 32 columns x one frame tile), not by plan_long_run
   int layout;
 };
 constexpr int kPlanLongFloats = 8192;  // LDS of a plan workgroup: C x (16 nft + 20) values of M
@@ -837,11 +846,132 @@ __device__ __forceinline__ void plan_dif8_run(const PlanLongDet& a, const PlanLo
   if (live) p.list[1 + *list_base_p + base + __popcll(mask & ((1ull << lane) - 1ull))] = block;
 }
 
+// The plan for 262144-point frames (layout 3): the fold's decomposition — one block = 32 consecutive tile columns x ONE frame tile, 256
+// threads, a thread's forty loads in one flight — over max_key values at [run g < 8][column < 1024] per frame. Block b: column group
+// b mod 32, frame tile b / 32 in dispatch order. A key of "NaN" (a NaN bin in the run: cannot be bounded) counts as +inf: the tile is
+// evaluated. `lds`: kPlanDif8Floats floats + kPlanLongInts ints behind them.
+__host__ __device__ inline int plan_x256_blocks(int nframes, int shift) { return ((nframes + shift + 15) / 16) << 5; }
+template <int G, int GX, int TF, int TB_ = 256>
+__device__ __forceinline__ void plan_x256_run(const PlanLongDet& a, const PlanLongArgs& p, int block_no, int tid, float* __restrict__ lds, int* __restrict__ book) {
+  static_assert(TB_ == 256 && TF == 16 && G == 21, "tile columns of 256 bins, tiles of 16 frames");
+  constexpr int ROWS = TF + G - 1, RP = ROWS + 1;  // 36 frame rows per tile, LDS pitch 37
+  float* R = lds;              // [34][RP]
+  float* S = lds + 34 * RP;    // [32][TF]
+  int* wave_cnt = book;        // [4]
+  int* stat_cnt = book + 4;    // [4][2]
+  int* list_base_p = book + 12;
+  constexpr int tiles_per_row = 1024;
+  const int nframes = a.nframes;
+  const int nft = (nframes + a.shift + TF - 1) / TF;
+  const int cg = block_no & 31, ft_seq = block_no >> 5;
+  const bool in_range = ft_seq < nft;  // (a workgroup's second block may lie past the end: it keeps the barriers company)
+  const int ft = in_range ? (ft_seq + nft - 1) % nft : 0;
+  const int f0 = ft * TF - a.shift;  // batch-relative frame of the tile's first row of outputs
+  const int c0 = 32 * cg;
+  if (in_range) {
+    constexpr int NE = (34 * ROWS + 255) / 256;
+    const unsigned* src[NE];
+    unsigned m[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = min(tid + 256 * i, 34 * ROWS - 1);
+      const int colx = e % 34, r = e / 34;
+      const int col = min(max(c0 - 1 + colx, 0), tiles_per_row - 1);  // (the band's edges: the edge column once more)
+      src[i] = reinterpret_cast<const unsigned*>(p.smax) + ((size_t)((p.abs0 + f0 - (G - 1) + r) & p.smax_mask) << 13) + col;
+    }
+    unsigned v[NE][8];
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+#pragma unroll
+      for (int g = 0; g < 8; ++g) v[i][g] = src[i][1024 * g];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      m[i] = 0u;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) m[i] = max(m[i], v[i][g]);  // (order-preserving keys: the NaN key is the largest)
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + 256 * i;
+      if (e < 34 * ROWS) R[(e % 34) * RP + e / 34] = m[i] == 0xffffffffu ? __builtin_inff() : max_key_value(m[i]);
+    }
+  }
+  __syncthreads();
+  if (in_range) {
+    for (int e = tid; e < 32 * TF; e += 256) {
+      const int cl = e >> 4, j = e & 15;
+      const float *r0 = R + cl * RP + j, *r1 = r0 + RP, *r2 = r1 + RP;
+      float sum = 0.0f;
+#pragma unroll
+      for (int k = 0; k < G; ++k) sum += fmaxf(fmaxf(r0[k], r1[k]), r2[k]);  // M of frame f0 - 20 + j + k (no NaN among them: see above)
+      S[e] = sum;
+    }
+  }
+  __syncthreads();
+  bool live = false, tested = false;
+  int block = 0;
+  if (in_range && tid < 32) {
+    const int col = c0 + tid;
+    block = ft_seq * tiles_per_row + col;
+    live = true;
+    if (a.n_learn == 0 && f0 - (G - 1) >= p.clean_rel && !a.planes_out) {
+      tested = true;
+      float best = -__builtin_inff();
+      bool unsure = false;
+#pragma unroll
+      for (int j = 0; j < TF; ++j) {
+        const float sum = S[tid * TF + j];
+        if (f0 + j >= 0 && f0 + j < nframes) {  // the frames of this batch the tile answers for
+          unsure = unsure || (sum != sum);  // (+inf and -inf in one window)
+          best = fmaxf(best, sum);
+        }
+      }
+      const float bound = best * (1.0f / (float)G) - a.thr_tilemin[col];
+      live = unsure || !(bound < a.start_level - kCullMargin);  // (a NaN difference: live)
+    }
+  }
+  // this block's share of the list, in thread order (as plan_long_run)
+  const int lane = tid & 63, w = tid >> 6;
+  const unsigned long long mask = __ballot(live);
+  if (lane == 0) wave_cnt[w] = __popcll(mask);
+  if (a.stats) {
+    const int n_tested = __popcll(__ballot(tested)), n_culled = __popcll(__ballot(tested && !live));
+    if (lane == 0) {
+      stat_cnt[2 * w] = n_tested;
+      stat_cnt[2 * w + 1] = n_culled;
+    }
+  }
+  __syncthreads();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    base += k < w ? wave_cnt[k] : 0;
+    total += wave_cnt[k];
+  }
+  if (tid == 0) *list_base_p = total ? atomicAdd(&p.list[0], total) : 0;
+  if (tid == 1 && a.stats) {
+    const int nt = stat_cnt[0] + stat_cnt[2] + stat_cnt[4] + stat_cnt[6], nc = stat_cnt[1] + stat_cnt[3] + stat_cnt[5] + stat_cnt[7];
+    if (nt) {
+      atomicAdd(stat_word(a.stats, kStatTested), (unsigned long long)nt);
+      atomicAdd(stat_word(a.stats, kStatCulled), (unsigned long long)nc);
+    }
+  }
+  __syncthreads();
+  if (live) p.list[1 + *list_base_p + base + __popcll(mask & ((1ull << lane) - 1ull))] = block;
+}
+// workgroups (blocks) of a long transform's plan, whatever its layout
+__host__ __device__ inline int plan_blocks_of(const PlanLongDet& a, const PlanLongArgs& p, int n) {
+  if (p.layout == 3) return plan_x256_blocks(a.nframes, a.shift);
+  if (p.layout == 2) return plan_dif8_blocks(a.nframes, a.shift, p.logn - 13);
+  return plan_long_blocks(p.layout, p.cols, n);
+}
+
 template <int G, int GX, int TF, int TB_ = 256>
 __global__ __launch_bounds__(256) void k_plan_long(PlanLongDet a, PlanLongArgs p) {
   __shared__ float mrow[kPlanLongFloats];
   __shared__ int book[kPlanLongInts];
   if (p.layout == 2) return plan_dif8_run<G, GX, TF, TB_>(a, p, (int)blockIdx.x, (int)threadIdx.x, mrow, book);
+  if (p.layout == 3) return plan_x256_run<G, GX, TF, TB_>(a, p, (int)blockIdx.x, (int)threadIdx.x, mrow, book);
   plan_long_run<G, GX, TF, TB_>(a, p, (int)blockIdx.x, (int)threadIdx.x, mrow, book);
 }
 

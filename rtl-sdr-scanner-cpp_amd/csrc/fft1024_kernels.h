@@ -230,11 +230,19 @@ __host__ __device__ __forceinline__ float max_key_value(unsigned key) {
 }
 // which rows a row tile takes: block = ((f * 16) + v) * 8 + x -> frame f, first row r0 (XCD x takes rows [128 x, 128 x + 128) of
 // every frame, v its 16 tiles in turn: the four tiles that fill the 128-byte lines of the dB plane are consecutive blocks of one XCD)
+// (LOGN1 = 8 — 262144 points as 256 columns x 1024-point rows, round 6: 32 tiles per frame, XCD x takes rows [32 x, 32 x + 32), its four
+// tiles — the ones that fill the 128-byte lines — in turn)
+template <int LOGN1 = 10>
 __host__ __device__ inline void rows1024_block(int block, int* f, int* r0) {
+  static_assert(LOGN1 == 10 || LOGN1 == 8, "1024 or 256 rows of 1024 points");
   const int xc = block & 7, v = block >> 3;
-  *f = v >> 4;
-  *r0 = (xc << 7) + ((v & 15) << 3);
+  *f = v >> (LOGN1 - 6);
+  *r0 = (xc << (LOGN1 - 3)) + ((v & ((1 << (LOGN1 - 6)) - 1)) << 3);
 }
+// 262144 points: where the maximum of 32-bin run `run` (0..7: rows k1 in [32 run, 32 run + 32)) of tile column `col` (output order:
+// k2 ^ 512, DC in the middle) lies in a frame's 8192 words of the ring — [run][col], max_key values gathered by atomic maxima (four
+// row tiles share a run; the column tiles clear the frame's words one launch earlier, fft256_kernels.h). PlanLongArgs::layout 3.
+__host__ __device__ inline int rows1024x256_smax_index(int run, int col) { return (run << 10) | col; }
 // where the maximum of 32-bin run R (= bin >> 5, output order: DC in the middle) lies in a frame's row of the ring: the rows
 // kernel's lanes run along k2, so [k1 group][k2] makes its atomics contiguous
 __host__ __device__ inline int rows1024_smax_index(int run) { return ((run & 31) << 10) | (run >> 5); }
@@ -251,7 +259,12 @@ struct Rows1024Args {
 // One row tile: 8 rows k1 x 1024 points. block = ((f * 16) + v) * 8 + x: XCD x takes rows [128 x, 128 x + 128) of every
 // frame, v its 16 tiles in turn — the four tiles that fill the 128-byte lines of the dB plane (32 consecutive k1 for every k2)
 // are consecutive blocks of one XCD.
+// LOGN1: 10 = a 2^20-point frame (1024 rows); 8 = a 262144-point frame behind 256-point column tiles (fft256_kernels.h): 256 rows of
+// 1024 points, bin k1 + 256 k2 — the size getFft picks at 61.44 MS/s (utils/radio_utils.cpp:98-104), which until round 6 went through
+// k_fft_rows256xR_psd: no run maxima, no ring rows, a dB plane always written, every averaging tile evaluated.
+template <int LOGN1 = 10>
 __device__ __forceinline__ void fft_rows1024_tile(const Rows1024Args& g, int block, unsigned char* __restrict__ smem_raw, int t) {
+  constexpr int LOGN = LOGN1 + 10;
   float* s = reinterpret_cast<float*>(smem_raw);
   float2* tw_lds = reinterpret_cast<float2*>(smem_raw + kFft1024ColsPlaneBytes);
   float2* tw1024_lds = tw_lds + 256;
@@ -259,10 +272,10 @@ __device__ __forceinline__ void fft_rows1024_tile(const Rows1024Args& g, int blo
   const RowsExtra& x = g.x;
   if (x.zero_word && block == 0 && t == 0) *x.zero_word = 0;
   int f, r0;
-  rows1024_block(block, &f, &r0);
+  rows1024_block<LOGN1>(block, &f, &r0);
   const int fl = t >> 6, tt = t & 63;
   const int q = tt & 3, j = tt >> 2;
-  const float2* row = g.work + ((size_t)f << 20) + ((size_t)(r0 + fl) << 10);
+  const float2* row = g.work + ((size_t)f << LOGN) + ((size_t)(r0 + fl) << 10);
   float2 a[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) a[r] = row[tt + 64 * r];
@@ -309,9 +322,9 @@ __device__ __forceinline__ void fft_rows1024_tile(const Rows1024Args& g, int blo
     for (int kap = 0; kap < 4; ++kap) s[((p & 255) + 256 * kap) * 9 + (p >> 8)] = dbv[u * 4 + kap];
   }
   __syncthreads();
-  constexpr int half = 1 << 19;
+  constexpr int half = 1 << (LOGN - 1);
   if (x.smax) {  // the largest dB value of this tile's 8 rows for every k2: a quarter of the 32-bin run (r0 / 32, k2)
-    unsigned* srow = reinterpret_cast<unsigned*>(x.smax) + ((size_t)((x.abs0 + f) & x.smax_mask) << 15);
+    unsigned* srow = reinterpret_cast<unsigned*>(x.smax) + ((size_t)((x.abs0 + f) & x.smax_mask) << (LOGN - 5));  // (a word per 32-bin run)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int k2 = t + 512 * e;
@@ -323,17 +336,19 @@ __device__ __forceinline__ void fft_rows1024_tile(const Rows1024Args& g, int blo
         bad = bad || (vv != vv);
         m = fmaxf(m, vv);
       }
-      atomicMax(&srow[rows1024_smax_index((((r0 + (k2 << 10)) ^ half) >> 5))], bad ? 0xffffffffu : max_key(m));
+      if constexpr (LOGN1 == 10) atomicMax(&srow[rows1024_smax_index((((r0 + (k2 << 10)) ^ half) >> 5))], bad ? 0xffffffffu : max_key(m));
+      else atomicMax(&srow[rows1024x256_smax_index(r0 >> 5, k2 ^ 512)], bad ? 0xffffffffu : max_key(m));
     }
   }
-  float* out = g.psd ? g.psd + ((size_t)f << 20) : nullptr;
-  float* hrow = (x.hist_out && f >= x.first_hist) ? x.hist_out + ((size_t)(f - x.first_hist) << 20) : nullptr;  // (workgroup-uniform)
+  float* out = g.psd ? g.psd + ((size_t)f << LOGN) : nullptr;
+  float* hrow = (x.hist_out && f >= x.first_hist) ? x.hist_out + ((size_t)(f - x.first_hist) << LOGN) : nullptr;  // (workgroup-uniform)
   const int rr = t & 7, kb = t >> 3;
-  // bin of output i: ((r0 + rr) + ((kb + 64 i) << 10)) ^ half — fft_v shift=true: X[k] lands at k ^ (N/2)
-  const int bin0 = ((r0 + rr) + (kb << 10)) ^ half;
+  // bin of output i: ((r0 + rr) + ((kb + 64 i) << LOGN1)) ^ half — fft_v shift=true: X[k] lands at k ^ (N/2)
+  const int bin0 = ((r0 + rr) + (kb << LOGN1)) ^ half;
+  constexpr int ISH = LOGN1 + 6;  // (64 k2 further on: 64 << LOGN1 bins)
   if (out) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) out[bin0 ^ (i << 16)] = s[(kb + 64 * i) * 9 + rr];
+    for (int i = 0; i < 16; ++i) out[bin0 ^ (i << ISH)] = s[(kb + 64 * i) * 9 + rr];
   }
   if (hrow) {
     // The sixteen ceiling values FIRST, all in flight together, then the sixteen stores. (Until session 16 of round 4 the loop was
@@ -345,21 +360,22 @@ __device__ __forceinline__ void fft_rows1024_tile(const Rows1024Args& g, int blo
     // evaluated subtract the ceiling, DetectArgs::ring_db_from)
     if (!x.thr) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) hrow[bin0 ^ (i << 16)] = s[(kb + 64 * i) * 9 + rr];
+      for (int i = 0; i < 16; ++i) hrow[bin0 ^ (i << ISH)] = s[(kb + 64 * i) * 9 + rr];
     } else {
       float th[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) th[i] = x.thr[bin0 ^ (i << 16)];
+      for (int i = 0; i < 16; ++i) th[i] = x.thr[bin0 ^ (i << ISH)];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) hrow[bin0 ^ (i << 16)] = s[(kb + 64 * i) * 9 + rr] - th[i];  // noise_learner.cpp:55, as detect_tile forms it
+      for (int i = 0; i < 16; ++i) hrow[bin0 ^ (i << ISH)] = s[(kb + 64 * i) * 9 + rr] - th[i];  // noise_learner.cpp:55, as detect_tile forms it
     }
   }
 }
 
 // Stand-alone launch (contexts without the step kernel; otherwise the row tiles run as a role of k_scan_step, scan_step.h).
+template <int LOGN1 = 10>
 __global__ __launch_bounds__(512, 8) void k_fft_rows1024_psd(Rows1024Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  fft_rows1024_tile(g, (int)blockIdx.x, smem_raw, (int)threadIdx.x);
+  fft_rows1024_tile<LOGN1>(g, (int)blockIdx.x, smem_raw, (int)threadIdx.x);
 }
 
 }  // namespace ss

@@ -115,6 +115,9 @@ __device__ __forceinline__ void fft_cols256_tile(const ColsArgs& g, int block, u
   const int tiles_per_frame = n2size >> 5;
   const int f = block / tiles_per_frame;
   const int n2 = ((block % tiles_per_frame) << 5) + q;
+  // tile culling with run maxima gathered by atomic maxima in the rows kernel (262144 points, fft1024_kernels.h: fft_rows1024_tile<8>):
+  // the frame's words of the ring start from zero — cleared here, one launch earlier, 256 of its N / 32 words per column tile
+  if (g.smax && t < 256) g.smax[(size_t)((g.abs0 + f) & g.smax_mask) * (size_t)(tiles_per_frame << 8) + ((block % tiles_per_frame) << 8) + t] = 0u;
   // sample n = (j + 16 r) N2 + n2: block-uniform part (frame, 16 r N2) in scalar registers, per-thread part one 32-bit offset
   constexpr uint32_t kInBytes = FMT == FMT_CF32 ? 8u : 2u;
   const char* in_frame = reinterpret_cast<const char*>(g.iq) + (size_t)f * (size_t)g.item_stride * kInBytes;

@@ -412,4 +412,115 @@ __device__ __forceinline__ void dif8_front2(const Dif8Front& d, size_t frame_in,
   }
 }
 
+// Round 6: the same two residues, the fold turned inside out — for one run rho ALL EIGHT samples of a point at once, and the sum over q as
+// the radix-8 butterfly it is instead of four complex multiply-accumulates per residue:
+//     s_q  = w[m] x[m] + (-1)^r w[m'] x[m']                      (q < 4: the pair sums, as before)
+//     E    = s_0 + W_8^(2r) s_2,    O = W_8^r s_1 + W_8^(3r) s_3 = W_8^r (s_1 + W_8^(2r) s_3)
+//     y_r  = E + O,                 y_(r+4) = E - O
+// W_8^(2r) is a power of -i (operands swapped, no arithmetic) and W_8^r is 1, -i or (+-1 - i) / sqrt 2 — with R a template parameter the
+// butterfly is 8 (R even) or 10 (R odd) vector instructions per point where the accumulating form spends 32; per point 56-58 instead of 80,
+// 912 instead of 1280 per thread and fold. What it needs is all eight taps of a point: the rotating part of the taps for every q,
+// (cos, sin)(theta_t + 2 pi 8192 q / 65535), sixteen registers kept through the loop (the accumulating form keeps 64 accumulators
+// instead; here a[rho] and a2[rho] are written once) — and straight-line code for the sixteen runs (a loop's counter cannot index
+// registers): 9 KiB where the accumulating form's loop has 2.5. The residue is a run-time value (one copy of the code): the four shapes
+// of the butterfly sit behind scalar branches. A piece of LDS-DMA is two runs rho x eight q (sixteen runs of 1 KiB, as before: wave w
+// fetches q = w of both).
+
+__device__ __forceinline__ void dif8_bfly2(int R, const float2 (&s)[4], float2& y, float2& y2) {  // R: workgroup-uniform (scalar branches)
+  constexpr float kH = 0.70710678118654752f;
+  if (R == 0) {  // W_8^0 = 1 throughout
+    const float2 e = make_float2(s[0].x + s[2].x, s[0].y + s[2].y), o = make_float2(s[1].x + s[3].x, s[1].y + s[3].y);
+    y = make_float2(e.x + o.x, e.y + o.y);
+    y2 = make_float2(e.x - o.x, e.y - o.y);
+  } else if (R == 2) {  // W_8^4 = -1, W_8^2 = -i, W_8^6 = i: E = s0 - s2, O = -i (s1 - s3)
+    const float2 e = make_float2(s[0].x - s[2].x, s[0].y - s[2].y), d = make_float2(s[1].x - s[3].x, s[1].y - s[3].y);
+    y = make_float2(e.x + d.y, e.y - d.x);
+    y2 = make_float2(e.x - d.y, e.y + d.x);
+  } else if (R == 1) {  // W_8^2 = -i, W_8 = (1 - i) / sqrt 2: E = s0 - i s2, O = W_8 (s1 - i s3)
+    const float2 e = make_float2(s[0].x + s[2].y, s[0].y - s[2].x), d = make_float2(s[1].x + s[3].y, s[1].y - s[3].x);
+    const float2 g = make_float2(d.x + d.y, d.y - d.x);  // (1 - i) d
+    y = make_float2(fmaf(kH, g.x, e.x), fmaf(kH, g.y, e.y));
+    y2 = make_float2(fmaf(-kH, g.x, e.x), fmaf(-kH, g.y, e.y));
+  } else {  // R == 3: W_8^6 = i, W_8^3 = (-1 - i) / sqrt 2, W_8^9 = W_8: E = s0 + i s2, O = W_8 (s3 - i s1)
+    const float2 e = make_float2(s[0].x - s[2].y, s[0].y + s[2].x), d = make_float2(s[3].x + s[1].y, s[3].y - s[1].x);
+    const float2 g = make_float2(d.x + d.y, d.y - d.x);
+    y = make_float2(fmaf(kH, g.x, e.x), fmaf(kH, g.y, e.y));
+    y2 = make_float2(fmaf(-kH, g.x, e.x), fmaf(-kH, g.y, e.y));
+  }
+}
+
+template <int FMT, class F>
+__device__ __forceinline__ void dif8_front2_bfly(const Dif8Front& d, size_t frame_in, int R, unsigned char* __restrict__ smem_raw, int t, float2 (&a)[16], float2 (&a2)[16],
+                                                 F&& after_first_issue) {
+  static_assert(FMT == FMT_CS8 || FMT == FMT_CU8, "two-byte samples");
+  const char* fb = reinterpret_cast<const char*>(d.iq) + frame_in * (size_t)d.item_stride * 2;
+  const __amdgpu_buffer_rsrc_t rin = buffer_of(fb, 65536 * 2);
+  const dif8_const_fp cq = (dif8_const_fp)(uintptr_t)d.wq;
+  const dif8_const_fp crho = (dif8_const_fp)(uintptr_t)(d.wrho + R * 16), crho2 = (dif8_const_fp)(uintptr_t)(d.wrho + (R + 4) * 16);
+  const float sg = (R & 1) ? -1.0f : 1.0f;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63;
+  // piece p: runs rho = 2 p + j, j < 2, of every q; run (j, q) at half * 16 KiB + (8 j + q) KiB; wave w fetches q = w of both
+  const auto issue = [&](int p, int half) {
+    if (SS_DIF_NODMA) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem_raw + half * 16384 + (8 * j + w) * 1024), 16, lane * 16,
+                                               1024 * (2 * p + j) + 16384 * w, 0, SS_AUX_DIF_IQ);
+  };
+  issue(0, 0);
+  issue(1, 1);
+  after_first_issue();
+  const float2 th = d.wthe[t];
+  // (cos, sin)(theta_t + phi_q) for the eight q — those of q + 4 times (-1)^R, the sign of their samples in the pair sums
+  float tc[8], ts[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float qc = cq[2 * q] * (q >= 4 ? sg : 1.0f), qs = cq[2 * q + 1] * (q >= 4 ? sg : 1.0f);
+    tc[q] = fmaf(th.x, qc, -(th.y * qs));
+    ts[q] = fmaf(th.y, qc, th.x * qs);
+  }
+  const float k1 = 0.54f, k2 = 0.54f * sg;
+  const unsigned short* mine = reinterpret_cast<const unsigned short*>(smem_raw) + t;
+  // (straight-line code, sixteen points: a[] and a2[] are registers, and a loop's counter cannot index registers)
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (!SS_DIF_NODMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (!(pp == 0 && half == 0) && !(pp == 3 && half == 1)) issue(2 * pp + half + 1, half ^ 1);  // (the other half's next piece: its place was read a piece ago)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rho = 4 * pp + 2 * half + j;
+        const float tp = kDif8P[rho], tq = kDif8Q[rho];
+        unsigned raw[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) raw[q] = mine[half * 8192 + 512 * (8 * j + q)];
+        float2 s[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float re1, im1, re2, im2;
+          dif8_convert<FMT>(raw[q], re1, im1);
+          dif8_convert<FMT>(raw[q + 4], re2, im2);
+          const float t1 = fmaf(tc[q], tp, fmaf(ts[q], tq, k1));
+          const float t2 = fmaf(tc[q + 4], tp, fmaf(ts[q + 4], tq, k2));
+          s[q] = make_float2(fmaf(t2, re2, t1 * re1), fmaf(t2, im2, t1 * im1));  // volk_32fc_32f_multiply_32fc (the format's scale rides on wt)
+        }
+        dif8_bfly2(R, s, a[rho], a2[rho]);
+        asm volatile("" : "+v"(a[rho].x), "+v"(a[rho].y), "+v"(a2[rho].x), "+v"(a2[rho].y));  // (formed HERE, not sunk below the next barrier)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __syncthreads();  // the plane goes back to the transform
+  const float2 wt = d.wt[R * 512 + t], wt2 = d.wt[(R + 4) * 512 + t];
+#pragma unroll
+  for (int rho = 0; rho < 16; ++rho) {
+    a[rho] = cmul(a[rho], cmul(wt, make_float2(crho[2 * rho], crho[2 * rho + 1])));
+    a2[rho] = cmul(a2[rho], cmul(wt2, make_float2(crho2[2 * rho], crho2[2 * rho + 1])));
+  }
+}
+
 }  // namespace ss

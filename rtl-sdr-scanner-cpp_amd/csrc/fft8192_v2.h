@@ -460,7 +460,8 @@ __device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Ar
 //        LOADV = FRONT - 1: the load stage is the radix-8 fold, g.iq / g.win / g.item_stride are not read), `frame` = the row
 //        the residue's bins go to, as 8 x (the ring's row) + residue (the bins land in that row's blocks, fft65536_dif8.h); 3 = residues `residue` (< 4)
 //        AND residue + 4 by the same workgroup, one fold for both, rows `frame` and `frame` + 4 (twice the registers: four waves per SIMD);
-//        4 = the same for a 131072-point frame: radix 16, residues `residue` (< 8) and residue + 8, rows `frame` and `frame` + 8.
+//        4 = the same for a 131072-point frame: radix 16, residues `residue` (< 8) and residue + 8, rows `frame` and `frame` + 8;
+//        5 = 3 with the fold as a radix-8 butterfly per point (round 6, fft65536_dif8.h: dif8_front2_bfly).
 template <int FMT, int TW, bool SWZ = false, bool NOWIN = false, int FRONT = 0>
 __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t frame, unsigned char* __restrict__ smem_raw, int t, int* hdr,
                                                  const Dif8Front* dif = nullptr, size_t frame_in = 0, int residue = 0) {
@@ -494,6 +495,7 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
       if (t < 128) lane_l[256 + t] = tabs.lane[256 + t];
     };
     if constexpr (FRONT == 3) dif8_front2<FMT, 8>(*dif, frame_in, residue, smem_raw, t, a, a2, tables_to_lds);
+    else if constexpr (FRONT == 5) dif8_front2_bfly<FMT>(*dif, frame_in, residue, smem_raw, t, a, a2, tables_to_lds);
     else if constexpr (FRONT == 4) dif8_front2<FMT, 16>(*dif, frame_in, residue, smem_raw, t, a, a2, tables_to_lds);
     else dif8_front<FMT, FRONT - 1>(*dif, frame_in, residue, smem_raw, t, a, tables_to_lds);
     (void)iq;
@@ -530,7 +532,7 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
     tw2_l[t] = tf0;  // tw2_l and lane_l are contiguous: entries 0..511
     if (t < 128) lane_l[256 + t] = tf1;
   }
-  if constexpr (FRONT == 3 || FRONT == 4) {
+  if constexpr (FRONT == 3 || FRONT == 4 || FRONT == 5) {
     // two residues by one workgroup (fft65536_dif8.h, dif8_front2): r's transform, then (r + Q/2)'s from the registers that kept it
     constexpr int HQ = FRONT == 4 ? 8 : 4;
 #pragma unroll 1

@@ -58,6 +58,11 @@
 #ifndef SS_DIF8_W
 #define SS_DIF8_W 4
 #endif
+// ... and the fold of the two-residue form: 1 = a radix-8 butterfly per point (round 6, fft65536_dif8.h: dif8_front2_bfly — 912 vector
+// instructions per thread and fold), 0 = round 5's accumulating loop over q (1280). Build-time for the same reason.
+#ifndef SS_DIF8_BFLY
+#define SS_DIF8_BFLY 1
+#endif
 
 namespace ss {
 
@@ -122,6 +127,8 @@ struct StepArgs {
   // stage of two calls later reads; the plan of call k - 1, detect(k - 2) (PERM8 tiles) and emit(k - 3) ride on the launch as they ride
   // on the column launch of the four-step form (KIND 2). `fft` carries the transform's tables and the rows' place, `dif` the fold's.
   // KIND 9 — the same for 131072-point frames (what getFft picks at 20 MS/s): radix 16, residues r and r + 8 per workgroup, n_fft = 8 x frames.
+  // KIND 10 — 262144 points (round 6): KIND 2 — 256-point column tiles as the FFT role, the plan of call k - 1, detect(k - 2), emit(k - 3) —
+  // whose plan role is plan_x256_run (PlanLongArgs::layout 3); an instantiation of its own so that the others keep their registers.
   Dif8Front dif;
   int n_emit;  // frames of the emit role
   int emit_per_wg;  // 8: one wave per frame; 1 (KIND 2): rows of 2048 mask words and more, the eight waves share one frame
@@ -227,10 +234,11 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;
     }
   } else if (role == ROLE_PLAN) {
-    if constexpr (KIND == 1 || KIND == 2 || KIND == 7 || KIND == 8 || KIND == 9) {  // a long transform's plan: two blocks of k_plan_long's numbering
+    if constexpr (KIND == 1 || KIND == 2 || KIND == 7 || KIND == 8 || KIND == 9 || KIND == 10) {  // a long transform's plan: two blocks of k_plan_long's numbering
       const int sub = tid >> 8;
       float* mrow = reinterpret_cast<float*>(smem_raw) + sub * (kPlanFusedFloats + kPlanLongInts);
       if constexpr (KIND == 8 || KIND == 9) plan_dif8_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));  // (the fold's rows: layout 2)
+      else if constexpr (KIND == 10) plan_x256_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));  // (262144 points: layout 3)
       else plan_long_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));
       return;
     }
@@ -248,7 +256,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
 #ifdef SS_DIAG
         if (a.hint_mode != 4)  // (timing ablation, garbage results: the passengers of the launch by themselves)
 #endif
-        fft8192_v2_frame<FMT, 2, true, false, SS_DIF8_W == 4 ? 3 : 2>(a.fft, (size_t)(8 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
+        fft8192_v2_frame<FMT, 2, true, false, SS_DIF8_W == 4 ? (SS_DIF8_BFLY ? 5 : 3) : 2>(a.fft, (size_t)(8 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
       }
     }
     else if constexpr (KIND == 9) {  // 131072 points, radix 16: residues r (< 8) and r + 8 of a frame, eight workgroups per frame

@@ -134,6 +134,7 @@ struct ss_ctx {
     bool det_lag2 = true;          // 65536 points with tile culling: detect(k - 2) on the column launch of call k (SS_DET_LAG2=0: detect(k - 1) on the row launch, session 19's form)
     bool dif8 = true;              // 65536 points, int8 IQ, default window, calls that keep no plane: NO work buffer — the radix-8 fold in the load stage of the 8192-point transform, eight workgroups per frame, one launch per call whatever its length (scan_step.h KIND 8, fft65536_dif8.h; SS_DIF8=0: the four-step forms of round 4)
     int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
+    bool rows1024x256 = true;      // 262144 points (what getFft picks at 61.44 MS/s): rows through the 1024-point row tile with run maxima and ring rows — culled, no dB plane in detect mode, the 65536-point two-launch pipeline (SS_ROWS1024X256=0: round 2's path, k_fft_rows256xR_psd, every tile evaluated)
     int chunk_65536 = 256;         // 65536 points with tile culling: calls of more frames go through in chunks of this many (SS_CHUNK_65536=0: in one piece)
     int chunk_long = 16;           // 2^20 points in two passes: calls of more frames go through in chunks of this many (SS_CHUNK_LONG=0: in one piece)
     bool halo_maxima = true;       // 8192 points, deep pipelining: the re-transformed halo frames leave per-column maxima, so that the tiles of a batch's first two frame tiles are tested like the others (SS_HALO_MAXIMA=0: evaluated whatever they hold, as until session 36 of round 5)
@@ -204,6 +205,7 @@ struct ss_ctx {
       list_first_fold = getenv("SS_LIST_FIRST") ? list_first + 1 : num("SS_LIST_FIRST_FOLD", list_first_fold);
       chunk_long = num("SS_CHUNK_LONG", chunk_long);
       chunk_65536 = num("SS_CHUNK_65536", chunk_65536);
+      rows1024x256 = tri("SS_ROWS1024X256") != 0;
       plan_first = num("SS_PLAN_FIRST", plan_first);
       det_lag2 = tri("SS_DET_LAG2") != 0;
       dif8 = tri("SS_DIF8") != 0;
@@ -293,6 +295,8 @@ struct ss_ctx {
   // 2^20 points in two passes: the plan of the last call (which of its tiles the detect stage must evaluate, k_plan_long) is not a
   // launch of its own but rides at the front of the NEXT call's column launch (k_fft_cols1024_plan, detect_fused.h); until then
   // — or until flush_stages launches it on its own — its arguments wait here. pend_det.tile_list points at the list it fills.
+  bool x256_tile = false;     // 262144 points: the row half through the 1024-point row tile (k_fft_rows1024_psd<8>) in every context, culled or not — the same bits either way
+  bool rows1024x256 = false;  // 262144 points with tile culling (round 6): 256-point column tiles as k_scan_step's FFT role with the plan of the call before, detect(k - 2) and emit(k - 3); the rows as a launch of k_fft_rows1024_psd<8>
   bool rows256_step = false;  // 65536 points with tile culling: columns as their own launch, rows as k_scan_step's FFT role (see Diag::rows256_step)
   bool have_plan = false;
   ss::PlanLongDet pend_plan_det{};
@@ -682,7 +686,7 @@ ss::ColsArgs cols256_args(ss_ctx* c, const void* d_iq, long long item_stride) {
   g.scale = c->cfg.int_scale;
   g.work = c->d_work;
   g.logn2 = c->two_pass ? 10 : c->logn - 8;
-  if (c->two_pass && c->cull_long) {  // (the column tiles clear the frames' rows of the run-maxima ring: the rows kernel gathers them by atomic maxima)
+  if ((c->two_pass || c->rows1024x256) && c->cull_long) {  // (the column tiles clear the frames' rows of the run-maxima ring: the rows kernel gathers them by atomic maxima)
     g.smax = reinterpret_cast<unsigned*>(c->d_smax);
     g.smax_mask = c->smax_rows - 1;
     g.abs0 = (int)(c->abs_frames & 0x3fffffff);
@@ -740,6 +744,17 @@ ss::Rows1024Args rows1024_args(ss_ctx* c, float* d_psd, const ss::RowsExtra& rx)
   g.x = rx;
   return g;
 }
+// 262144 points: the same tile over 256 rows of 1024 points behind the 256-point column tiles (W_1024^k' is row 1 of the x R rows kernel's table)
+ss::Rows1024Args rows1024x256_args(ss_ctx* c, float* d_psd, const ss::RowsExtra& rx) {
+  ss::Rows1024Args g{};
+  g.work = c->d_work;
+  g.tw256 = c->d_tw256;
+  g.tw1024 = c->d_tw_rowsR + 256;
+  g.db_off = c->db_off;
+  g.psd = d_psd;
+  g.x = rx;
+  return g;
+}
 ss::Rows256Args rows256_args(ss_ctx* c, float* d_psd, const ss::RowsExtra& rx) {
   ss::Rows256Args g{};
   g.work = c->d_work;
@@ -753,7 +768,11 @@ ss::Rows256Args rows256_args(ss_ctx* c, float* d_psd, const ss::RowsExtra& rx) {
 }
 void launch_rows1024(ss_ctx* c, int nframes, float* d_psd, const ss::RowsExtra& rx) {
   const ss::Rows1024Args g = rows1024_args(c, d_psd, rx);
-  SS_LAUNCH_SLOT(c, SS_KSLOT_ROWS, ss::k_fft_rows1024_psd, dim3(nframes * 128), dim3(512), ss::kFft1024RowsLdsBytes, g);
+  SS_LAUNCH_SLOT(c, SS_KSLOT_ROWS, ss::k_fft_rows1024_psd<10>, dim3(nframes * 128), dim3(512), ss::kFft1024RowsLdsBytes, g);
+}
+void launch_rows1024x256(ss_ctx* c, int nframes, float* d_psd, const ss::RowsExtra& rx) {
+  const ss::Rows1024Args g = rows1024x256_args(c, d_psd, rx);
+  SS_LAUNCH_SLOT(c, SS_KSLOT_ROWS, ss::k_fft_rows1024_psd<8>, dim3(nframes * 32), dim3(512), ss::kFft1024RowsLdsBytes, g);
 }
 
 // with_cols = false: the column half ran as a role of k_scan_step (run_batch), only the row half is launched here
@@ -767,8 +786,14 @@ void launch_four_step256(ss_ctx* c, const void* d_iq, long long item_stride, int
                    (const float2*)c->d_tw256, c->db_off, d_psd, 16, 0, rx);
   } else {
     bool done = false;
+    if constexpr (LOGN2 == 10) {
+      if (c->x256_tile) {  // 262144 points: the 1024-point row tile (with tile culling: run maxima, ring rows, the dB plane only where one is wanted)
+        launch_rows1024x256(c, nframes, d_psd, rx);
+        done = true;
+      }
+    }
     if constexpr (LOGN2 >= 9 && LOGN2 <= 12) {
-      if (c->d_tw_rowsR) {  // rows of 256 R points: R sub-sequences through the register passes, an R-point DFT across them
+      if (!done && c->d_tw_rowsR) {  // rows of 256 R points: R sub-sequences through the register passes, an R-point DFT across them
         constexpr int LOGR = LOGN2 - 8;
         SS_LAUNCH_SLOT(c, SS_KSLOT_ROWS, (ss::k_fft_rows256xR_psd<LOGR>), dim3(nframes * (256 / (32 >> LOGR))), dim3(512), ss::fft_rowsR_lds_bytes(LOGR),
                        (const float2*)c->d_work, (const float2*)c->d_tw256, (const float2*)c->d_tw_rowsR, c->db_off, d_psd,
@@ -921,6 +946,9 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
     if (!c->use_fft8192 && c->ring_perm8) return c->dif_logq == 4 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 9>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 8>);
   }
   if (!c->use_fft8192 && a.n_fft && a.rows256.work && !a.n_rows) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 6>);  // (65536 points: the row tiles as the FFT role; rows of 2048 mask words: the wide emit role)
+  if constexpr (!SPEC) {
+    if (!c->use_fft8192 && c->rows1024x256) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 10>);  // (262144 points: KIND 2 with the plan of layout 3)
+  }
   if (!c->use_fft8192 && c->merge) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 7>);  // (one launch per call: KIND 2's roles and the row tiles as one more; its drains too)
   if (!c->use_fft8192) return a.emit_per_wg == 1 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 2>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 1>);
 #ifdef SS_DIAG
@@ -1022,7 +1050,7 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   if (with_long_plan && c->have_plan) {  // 65536 points: the plan of the call before as a role of this (column) launch
     a.plan_det = c->pend_plan_det;
     a.plan_long = c->pend_plan;
-    a.n_plan_long = ((c->pend_plan.layout == 2 ? ss::plan_dif8_blocks(c->pend_plan_det.nframes, c->pend_plan_det.shift, c->dif_logq) : ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n)) + 1) / 2;
+    a.n_plan_long = (ss::plan_blocks_of(c->pend_plan_det, c->pend_plan, c->n) + 1) / 2;
     c->have_plan = false;
   }
   if (ss::step_items(a) == 0) return;
@@ -1195,8 +1223,7 @@ void launch_nan_stage(ss_ctx* c, const NanStage& g) {
 // The plan of the last call as a launch of its own (it would have ridden on the next call's column launch, ss_ctx::have_plan).
 void launch_pending_plan(ss_ctx* c) {
   if (!c->have_plan) return;
-  const int plan_wgs = c->pend_plan.layout == 2 ? ss::plan_dif8_blocks(c->pend_plan_det.nframes, c->pend_plan_det.shift, c->dif_logq)
-                                                : ss::plan_long_blocks(c->pend_plan.layout, c->pend_plan.cols, c->n);  // (groups past the band's end find no column)
+  const int plan_wgs = ss::plan_blocks_of(c->pend_plan_det, c->pend_plan, c->n);  // (groups past the band's end find no column)
   hipLaunchKernelGGL((ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, c->stream, c->pend_plan_det, c->pend_plan);
   c->have_plan = false;
 }
@@ -1948,7 +1975,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     };
     const bool reused = (c->have_det && clashes(c->pend_det, c->pend_det_emit)) || (c->have_det2 && clashes(c->pend_det2, c->pend_det2_emit));
     if (!overlap || reused) flush_stages(c);
-    const bool rows_by_step = (c->two_pass && c->diag.cols1024_wide) || c->rows256_step;
+    const bool rows_by_step = (c->two_pass && c->diag.cols1024_wide) || c->rows256_step || c->rows1024x256;
     // one launch per call (SS_MERGE_65536): calls that keep no dB plane, in one piece, with stages allowed to overlap; any other call
     // drains what waits in that form and goes the two-launch way
     // (up to 128 frames: two 64 MiB work buffers in flight are what the Infinity Cache holds beside the rest — 256-frame calls lose a tenth
@@ -2024,6 +2051,29 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         rrole.n = nf * 8;
         launch_step(c, &rrole, (first && !det_on_cols && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec,
                     (first && emit_on_rows && c->have_emit) ? &c->pend_emit : nullptr);
+      }
+    } else if (c->rows1024x256) {
+      // 262144 points (round 6): the 65536-point two-launch pipeline — the column launch of call k (256-point column tiles as k_scan_step's
+      // FFT role) carries the plan of call k - 1, detect(k - 2) on the tiles that plan listed and emit(k - 3); the row half is a launch of
+      // k_fft_rows1024_psd<8> that carries nothing. Calls of more than 64 frames go through in chunks (a chunk's work buffer: 128 MiB).
+      const size_t sample = c->cfg.in_format == SS_FMT_CF32 ? 8 : 2;
+      const int chunk = std::min(nframes, 64);
+      for (int f0 = 0; f0 < nframes; f0 += chunk) {
+        const int nf = std::min(chunk, nframes - f0);
+        const bool first = f0 == 0;
+        c->prof_launch_frames = nf;
+        ss::ColsArgs gcc = gc;
+        gcc.iq = static_cast<const char*>(d_iq) + (size_t)f0 * (size_t)item_stride * sample;
+        gcc.abs0 += f0;  // (the column tiles clear the ring words of THEIR frames' run maxima)
+        FftRole crole;
+        crole.cols = &gcc;
+        crole.n = nf * (c->n >> 13);
+        launch_step(c, &crole, (first && c->have_det) ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, (first && c->have_emit) ? &c->pend_emit : nullptr, nullptr, first);
+        ss::RowsExtra rxc = rx;
+        rxc.abs0 += f0;
+        rxc.first_hist -= f0;
+        if (!first) rxc.zero_word = nullptr;
+        launch_rows1024x256(c, nf, (ring_only || !d_psd) ? nullptr : d_psd + (size_t)f0 * (size_t)c->n, rxc);
       }
     } else if (rows_by_step) {
       // 2^20 points: the column half of call k as a launch of its own (16 columns x 1024 rows per 1024-thread workgroup: too many
@@ -2116,7 +2166,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         pl.cols = plan_cols;
         pl.logn = c->logn;
         pl.list = list;
-        pl.layout = c->two_pass ? 1 : dif_call ? 2 : 0;
+        pl.layout = c->two_pass ? 1 : dif_call ? 2 : c->rows1024x256 ? 3 : 0;
         if (merged_call) {  // (not ready before this call's row half has run: one launch from now)
           c->have_plan2 = true;
           c->pend_plan2 = pl;
@@ -2126,7 +2176,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
           c->pend_plan = pl;
           c->pend_plan_det = ss::plan_long_det(nd);
         } else {
-          const int plan_wgs = pl.layout == 2 ? ss::plan_dif8_blocks(nframes, nd.shift, c->dif_logq) : ss::plan_long_blocks(pl.layout, plan_cols, c->n);  // (groups past the band's end find no column)
+          const int plan_wgs = ss::plan_blocks_of(ss::plan_long_det(nd), pl, c->n);  // (groups past the band's end find no column)
           SS_LAUNCH_SLOT(c, SS_KSLOT_PLAN, (ss::k_plan_long<21, 21, kFusedTF, 256>), dim3(plan_wgs), dim3(256), 0, ss::plan_long_det(nd), pl);
         }
         nd.tile_list = list;
@@ -2432,12 +2482,13 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   // (131072 points — what getFft picks at 20 MS/s — have the pipeline of 65536 points where the fold can run at all: int8 IQ, default window)
   const bool fold_ok = c->diag.dif8 && c->diag.emit_wide && c->diag.ring_only && (cfg->in_format == SS_FMT_CS8 || cfg->in_format == SS_FMT_CU8) && !cfg->window &&
                        !(cfg->flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN | SS_FLAG_KEEP_PLANES | SS_FLAG_SPECTROGRAM));
-  c->det_lag2 = !c->deep && c->step_path && (n == 65536 || (n == 131072 && fold_ok)) && !c->diag.fft_generic && c->diag.cull_65536 && c->diag.cull && !(cfg->flags & SS_FLAG_NO_CULL) &&
+  const bool x256_ok = n == 262144 && c->diag.rows1024x256 && c->diag.emit_wide && c->diag.fft_rows_r < 0 && c->diag.fft_sub < 0 && !(cfg->flags & SS_FLAG_SPECTROGRAM);
+  c->det_lag2 = !c->deep && c->step_path && (n == 65536 || (n == 131072 && fold_ok) || x256_ok) && !c->diag.fft_generic && c->diag.cull_65536 && c->diag.cull && !(cfg->flags & SS_FLAG_NO_CULL) &&
                 c->diag.rows256_step && c->diag.step_long && c->diag.det_lag2 && c->fused;
   c->merge = c->det_lag2 && n == 65536 && c->diag.merge_65536 && c->diag.emit_wide;  // (one launch per call: scan_step.h KIND 7, whose emit role is the wide one)
   // ... and with int8 IQ and the default window no work buffer at all: the radix-8 fold (scan_step.h KIND 8). It takes every call the
   // one-launch form above would take — and longer ones — so that form is off then.
-  c->dif8 = c->det_lag2 && fold_ok;
+  c->dif8 = c->det_lag2 && fold_ok && (n == 65536 || n == 131072);
   c->dif_logq = n == 131072 ? 4 : 3;
   c->cull_fold_only = c->dif8 && n == 131072;
   if (c->dif8) c->merge = false;
@@ -2686,12 +2737,15 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   // (57.4 against 56.9 us per 128-frame call now that detect-mode calls write no dB plane, run_batch: ring_only; 57.1 against
   // 53.4 before; 38 against 29 us per 16-frame call either way: profiles/r04/s11_summary.txt, profiles/r03/s53_summary.txt).
   // There only the diagnostics build switches it on (SS_CULL_65536=1; tests/test_gpu_cull.py keeps it honest).
-  c->cull_long = c->step_path && c->use_fft256 && ((n == 65536 && c->diag.cull_65536) || (n > 65536 && c->d_tw_sub && !c->d_tw_rowsR) || c->two_pass || c->cull_fold_only) &&
+  c->x256_tile = n == 262144 && c->use_fft256 && c->d_tw_rowsR != nullptr && c->diag.rows1024x256 && c->diag.fft_rows_r < 0 && c->diag.fft_sub < 0;
+  c->rows1024x256 = c->det_lag2 && c->x256_tile;
+  c->cull_long = c->step_path && c->use_fft256 && ((n == 65536 && c->diag.cull_65536) || (n > 65536 && c->d_tw_sub && !c->d_tw_rowsR) || c->two_pass || c->cull_fold_only || c->rows1024x256) &&
                  !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
+  if (!c->cull_long) c->rows1024x256 = false;
   // 65536 points: with the plan of call k at the front of call k + 1's column launch — which therefore is a launch of its own, the
   // row tiles taking the FFT role of k_scan_step in its place (KIND 6) — the culling pays there too (session 17 of round 4).
   c->rows256_step = c->cull_long && !c->two_pass && c->logn == 16 && c->diag.rows256_step && c->diag.step_long;  // (no emit stage ever rides on the row launch — KIND 6, whose emit role is the wide one — but under SS_EMIT_ON_ROWS)
-  if (!c->rows256_step && !c->cull_fold_only) c->det_lag2 = false;  // (never: the two are decided from the same switches; the rotating buffers sized for it do no harm)
+  if (!c->rows256_step && !c->cull_fold_only && !c->rows1024x256) c->det_lag2 = false;  // (never: the two are decided from the same switches; the rotating buffers sized for it do no harm)
   if (c->dif8 && !c->cull_long) c->dif8 = c->cull_fold_only = false;
   if (c->cull_long) {
     CREATE_HIP(hipMalloc(&c->d_zero_row, sizeof(float) * (size_t)n));  // (what a ring-only call's detect stage subtracts from rows that are noise-relative already)
@@ -2702,6 +2756,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     while (rows < 2 * cfg->max_batch + kHistRows + 1) rows <<= 1;
     c->smax_rows = rows;
     CREATE_HIP(hipMalloc(&c->d_smax, sizeof(float) * (size_t)rows * (size_t)(n / 32)));
+    if (c->rows1024x256) CREATE_HIP(hipMemsetAsync(c->d_smax, 0, sizeof(float) * (size_t)rows * (size_t)(n / 32), c->stream));  // (keys: 0 = nothing seen)
     const size_t max_tiles = ((size_t)cfg->max_batch / kFusedTF + 2) * (size_t)(n / 256);
     for (int k = 0; k < std::max(2, c->nbuf); ++k) CREATE_HIP(hipMalloc(&c->d_tlist[k], sizeof(int) * (max_tiles + 2)));  // (count, entries, one slot behind an odd count)
   }
@@ -2920,8 +2975,10 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
   const size_t row_bytes = (size_t)n * bps;
   if (!c->d_in) SS_HIP(c, hipMalloc(&c->d_in, row_bytes * (size_t)c->cfg.max_batch));
   // Decimator: only the first N samples of each N*D item ever reach the GPU (decimator.h:15-22)
-  SS_HIP(c, hipMemcpy2DAsync(c->d_in, row_bytes, iq, row_bytes * (size_t)c->cfg.decim, row_bytes, (size_t)nframes, hipMemcpyHostToDevice,
-                             c->stream));
+  // (D = 1: the items are one run of bytes — a plain copy. The 2-D form of the runtime takes pageable memory through in small pieces:
+  // 16 frames of 2^20 CF32 samples took 29 ms of a 31.6 ms call that way, against 2.4 ms — 56 GB/s — as one run: profiles/r06/s1_summary.txt)
+  if (c->cfg.decim == 1) SS_HIP(c, hipMemcpyAsync(c->d_in, iq, row_bytes * (size_t)nframes, hipMemcpyHostToDevice, c->stream));
+  else SS_HIP(c, hipMemcpy2DAsync(c->d_in, row_bytes, iq, row_bytes * (size_t)c->cfg.decim, row_bytes, (size_t)nframes, hipMemcpyHostToDevice, c->stream));
   if (cand_cap > c->cand_cap_alloc) {
     (void)hipFree(c->d_cand_idx);
     (void)hipFree(c->d_cand_avg);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512, FRONT >= 3 ? 4 : 8) void k_dif8_lab(ss::Fft819
     ss::fft8192_v2_frame<FMT, 2, true, false, FRONT>(g, (size_t)(16 * f + r), smem_raw, (int)threadIdx.x, &hdr, &d, (size_t)f, r);
     return;
   }
-  if (FRONT == 3) {  // four workgroups per frame (residues r and r + 4 each)
+  if (FRONT == 3 || FRONT == 5) {  // four workgroups per frame (residues r and r + 4 each; 5: the fold as a butterfly per point)
     ss::dif8_item<4>(b, d.nframes, &f, &r);
   } else if (XMAP) {
     ss::dif8_item<8>(b, d.nframes, &f, &r);
@@ -157,8 +157,9 @@ int main(int argc, char** argv) {
       {"LDS-DMA pieces, residues over eight XCDs", 2, 0},
       {"LDS-DMA pieces, TWO residues per workgroup (128 VGPRs), ONE XCD", 3, 1},
       {"131072 points, radix 16, TWO residues per workgroup, ONE XCD", 4, 1},
+      {"LDS-DMA pieces, TWO residues per workgroup, radix-8 BUTTERFLY per point", 5, 1},
   };
-  const int nvariants = 6;
+  const int nvariants = 7;
   const auto launch = [&](const Variant& v, int set, int frames, hipEvent_t e0, hipEvent_t e1) {
     ss::Fft8192Args g{};
     g.tabs = tabs;
@@ -169,9 +170,10 @@ int main(int argc, char** argv) {
     d.smax = d_seg[set];
     d.smax_mask = 1023;
     d.nframes = frames;
-    const dim3 grid((v.front == 3 ? 4 : 8) * frames), block(512);  // (radix 16, two residues each: eight per frame too)
+    const dim3 grid((v.front == 3 || v.front == 5 ? 4 : 8) * frames), block(512);  // (radix 16, two residues each: eight per frame too)
 #define GO(FRONT, XMAP) hipExtLaunchKernelGGL((k_dif8_lab<ss::FMT_CS8, FRONT, XMAP>), grid, block, ss::kFft8192V2LdsBytes, st, e0, e1, 0, g, d)
     if (v.front == 4) GO(4, 1);
+    else if (v.front == 5) GO(5, 1);
     else if (v.front == 3) GO(3, 1);
     else if (v.front == 1 && v.xmap == 1) GO(1, 1);
     else if (v.front == 2 && v.xmap == 1) GO(2, 1);

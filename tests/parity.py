@@ -200,9 +200,15 @@ def all_bins_vs_fp64(iq, got_psd, ref_psd, fs, max_rows=None):
         return None
     de = np.abs(got_psd[rows].astype(np.float64) - truth)[fin]
     dr = np.abs(ref_psd[rows].astype(np.float64) - truth)[fin]
-    q = lambda e: {"rms": float(np.sqrt(np.mean(e ** 2))), "p99.9": float(np.quantile(e, 0.999)), "max": float(e.max())}  # noqa: E731
+    # (the rms of |dB - fp64| has a heavy tail — a deep null's error is its fp32-floor error times the null's depth: on the benchmark's band
+    # the five largest of half a million bins hold 15-45 % of the sum of squares, scripts/fft8192_accuracy_model.py — so the ratio of the
+    # rms values moves by +-0.2 with the data; the median and the 99th percentile beside it say what is systematic)
+    q = lambda e: {"rms": float(np.sqrt(np.mean(e ** 2))), "median": float(np.median(e)), "p99": float(np.quantile(e, 0.99)), "p99.9": float(np.quantile(e, 0.999)), "max": float(e.max()),  # noqa: E731
+                   "top5_share_of_squares": float(np.sum(np.sort(e)[-5:] ** 2) / max(np.sum(e ** 2), 1e-300))}
     out = {"rows": int(rows.size), "bins": int(fin.sum()), "engine": q(de), "reference": q(dr)}
     out["engine_over_reference_rms"] = out["engine"]["rms"] / max(out["reference"]["rms"], 1e-30)
+    out["engine_over_reference_median"] = out["engine"]["median"] / max(out["reference"]["median"], 1e-30)
+    out["engine_over_reference_p99"] = out["engine"]["p99"] / max(out["reference"]["p99"], 1e-30)
     return out
 
 
@@ -211,7 +217,8 @@ def format_all_bins(v):
         return "no finite bins"
     e, r = v["engine"], v["reference"]
     return (f"all {v['bins']} ordinary bins of {v['rows']} rows against an fp64 FFT of the same windowed frames: engine rms {e['rms']:.2e} p99.9 {e['p99.9']:.1e} max {e['max']:.1e}; "
-            f"reference's fp32 FFT rms {r['rms']:.2e} p99.9 {r['p99.9']:.1e} max {r['max']:.1e} dB; engine / reference rms {v['engine_over_reference_rms']:.2f}")
+            f"reference's fp32 FFT rms {r['rms']:.2e} p99.9 {r['p99.9']:.1e} max {r['max']:.1e} dB; engine / reference rms {v['engine_over_reference_rms']:.2f}, "
+            f"median {v['engine_over_reference_median']:.2f}, p99 {v['engine_over_reference_p99']:.2f} (the five largest bins hold {e['top5_share_of_squares']:.0%} / {r['top5_share_of_squares']:.0%} of the squares)")
 
 
 def excess_vs_fp64_rel(iq, got_rel, ref_rel, fs, n_learn, max_rows=256):

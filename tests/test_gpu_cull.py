@@ -232,6 +232,31 @@ def test_long_rows_device_calls_without_sync_culled_equal_unculled(cull_65536, n
     _device_calls_culled_equal_unculled(65536, 20_000_000, nb, ncalls)
 
 
+@pytest.mark.parametrize("nb,ncalls", [(32, 7), (16, 12), (80, 4), (11, 9)])
+def test_long_rows_262144_device_calls_without_sync_culled_equal_unculled(nb, ncalls):
+    """262144 points — the size getFft picks at 61.44 MS/s — through round 6's path: 256-point column tiles, the 1024-point row tile with
+    run maxima (a value per 8 bins, plan layout 3) and ring rows, the 65536-point two-launch pipeline (plan of call k - 1, detect(k - 2)
+    and emit(k - 3) on the column launch of call k). 80-frame calls go through in chunks of 64; 11-frame calls do not start on a tile
+    boundary and slide the ring's window along its buffer."""
+    _device_calls_culled_equal_unculled(1 << 18, 61_440_000, nb, ncalls, min_candidates=2_000)
+
+
+def test_long_rows_262144_host_calls_retune_reset_and_degenerate_frames():
+    n, fs, nframes = 1 << 18, 61_440_000, 150
+    band = pkg.synth.SyntheticBand(n, seed=53, on_frame=40, off_frame=140, rel_db=19.0, centres=(0.05, -0.11, 0.23, -0.31, 0.37, -0.45, 0.49))
+    iq = band.frames_cf32(nframes)
+    iq[60] = 0           # -inf rows
+    iq[75, :100] = np.nan
+    iq[85] *= 1e15
+    cuts = [0, 30, 62, 63, 95, 110, 128, 150]
+    res = {}
+    for name, flags in (("cull", 0), ("nocull", pkg.abi.SS_FLAG_NO_CULL)):
+        res[name] = _long_session(n, fs, iq, cuts, flags, pkg.abi.SS_FMT_CF32, retune_at=(95,), reset_at=(128,), learn_frames=20)
+    _same(res["cull"][0], res["nocull"][0])
+    assert np.array_equal(res["cull"][1], res["nocull"][1], equal_nan=True)
+    assert sum(len(x) for x in res["cull"][0]) > 1_000
+
+
 # the forms the 65536- and 2^20-point chains went through in round 4 (switches of the diagnostics build, DESIGN.md 4.4 / 8; SS_DIF8=0:
 # int8 input through the four-step chain, as CF32 input still goes): each of them in detect mode with calls in flight, culled == unculled
 @pytest.mark.parametrize("env,n,fs,nb,ncalls", [
@@ -248,6 +273,8 @@ def test_long_rows_device_calls_without_sync_culled_equal_unculled(cull_65536, n
     ({"SS_LIST_FIRST_FOLD": "65"}, 65536, 20_000_000, 128, 7),
     ({"SS_LIST_FIRST_FOLD": "1", "SS_STEP_ORDER": "F*,E*,D*"}, 65536, 20_000_000, 48, 9),
     ({"SS_STEP_ORDER": "D64,F*,E*,P*,D*"}, 65536, 20_000_000, 128, 7),
+    # 262144 points (round 6): the plan as a launch of its own, every listed pair behind the column tiles
+    ({"SS_PLAN_FUSED": "0", "SS_LIST_FIRST": "0"}, 1 << 18, 61_440_000, 32, 6),
 ], ids=lambda v: "-".join(f"{k}={x}" for k, x in v.items()) if isinstance(v, dict) else str(v))
 def test_long_rows_intermediate_forms_culled_equal_unculled(cull_65536, monkeypatch, env, n, fs, nb, ncalls):
     for k, v in env.items():
@@ -288,9 +315,11 @@ def _cull_scenario(seed):
     n = [8192, 65536, 8192, 65536, 1 << 20][seed % 5] if seed % 10 != 9 else 16384  # (16384: a long transform without culling support)
     if seed % 10 == 7:
         n = 131072  # (round 5: the size getFft picks at 20 MS/s — int8 sessions go through the radix-16 fold, CF32 sessions through round 2's path)
-    fs = {8192: 2_048_000, 16384: 4_096_000, 65536: 20_000_000, 131072: 20_000_000, 1 << 20: 61_440_000}[n]
-    nframes = {8192: int(rng.integers(300, 700)), 16384: 200, 65536: int(rng.integers(120, 260)), 131072: int(rng.integers(100, 180)), 1 << 20: 72}[n]
-    max_batch = {8192: int(rng.choice([64, 200, 512])), 16384: 64, 65536: int(rng.choice([16, 48, 128])), 131072: int(rng.choice([16, 40, 64])), 1 << 20: 16}[n]
+    if seed % 10 == 3:
+        n = 1 << 18  # (round 6: the size getFft picks at 61.44 MS/s — 256-point columns, the 1024-point row tile, plan layout 3)
+    fs = {8192: 2_048_000, 16384: 4_096_000, 65536: 20_000_000, 131072: 20_000_000, 1 << 18: 61_440_000, 1 << 20: 61_440_000}[n]
+    nframes = {8192: int(rng.integers(300, 700)), 16384: 200, 65536: int(rng.integers(120, 260)), 131072: int(rng.integers(100, 180)), 1 << 18: int(rng.integers(90, 150)), 1 << 20: 72}[n]
+    max_batch = {8192: int(rng.choice([64, 200, 512])), 16384: 64, 65536: int(rng.choice([16, 48, 128])), 131072: int(rng.choice([16, 40, 64])), 1 << 18: int(rng.choice([16, 32, 72])), 1 << 20: 16}[n]
     fmt = str(rng.choice(["cf32", "cs8"])) if n < (1 << 20) else "cs8"
     if n == 131072 and seed % 20 == 7:
         fmt = "cs8"
