@@ -12,13 +12,15 @@ running under a launcher. Bands shard across ranks (`--shard bands`, config 4) o
 contiguous ranges (`--shard frames`, config 5); there is no data-path collective either way, the scan configuration is
 broadcast once from rank 0.
 
-Prints ONE JSON line on rank 0:
+Prints ONE JSON line on rank 0 — a compact form of a few KB (compact_line: the contract's keys, roofline, cpu_baseline, a parity verdict
+and one short record per `also` entry); everything below in full goes to bench_full.json beside this file:
   value / ms_per_step   whole-job throughput, barrier + device sync on both sides of exactly --steps steps, max over ranks
   roofline              the dominant kernel (k_scan_step): algorithmic bytes per launch / its mean device time from start/stop
-                        events attached to launches on the engine's own streams inside the timed region. Consecutive launches
-                        overlap on two queues, so a launch lasts ~2x the time the GPU spends per launch: kernel_us is the
-                        measured mean duration (what rocprofv3 --stats reports), launches_in_flight = kernel_us / wall time
-                        per launch, achieved = bytes / (kernel_us / launches_in_flight)
+                        events attached to launches on the engine's own streams — in 32 more steps right behind the timed region
+                        (an event-timed launch costs its queue ~13 us: none rides inside the timed region; --time-every k puts
+                        them there). Consecutive launches overlap on two queues, so a launch lasts ~2x the time the GPU spends
+                        per launch: kernel_us is the measured mean duration (what rocprofv3 --stats reports), launches_in_flight
+                        = kernel_us / wall time per launch, achieved = bytes / (kernel_us / launches_in_flight)
   roofline.traffic      (default line, one GPU) fabric bytes per launch of that kernel, counted on this box: behind the timed region the
                         process runs its own command line once more under `rocprofv3 --pmc FETCH_SIZE` and under `--pmc WRITE_SIZE`
                         (two short passes); traffic_over_algorithmic = wasted re-reads, traffic_gbs = the counted bytes per second of
@@ -247,10 +249,12 @@ def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False, call_frames:
     # ---- the timed path: device calls, nothing synchronised in between ----
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
-    if call_frames and call_frames != chunk and n >= 65536:
+    own_stream = bool(call_frames and call_frames != chunk and (n >= 65536 or (n == 8192 and call_frames >= 512)))
+    if own_stream:
         # the timed region's call size: a stream of its own (the learning frames, then whole calls), the reference's code over all of it
+        # (8192 points, round 6: the headline's own 1024-frame calls, two of them behind the learning call — candidates only, ~0.3 s of the reference's code)
         chunk = call_frames
-        ncalls = 5 if n * call_frames <= (1 << 23) else (4 if n * call_frames <= (1 << 24) else 2)
+        ncalls = 2 if n == 8192 else (5 if n * call_frames <= (1 << 23) else (4 if n * call_frames <= (1 << 24) else 2))
         nframes = n_learn + ncalls * chunk
         band = pkg.synth.SyntheticBand(n, seed=78, on_frame=n_learn + 25, off_frame=nframes - 20)
         raw = band.frames_cs8(nframes) if fmt == "cs8" else (band.frames_cu8(nframes) if fmt == "cu8" else band.frames_cf32(nframes))
@@ -281,10 +285,12 @@ def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False, call_frames:
     for a, b in cuts:
         x = raw[a:b]
         d_iq.append(torch.from_numpy(x.view(np.float32) if x.dtype == np.complex64 else x).to(dev))
-        d_out.append(dict(off=torch.zeros(b - a + 1, dtype=torch.int32, device=dev), idx=torch.empty((b - a) * 1024, dtype=torch.int32, device=dev)))
+        d_out.append(dict(off=torch.zeros(b - a + 1, dtype=torch.int32, device=dev), idx=torch.empty((b - a) * 1024, dtype=torch.int32, device=dev),
+                          # (8192 points at the timed call size: the dB plane handed out like the timed region's — power mode)
+                          psd=torch.empty((b - a, n), dtype=torch.float32, device=dev) if (own_stream and n == 8192) else None))
     torch.cuda.synchronize()
     for d, o in zip(d_iq, d_out):
-        eng.process_device(d, d.shape[0], cand_off=o["off"], cand_idx=o["idx"])
+        eng.process_device(d, d.shape[0], psd=o["psd"], cand_off=o["off"], cand_idx=o["idx"])
     eng.sync()
     st = eng.stats()
     offs = [o["off"].cpu().numpy() for o in d_out]
@@ -296,7 +302,7 @@ def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False, call_frames:
     outside = [(f, i) for (f, i) in a_ ^ b_ if not near[f, i]]
     if outside:
         raise AssertionError(f"timed path: candidate lists differ from the reference outside the {BAND} dB band: {sorted(outside)[:6]}")
-    res["timed_path"] = {"what": f"{len(cuts)} ss_process_device calls of <= {chunk} frames, candidates only, no synchronisation in between", "reference_candidates": len(b_),
+    res["timed_path"] = {"what": f"{len(cuts)} ss_process_device calls of <= {chunk} frames, {'dB plane handed out, candidates compared' if (own_stream and n == 8192) else 'candidates only'}, no synchronisation in between", "reference_candidates": len(b_),
                          "inside_1e-3_dB_band": len(a_ ^ b_), "calls_overlapped": st["calls_overlapped"], "tiles_total": st["tiles_total"],
                          "tiles_tested": st["tiles_tested"], "tiles_culled": st["tiles_culled"], "wait_fallbacks": st["wait_fallbacks"]}
     return res
@@ -511,7 +517,7 @@ def parse_args(argv):
     ap.add_argument("--decim", type=int, default=1, help="frame decimation D: items of N*D samples, the first N of each are scanned (reference: 5 at 2.048 MS/s)")
     ap.add_argument("--sync-every-step", action="store_true", help="ss_sync after every step: no overlap between consecutive calls (what a caller that reads every result before the next call sees)")
     ap.add_argument("--sets", type=int, default=0, help="input batches / output sets in rotation (0 = enough to exceed 2.5x the Infinity Cache, at least 6)")
-    ap.add_argument("--time-every", type=int, default=0, help="attach start/stop events to every k-th launch of the FFT kernel (0 = pick so that >= 8 launches are timed)")
+    ap.add_argument("--time-every", type=int, default=0, help="attach start/stop events to the launches of every k-th call INSIDE the timed region (0 = none there: the launches are timed in 32 more steps behind it)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not attach per-launch events to the FFT kernel (roofline omitted)")
     ap.add_argument("--preheat-ms", type=float, default=400.0, help="run untimed steps for this long before the W warm-up steps: the GPU's clocks take a few hundred steps to settle (a cold start reads ~10 %% slow)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -891,13 +897,13 @@ def run(args):
     for _ in range(max(args.warmup, 1)):
         step()
     eng.sync()
+    # No event-timed launch inside the timed region (round 6): each one costs its queue ~13 us (the start packet ~7 us before it, the stop
+    # packet ~6 us before the queue's next launch: profiles/r03/s37_timeline_k20.txt) — one was 2.7 % of the driver's 20-step run, and a
+    # chain of two launches per call with every 8th call sampled paid 3 us per call (5 % of a 65 us call of 262144 points). The launches
+    # are timed in 32 more steps right behind the timed region instead (below); --time-every k puts events on every k-th call inside it.
     every = 0
-    short_run = args.steps <= 32
-    if not args.no_kernel_timing and not short_run:
-        # each timed launch costs its queue ~13 us (the start packet ~7 us before it, the stop packet ~6 us before the queue's next
-        # launch: profiles/r03/s37_timeline_k20.txt): every 8th launch in a long run (25 samples in 200 steps). A run of up to 32 steps
-        # (the driver's form) carries NO events inside its timed region: its launches are timed in 32 more steps right behind it.
-        every = args.time_every or 8
+    if not args.no_kernel_timing and args.time_every > 0:
+        every = args.time_every
         eng.kernel_timing(every)
     dist.barrier()
     torch.cuda.synchronize()
@@ -919,11 +925,10 @@ def run(args):
         slots = eng.kernel_timing_read_frames()  # {slot: (ms, launches, frames those launches covered)}
         kern_ms, launches, _ = slots["step"]
         eng.kernel_timing(0)
-    # A run of up to 32 steps has no event-timed launch inside its timed region (each costs its queue ~13 us: one was 2.7 % of a 20-step
-    # run). Right behind the timed region — same clocks, same working set, nothing of it inside — 32 more steps with every 4th launch
-    # timed give eight samples per kernel of the chain; they are what roofline.kernel_us is made of in such a run.
+    # Right behind the timed region — same clocks, same working set, nothing of it inside — 32 more steps with every 4th call's launches
+    # timed give eight samples per kernel of the chain; they are what roofline.kernel_us is made of.
     kern_after = None
-    if short_run and not args.no_kernel_timing:
+    if not args.no_kernel_timing and not every:
         eng.kernel_timing(4)
         for _ in range(32):
             step()
@@ -933,7 +938,7 @@ def run(args):
         eng.kernel_timing(0)
         every = 4
         if launches:
-            kern_after = {"us": round(kern_ms / launches * 1e3, 2), "launches": launches, "what": "32 more steps right behind the timed region, every 4th launch timed"}
+            kern_after = {"us": round(kern_ms / launches * 1e3, 2), "launches": launches, "what": "32 more steps right behind the timed region, every 4th call's launches timed"}
     elapsed = dist.max_over_ranks(t1 - t0, device=coll_dev)
     devices_of_ranks = dist.ints_of_ranks(device_index, device=coll_dev)  # (rank r -> the device it worked on: LOCAL_RANK modulo the box's device count)
     cands_of_ranks = dist.ints_of_ranks(int(outs[(counter[0] - 1) % nout]["off"][-1].item()), device=coll_dev)

@@ -335,13 +335,12 @@ __device__ __forceinline__ void plan_tiles(const DetectArgs& a, int seg, int col
     tm = a.thr_tilemin[col];
     // (eight loads in flight per trip: one after the other — load, wait, store, sixteen times for a 1024-frame batch — the copy alone
     // took the plan workgroups 8-13 us, and the launch's frame workgroups are through after 12: they wait for this list)
-    // (round 6: sixteen at a time — ONE round trip for a 1024-frame batch, the halo frames' maxima in the same flight: with two trips of
-    // eight the plan workgroups were through after 11-12 us, the frame workgroups ask for their list's count 9-11 us into the launch, most
-    // were told "not ready" and polled for it when their frame was done, profiles/r05/s37_summary.txt)
+    // (round 6 tried sixteen at a time — ONE round trip for a 1024-frame batch: 23.2 against 22.8-23.1 us per step in alternating runs,
+    // profiles/r06/s4_summary.txt: no gain, the frame workgroups do not wait for the plan as a rule; SS_PLAN_COPY_LOADS=16 keeps the form)
     float hm = 0.0f;
     if (lane < before) hm = a.halo_segsum[col * kHaloSegPitch + (a.halo_rows - before) + lane];
-#ifndef SS_PLAN_COPY_LOADS  // (A/B builds, scripts/build_ab.py: 8 = round 5's two trips)
-#define SS_PLAN_COPY_LOADS 16
+#ifndef SS_PLAN_COPY_LOADS  // (A/B builds, scripts/build_ab.py: 16 = one trip)
+#define SS_PLAN_COPY_LOADS 8
 #endif
     for (int fb = 0; fb < nframes; fb += 64 * SS_PLAN_COPY_LOADS) {
       float v[SS_PLAN_COPY_LOADS];
@@ -1119,10 +1118,11 @@ __device__ __forceinline__ int tile_column_of(int pass_c, int tid) {
 // `tile` / `cnt` = this tile's LDS (TF * P floats, TF ints). `valid` = false: the caller has no tile for these threads (odd
 // tile count in a two-tile workgroup) — they only keep the workgroup's barriers company. Every __syncthreads() below is
 // reached by all threads of the workgroup whatever `valid`, `steady` or `interior` are.
-// PERM8 (0, or log2 of the fold's radix: 3, 4): the rows the tile reads (a.psd, the ring) and writes (the ring) are RESIDUE-MAJOR rows of
-// 8192 Q bins — bin i at (i mod Q) * 8192 + i / Q, fft65536_dif8.h: the rows the radix-Q fold leaves; calls that hand out no plane only
-// (no rel_out). A lane's 36 row loads then sit in Q runs of 256 / Q bytes per wave instead of one of 256; everything else — the noise
-// ceiling, the pass mask, mask bits, sparse averages — stays in bin order.
+// PERM8 (0, or log2 of the fold's radix: 3, 4): the rows the tile reads (a.psd, the ring) and writes (the ring) are the radix-Q fold's rows
+// of 8192 Q bins in BLOCKS of 32 Q bins — bin Q k' + g at (k' / 32) * 32 Q + 32 g + k' % 32 (fft65536_dif8.h: dif_bin_offset; dB values
+// from ring_db_from on) —; calls that hand out no plane only (no rel_out). A tile's thread g * 32 + j takes the bin 8 j + g: a wave's 36
+// row loads are 256 contiguous bytes (Q = 8) or four runs of 64 (Q = 16); everything else — the noise ceiling, the pass mask, mask bits,
+// sparse averages — stays in bin order.
 template <int G, int GX, int TF, int TB_ = 256, bool SPEC = false, int PERM8 = 0>
 __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int tid, float* __restrict__ tile, int* __restrict__ cnt, bool valid) {
   using T = DetectTile<G, GX, TF, TB_>;

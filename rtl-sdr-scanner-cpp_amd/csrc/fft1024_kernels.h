@@ -202,7 +202,7 @@ __device__ __forceinline__ void fft_cols1024_tile(const ColsArgs& g, int block, 
       const float2 tw = kap == 0 ? pu : cmul(pu, kap == 1 ? g1 : kap == 2 ? g2 : g3);
       const float2 y = cmul(a[4 * u + kap], tw);
       if ((SS_C1024_ABL & 2) && y.x != 12345.678f) continue;
-      __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned*>(&y), rw, voff, ((64 * u + 256 * kap) << 10) * 8, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const __attribute__((ext_vector_type(2))) unsigned*>(&y), rw, voff, ((64 * u + 256 * kap) << 10) * 8, SS_AUX_WORK);
     }
     if (u < 3) pu = cmul(pu, t64);
   }
@@ -348,7 +348,7 @@ __device__ __forceinline__ void fft_rows1024_tile(const Rows1024Args& g, int blo
   constexpr int ISH = LOGN1 + 6;  // (64 k2 further on: 64 << LOGN1 bins)
   if (out) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) out[bin0 ^ (i << ISH)] = s[(kb + 64 * i) * 9 + rr];
+    for (int i = 0; i < 16; ++i) store_f1_policy<SS_AUX_ROWS>(&out[bin0 ^ (i << ISH)], s[(kb + 64 * i) * 9 + rr]);
   }
   if (hrow) {
     // The sixteen ceiling values FIRST, all in flight together, then the sixteen stores. (Until session 16 of round 4 the loop was
@@ -360,13 +360,13 @@ __device__ __forceinline__ void fft_rows1024_tile(const Rows1024Args& g, int blo
     // evaluated subtract the ceiling, DetectArgs::ring_db_from)
     if (!x.thr) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) hrow[bin0 ^ (i << ISH)] = s[(kb + 64 * i) * 9 + rr];
+      for (int i = 0; i < 16; ++i) store_f1_policy<SS_AUX_ROWS>(&hrow[bin0 ^ (i << ISH)], s[(kb + 64 * i) * 9 + rr]);
     } else {
       float th[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) th[i] = x.thr[bin0 ^ (i << ISH)];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) hrow[bin0 ^ (i << ISH)] = s[(kb + 64 * i) * 9 + rr] - th[i];  // noise_learner.cpp:55, as detect_tile forms it
+      for (int i = 0; i < 16; ++i) store_f1_policy<SS_AUX_ROWS>(&hrow[bin0 ^ (i << ISH)], s[(kb + 64 * i) * 9 + rr] - th[i]);  // noise_learner.cpp:55, as detect_tile forms it
     }
   }
 }

@@ -60,6 +60,33 @@ __device__ __forceinline__ void fft256_passes(float2 (&a)[16], float2 (&c)[16], 
   dft16(c);  // X[j + 16 k] in c[slot16(k)]
 }
 
+// Cache policy of the long transforms' big stores — the column tiles' work buffer (SS_AUX_WORK) and the row tiles' dB / ring rows
+// (SS_AUX_ROWS): 0 = the default write-back policy (ships), 16 = sc1, write-through, as the 8192-point kernel's dB rows (fft8192_v2.h
+// SS_AUX_PSD), 2 = nt. Measured in round 6 (profiles/r06/s5_summary.txt, alternating runs): write-through LOSES here — the row tiles
+// store 32-byte runs that four workgroups of one XCD complete to 128-byte lines in their L2, and written through every piece goes to
+// memory by itself: row launch 22.6 -> 32.6 us per 32 frames of 262144 points, 43 -> 60 us per 16 frames of 2^20; the work buffer
+// (whole lines) a wash: column launch 35.0 -> 33.6 us at 262144 points, 57.7 -> 59.4 at 2^20. Build-time switches (scripts/build_ab.py).
+#ifndef SS_AUX_WORK
+#define SS_AUX_WORK 0
+#endif
+#ifndef SS_AUX_ROWS
+#define SS_AUX_ROWS 0
+#endif
+template <int AUX>
+__device__ __forceinline__ void store_f1_policy(float* p, float v) {
+  if constexpr (AUX == 16) asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  else if constexpr (AUX == 2) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+template <int AUX>
+__device__ __forceinline__ void store_f2_policy(float2* p, float2 v) {
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  const f2v vv = {v.x, v.y};
+  if constexpr (AUX == 16) asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(vv) : "memory");
+  else if constexpr (AUX == 2) __builtin_nontemporal_store(vv, reinterpret_cast<f2v*>(p));
+  else *p = v;
+}
+
 struct ColsArgs {
   const void* iq;
   long long item_stride;
@@ -172,7 +199,7 @@ __device__ __forceinline__ void fft_cols256_tile(const ColsArgs& g, int block, u
       const float2 wa = a == 1 ? wa1 : a == 2 ? wa2 : wa3, wb = b == 1 ? wb1 : b == 2 ? wb2 : wb3;
       y = cmul(y, a == 0 ? wb : b == 0 ? wa : cmul(wa, wb));
     }
-    *reinterpret_cast<float2*>(wf + 8u * ((k1 << logn2) + (uint32_t)n2)) = y;
+    store_f2_policy<SS_AUX_WORK>(reinterpret_cast<float2*>(wf + 8u * ((k1 << logn2) + (uint32_t)n2)), y);
   }
 #else
 #pragma unroll
@@ -294,7 +321,7 @@ __device__ __forceinline__ void fft_rows256_tile(const Rows256Args& g, int block
   const auto bin_of = [&](int i) { return ((r0 + rr) + (c << 8) + ((kb + 16 * i) << log_row)) ^ half; };
   if (psd) {  // (null: a call that keeps no dB plane, specscan.hip run_batch)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) out[bin_of(i)] = s[(kb + 16 * i) * 33 + rr];
+    for (int i = 0; i < 16; ++i) store_f1_policy<SS_AUX_ROWS>(&out[bin_of(i)], s[(kb + 16 * i) * 33 + rr]);
   }
   if (hrow) {
     // the ceiling values first, all in flight together, then the stores: load, subtract, store per output is what the compiler keeps
@@ -302,13 +329,13 @@ __device__ __forceinline__ void fft_rows256_tile(const Rows256Args& g, int block
     // load and for the store before it (fft1024_kernels.h: fft_rows1024_tile)
     if (!x.thr) {  // (workgroup-uniform) the rows leave as dB values: the tiles that are evaluated subtract the ceiling (DetectArgs::ring_db_from)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) hrow[bin_of(i)] = s[(kb + 16 * i) * 33 + rr];
+      for (int i = 0; i < 16; ++i) store_f1_policy<SS_AUX_ROWS>(&hrow[bin_of(i)], s[(kb + 16 * i) * 33 + rr]);
     } else {
       float th[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) th[i] = x.thr[bin_of(i)];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) hrow[bin_of(i)] = s[(kb + 16 * i) * 33 + rr] - th[i];  // noise_learner.cpp:55, as detect_tile forms it
+      for (int i = 0; i < 16; ++i) store_f1_policy<SS_AUX_ROWS>(&hrow[bin_of(i)], s[(kb + 16 * i) * 33 + rr] - th[i]);  // noise_learner.cpp:55, as detect_tile forms it
     }
   }
 }

@@ -24,10 +24,12 @@
 // — two FMAs per sample with literal constants. Behind the loop  a[rho] = acc[rho] * W_N^(t r) * W_128^(rho r)  (a per-thread table
 // entry and sixteen wave-uniform ones): sixteen vector instructions per pair of samples on top of the transform's own.
 //
-// The bins of residue r leave the transform in the order k' — X[8 k' + r], k' = 0 .. 8191 — and are stored that way: a frame's
-// row is RESIDUE-MAJOR, eight runs of 8192 floats, bin i (DC in the middle: fft_v's shift) at (i & 7) * 8192 + (i >> 3). (The
-// half rotation adds N/2 = 0 mod 8 to a bin number: it stays inside the residue and becomes the 8192-point transform's own half
-// rotation.) Whoever reads such rows — the detect tiles, ss_read_window — permutes the bin number; nothing is transposed.
+// The bins of residue r leave the transform in the order k' — X[8 k' + r], k' = 0 .. 8191 — and a frame's row holds them in BLOCKS of
+// 32 Q bins: the 32 consecutive k' of every residue side by side, bin Q k' + g (DC in the middle: fft_v's shift) at
+// (k' / 32) * 32 Q + 32 g + k' % 32 (dif_bin_offset below; until session 28 of round 5 the rows were residue-major, bin i at
+// (i & 7) * 8192 + (i >> 3)). (The half rotation adds N/2 = 0 mod 8 to a bin number: it stays inside the residue and becomes the
+// 8192-point transform's own half rotation.) Whoever reads such rows — the detect tiles, ss_read_window — permutes the bin number;
+// nothing is transposed. The rows hold dB values (the tiles that are evaluated subtract the noise ceiling: DetectArgs::ring_db_from).
 //
 // How the samples reach the threads: LOADV = 0 — 128 two-byte loads per thread straight from global memory (each wave-load is
 // one 128-byte line); LOADV = 1 — the frame comes through LDS in eight pieces of 16 KiB (eight values of rho x {q, q + 4}: sixteen
@@ -516,6 +518,146 @@ __device__ __forceinline__ void dif8_front2_bfly(const Dif8Front& d, size_t fram
   }
   __syncthreads();  // the plane goes back to the transform
   const float2 wt = d.wt[R * 512 + t], wt2 = d.wt[(R + 4) * 512 + t];
+#pragma unroll
+  for (int rho = 0; rho < 16; ++rho) {
+    a[rho] = cmul(a[rho], cmul(wt, make_float2(crho[2 * rho], crho[2 * rho + 1])));
+    a2[rho] = cmul(a2[rho], cmul(wt2, make_float2(crho2[2 * rho], crho2[2 * rho + 1])));
+  }
+}
+
+// ... and the radix-16 fold (131072 points, residues R < 8 and R + 8) the same way: all SIXTEEN samples of a point at once,
+//     s_q = w[m] x[m] + (-1)^R w[m'] x[m']   (q < 8, m' = m + 65536),
+//     A = s_0 + (-i)^R s_4,  B = s_2 + (-i)^R s_6,  C = s_1 + (-i)^R s_5,  D = s_3 + (-i)^R s_7       (four shapes of R mod 4: scalar branches)
+//     E = A + W_8^R B,       O = W_16^R (C + W_8^R D),       y_R = E + O,   y_(R+8) = E - O          (two complex constants in scalar registers)
+// 24 vector instructions per point for the sums where the accumulating form spends 64 (eight pairs x two residues x four FMAs); with the
+// conversions, taps and pair sums (96) 120 instead of 160 per point. The taps of sixteen samples would need thirty-two rotated table
+// entries in registers; instead every tap is 0.54 + c cos theta_t + s sin theta_t with (c, s) = (-0.46 cos Phi, 0.46 sin Phi),
+// Phi = 2 pi (512 rho + 8192 q) / 131071, as LITERALS (kDif16TapC / kDif16TapS, rounded once from fp64) — two FMAs per sample as before.
+// A piece of LDS-DMA is one run rho x sixteen q (wave w fetches q = w and q = w + 8).
+__device__ constexpr float kDif16TapC[16][16] = {
+    {-0.460000008f, -0.424984068f, -0.325267166f, -0.176030561f, 5.51278572e-06f, 0.176040739f, 0.325274974f, 0.42498827f, 0.460000008f, 0.424979836f, 0.325259387f, 0.176020369f, -1.65383572e-05f, -0.176050931f, -0.325282753f, -0.424992502f},
+    {-0.459861457f, -0.420535892f, -0.317186594f, -0.165547773f, 0.0112945624f, 0.186417386f, 0.333159417f, 0.429180205f, 0.459861189f, 0.420531422f, 0.317178607f, 0.165537491f, -0.0113055846f, -0.186427459f, -0.333167017f, -0.429184169f},
+    {-0.459445894f, -0.415834397f, -0.308914959f, -0.154965281f, 0.0225768089f, 0.196681723f, 0.340843201f, 0.433113575f, 0.459445357f, 0.415829688f, 0.308906794f, 0.154954895f, -0.0225878209f, -0.196691692f, -0.340850592f, -0.4331173f},
+    {-0.458753586f, -0.410882443f, -0.300457239f, -0.144289434f, 0.0338454545f, 0.206827596f, 0.348321646f, 0.436786056f, 0.458752781f, 0.410877496f, 0.300448865f, 0.144278958f, -0.0338564515f, -0.206837445f, -0.348328829f, -0.436789542f},
+    {-0.457784951f, -0.405682981f, -0.2918185f, -0.133526668f, 0.0450937152f, 0.21684888f, 0.355590284f, 0.440195441f, 0.457783848f, 0.405677766f, 0.291809976f, 0.133516118f, -0.0451046862f, -0.216858611f, -0.355597258f, -0.44019866f},
+    {-0.456540525f, -0.40023911f, -0.283004016f, -0.122683465f, 0.0563148111f, 0.226739541f, 0.362644702f, 0.443339676f, 0.456539184f, 0.400233686f, 0.282995313f, 0.122672841f, -0.0563257523f, -0.226749137f, -0.362651497f, -0.443342626f},
+    {-0.455021113f, -0.394554198f, -0.274019063f, -0.111766368f, 0.0675019845f, 0.236493617f, 0.369480699f, 0.446216851f, 0.455019504f, 0.394548506f, 0.274010181f, 0.111755677f, -0.0675128922f, -0.23650308f, -0.369487256f, -0.446219534f},
+    {-0.453227609f, -0.388631582f, -0.264869034f, -0.100781947f, 0.0786484927f, 0.246105239f, 0.376094133f, 0.44882524f, 0.453225732f, 0.388625681f, 0.264860004f, 0.100771189f, -0.0786593556f, -0.246114552f, -0.376100481f, -0.448827654f},
+    {-0.451161087f, -0.382474869f, -0.255559444f, -0.0897368193f, 0.0897476301f, 0.255568624f, 0.382481009f, 0.451163232f, 0.451158941f, 0.38246876f, 0.255550265f, 0.089726001f, -0.0897584409f, -0.255577773f, -0.382487118f, -0.451165408f},
+    {-0.448822796f, -0.376087785f, -0.246095926f, -0.0786376297f, 0.100792706f, 0.264878035f, 0.388637483f, 0.453229487f, 0.448820382f, 0.376081437f, 0.246086612f, 0.0786267668f, -0.100803465f, -0.264887065f, -0.388643384f, -0.453231394f},
+    {-0.446214169f, -0.369474143f, -0.236484155f, -0.0674910769f, 0.111777067f, 0.274027914f, 0.39455986f, 0.455022722f, 0.446211487f, 0.369467556f, 0.236474708f, 0.0674801692f, -0.111787759f, -0.274036765f, -0.394565523f, -0.455024362f},
+    {-0.443336725f, -0.362637937f, -0.226729944f, -0.0563038662f, 0.122694097f, 0.283012718f, 0.400244564f, 0.456541896f, 0.443333805f, 0.362631142f, 0.226720348f, 0.056292925f, -0.122704722f, -0.28302139f, -0.400249988f, -0.456543237f},
+    {-0.440192252f, -0.35558328f, -0.21683915f, -0.0450827405f, 0.133537218f, 0.291827023f, 0.405688167f, 0.457786024f, 0.440189064f, 0.355576277f, 0.216829434f, 0.0450717695f, -0.133547768f, -0.291835546f, -0.405693352f, -0.457787097f},
+    {-0.436782598f, -0.348314434f, -0.206817746f, -0.0338344574f, 0.144299895f, 0.300465584f, 0.41088739f, 0.45875439f, 0.436779141f, 0.348307222f, 0.206807896f, 0.0338234641f, -0.14431037f, -0.300473928f, -0.410892367f, -0.458755225f},
+    {-0.43310985f, -0.34083578f, -0.196671754f, -0.022565797f, 0.154975653f, 0.308923125f, 0.415839136f, 0.45944643f, 0.433106154f, 0.340828389f, 0.1966618f, 0.0225547832f, -0.154986039f, -0.308931291f, -0.415843844f, -0.459446996f},
+    {-0.429176211f, -0.333151817f, -0.186407298f, -0.0112835402f, 0.16555807f, 0.317194581f, 0.420540363f, 0.459861726f, 0.429172248f, 0.333144218f, 0.186397225f, 0.011272518f, -0.165568352f, -0.317202568f, -0.420544833f, -0.459861994f},
+};
+__device__ constexpr float kDif16TapS[16][16] = {
+    {0.0f, 0.176035658f, 0.32527107f, 0.424986154f, 0.460000008f, 0.424981952f, 0.325263262f, 0.176025465f, -1.10255714e-05f, -0.176045835f, -0.325278878f, -0.424990386f, -0.460000008f, -0.42497772f, -0.325255483f, -0.176015273f},
+    {0.0112890508f, 0.186412349f, 0.333155632f, 0.429178208f, 0.459861308f, 0.420533657f, 0.3171826f, 0.165542632f, -0.0113000739f, -0.186422423f, -0.333163232f, -0.429182172f, -0.45986104f, -0.420529187f, -0.317174613f, -0.165532351f},
+    {0.022571303f, 0.196676746f, 0.340839475f, 0.433111727f, 0.459445626f, 0.415832043f, 0.308910877f, 0.154960081f, -0.0225823149f, -0.196686715f, -0.340846896f, -0.433115423f, -0.459445089f, -0.415827334f, -0.308902681f, -0.15494971f},
+    {0.0338399559f, 0.206822678f, 0.34831804f, 0.436784327f, 0.458753198f, 0.41087997f, 0.300453037f, 0.144284189f, -0.033850953f, -0.206832528f, -0.348325253f, -0.436787814f, -0.458752364f, -0.410874993f, -0.300444692f, -0.144273728f},
+    {0.0450882278f, 0.216844022f, 0.355586767f, 0.440193862f, 0.457784414f, 0.405680358f, 0.291814238f, 0.133521393f, -0.0450991988f, -0.216853738f, -0.355593771f, -0.440197051f, -0.457783312f, -0.405675173f, -0.291805714f, -0.133510843f},
+    {0.0563093387f, 0.226734743f, 0.362641305f, 0.443338215f, 0.456539869f, 0.400236398f, 0.282999665f, 0.122678153f, -0.0563202798f, -0.226744339f, -0.3626481f, -0.443341136f, -0.456538498f, -0.400230974f, -0.282990992f, -0.122667529f},
+    {0.0674965307f, 0.236488894f, 0.369477421f, 0.44621551f, 0.455020308f, 0.394551367f, 0.274014622f, 0.111761026f, -0.0675074384f, -0.236498341f, -0.369483978f, -0.446218193f, -0.455018699f, -0.394545674f, -0.274005771f, -0.111750327f},
+    {0.0786430612f, 0.246100575f, 0.376090944f, 0.448824018f, 0.453226656f, 0.388628632f, 0.264864504f, 0.100776568f, -0.0786539242f, -0.246109888f, -0.376097292f, -0.448826432f, -0.453224778f, -0.388622731f, -0.264855504f, -0.100765809f},
+    {0.0897422209f, 0.255564034f, 0.382477939f, 0.451162159f, 0.451160014f, 0.3824718f, 0.255554855f, 0.0897314101f, -0.0897530392f, -0.255573183f, -0.382484049f, -0.451164335f, -0.451157868f, -0.38246569f, -0.255545706f, -0.0897205994f},
+    {0.100787327f, 0.264873534f, 0.388634533f, 0.453228563f, 0.448821604f, 0.376084596f, 0.246091262f, 0.0786321983f, -0.100798085f, -0.264882535f, -0.388640434f, -0.453230441f, -0.44881919f, -0.376078248f, -0.246081948f, -0.0786213353f},
+    {0.111771718f, 0.274023473f, 0.394557029f, 0.455021918f, 0.446212828f, 0.369470835f, 0.236479431f, 0.0674856231f, -0.111782417f, -0.274032325f, -0.394562691f, -0.455023557f, -0.446210146f, -0.369464278f, -0.236469969f, -0.0674747154f},
+    {0.122688785f, 0.283008367f, 0.400241852f, 0.45654121f, 0.443335265f, 0.36263454f, 0.226725146f, 0.0562983938f, -0.12269941f, -0.283017069f, -0.400247276f, -0.456542552f, -0.443332314f, -0.362627745f, -0.22671555f, -0.0562874526f},
+    {0.133531943f, 0.291822761f, 0.405685574f, 0.457785487f, 0.440190643f, 0.355579793f, 0.216834292f, 0.0450772531f, -0.133542493f, -0.291831285f, -0.405690759f, -0.45778656f, -0.440187454f, -0.35557279f, -0.216824576f, -0.0450662822f},
+    {0.144294664f, 0.300461411f, 0.410884917f, 0.458754003f, 0.43678087f, 0.348310828f, 0.206812829f, 0.0338289626f, -0.14430514f, -0.300469756f, -0.410889864f, -0.458754808f, -0.436777413f, -0.348303646f, -0.206802979f, -0.0338179655f},
+    {0.154970467f, 0.308919042f, 0.415836781f, 0.459446162f, 0.433108002f, 0.340832084f, 0.196666777f, 0.0225602891f, -0.154980853f, -0.308927208f, -0.41584149f, -0.459446698f, -0.433104306f, -0.340824664f, -0.196656808f, -0.0225492772f},
+    {0.165552929f, 0.317190588f, 0.420538127f, 0.459861577f, 0.429174244f, 0.333148003f, 0.186402261f, 0.0112780286f, -0.165563211f, -0.317198575f, -0.420542598f, -0.459861875f, -0.429170281f, -0.333140403f, -0.186392188f, -0.0112670064f},
+};
+
+template <int FMT, class F>
+__device__ __forceinline__ void dif16_front2_bfly(const Dif8Front& d, size_t frame_in, int R, unsigned char* __restrict__ smem_raw, int t, float2 (&a)[16], float2 (&a2)[16],
+                                                  F&& after_first_issue) {
+  static_assert(FMT == FMT_CS8 || FMT == FMT_CU8, "two-byte samples");
+  const char* fb = reinterpret_cast<const char*>(d.iq) + frame_in * (size_t)d.item_stride * 2;
+  const __amdgpu_buffer_rsrc_t rin = buffer_of(fb, 131072 * 2);
+  const dif8_const_fp c16 = (dif8_const_fp)(uintptr_t)(d.w8 + R * 16);  // W_16^(q R), q = 0 .. 15
+  const dif8_const_fp crho = (dif8_const_fp)(uintptr_t)(d.wrho + R * 16), crho2 = (dif8_const_fp)(uintptr_t)(d.wrho + (R + 8) * 16);
+  const float sg = (R & 1) ? -1.0f : 1.0f;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63;
+  // piece rho: run q of it at half * 16 KiB + q KiB; wave w fetches q = w and q = w + 8
+  const auto issue = [&](int rho, int half) {
+    if (SS_DIF_NODMA) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(smem_raw + half * 16384 + (8 * j + w) * 1024), 16, lane * 16,
+                                               1024 * rho + 16384 * (8 * j + w), 0, SS_AUX_DIF_IQ);
+  };
+  issue(0, 0);
+  issue(1, 1);
+  after_first_issue();
+  const float2 th = d.wthe[t];
+  const float thx2 = th.x * sg, thy2 = th.y * sg, k2 = 0.54f * sg;  // (the samples of q + 8 enter the pair sums with the sign (-1)^R)
+  const float w8x = c16[4], w8y = c16[5], w16x = c16[2], w16y = c16[3];  // W_8^R = W_16^(2 R), W_16^R
+  const int rq = R & 3;
+  const unsigned short* mine = reinterpret_cast<const unsigned short*>(smem_raw) + t;
+#pragma unroll
+  for (int rho = 0; rho < 16; ++rho) {
+    const int half = rho & 1;
+    if (!SS_DIF_NODMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (rho >= 1 && rho <= 14) issue(rho + 1, half ^ 1);  // (the other half's next piece: its place was read a piece ago)
+    float2 s[8];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      unsigned raw[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        raw[i] = mine[half * 8192 + 512 * (4 * sub + i)];
+        raw[4 + i] = mine[half * 8192 + 512 * (4 * sub + i + 8)];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = 4 * sub + i;
+        float re1, im1, re2, im2;
+        dif8_convert<FMT>(raw[i], re1, im1);
+        dif8_convert<FMT>(raw[4 + i], re2, im2);
+        const float t1 = fmaf(kDif16TapC[rho][q], th.x, fmaf(kDif16TapS[rho][q], th.y, 0.54f));
+        const float t2 = fmaf(kDif16TapC[rho][q + 8], thx2, fmaf(kDif16TapS[rho][q + 8], thy2, k2));
+        s[q] = make_float2(fmaf(t2, re2, t1 * re1), fmaf(t2, im2, t1 * im1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float2 A, B, C, D;
+    if (rq == 0) {
+      A = make_float2(s[0].x + s[4].x, s[0].y + s[4].y);
+      B = make_float2(s[2].x + s[6].x, s[2].y + s[6].y);
+      C = make_float2(s[1].x + s[5].x, s[1].y + s[5].y);
+      D = make_float2(s[3].x + s[7].x, s[3].y + s[7].y);
+    } else if (rq == 1) {  // times -i: (x, y) -> (y, -x)
+      A = make_float2(s[0].x + s[4].y, s[0].y - s[4].x);
+      B = make_float2(s[2].x + s[6].y, s[2].y - s[6].x);
+      C = make_float2(s[1].x + s[5].y, s[1].y - s[5].x);
+      D = make_float2(s[3].x + s[7].y, s[3].y - s[7].x);
+    } else if (rq == 2) {
+      A = make_float2(s[0].x - s[4].x, s[0].y - s[4].y);
+      B = make_float2(s[2].x - s[6].x, s[2].y - s[6].y);
+      C = make_float2(s[1].x - s[5].x, s[1].y - s[5].y);
+      D = make_float2(s[3].x - s[7].x, s[3].y - s[7].y);
+    } else {  // times i: (x, y) -> (-y, x)
+      A = make_float2(s[0].x - s[4].y, s[0].y + s[4].x);
+      B = make_float2(s[2].x - s[6].y, s[2].y + s[6].x);
+      C = make_float2(s[1].x - s[5].y, s[1].y + s[5].x);
+      D = make_float2(s[3].x - s[7].y, s[3].y + s[7].x);
+    }
+    const float2 E = make_float2(fmaf(B.x, w8x, fmaf(-B.y, w8y, A.x)), fmaf(B.x, w8y, fmaf(B.y, w8x, A.y)));
+    const float2 Op = make_float2(fmaf(D.x, w8x, fmaf(-D.y, w8y, C.x)), fmaf(D.x, w8y, fmaf(D.y, w8x, C.y)));
+    const float2 O = make_float2(fmaf(Op.x, w16x, -(Op.y * w16y)), fmaf(Op.x, w16y, Op.y * w16x));
+    a[rho] = make_float2(E.x + O.x, E.y + O.y);
+    a2[rho] = make_float2(E.x - O.x, E.y - O.y);
+    asm volatile("" : "+v"(a[rho].x), "+v"(a[rho].y), "+v"(a2[rho].x), "+v"(a2[rho].y));  // (formed HERE, not sunk below the next barrier)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();  // the plane goes back to the transform
+  const float2 wt = d.wt[R * 512 + t], wt2 = d.wt[(R + 8) * 512 + t];
 #pragma unroll
   for (int rho = 0; rho < 16; ++rho) {
     a[rho] = cmul(a[rho], cmul(wt, make_float2(crho[2 * rho], crho[2 * rho + 1])));

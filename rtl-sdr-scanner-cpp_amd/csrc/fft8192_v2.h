@@ -292,7 +292,7 @@ __device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Ar
   u[15] = mulw32_if<15>(a[slot16(15)], odd);
   // FRONT != 0: `frame` = Q * (row of the ring) + residue, and the row is in the fold's layout (fft65536_dif8.h: blocks of 32 Q bins,
   // 32 outputs of every residue side by side) — this thread's output k' = j + 2048 h + 256 kk (+ 4096) at block k' / 32, place j % 32
-  constexpr int LOGQ = FRONT == 4 ? 4 : 3;
+  constexpr int LOGQ = (FRONT == 4 || FRONT == 6) ? 4 : 3;
   float* out = FRONT != 0 ? psd + (((frame >> LOGQ) << LOGQ) * 8192 + (frame & ((1 << LOGQ) - 1)) * 32) : psd + frame * 8192;
   const __amdgpu_buffer_rsrc_t rout = buffer_of(out, FRONT != 0 ? ((8192 << LOGQ) - 32 * (int)(frame & ((1 << LOGQ) - 1))) * 4 : 8192 * 4);
   const int voff = (j + 2048 * h) * 4;
@@ -461,7 +461,7 @@ __device__ __forceinline__ void fft8192_v2_core(float2 (&a)[16], const Fft8192Ar
 //        the residue's bins go to, as 8 x (the ring's row) + residue (the bins land in that row's blocks, fft65536_dif8.h); 3 = residues `residue` (< 4)
 //        AND residue + 4 by the same workgroup, one fold for both, rows `frame` and `frame` + 4 (twice the registers: four waves per SIMD);
 //        4 = the same for a 131072-point frame: radix 16, residues `residue` (< 8) and residue + 8, rows `frame` and `frame` + 8;
-//        5 = 3 with the fold as a radix-8 butterfly per point (round 6, fft65536_dif8.h: dif8_front2_bfly).
+//        5 = 3 with the fold as a radix-8 butterfly per point (round 6, fft65536_dif8.h: dif8_front2_bfly); 6 = 4 likewise (dif16_front2_bfly).
 template <int FMT, int TW, bool SWZ = false, bool NOWIN = false, int FRONT = 0>
 __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t frame, unsigned char* __restrict__ smem_raw, int t, int* hdr,
                                                  const Dif8Front* dif = nullptr, size_t frame_in = 0, int residue = 0) {
@@ -496,6 +496,7 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
     };
     if constexpr (FRONT == 3) dif8_front2<FMT, 8>(*dif, frame_in, residue, smem_raw, t, a, a2, tables_to_lds);
     else if constexpr (FRONT == 5) dif8_front2_bfly<FMT>(*dif, frame_in, residue, smem_raw, t, a, a2, tables_to_lds);
+    else if constexpr (FRONT == 6) dif16_front2_bfly<FMT>(*dif, frame_in, residue, smem_raw, t, a, a2, tables_to_lds);
     else if constexpr (FRONT == 4) dif8_front2<FMT, 16>(*dif, frame_in, residue, smem_raw, t, a, a2, tables_to_lds);
     else dif8_front<FMT, FRONT - 1>(*dif, frame_in, residue, smem_raw, t, a, tables_to_lds);
     (void)iq;
@@ -532,9 +533,9 @@ __device__ __forceinline__ void fft8192_v2_frame(const Fft8192Args& g, size_t fr
     tw2_l[t] = tf0;  // tw2_l and lane_l are contiguous: entries 0..511
     if (t < 128) lane_l[256 + t] = tf1;
   }
-  if constexpr (FRONT == 3 || FRONT == 4 || FRONT == 5) {
+  if constexpr (FRONT == 3 || FRONT == 4 || FRONT == 5 || FRONT == 6) {
     // two residues by one workgroup (fft65536_dif8.h, dif8_front2): r's transform, then (r + Q/2)'s from the registers that kept it
-    constexpr int HQ = FRONT == 4 ? 8 : 4;
+    constexpr int HQ = (FRONT == 4 || FRONT == 6) ? 8 : 4;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       if (pass) {

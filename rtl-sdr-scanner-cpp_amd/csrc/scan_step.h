@@ -263,7 +263,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       if constexpr (FMT != FMT_CF32) {
         int f, r, hdr;
         dif8_item<8>(item, a.dif.nframes, &f, &r);
-        fft8192_v2_frame<FMT, 2, true, false, 4>(a.fft, (size_t)(16 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
+        fft8192_v2_frame<FMT, 2, true, false, SS_DIF8_BFLY ? 6 : 4>(a.fft, (size_t)(16 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
       }
     }
     else if constexpr (KIND == 6) fft_rows256_tile(a.rows256, item, smem_raw, tid);  // (the ROW half of call k: its column half ran as its own launch right before)

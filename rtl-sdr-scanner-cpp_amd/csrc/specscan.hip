@@ -313,8 +313,8 @@ struct ss_ctx {
   // pend_det2 (its plan is have_plan / pend_plan).
   bool det_lag2 = false;
   // 65536 points, int8 IQ (fft65536_dif8.h): calls that keep no plane go through the radix-8 fold — one launch of 8 x frames
-  // workgroups that leaves noise-relative rows in RESIDUE-MAJOR order in the averager ring's buffer and run maxima in the plan's
-  // layout 2; every other call (learning frames, planes handed out, stream-ordered contexts) takes the four-step form, whose rows
+  // workgroups (4 x frames since two residues share one) that leaves dB rows in the fold's BLOCKED order (32 Q bins per block,
+  // fft65536_dif8.h: dif_bin_offset; ring_db_rows) in the averager ring's buffer and run maxima in the plan's layout 2; every other call (learning frames, planes handed out, stream-ordered contexts) takes the four-step form, whose rows
   // are in bin order. ring_perm8 says which order the ring's window and the stages that wait are in; a call of the other kind
   // drains what waits and has the window's 35 rows rewritten first (set_ring_form).
   bool dif8 = false;

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(512, FRONT >= 3 ? 4 : 8) void k_dif8_lab(ss::Fft819
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int b = (int)blockIdx.x;
   int f, r;
-  if (FRONT == 4) {  // 131072 points, radix 16: eight workgroups per frame (residues r and r + 8 each)
+  if (FRONT == 4 || FRONT == 6) {  // 131072 points, radix 16: eight workgroups per frame (residues r and r + 8 each; 6: the fold as a butterfly per point)
     ss::dif8_item<8>(b, d.nframes, &f, &r);
     int hdr;
     ss::fft8192_v2_frame<FMT, 2, true, false, FRONT>(g, (size_t)(16 * f + r), smem_raw, (int)threadIdx.x, &hdr, &d, (size_t)f, r);
@@ -158,8 +158,9 @@ int main(int argc, char** argv) {
       {"LDS-DMA pieces, TWO residues per workgroup (128 VGPRs), ONE XCD", 3, 1},
       {"131072 points, radix 16, TWO residues per workgroup, ONE XCD", 4, 1},
       {"LDS-DMA pieces, TWO residues per workgroup, radix-8 BUTTERFLY per point", 5, 1},
+      {"131072 points, radix 16, TWO residues per workgroup, BUTTERFLY per point", 6, 1},
   };
-  const int nvariants = 7;
+  const int nvariants = 8;
   const auto launch = [&](const Variant& v, int set, int frames, hipEvent_t e0, hipEvent_t e1) {
     ss::Fft8192Args g{};
     g.tabs = tabs;
@@ -173,6 +174,7 @@ int main(int argc, char** argv) {
     const dim3 grid((v.front == 3 || v.front == 5 ? 4 : 8) * frames), block(512);  // (radix 16, two residues each: eight per frame too)
 #define GO(FRONT, XMAP) hipExtLaunchKernelGGL((k_dif8_lab<ss::FMT_CS8, FRONT, XMAP>), grid, block, ss::kFft8192V2LdsBytes, st, e0, e1, 0, g, d)
     if (v.front == 4) GO(4, 1);
+    else if (v.front == 6) GO(6, 1);
     else if (v.front == 5) GO(5, 1);
     else if (v.front == 3) GO(3, 1);
     else if (v.front == 1 && v.xmap == 1) GO(1, 1);
@@ -199,7 +201,7 @@ int main(int argc, char** argv) {
     }
     for (int vi = 0; vi < nvariants; ++vi) {
       if (only >= 0 && vi != only) continue;
-      if ((Q == 16) != (variants[vi].front == 4)) continue;
+      if ((Q == 16) != (variants[vi].front == 4 || variants[vi].front == 6)) continue;
       CK(hipMemset(d_out[0], 0xff, out_bytes));
       launch(variants[vi], 0, max_frames, nullptr, nullptr);
       CK(hipStreamSynchronize(st));
@@ -229,7 +231,7 @@ int main(int argc, char** argv) {
   for (int frames : frame_counts) {
     for (int vi = 0; vi < nvariants; ++vi) {
       if (only >= 0 && vi != only) continue;
-      if ((Q == 16) != (variants[vi].front == 4)) continue;
+      if ((Q == 16) != (variants[vi].front == 4 || variants[vi].front == 6)) continue;
       for (int k = 0; k < 12; ++k) launch(variants[vi], k % nsets, frames, nullptr, nullptr);
       CK(hipStreamSynchronize(st));
       hipEvent_t w0, w1;

@@ -74,6 +74,35 @@ int main() {
     }
     for (int run = 0; run < runs; ++run)
       if (written[(size_t)run] != 8) ++bad;  // (4 tiles x the two `frames` passes above)
+    // ---- 262144 points behind 256-point column tiles (round 6): the same row tile over 256 rows — every (frame, 8-row group) once, the four
+    // tiles of a 32-row group in consecutive slots of one XCD, every word of a frame's 8192 run maxima written by four tiles, a tile
+    // column's eight runs at [run][column] with the column in output order (k2 ^ 512) ----
+    {
+      const int n2 = 1 << 18, half2 = n2 >> 1, runs2 = n2 >> 5;
+      std::vector<int> written2((size_t)runs2, 0);
+      for (int frames : {1, 3}) {
+        std::vector<int> rows_seen((size_t)frames * 32, 0);
+        for (int b = 0; b < frames * 32; ++b) {
+          int f, r0;
+          ss::rows1024_block<8>(b, &f, &r0);
+          if (f < 0 || f >= frames || r0 < 0 || r0 >= 256 || (r0 & 7) || rows_seen[(size_t)f * 32 + (r0 >> 3)]++) ++bad;
+          int f2, r2;
+          ss::rows1024_block<8>(b ^ 8, &f2, &r2);  // the neighbouring slot of the same XCD
+          if (((r0 >> 3) & 3) < 2 && (f2 != f || (r2 >> 5) != (r0 >> 5))) ++bad;
+          if (f == 0)
+            for (int k2 = 0; k2 < 1024; ++k2) {
+              const int idx = ss::rows1024x256_smax_index(r0 >> 5, k2 ^ 512);
+              const int bin = (r0 + (k2 << 8)) ^ half2;  // the tile's first bin of this k2, in output order
+              if (idx < 0 || idx >= runs2 || (bin >> 8) != (k2 ^ 512) || ((bin & 255) >> 5) != (r0 >> 5)) ++bad;
+              else ++written2[(size_t)idx];
+            }
+        }
+      }
+      for (int run = 0; run < runs2; ++run)
+        if (written2[(size_t)run] != 8) ++bad;  // (4 tiles x the two `frames` passes above)
+      // the column tiles clear 256 words each: 32 tiles cover the frame's 8192 words once
+      if (ss::plan_x256_blocks(32, 0) != 64 || ss::plan_x256_blocks(32, 5) != 96 || ss::plan_x256_blocks(16, 0) != 32) ++bad;
+    }
     // the column tiles, 8 and 16 columns wide: every (frame, tile) once; the window in the kernel's order is a permutation of the taps
     for (int logc : {3, 4}) {
       const int tiles = 1024 >> logc;

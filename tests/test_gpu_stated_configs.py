@@ -43,10 +43,17 @@ def _report(name, got, ref, ncand, ndc, iq=None, fs=None):
     vs64 = excess_vs_fp64(iq, got["psd"], ref["psd"], fs) if iq is not None and "psd" in got else None
     print(f"[{name}] outside the bare 1e-4 tolerance: {format_excess(strict_excess(got, ref), vs64)}")
     if iq is not None and "psd" in got:
-        # ... and over ALL bins: is the engine's transform systematically farther from the truth than the reference's? (held to 1.5 x, like the bins where the two part)
+        # ... and over ALL bins: is the engine's transform systematically farther from the truth than the reference's? The rms has a heavy
+        # tail — five of half a million bins hold a quarter to a half of the sum of squares (deep nulls: the fp32 floor times the null's
+        # depth), so its ratio moves by +-0.2 with the data (scripts/fft8192_accuracy_model.py: 0.79 .. 1.00 over six bands for a transform
+        # whose median ratio is 0.96 every time) and stays held to 1.5 x; what is systematic shows in the 99th percentile — the bins the
+        # FFT's rounding floor decides — held to 1.15 x (measured 0.98 at 8192 points, 1.03 at 262144). (The MEDIAN, 2-4e-6 dB, is the dB
+        # conversion's, not the transform's: hardware log2 times 3.0103 against log10f — 1.16 x at 8192 points, 2.2 x at 262144, both
+        # thirty times below the contract's 1e-4.)
         allb = all_bins_vs_fp64(iq, got["psd"], ref["psd"], fs)
         print(f"[{name}] {format_all_bins(allb)}")
         assert allb is None or allb["engine_over_reference_rms"] <= 1.5, allb
+        assert allb is None or allb["engine_over_reference_p99"] <= 1.15, allb
 
 
 def test_config2_8192_points_1024_frames_in_one_call(ref_mod):
