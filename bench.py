@@ -427,10 +427,14 @@ def chain_kernels(n: int, fmt: str, nb: int | None = None, detect_mode: bool = F
                 ("plan", "k_plan_long", "k_plan_long as a launch of its own (drains only: in a run of calls the plan is a role of the column launch)", 0.0)]
     if n == 1 << 18 and os.environ.get("SS_ROWS1024X256") != "0" and os.environ.get("SS_CULL") != "0":
         # 262144 points — the size getFft picks at 61.44 MS/s — as they ship since round 6: 256-point column tiles + the 1024-point row tile, culled
-        return [("step", "k_scan_step", "k_scan_step (KIND 2): column half of the four-step FFT of call k (load, window, 256-point FFTs, twiddle -> work buffer), carrying the plan of "
-                 "call k-1 (which averaging tiles can hold a candidate, from a maximum per 8 bins the row tiles left), the listed tiles of call k-2 and the candidate lists of call k-3", in_b + 8.0),
+        if detect_mode and os.environ.get("SS_MERGE_65536") != "0" and (nb is None or nb <= 32):
+            return [("step", "k_scan_step", "k_scan_step (KIND 12), one launch per call: the column half of the four-step FFT of call k (256-point column tiles -> one of two work "
+                     "buffers) and, dispatched behind its tiles, the ROW half of call k-1 (8 rows of 1024 points per workgroup -> dB rows straight into the averager ring's buffer, no "
+                     "dB plane in detect mode, + run maxima by atomic maxima), carrying the plan of call k-2, the listed tiles of call k-3 and the candidate lists of call k-4", in_b + 8.0 + 12.0)]
+        return [("step", "k_scan_step", "k_scan_step (KIND 10 / 12): column half of the four-step FFT of call k (load, window, 256-point FFTs, twiddle -> work buffer), carrying the plan of "
+                 "call k-1 (which averaging tiles can hold a candidate, from the run maxima the row tiles left), the listed tiles of call k-2 and the candidate lists of call k-3", in_b + 8.0),
                 ("rows", "k_fft_rows1024_psd", "k_fft_rows1024_psd<8>: row half — 8 rows of 1024 points per workgroup (four interleaved 256-point FFTs and a radix-4 step) -> dB -> dB rows "
-                 "straight into the averager ring's buffer (no dB plane in detect mode) + the maxima for the tile culling; carries nothing", 12.0),
+                 "straight into the averager ring's buffer (no dB plane in detect mode) + the run maxima for the tile culling (atomic maxima on keys); carries nothing", 12.0),
                 ("plan", "k_plan_long", "k_plan_long as a launch of its own (drains only: in a run of calls the plan is a role of the column launch)", 0.0)]
     n2 = n // 256
     ks = [("step", "k_scan_step", "k_scan_step: column half of the four-step FFT of call k (load, window, 256-point FFTs, twiddle -> work buffer), carrying the "

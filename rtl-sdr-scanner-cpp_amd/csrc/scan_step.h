@@ -127,6 +127,8 @@ struct StepArgs {
   // stage of two calls later reads; the plan of call k - 1, detect(k - 2) (PERM8 tiles) and emit(k - 3) ride on the launch as they ride
   // on the column launch of the four-step form (KIND 2). `fft` carries the transform's tables and the rows' place, `dif` the fold's.
   // KIND 9 — the same for 131072-point frames (what getFft picks at 20 MS/s): radix 16, residues r and r + 8 per workgroup, n_fft = 8 x frames.
+  // KIND 12 — 262144 points, ONE launch per call (round 6): KIND 10's roles and the 1024-point ROW tiles of call k - 1 (ROLE_ROWS: `rows`, n_rows of
+  // them, from the other of two work buffers) behind the column tiles of call k — KIND 7's shape with this size's row tile and plan.
   // KIND 10 — 262144 points (round 6): KIND 2 — 256-point column tiles as the FFT role, the plan of call k - 1, detect(k - 2), emit(k - 3) —
   // whose plan role is plan_x256_run (PlanLongArgs::layout 3); an instantiation of its own so that the others keep their registers.
   Dif8Front dif;
@@ -189,6 +191,12 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       return;
     }
   }
+  if constexpr (KIND == 12) {  // 262144 points, one launch per call: the same with the 1024-point row tile (StepArgs::rows)
+    if (role == ROLE_ROWS) {
+      fft_rows1024_tile<8>(a.rows, item, smem_raw, tid);
+      return;
+    }
+  }
   if (role == ROLE_EMIT) {
     if constexpr (KIND >= 2) {
       // ---- emit role, long rows: the eight waves share one frame ----
@@ -234,11 +242,11 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;
     }
   } else if (role == ROLE_PLAN) {
-    if constexpr (KIND == 1 || KIND == 2 || KIND == 7 || KIND == 8 || KIND == 9 || KIND == 10) {  // a long transform's plan: two blocks of k_plan_long's numbering
+    if constexpr (KIND == 1 || KIND == 2 || KIND == 7 || KIND == 8 || KIND == 9 || KIND == 10 || KIND == 12) {  // a long transform's plan: two blocks of k_plan_long's numbering
       const int sub = tid >> 8;
       float* mrow = reinterpret_cast<float*>(smem_raw) + sub * (kPlanFusedFloats + kPlanLongInts);
       if constexpr (KIND == 8 || KIND == 9) plan_dif8_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));  // (the fold's rows: layout 2)
-      else if constexpr (KIND == 10) plan_x256_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));  // (262144 points: layout 3)
+      else if constexpr (KIND == 10 || KIND == 12) plan_x256_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));  // (262144 points: layout 3)
       else plan_long_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));
       return;
     }

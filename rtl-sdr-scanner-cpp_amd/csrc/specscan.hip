@@ -346,10 +346,12 @@ struct ss_ctx {
   // Waiting on the host besides pend_det / pend_det2 / pend_plan / pend_emit: the row stage of the last call, its plan (not ready
   // before that row stage has run) and its detect stage.
   bool merge = false;
+  int merge_max = 128;  // the largest call (frames) that is one launch
   float2* d_work2 = nullptr;
   int work_cur = 0;
   bool have_rows = false;
   ss::Rows256Args pend_rows{};
+  ss::Rows1024Args pend_rows1024{};  // (262144 points: the row stage that waits is one of 1024-point row tiles)
   int pend_rows_tiles = 0;
   bool have_plan2 = false;
   ss::PlanLongDet pend_plan2_det{};
@@ -947,7 +949,7 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
   }
   if (!c->use_fft8192 && a.n_fft && a.rows256.work && !a.n_rows) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 6>);  // (65536 points: the row tiles as the FFT role; rows of 2048 mask words: the wide emit role)
   if constexpr (!SPEC) {
-    if (!c->use_fft8192 && c->rows1024x256) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 10>);  // (262144 points: KIND 2 with the plan of layout 3)
+    if (!c->use_fft8192 && c->rows1024x256) return c->merge ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 12>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 10>);  // (262144 points: KIND 2 with the plan of layout 3; with the row tiles as one more role)
   }
   if (!c->use_fft8192 && c->merge) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 7>);  // (one launch per call: KIND 2's roles and the row tiles as one more; its drains too)
   if (!c->use_fft8192) return a.emit_per_wg == 1 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 2>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 1>);
@@ -978,7 +980,7 @@ struct FftRole {
 
 // fft / det / emit: null = role absent. Start/stop events ride on launches that carry an FFT role (the dominant work).
 void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n_det_tiles, bool spec, const ss::EmitArgs* emit, hipStream_t stream = nullptr,
-                 bool with_long_plan = false, const ss::Rows256Args* rows_role = nullptr, int n_rows = 0) {
+                 bool with_long_plan = false, const ss::Rows256Args* rows_role = nullptr, int n_rows = 0, const ss::Rows1024Args* rows1024_role = nullptr) {
   if (!stream) stream = c->stream;
 #ifdef SS_DIAG
   if (c->diag.ablate_roles & 1) det = nullptr;
@@ -1045,6 +1047,9 @@ void launch_step(ss_ctx* c, const FftRole* fft, const ss::DetectArgs* det, int n
   }
   if (rows_role && n_rows > 0) {  // one launch per call (KIND 7): the row half of the call before beside this call's column half
     a.rows256 = *rows_role;
+    a.n_rows = n_rows;
+  } else if (rows1024_role && n_rows > 0) {  // ... of 262144-point frames (KIND 12)
+    a.rows = *rows1024_role;
     a.n_rows = n_rows;
   }
   if (with_long_plan && c->have_plan) {  // 65536 points: the plan of the call before as a role of this (column) launch
@@ -1271,7 +1276,7 @@ void flush_stages(ss_ctx* c) {
     // nothing waits (a plan is a ROLE of these launches: a launch boundary orders it ahead of the detect stage it plans)
     while (c->have_rows || c->have_plan || c->have_plan2 || c->have_det || c->have_det2 || c->have_det3 || c->have_emit) {
       launch_step(c, nullptr, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr, nullptr, true,
-                  c->have_rows ? &c->pend_rows : nullptr, c->have_rows ? c->pend_rows_tiles : 0);
+                  (c->have_rows && !c->rows1024x256) ? &c->pend_rows : nullptr, c->have_rows ? c->pend_rows_tiles : 0, (c->have_rows && c->rows1024x256) ? &c->pend_rows1024 : nullptr);
       shift_pending(c);
     }
     return;
@@ -1980,7 +1985,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     // drains what waits in that form and goes the two-launch way
     // (up to 128 frames: two 64 MiB work buffers in flight are what the Infinity Cache holds beside the rest — 256-frame calls lose a tenth
     // this way and have two rounds of workgroups per launch anyway, profiles/r04/s34_summary.txt)
-    const bool merged_call = c->merge && c->rows256_step && overlap && ring_only && !spec && nframes <= c->diag.merge_max_frames;
+    const bool merged_call = c->merge && (c->rows256_step || c->rows1024x256) && overlap && ring_only && !spec && nframes <= c->merge_max;
     if (c->merge && !merged_call && (c->have_rows || c->have_plan2 || c->have_det3)) flush_stages(c);
     if (dif_call) {
       if (!ring_only || !rx.hist_out) return fail(c, SS_ERR_INVALID, "internal: a fold call without a place for its rows");
@@ -2009,7 +2014,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       crole.cols = &gcm;
       crole.n = nframes * (c->n >> 13);
       launch_step(c, &crole, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr, nullptr, true,
-                  c->have_rows ? &c->pend_rows : nullptr, c->have_rows ? c->pend_rows_tiles : 0);
+                  (c->have_rows && !c->rows1024x256) ? &c->pend_rows : nullptr, c->have_rows ? c->pend_rows_tiles : 0, (c->have_rows && c->rows1024x256) ? &c->pend_rows1024 : nullptr);
     } else if (c->rows256_step) {
       // 65536 points with tile culling: both halves of the FFT as FFT roles of k_scan_step, the deferred stages shared out between
       // them — the column launch of call k carries the plan of call k - 1 (which of its tiles the detect stage must evaluate) and
@@ -2103,7 +2108,13 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     } else
     launch_step(c, &role, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr);
     shift_pending(c);
-    if (merged_call) {  // this call's row half waits for the next launch; it reads the work buffer this call's column half has just been told to fill
+    if (merged_call && c->rows1024x256) {  // (262144 points: 32 row tiles of 8 rows x 1024 points per frame)
+      c->pend_rows1024 = rows1024x256_args(c, nullptr, rx);
+      c->pend_rows1024.work = c->work_cur ? c->d_work2 : c->d_work;
+      c->pend_rows_tiles = nframes * 32;
+      c->have_rows = true;
+      c->work_cur ^= 1;
+    } else if (merged_call) {  // this call's row half waits for the next launch; it reads the work buffer this call's column half has just been told to fill
       c->pend_rows = rows256_args(c, nullptr, rx);
       c->pend_rows.work = c->work_cur ? c->d_work2 : c->d_work;
       c->pend_rows_tiles = nframes * 8;
@@ -2485,7 +2496,8 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   const bool x256_ok = n == 262144 && c->diag.rows1024x256 && c->diag.emit_wide && c->diag.fft_rows_r < 0 && c->diag.fft_sub < 0 && !(cfg->flags & SS_FLAG_SPECTROGRAM);
   c->det_lag2 = !c->deep && c->step_path && (n == 65536 || (n == 131072 && fold_ok) || x256_ok) && !c->diag.fft_generic && c->diag.cull_65536 && c->diag.cull && !(cfg->flags & SS_FLAG_NO_CULL) &&
                 c->diag.rows256_step && c->diag.step_long && c->diag.det_lag2 && c->fused;
-  c->merge = c->det_lag2 && n == 65536 && c->diag.merge_65536 && c->diag.emit_wide;  // (one launch per call: scan_step.h KIND 7, whose emit role is the wide one)
+  c->merge = c->det_lag2 && (n == 65536 || x256_ok) && c->diag.merge_65536 && c->diag.emit_wide;  // (one launch per call: scan_step.h KIND 7 / KIND 12, whose emit role is the wide one)
+  c->merge_max = std::max(1, (int)((long long)c->diag.merge_max_frames * 65536 / n));  // (128 frames of 65536 points, 32 of 262144: 64 MiB of work buffer either way)
   // ... and with int8 IQ and the default window no work buffer at all: the radix-8 fold (scan_step.h KIND 8). It takes every call the
   // one-launch form above would take — and longer ones — so that form is off then.
   c->dif8 = c->det_lag2 && fold_ok && (n == 65536 || n == 131072);
@@ -2506,6 +2518,11 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
       const long long min_rows = (long long)n >= 65536 ? 10 * kHistRows : 3 * kHistRows;
       if (rows < min_rows) rows = min_rows;
       if (rows > 64 * kHistRows) rows = 64 * kHistRows;
+      // (round 6: long transforms on the step path get 1024 rows — 1 GiB at 262144 points, 4 GiB at 2^20: a call shorter than the window
+      // slides it along the buffer, and every return to the front is a drain of the stages that still read the old place; with 350 rows
+      // 32-frame calls of 262144 points drained every eighth call, 74 us each: 9.6 of their 63 us per call, profiles/r06/s7_summary.txt;
+      // 16-frame calls of 2^20 points every thirteenth. HBM is what this chip has most of.)
+      if (c->step_path && n >= 65536 && rows < 1024) rows = 1024;
       // (long transforms, whose rows kernel may write ALL of a batch's rows into this buffer: three batches and the averager's reach,
       // so that a batch can go back to the front of the buffer while the one before it is still to be read — ring_place.h)
       if (n >= 65536 && c->step_path && rows < 3ll * cfg->max_batch + 3 * kHistRows) rows = 3ll * cfg->max_batch + 3 * kHistRows;
@@ -2592,7 +2609,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   }
   if (c->logn > 13) CREATE_HIP(hipMalloc(&c->d_work, sizeof(float2) * (size_t)n * (size_t)cfg->max_batch));
   // (the one-launch form only takes calls of up to merge_max_frames: the second work buffer need not hold more)
-  if (c->merge) CREATE_HIP(hipMalloc(&c->d_work2, sizeof(float2) * (size_t)n * (size_t)std::min(cfg->max_batch, std::max(1, c->diag.merge_max_frames))));
+  if (c->merge) CREATE_HIP(hipMalloc(&c->d_work2, sizeof(float2) * (size_t)n * (size_t)std::min(cfg->max_batch, c->merge_max)));
 
   // window: caller's taps or gr::fft::window::hamming(N) (sdr_device.cpp:164; GNU Radio's definition:
   // 0.54 - 0.46*cos(2*pi*n/(N-1)) in double, stored as float). Twiddles W_N^k from double.
@@ -2742,6 +2759,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   c->cull_long = c->step_path && c->use_fft256 && ((n == 65536 && c->diag.cull_65536) || (n > 65536 && c->d_tw_sub && !c->d_tw_rowsR) || c->two_pass || c->cull_fold_only || c->rows1024x256) &&
                  !(cfg->flags & SS_FLAG_NO_CULL) && c->diag.cull;
   if (!c->cull_long) c->rows1024x256 = false;
+  if (n == 262144 && !c->rows1024x256) c->merge = false;  // (never: decided from the same switches; the second work buffer and the rotating sets sized for it do no harm)
   // 65536 points: with the plan of call k at the front of call k + 1's column launch — which therefore is a launch of its own, the
   // row tiles taking the FFT role of k_scan_step in its place (KIND 6) — the culling pays there too (session 17 of round 4).
   c->rows256_step = c->cull_long && !c->two_pass && c->logn == 16 && c->diag.rows256_step && c->diag.step_long;  // (no emit stage ever rides on the row launch — KIND 6, whose emit role is the wide one — but under SS_EMIT_ON_ROWS)
@@ -2753,7 +2771,9 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     int rows = 64;
     // (two batches and the averager's reach: the plan of call k — which reads the maxima of its frames and of the 35 before —
     // runs beside the column tiles of call k + 1, which clear the rows of THEIR frames: k_fft_cols1024_plan)
-    while (rows < 2 * cfg->max_batch + kHistRows + 1) rows <<= 1;
+    // (262144 points in one launch per call: the column tiles of call k clear their frames' words while the plan of call k - 2 rides on the
+    // same launch: three batches)
+    while (rows < ((c->merge && c->rows1024x256) ? 3 : 2) * cfg->max_batch + kHistRows + 1) rows <<= 1;
     c->smax_rows = rows;
     CREATE_HIP(hipMalloc(&c->d_smax, sizeof(float) * (size_t)rows * (size_t)(n / 32)));
     if (c->rows1024x256) CREATE_HIP(hipMemsetAsync(c->d_smax, 0, sizeof(float) * (size_t)rows * (size_t)(n / 32), c->stream));  // (keys: 0 = nothing seen)
