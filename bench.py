@@ -574,13 +574,18 @@ def drop_in_lines():
             batch = band.frames_cs8(nb) if fmt == "cs8" else band.frames_cf32(nb)
             kw = dict(fft_size=n, decim=1, in_format=in_format, learn_frames=32, max_batch=max(nb, 32))
             eng = pkg.SpectrumEngine(fs, 145_000_000, **kw)
-            eng.process(learn, want=())
+            # (candidate capacity 2^20 per call, as a block with output buffers of its own has: the wrapper's default — nframes x N entries,
+            # two fresh 64 MiB numpy arrays per call at 2^20 points, unmapped again when the call returns — made THIS entry ten times
+            # slower at the end of a long-lived process than alone in one: the copy in took 19-29 ms instead of 2.4 whenever such arrays
+            # had just been unmapped, profiles/r06/s10_summary.txt)
+            ccap = 1 << 20
+            eng.process(learn, want=(), cand_cap=ccap)
             for _ in range(2):
-                eng.process(batch, want=())
+                eng.process(batch, want=(), cand_cap=ccap)
             reps = 6
             t0 = time.perf_counter()
             for _ in range(reps):
-                eng.process(batch, want=())
+                eng.process(batch, want=(), cand_cap=ccap)
             dt_proc = (time.perf_counter() - t0) / reps
             # ... and its pieces, each alone (the 2^20-point entry read 1.8 GS/s on round 5's driver box and 6.2 on the builder's):
             # the same pageable buffer to the device through the runtime (what hipMemcpy2DAsync of ss_process does: the runtime
@@ -790,6 +795,60 @@ def run(args):
     import rtl_sdr_scanner_cpp_amd as pkg
     from rtl_sdr_scanner_cpp_amd import dist
 
+    def _probe(stage):  # (diagnosis, scripts/r06/s10.sh: SS_BENCH_DROPIN_AT=<stage> measures the drop-in lines at that point of the run and goes on)
+        if os.environ.get("SS_BENCH_DROPIN_AT") == stage:
+            if os.environ.get("SS_TRACE_PROCESS"):
+                pkg.engine.use_diag_library(True)  # (the diagnostics build prints ss_process's phases)
+            for e in drop_in_lines():
+                print("PROBE", stage, {k: e.get(k) for k in ("fft_size", "ss_process_MSps", "ss_process_pieces_ms", "error")}, file=sys.stderr, flush=True)
+            # ... is it the SOURCE? the same context fed from a synthetic batch (made by numpy arithmetic) and from one fresh allocation
+            n_, nb_ = 1 << 20, 16
+            band_ = pkg.synth.SyntheticBand(n_, seed=9, on_frame=40, off_frame=10_000)
+            learn_, synth_ = band_.frames_cf32(32), band_.frames_cf32(nb_)
+            fresh_ = np.empty((nb_, n_), np.complex64)
+            fresh_[:] = synth_
+            e_ = pkg.SpectrumEngine(61_440_000, 145_000_000, fft_size=n_, decim=1, in_format=0, learn_frames=32, max_batch=32)
+            e_.process(learn_, want=())
+            for name_, src_ in (("synthetic batch", synth_), ("fresh np.empty filled once", fresh_), ("synthetic batch again", synth_)):
+                e_.process(src_, want=(), cand_cap=1 << 20)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    e_.process(src_, want=(), cand_cap=1 << 20)
+                print("PROBE", stage, f"ss_process fed from {name_}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", file=sys.stderr, flush=True)
+            e_.close()
+            # ... and a pageable 128 MiB buffer into device memory obtained NOW from hipMalloc, against memory torch's allocator holds
+            import ctypes as C
+            import torch
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            hip.hipFree.argtypes = [C.c_void_p]
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            nbytes = 128 << 20
+            host = np.ones(nbytes, np.uint8)
+            fresh = C.c_void_p()
+            assert hip.hipMalloc(C.byref(fresh), nbytes) == 0
+            held = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            for name, ptr in (("fresh hipMalloc", fresh.value), ("torch's pool", held.data_ptr())):
+                hip.hipMemcpy(ptr, host.ctypes.data, nbytes, 1)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    hip.hipMemcpy(ptr, host.ctypes.data, nbytes, 1)
+                print("PROBE", stage, f"hipMemcpy of 128 MiB pageable into {name}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", file=sys.stderr, flush=True)
+            hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+            hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+            hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+            for flag, name in ((1, "a new non-blocking stream"), (0, "a new blocking stream")):
+                st = C.c_void_p()
+                assert hip.hipStreamCreateWithFlags(C.byref(st), flag) == 0
+                hip.hipMemcpyAsync(fresh.value, host.ctypes.data, nbytes, 1, st)
+                hip.hipStreamSynchronize(st)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    hip.hipMemcpyAsync(fresh.value, host.ctypes.data, nbytes, 1, st)
+                    hip.hipStreamSynchronize(st)
+                print("PROBE", stage, f"hipMemcpyAsync + hipStreamSynchronize on {name}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", file=sys.stderr, flush=True)
+            hip.hipFree(fresh)
+
     # RCCL ("nccl") over xGMI in production; SS_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box
     # with fewer GPUs than ranks (ranks then share devices, results are functional only)
     backend = os.environ.get("SS_DIST_BACKEND", "nccl")
@@ -839,7 +898,9 @@ def run(args):
                   flags=(pkg.abi.SS_FLAG_SPECTROGRAM if args.spectrogram else 0) | (pkg.abi.SS_FLAG_NO_CULL if args.no_cull else 0))
     if args.diag_lib or args.lib:
         pkg.engine.use_diag_library(args.lib or True)
+    _probe("before_engine")
     eng = pkg.SpectrumEngine(int(cfg["sample_rate"]), dist.band_center(cfg, band), **eng_kw)
+    _probe("engine_created")
 
     # ---- working set: `nsets` distinct input batches and output sets in rotation, well past the Infinity Cache ----
     in_bytes = nb * n * args.decim * (8 if args.fmt == "cf32" else 2)
@@ -873,6 +934,7 @@ def run(args):
                  avg_plane=torch.empty((nb, n), dtype=torch.float32, device=dev) if args.planes else None)
             for _ in range(nout)]
     torch.cuda.synchronize()
+    _probe("working_set")
     counter = [0]
 
     def step(iq=None):
@@ -898,9 +960,11 @@ def run(args):
             step()
         eng.sync()
         preheat_steps += 50
+    _probe("learned")
     for _ in range(max(args.warmup, 1)):
         step()
     eng.sync()
+    _probe("warmed_up")
     # No event-timed launch inside the timed region (round 6): each one costs its queue ~13 us (the start packet ~7 us before it, the stop
     # packet ~6 us before the queue's next launch: profiles/r03/s37_timeline_k20.txt) — one was 2.7 % of the driver's 20-step run, and a
     # chain of two launches per call with every 8th call sampled paid 3 us per call (5 % of a 65 us call of 262144 points). The launches
@@ -947,7 +1011,9 @@ def run(args):
     devices_of_ranks = dist.ints_of_ranks(device_index, device=coll_dev)  # (rank r -> the device it worked on: LOCAL_RANK modulo the box's device count)
     cands_of_ranks = dist.ints_of_ranks(int(outs[(counter[0] - 1) % nout]["off"][-1].item()), device=coll_dev)
     ncand = int(outs[(counter[0] - 1) % nout]["off"][-1].item())
+    _probe("timed")
     lib_stats = eng.stats()  # what the library says it did (counters from creation: learning, preheat, warm-up and the timed steps)
+    _probe("stats")
 
     if rank == 0:
         samples_per_step = nb * n * world
@@ -1051,8 +1117,10 @@ def run(args):
                 out["roofline"]["traffic_gbs"] = round(live["bytes_per_launch"] / step_s / 1e9, 1)
                 out["roofline"]["traffic_frac_of_peak"] = round(live["bytes_per_launch"] / step_s / 1e9 / HBM_PEAK_GBS, 4)
         if plan["also"]:
-            out["also"] = also_lines(args.also_all)
+            out["also"] = [] if os.environ.get("SS_BENCH_SKIP_ALSO_RUNS") else also_lines(args.also_all)  # (the switch: diagnosing the drop-in lines alone, scripts/r06/s10.sh)
+            _probe("before_close")
             eng.close()  # (the drop-in lines below make contexts of their own; this one's memory goes back first)
+            _probe("closed")
             out["also"] += drop_in_lines()
         if plan["cpu_baseline"]:
             out["cpu_baseline"] = cpu_baseline(n, fs, args.cpu_seconds)

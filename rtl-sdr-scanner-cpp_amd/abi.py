@@ -167,8 +167,12 @@ class Chain:
         if cand_cap is None:
             cand_cap = nframes * n
         off = np.zeros(nframes + 1, dtype=np.int32)
-        idx = np.empty(max(cand_cap, 1), dtype=np.int32)
-        cav = np.empty(max(cand_cap, 1), dtype=np.float32)
+        # the candidate arrays are kept from call to call (grow-only): with the default capacity — every bin of every frame — they are
+        # two 64 MiB arrays per 16-frame call of 2^20 points, and mapping and unmapping those around every call made the runtime's copy
+        # of the NEXT call's input take 19-29 ms instead of 2.4 (profiles/r06/s10_summary.txt)
+        if getattr(self, "_cand_bufs", None) is None or self._cand_bufs[0].size < max(cand_cap, 1):
+            self._cand_bufs = (np.empty(max(cand_cap, 1), dtype=np.int32), np.empty(max(cand_cap, 1), dtype=np.float32))
+        idx, cav = self._cand_bufs
         t = None
         if t_ms is not None:
             t = np.ascontiguousarray(t_ms, dtype=np.int64)

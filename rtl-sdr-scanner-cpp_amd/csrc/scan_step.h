@@ -127,6 +127,8 @@ struct StepArgs {
   // stage of two calls later reads; the plan of call k - 1, detect(k - 2) (PERM8 tiles) and emit(k - 3) ride on the launch as they ride
   // on the column launch of the four-step form (KIND 2). `fft` carries the transform's tables and the rows' place, `dif` the fold's.
   // KIND 9 — the same for 131072-point frames (what getFft picks at 20 MS/s): radix 16, residues r and r + 8 per workgroup, n_fft = 8 x frames.
+  // KIND 11 — KIND 8 with ONE residue per workgroup (fft65536_dif8.h: dif8_front, 64 registers, eight waves per SIMD), n_fft = 8 x frames: calls
+  // of up to 32 frames, whose 4 x frames two-residue workgroups leave most of the chip's 256 CUs idle for 18 us each (round 6).
   // KIND 12 — 262144 points, ONE launch per call (round 6): KIND 10's roles and the 1024-point ROW tiles of call k - 1 (ROLE_ROWS: `rows`, n_rows of
   // them, from the other of two work buffers) behind the column tiles of call k — KIND 7's shape with this size's row tile and plan.
   // KIND 10 — 262144 points (round 6): KIND 2 — 256-point column tiles as the FFT role, the plan of call k - 1, detect(k - 2), emit(k - 3) —
@@ -242,10 +244,10 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
       tile_b = 2 * item + 1 < a.n_det ? 2 * item + 1 : -1;
     }
   } else if (role == ROLE_PLAN) {
-    if constexpr (KIND == 1 || KIND == 2 || KIND == 7 || KIND == 8 || KIND == 9 || KIND == 10 || KIND == 12) {  // a long transform's plan: two blocks of k_plan_long's numbering
+    if constexpr (KIND == 1 || KIND == 2 || KIND == 7 || KIND == 8 || KIND == 9 || KIND == 10 || KIND == 11 || KIND == 12) {  // a long transform's plan: two blocks of k_plan_long's numbering
       const int sub = tid >> 8;
       float* mrow = reinterpret_cast<float*>(smem_raw) + sub * (kPlanFusedFloats + kPlanLongInts);
-      if constexpr (KIND == 8 || KIND == 9) plan_dif8_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));  // (the fold's rows: layout 2)
+      if constexpr (KIND == 8 || KIND == 9 || KIND == 11) plan_dif8_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));  // (the fold's rows: layout 2)
       else if constexpr (KIND == 10 || KIND == 12) plan_x256_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));  // (262144 points: layout 3)
       else plan_long_run<21, 21, 16, 256>(a.plan_det, a.plan_long, 2 * item + sub, tid & 255, mrow, reinterpret_cast<int*>(mrow + kPlanFusedFloats));
       return;
@@ -265,6 +267,13 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
         if (a.hint_mode != 4)  // (timing ablation, garbage results: the passengers of the launch by themselves)
 #endif
         fft8192_v2_frame<FMT, 2, true, false, SS_DIF8_W == 4 ? (SS_DIF8_BFLY ? 5 : 3) : 2>(a.fft, (size_t)(8 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
+      }
+    }
+    else if constexpr (KIND == 11) {  // a 65536-point frame's residue r alone: eight workgroups per frame (short calls, round 6)
+      if constexpr (FMT != FMT_CF32) {
+        int f, r, hdr;
+        dif8_item<8>(item, a.dif.nframes, &f, &r);
+        fft8192_v2_frame<FMT, 2, true, false, 2>(a.fft, (size_t)(8 * (f - a.dif.first_hist) + r), smem_raw, tid, &hdr, &a.dif, (size_t)f, r);
       }
     }
     else if constexpr (KIND == 9) {  // 131072 points, radix 16: residues r (< 8) and r + 8 of a frame, eight workgroups per frame
@@ -380,7 +389,7 @@ __device__ __forceinline__ void step_run_item(const StepArgs& a, int role, int i
     float* tile = reinterpret_cast<float*>(smem_raw) + half * (16 * T::P + 16);
     int* cnt = reinterpret_cast<int*>(tile + 16 * T::P);
     const int mine = half ? tile_b : tile_a;
-    detect_tile<21, 21, 16, 256, SPEC, KIND == 8 ? 3 : KIND == 9 ? 4 : 0>(a.det, mine < 0 ? tile_a : mine, tid & 255, tile, cnt, mine >= 0);
+    detect_tile<21, 21, 16, 256, SPEC, (KIND == 8 || KIND == 11) ? 3 : KIND == 9 ? 4 : 0>(a.det, mine < 0 ? tile_a : mine, tid & 255, tile, cnt, mine >= 0);
   }
 }
 

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/specscan.h"
@@ -135,6 +136,7 @@ struct ss_ctx {
     bool dif8 = true;              // 65536 points, int8 IQ, default window, calls that keep no plane: NO work buffer — the radix-8 fold in the load stage of the 8192-point transform, eight workgroups per frame, one launch per call whatever its length (scan_step.h KIND 8, fft65536_dif8.h; SS_DIF8=0: the four-step forms of round 4)
     int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
     bool rows1024x256 = true;      // 262144 points (what getFft picks at 61.44 MS/s): rows through the 1024-point row tile with run maxima and ring rows — culled, no dB plane in detect mode, the 65536-point two-launch pipeline (SS_ROWS1024X256=0: round 2's path, k_fft_rows256xR_psd, every tile evaluated)
+    int dif8_single_max = 32;      // 65536 points, the fold: calls of up to this many frames take ONE residue per workgroup (scan_step.h KIND 11; SS_DIF8_SINGLE_MAX=0: never)
     int chunk_65536 = 256;         // 65536 points with tile culling: calls of more frames go through in chunks of this many (SS_CHUNK_65536=0: in one piece)
     int chunk_long = 16;           // 2^20 points in two passes: calls of more frames go through in chunks of this many (SS_CHUNK_LONG=0: in one piece)
     bool halo_maxima = true;       // 8192 points, deep pipelining: the re-transformed halo frames leave per-column maxima, so that the tiles of a batch's first two frame tiles are tested like the others (SS_HALO_MAXIMA=0: evaluated whatever they hold, as until session 36 of round 5)
@@ -206,6 +208,7 @@ struct ss_ctx {
       chunk_long = num("SS_CHUNK_LONG", chunk_long);
       chunk_65536 = num("SS_CHUNK_65536", chunk_65536);
       rows1024x256 = tri("SS_ROWS1024X256") != 0;
+      dif8_single_max = num("SS_DIF8_SINGLE_MAX", dif8_single_max);
       plan_first = num("SS_PLAN_FIRST", plan_first);
       det_lag2 = tri("SS_DET_LAG2") != 0;
       dif8 = tri("SS_DIF8") != 0;
@@ -945,6 +948,7 @@ void launch_step_variant(ss_ctx* c, const ss::StepArgs& a, hipEvent_t e0, hipEve
 #ifdef SS_DIAG
     if (!c->use_fft8192 && c->ring_perm8 && c->dif_logq == 3 && (c->diag.prio_fft || c->diag.prio_other)) return go(ss::k_scan_step<FMT, SPEC, 2, true, true, 8>);
 #endif
+    if (!c->use_fft8192 && c->ring_perm8 && c->dif_logq == 3 && a.dif.iq && a.n_fft == 8 * a.dif.nframes && SS_DIF8_W == 4) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 11>);  // (a short call: one residue per workgroup)
     if (!c->use_fft8192 && c->ring_perm8) return c->dif_logq == 4 ? go(ss::k_scan_step<FMT, SPEC, 2, true, false, 9>) : go(ss::k_scan_step<FMT, SPEC, 2, true, false, 8>);
   }
   if (!c->use_fft8192 && a.n_fft && a.rows256.work && !a.n_rows) return go(ss::k_scan_step<FMT, SPEC, 2, true, false, 6>);  // (65536 points: the row tiles as the FFT role; rows of 2048 mask words: the wide emit role)
@@ -2004,7 +2008,10 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       FftRole drole;
       drole.frames = &gf;
       drole.dif = &df;
-      drole.n = (c->dif_logq == 4 ? 8 : SS_DIF8_W) * nframes;  // (two residues per workgroup: four per frame at radix 8, eight at radix 16)
+      // (two residues per workgroup: four per frame at radix 8, eight at radix 16 — but a radix-8 call of up to dif8_single_max frames takes one
+      // residue per workgroup, eight per frame: 4 x 16 workgroups of 18 us each leave three quarters of the chip idle, KIND 11)
+      const bool single = c->dif_logq == 3 && nframes <= c->diag.dif8_single_max;
+      drole.n = (c->dif_logq == 4 || single ? 8 : SS_DIF8_W) * nframes;
       // the plan of the call before, the planned detect stage (of the call before that) and the emit stage behind it ride on the launch
       launch_step(c, &drole, c->have_det ? &c->pend_det : nullptr, c->pend_det_tiles, c->pend_det_spec, c->have_emit ? &c->pend_emit : nullptr, nullptr, true);
     } else if (merged_call) {
@@ -2990,15 +2997,32 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
     return SS_OK;
   }
   SS_HIP(c, hipSetDevice(c->cfg.device_id));
+#ifdef SS_DIAG
+  static const bool trace = getenv("SS_TRACE_PROCESS") != nullptr;  // (where a call's time goes, phase by phase: stderr)
+  auto t_last = std::chrono::steady_clock::now();
+  const auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[ss_process] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+#else
+  const auto lap = [](const char*) {};
+#endif
   const int n = c->n;
   const size_t bps = in_bytes_per_sample(c->cfg.in_format);
   const size_t row_bytes = (size_t)n * bps;
   if (!c->d_in) SS_HIP(c, hipMalloc(&c->d_in, row_bytes * (size_t)c->cfg.max_batch));
+  lap("set device, input buffer");
   // Decimator: only the first N samples of each N*D item ever reach the GPU (decimator.h:15-22)
-  // (D = 1: the items are one run of bytes — a plain copy. The 2-D form of the runtime takes pageable memory through in small pieces:
-  // 16 frames of 2^20 CF32 samples took 29 ms of a 31.6 ms call that way, against 2.4 ms — 56 GB/s — as one run: profiles/r06/s1_summary.txt)
-  if (c->cfg.decim == 1) SS_HIP(c, hipMemcpyAsync(c->d_in, iq, row_bytes * (size_t)nframes, hipMemcpyHostToDevice, c->stream));
-  else SS_HIP(c, hipMemcpy2DAsync(c->d_in, row_bytes, iq, row_bytes * (size_t)c->cfg.decim, row_bytes, (size_t)nframes, hipMemcpyHostToDevice, c->stream));
+  // The caller's buffer is pageable (the scheduler's) and the call hands its results back before it returns: a synchronous copy — D = 1:
+  // the items are one run of bytes. (128 MiB reach the device in 2.4 ms, 56 GB/s, by hipMemcpy, hipMemcpyAsync on any stream or the 2-D form
+  // alike — profiles/r06/s7_pageable_copy_lab.txt; what made this copy take 19-29 ms in round 5's and this round's bench lines was the
+  // CALLER unmapping 128 MiB of host memory between calls — the Python wrapper's default candidate arrays —, profiles/r06/s10_summary.txt.)
+  // Everything this context enqueued earlier is complete (the previous call drained it), so nothing else has to be ordered with the copy.
+  if (c->cfg.decim == 1) SS_HIP(c, hipMemcpy(c->d_in, iq, row_bytes * (size_t)nframes, hipMemcpyHostToDevice));
+  else SS_HIP(c, hipMemcpy2D(c->d_in, row_bytes, iq, row_bytes * (size_t)c->cfg.decim, row_bytes, (size_t)nframes, hipMemcpyHostToDevice));
+  lap("copy in");
   if (cand_cap > c->cand_cap_alloc) {
     (void)hipFree(c->d_cand_idx);
     (void)hipFree(c->d_cand_avg);
@@ -3019,10 +3043,13 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
     if (!c->d_relplane) SS_HIP(c, hipMalloc(&c->d_relplane, sizeof(float) * (size_t)n * (size_t)c->cfg.max_batch));
     d_rel_plane = c->d_relplane;
   }
+  lap("noise state, buffers");
   st = run_batch(c, c->d_in, (long long)n, nframes, n_learn, z, nullptr, d_rel_plane, (c->fused && avg_db) ? c->d_avg2[c->buf_cur] : nullptr, nullptr,
                  want_cands ? c->d_cand_idx : nullptr, want_cands && cand_avg ? c->d_cand_avg : nullptr, cand_cap);
   if (st != SS_OK) return st;
+  lap("run_batch (enqueue)");
   flush_stages(c);  // a work() call hands its results back before it returns
+  lap("flush_stages (enqueue)");
   const size_t plane = sizeof(float) * (size_t)n * (size_t)nframes;
   if (psd_db) SS_HIP(c, hipMemcpyAsync(psd_db, c->last_psd, plane, hipMemcpyDeviceToHost, c->stream));
   if (rel_db) {
@@ -3033,6 +3060,7 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
   std::vector<int> off((size_t)nframes + 1);
   SS_HIP(c, hipMemcpyAsync(off.data(), c->d_off, sizeof(int) * ((size_t)nframes + 1), hipMemcpyDeviceToHost, c->stream));
   SS_HIP(c, stream_wait(c->stream));
+  lap("wait for the stream");
   if (cand_off) memcpy(cand_off, off.data(), sizeof(int) * ((size_t)nframes + 1));
   const int total = off[(size_t)nframes];
   if (want_cands) {
@@ -3042,6 +3070,7 @@ int ss_process(ss_ctx* c, const void* iq, int32_t nframes, const int64_t* t_ms, 
       if (cand_avg) SS_HIP(c, hipMemcpy(cand_avg, c->d_cand_avg, sizeof(float) * (size_t)ncopy, hipMemcpyDeviceToHost));
     }
   }
+  lap("candidates out");
   if (cand_cap > 0 && total > cand_cap) return fail(c, SS_ERR_CAND_OVERFLOW, "%d candidates > cand_cap %d", total, cand_cap);
   return SS_OK;
 }

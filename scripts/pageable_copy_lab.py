@@ -69,3 +69,46 @@ for mib in (128, 16):
     print(f"{mib} MiB pageable -> device:")
     for k, v in res.items():
         print(f"   {k:48s} {v * 1e3:8.2f} ms  {nbytes / v / 1e9:6.1f} GB/s")
+
+
+# ---- does destroying streams change what a stream created afterwards gets? (ss_process was ten times slower on a context created after
+# another one had been destroyed: profiles/r06/s10_summary.txt) ----
+import sys
+nbytes = 128 << 20
+host = np.random.default_rng(1).integers(0, 255, nbytes, dtype=np.uint8)
+d = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+hp, dp = host.ctypes.data, d.data_ptr()
+hip.hipStreamDestroy.argtypes = [C.c_void_p]
+
+
+def copy_ms(stream, reps=4):
+    hip.hipMemcpyAsync(dp, hp, nbytes, H2D, stream)
+    hip.hipStreamSynchronize(stream)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        assert hip.hipMemcpyAsync(dp, hp, nbytes, H2D, stream) == 0
+        assert hip.hipStreamSynchronize(stream) == 0
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def new_stream():
+    st = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(st), 1) == 0
+    return st
+
+
+print("128 MiB pageable -> device on streams created at different times:")
+a = new_stream()
+print(f"   stream A (new): {copy_ms(a):.2f} ms")
+others = [new_stream() for _ in range(5)]
+for o in others:
+    copy_ms(o, 1)
+print(f"   stream A with five more streams alive: {copy_ms(a):.2f} ms; the fifth of them: {copy_ms(others[-1]):.2f} ms")
+for o in others:
+    hip.hipStreamDestroy(o)
+print(f"   stream A after the five were destroyed: {copy_ms(a):.2f} ms")
+b = new_stream()
+print(f"   stream B, created after that: {copy_ms(b):.2f} ms")
+hip.hipStreamDestroy(a)
+c2 = new_stream()
+print(f"   stream C, created after A was destroyed too: {copy_ms(c2):.2f} ms; stream B again: {copy_ms(b):.2f} ms; the null stream: {copy_ms(None):.2f} ms")
