@@ -68,7 +68,7 @@ typedef enum ss_plane {
 /* Also run the Spectrogram side branch (sources/radio/blocks/spectrogram.cpp): accumulate the bin-decimated raw
  * PSD per centre frequency; read it back with ss_spectrogram_read. */
 #define SS_FLAG_SPECTROGRAM 2u
-/* 8192-, 65536- and 2^20-point frames: evaluate every averaging tile, also those whose per-frame maxima show that no window
+/* 8192-, 65536-, 131072- (int8), 262144- and 2^20-point frames: evaluate every averaging tile, also those whose per-frame maxima show that no window
  * mean of the tile can reach start_level (csrc/detect_fused.h, tile culling). Results are identical either way; the flag
  * exists so that the data-independent cost of the chain can be measured (bench.py reports both). */
 #define SS_FLAG_NO_CULL 4u
@@ -160,7 +160,8 @@ int ss_process(ss_ctx* ctx, const void* iq, int32_t nframes, const int64_t* t_ms
  * blocks each work on a different frame at any moment (sdr_device.cpp:161-171), consecutive calls overlap on the device —
  * a launch carries the FFT + dB stage of one call and the averaging / threshold and candidate-list stages of earlier calls
  * (csrc/scan_step.h); for 8192-point frames up to five calls are in flight, on two hardware queues of the library's own
- * (ss_ctx::deep in csrc/specscan.hip). 65536-point frames: the launch of call k carries the plan of call k - 1 (which of its
+ * (ss_ctx::deep in csrc/specscan.hip). 65536-point frames (and, since ABI 3 / round 6, 262144-point frames — the size getFft picks at
+ * 61.44 MS/s —, which take the same pipeline): the launch of call k carries the plan of call k - 1 (which of its
  * averaging tiles can hold a candidate), the averaging / threshold stage of call k - 2 and the candidate lists of call k - 3 — the
  * lists of a call exist three calls later, or after ss_flush / ss_sync —, mask / counter / list sets rotate over four to six, and
  * the averager ring's buffer holds four batches (csrc/ring_place.h). 2^20-point frames: two launches per call, the stages of
@@ -207,7 +208,7 @@ typedef struct ss_stats {
   uint64_t drains;            /* times the deferred stages were drained (ss_sync, ss_flush, reads, retunes, resets, buffer clashes) */
   uint64_t demotions;         /* times a caller refilling an input buffer in flight took the context off the overlapped path */
   uint64_t tiles_total;       /* 16-frame x 256-bin averaging tiles of the batches processed (21 x 21 grouping) */
-  uint64_t tiles_tested;      /* ... that went through the culling test (tile culling: 8192, 65536 and 2^20 points, not with SS_FLAG_NO_CULL) */
+  uint64_t tiles_tested;      /* ... that went through the culling test (tile culling: 8192, 65536, 131072 (int8), 262144 and 2^20 points, not with SS_FLAG_NO_CULL) */
   uint64_t tiles_culled;      /* ... that the test proved empty and nobody evaluated (tiles evaluated = tiles_total - tiles_culled) */
   uint64_t wait_fallbacks;    /* workgroups that stopped waiting for a launch's tile plan and made it themselves (csrc/detect_fused.h) */
 } ss_stats;
@@ -256,7 +257,7 @@ int ss_reset_noise(ss_ctx* ctx);
  * negative down to -(grouping_y-1) for SS_PLANE_REL, addressing the averager ring rows that
  * Transmission::getBestIndex walks (transmission.cpp:132-154). SS_PLANE_REL is always there. SS_PLANE_AVG needs
  * SS_FLAG_KEEP_PLANES. SS_PLANE_PSD is there after ss_process and after ss_process_device calls that were given d_psd_db; a
- * 65536-point or 2^20-point ss_process_device call in detect mode (no plane handed out, no SS_FLAG_KEEP_PLANES) writes no dB
+ * 65536-, 262144- or 2^20-point ss_process_device call in detect mode (no plane handed out, no SS_FLAG_KEEP_PLANES) writes no dB
  * plane at all — its rows go straight to the averager ring's buffer (65536 / 131072 points, int8 IQ: as dB values, in the blocked
  * order the fold leaves them in, csrc/fft65536_dif8.h; this call hands noise-relative values back in bin order all the
  * same) — and SS_PLANE_PSD / SS_PLANE_AVG then fail with SS_ERR_INVALID: pass d_psd_db, or SS_FLAG_KEEP_PLANES at ss_create,

@@ -127,8 +127,9 @@ struct StepArgs {
   // stage of two calls later reads; the plan of call k - 1, detect(k - 2) (PERM8 tiles) and emit(k - 3) ride on the launch as they ride
   // on the column launch of the four-step form (KIND 2). `fft` carries the transform's tables and the rows' place, `dif` the fold's.
   // KIND 9 — the same for 131072-point frames (what getFft picks at 20 MS/s): radix 16, residues r and r + 8 per workgroup, n_fft = 8 x frames.
-  // KIND 11 — KIND 8 with ONE residue per workgroup (fft65536_dif8.h: dif8_front, 64 registers, eight waves per SIMD), n_fft = 8 x frames: calls
-  // of up to 32 frames, whose 4 x frames two-residue workgroups leave most of the chip's 256 CUs idle for 18 us each (round 6).
+  // KIND 11 — KIND 8 with ONE residue per workgroup (fft65536_dif8.h: dif8_front, 64 registers, eight waves per SIMD), n_fft = 8 x frames: tried
+  // for short calls, whose 4 x frames two-residue workgroups leave most of the chip's 256 CUs idle for 18 us each (round 6) — no gain: a
+  // workgroup folds the WHOLE frame for one residue as for two and lives as long (SS_DIF8_SINGLE_MAX of the diagnostics build).
   // KIND 12 — 262144 points, ONE launch per call (round 6): KIND 10's roles and the 1024-point ROW tiles of call k - 1 (ROLE_ROWS: `rows`, n_rows of
   // them, from the other of two work buffers) behind the column tiles of call k — KIND 7's shape with this size's row tile and plan.
   // KIND 10 — 262144 points (round 6): KIND 2 — 256-point column tiles as the FFT role, the plan of call k - 1, detect(k - 2), emit(k - 3) —

@@ -136,7 +136,7 @@ struct ss_ctx {
     bool dif8 = true;              // 65536 points, int8 IQ, default window, calls that keep no plane: NO work buffer — the radix-8 fold in the load stage of the 8192-point transform, eight workgroups per frame, one launch per call whatever its length (scan_step.h KIND 8, fft65536_dif8.h; SS_DIF8=0: the four-step forms of round 4)
     int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
     bool rows1024x256 = true;      // 262144 points (what getFft picks at 61.44 MS/s): rows through the 1024-point row tile with run maxima and ring rows — culled, no dB plane in detect mode, the 65536-point two-launch pipeline (SS_ROWS1024X256=0: round 2's path, k_fft_rows256xR_psd, every tile evaluated)
-    int dif8_single_max = 32;      // 65536 points, the fold: calls of up to this many frames take ONE residue per workgroup (scan_step.h KIND 11; SS_DIF8_SINGLE_MAX=0: never)
+    int dif8_single_max = 0;       // 65536 points, the fold: calls of up to this many frames take ONE residue per workgroup (scan_step.h KIND 11; SS_DIF8_SINGLE_MAX=n) — measured in round 6 and not kept: a workgroup folds the whole frame whether it wants one residue of it or two, so it lives as long either way (16-frame calls 20.6 against 19.5 us, 32-frame calls 26.0 against 20.3: profiles/r06/s13_summary.txt)
     int chunk_65536 = 256;         // 65536 points with tile culling: calls of more frames go through in chunks of this many (SS_CHUNK_65536=0: in one piece)
     int chunk_long = 16;           // 2^20 points in two passes: calls of more frames go through in chunks of this many (SS_CHUNK_LONG=0: in one piece)
     bool halo_maxima = true;       // 8192 points, deep pipelining: the re-transformed halo frames leave per-column maxima, so that the tiles of a batch's first two frame tiles are tested like the others (SS_HALO_MAXIMA=0: evaluated whatever they hold, as until session 36 of round 5)
@@ -2008,8 +2008,8 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
       FftRole drole;
       drole.frames = &gf;
       drole.dif = &df;
-      // (two residues per workgroup: four per frame at radix 8, eight at radix 16 — but a radix-8 call of up to dif8_single_max frames takes one
-      // residue per workgroup, eight per frame: 4 x 16 workgroups of 18 us each leave three quarters of the chip idle, KIND 11)
+      // (two residues per workgroup: four per frame at radix 8, eight at radix 16; a radix-8 call of up to dif8_single_max frames — 0 in the
+      // product — takes one residue per workgroup, eight per frame: KIND 11, a switch of the diagnostics build)
       const bool single = c->dif_logq == 3 && nframes <= c->diag.dif8_single_max;
       drole.n = (c->dif_logq == 4 || single ? 8 : SS_DIF8_W) * nframes;
       // the plan of the call before, the planned detect stage (of the call before that) and the emit stage behind it ride on the launch

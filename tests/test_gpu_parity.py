@@ -118,6 +118,11 @@ ALTERNATIVES = [  # (environment, fft size, sample rate, format): every measurem
     ({"SS_EMIT_ON_ROWS": "1", "SS_LIST_FIRST": "0"}, 65536, 20_000_000, "cf32"),
     ({"SS_PLAN_FIRST": "32"}, 8192, 2_048_000, "cf32"),     # 8192 points: the first pairs of every list on detect workgroups of their own
     ({"SS_HALO_MAXIMA": "0"}, 8192, 2_048_000, "cf32"),     # 8192 points: the halo frames leave no maxima, the tiles at a batch's start are evaluated untested (until session 36 of round 5)
+    # round 6
+    ({"SS_ROWS1024X256": "0"}, 262144, 61_440_000, "cf32"),  # 262144 points on round 2's path (k_fft_rows256xR_psd, every tile evaluated)
+    ({"SS_MERGE_65536": "0"}, 262144, 61_440_000, "cs8"),   # ... culled, two launches per call (KIND 10 + k_fft_rows1024_psd<8>)
+    ({"SS_PLAN_FUSED": "0", "SS_LIST_FIRST": "0"}, 262144, 61_440_000, "cf32"),  # ... the plan (plan_x256_run) as a launch of its own
+    ({"SS_DIF8_SINGLE_MAX": "32"}, 65536, 20_000_000, "cs8"),  # the fold with ONE residue per workgroup for short calls (KIND 11: measured, not kept)
 ]
 
 
@@ -136,7 +141,7 @@ def test_alternative_implementations_meet_the_contract(oracle_mod, monkeypatch, 
 
 
 @pytest.mark.parametrize("n,fmt", [(512, "cs8"), (1024, "cf32"), (2048, "cs8"), (2048, "cf32"), (4096, "cu8"), (8192, "cf32"), (16384, "cs8"),
-                                   (65536, "cf32"), (131072, "cs8"), (1 << 20, "cs8")])
+                                   (65536, "cf32"), (131072, "cs8"), (262144, "cf32"), (1 << 20, "cs8")])
 def test_psd_of_a_frame_does_not_depend_on_its_position_in_the_batch(n, fmt):
     """Kernels that take several frames per workgroup must round every frame the same way (the two unrolled halves of the
     2048-point kernel once did not: the compiler chose the FMA operand per call site): frame-range sharding and
