@@ -14,7 +14,8 @@ broadcast once from rank 0.
 
 Prints ONE JSON line on rank 0 — a compact form of a few KB (compact_line: the contract's keys, roofline, cpu_baseline, a parity verdict
 and one short record per `also` entry); everything below in full goes to bench_full.json beside this file:
-  value / ms_per_step   whole-job throughput, barrier + device sync on both sides of exactly --steps steps, max over ranks
+  value / ms_per_step   whole-job throughput, barrier + device sync on both sides of exactly --steps steps, max over ranks (a rank's interval:
+                        from behind the opening barrier + sync to behind the closing sync; the closing barrier follows it)
   roofline              the dominant kernel (k_scan_step): algorithmic bytes per launch / its mean device time from start/stop
                         events attached to launches on the engine's own streams — in 32 more steps right behind the timed region
                         (an event-timed launch costs its queue ~13 us: none rides inside the timed region; --time-every k puts
@@ -1007,7 +1008,10 @@ def run(args):
         every = 4
         if launches:
             kern_after = {"us": round(kern_ms / launches * 1e3, 2), "launches": launches, "what": "32 more steps right behind the timed region, every 4th call's launches timed"}
-    elapsed = dist.max_over_ranks(t1 - t0, device=coll_dev)
+    # A rank's interval ends when ITS device is idle (t_dev, behind the contract's synchronisation); the barrier behind it brackets the region,
+    # and the job's time is the slowest rank's: MAX over ranks. (Until round 6 the interval ran to t1, behind the barrier — at N = 1 the same
+    # thing, at N > 1 it put the collective's own latency, 30-100 us of a 500 us region, into every rank's time: an artefact in the scaling curve.)
+    elapsed = dist.max_over_ranks(t_dev - t0, device=coll_dev)
     devices_of_ranks = dist.ints_of_ranks(device_index, device=coll_dev)  # (rank r -> the device it worked on: LOCAL_RANK modulo the box's device count)
     cands_of_ranks = dist.ints_of_ranks(int(outs[(counter[0] - 1) % nout]["off"][-1].item()), device=coll_dev)
     ncand = int(outs[(counter[0] - 1) % nout]["off"][-1].item())
