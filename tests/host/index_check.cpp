@@ -48,6 +48,11 @@ int main() {
       const int cols = ss::plan_cols_per_wg(nframes, shift), nft = ss::plan_frame_tiles(nframes, shift);
       if (cols != 0 && (cols * nft > ss::kLiveCap || cols * (nframes + (nframes >> 4) + 1) > ss::kPlanLdsFloats || 32 % cols != 0)) ++bad;
     }
+  // (the limits of the 8192-point plan since the halo frames' maxima have a place in every column, round 5: a plan workgroup takes 8 tile
+  // columns up to 1081-frame batches — the benchmark's 1024 among them —, 4 up to 2210; 2211 frames and more are not planned: DESIGN.md 4.1)
+  if (ss::plan_cols_per_wg(1024, 0) != 8 || ss::plan_cols_per_wg(1081, 0) != 8 || ss::plan_cols_per_wg(1082, 0) != 4 || ss::plan_cols_per_wg(2210, 0) != 4 ||
+      ss::plan_cols_per_wg(2211, 0) != 0)
+    ++bad;
   // ---- 2^20 points in two passes (csrc/fft1024_kernels.h) ----
   {
     const int n = 1 << 20, half = n >> 1, runs = n >> 5;
