@@ -790,66 +790,74 @@ def emit_line(full: dict, sub: bool = False) -> None:
 
 
 
+def drop_in_probe(stage):
+    """Diagnosis (scripts/r06/s10.sh, profiles/r06/s10_summary.txt): with SS_BENCH_DROPIN_AT=<stage> the drop-in lines are measured at that point
+    of the run — together with a few raw copies of a pageable 128 MiB buffer — and the run goes on. Without the variable: nothing."""
+    if os.environ.get("SS_BENCH_DROPIN_AT") != stage:
+        return
+    import numpy as np
+    import rtl_sdr_scanner_cpp_amd as pkg
+    if True:
+        if os.environ.get("SS_TRACE_PROCESS"):
+            pkg.engine.use_diag_library(True)  # (the diagnostics build prints ss_process's phases)
+        for e in drop_in_lines():
+            print("PROBE", stage, {k: e.get(k) for k in ("fft_size", "ss_process_MSps", "ss_process_pieces_ms", "error")}, file=sys.stderr, flush=True)
+        # ... is it the SOURCE? the same context fed from a synthetic batch (made by numpy arithmetic) and from one fresh allocation
+        n_, nb_ = 1 << 20, 16
+        band_ = pkg.synth.SyntheticBand(n_, seed=9, on_frame=40, off_frame=10_000)
+        learn_, synth_ = band_.frames_cf32(32), band_.frames_cf32(nb_)
+        fresh_ = np.empty((nb_, n_), np.complex64)
+        fresh_[:] = synth_
+        e_ = pkg.SpectrumEngine(61_440_000, 145_000_000, fft_size=n_, decim=1, in_format=0, learn_frames=32, max_batch=32)
+        e_.process(learn_, want=())
+        for name_, src_ in (("synthetic batch", synth_), ("fresh np.empty filled once", fresh_), ("synthetic batch again", synth_)):
+            e_.process(src_, want=(), cand_cap=1 << 20)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                e_.process(src_, want=(), cand_cap=1 << 20)
+            print("PROBE", stage, f"ss_process fed from {name_}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", file=sys.stderr, flush=True)
+        e_.close()
+        # ... and a pageable 128 MiB buffer into device memory obtained NOW from hipMalloc, against memory torch's allocator holds
+        import ctypes as C
+        import torch
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        hip.hipFree.argtypes = [C.c_void_p]
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        nbytes = 128 << 20
+        host = np.ones(nbytes, np.uint8)
+        fresh = C.c_void_p()
+        assert hip.hipMalloc(C.byref(fresh), nbytes) == 0
+        held = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        for name, ptr in (("fresh hipMalloc", fresh.value), ("torch's pool", held.data_ptr())):
+            hip.hipMemcpy(ptr, host.ctypes.data, nbytes, 1)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                hip.hipMemcpy(ptr, host.ctypes.data, nbytes, 1)
+            print("PROBE", stage, f"hipMemcpy of 128 MiB pageable into {name}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", file=sys.stderr, flush=True)
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        for flag, name in ((1, "a new non-blocking stream"), (0, "a new blocking stream")):
+            st = C.c_void_p()
+            assert hip.hipStreamCreateWithFlags(C.byref(st), flag) == 0
+            hip.hipMemcpyAsync(fresh.value, host.ctypes.data, nbytes, 1, st)
+            hip.hipStreamSynchronize(st)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                hip.hipMemcpyAsync(fresh.value, host.ctypes.data, nbytes, 1, st)
+                hip.hipStreamSynchronize(st)
+            print("PROBE", stage, f"hipMemcpyAsync + hipStreamSynchronize on {name}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", file=sys.stderr, flush=True)
+        hip.hipFree(fresh)
+
+
 # ---------------------------------------------------------------------------------------------- the measured job
 def run(args):
     import numpy as np
     import rtl_sdr_scanner_cpp_amd as pkg
     from rtl_sdr_scanner_cpp_amd import dist
 
-    def _probe(stage):  # (diagnosis, scripts/r06/s10.sh: SS_BENCH_DROPIN_AT=<stage> measures the drop-in lines at that point of the run and goes on)
-        if os.environ.get("SS_BENCH_DROPIN_AT") == stage:
-            if os.environ.get("SS_TRACE_PROCESS"):
-                pkg.engine.use_diag_library(True)  # (the diagnostics build prints ss_process's phases)
-            for e in drop_in_lines():
-                print("PROBE", stage, {k: e.get(k) for k in ("fft_size", "ss_process_MSps", "ss_process_pieces_ms", "error")}, file=sys.stderr, flush=True)
-            # ... is it the SOURCE? the same context fed from a synthetic batch (made by numpy arithmetic) and from one fresh allocation
-            n_, nb_ = 1 << 20, 16
-            band_ = pkg.synth.SyntheticBand(n_, seed=9, on_frame=40, off_frame=10_000)
-            learn_, synth_ = band_.frames_cf32(32), band_.frames_cf32(nb_)
-            fresh_ = np.empty((nb_, n_), np.complex64)
-            fresh_[:] = synth_
-            e_ = pkg.SpectrumEngine(61_440_000, 145_000_000, fft_size=n_, decim=1, in_format=0, learn_frames=32, max_batch=32)
-            e_.process(learn_, want=())
-            for name_, src_ in (("synthetic batch", synth_), ("fresh np.empty filled once", fresh_), ("synthetic batch again", synth_)):
-                e_.process(src_, want=(), cand_cap=1 << 20)
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    e_.process(src_, want=(), cand_cap=1 << 20)
-                print("PROBE", stage, f"ss_process fed from {name_}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", file=sys.stderr, flush=True)
-            e_.close()
-            # ... and a pageable 128 MiB buffer into device memory obtained NOW from hipMalloc, against memory torch's allocator holds
-            import ctypes as C
-            import torch
-            hip = C.CDLL("libamdhip64.so")
-            hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-            hip.hipFree.argtypes = [C.c_void_p]
-            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-            nbytes = 128 << 20
-            host = np.ones(nbytes, np.uint8)
-            fresh = C.c_void_p()
-            assert hip.hipMalloc(C.byref(fresh), nbytes) == 0
-            held = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-            for name, ptr in (("fresh hipMalloc", fresh.value), ("torch's pool", held.data_ptr())):
-                hip.hipMemcpy(ptr, host.ctypes.data, nbytes, 1)
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    hip.hipMemcpy(ptr, host.ctypes.data, nbytes, 1)
-                print("PROBE", stage, f"hipMemcpy of 128 MiB pageable into {name}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", file=sys.stderr, flush=True)
-            hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-            hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
-            hip.hipStreamSynchronize.argtypes = [C.c_void_p]
-            for flag, name in ((1, "a new non-blocking stream"), (0, "a new blocking stream")):
-                st = C.c_void_p()
-                assert hip.hipStreamCreateWithFlags(C.byref(st), flag) == 0
-                hip.hipMemcpyAsync(fresh.value, host.ctypes.data, nbytes, 1, st)
-                hip.hipStreamSynchronize(st)
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    hip.hipMemcpyAsync(fresh.value, host.ctypes.data, nbytes, 1, st)
-                    hip.hipStreamSynchronize(st)
-                print("PROBE", stage, f"hipMemcpyAsync + hipStreamSynchronize on {name}: {(time.perf_counter() - t0) / 3 * 1e3:.2f} ms", file=sys.stderr, flush=True)
-            hip.hipFree(fresh)
-
+    _probe = drop_in_probe
     # RCCL ("nccl") over xGMI in production; SS_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box
     # with fewer GPUs than ranks (ranks then share devices, results are functional only)
     backend = os.environ.get("SS_DIST_BACKEND", "nccl")
