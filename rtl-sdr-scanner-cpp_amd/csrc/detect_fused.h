@@ -40,6 +40,12 @@
 #define SS_DET_NT 0
 #endif
 
+// 8192 points, deep pipelining: the averaging tiles whose first rows are halo frames on a straight-line path of their own (1), or on the
+// general path like every non-steady tile (0: until round 6). Build-time so that the two can be timed against each other (scripts/build_ab.py).
+#ifndef SS_STEADY_HALO
+#define SS_STEADY_HALO 1
+#endif
+
 namespace ss {
 
 __device__ __forceinline__ float load_row_value(const char* p) {
@@ -1283,6 +1289,41 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
               if (f0 + j >= first_hist) store_row(a.hist_out, f0 + j - first_hist, n, coff, x[G - 1 + j]);
           }
         }
+      }
+    }
+  } else if (PERM8 == 0 && SS_STEADY_HALO && a.halo_psd && a.n_learn == 0 && f0 - (G - 1) >= -a.halo_rows && f0 + TF <= nframes && a.pushed_before >= G && !a.rel_out &&
+             !writes_hist) {
+    // Round 6 — a steady tile whose first rows lie before the batch, in the halo frames' dB plane (8192 points, deep pipelining: the first
+    // two frame tiles of every batch): every one of its 36 rows is a dB row of a full averager, as a steady tile's, only in two pieces of
+    // memory — a scalar select of the row's base, the straight-line path's arithmetic on the same values. (On the general path — an
+    // address and three masks per row for cases that cannot occur here — such a tile took 12 us against a steady tile's 6, and the
+    // workgroups that evaluate them were the last of their launch and the whole of a drain's detect launch: profiles/r05/s37_summary.txt,
+    // profiles/r06/s1_timeline_k20.txt.) The tile's frames before the batch (f0 + j < 0) get time means nobody reads: phase 2 skips them.
+#pragma unroll
+    for (int pass_c = 0; pass_c < 2; ++pass_c) {
+#ifdef SS_DIAG
+      if (pass_c == 1 && a.stamp_mid && tid == 0) a.stamp_mid[4 * (size_t)block + 1] = wall_clock64();
+#endif
+      const int c = tile_column_of<PERM8, A, TB>(pass_c, tid);
+      if (pass_c == 0 || tid < 2 * A) {
+        const int col = b0 - A + c;
+        const int colc = min(max(col, 0), n - 1);
+        const bool in_band = col == colc;
+        const float t = a.thr[colc];
+        const char* pb = reinterpret_cast<const char*>(a.psd);
+        const char* hb = reinterpret_cast<const char*>(a.halo_psd + (size_t)a.halo_rows * n);  // (its end: frame -1 is the row before it)
+        const uint32_t coff = (uint32_t)colc * 4u;
+        float x[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+          const int fr = f0 - (G - 1) + r;  // (block-uniform)
+          x[r] = load_row_value((fr < 0 ? hb : pb) + (ptrdiff_t)fr * (ptrdiff_t)n * 4 + coff) - t;
+        }
+        if (!interior) {
+#pragma unroll
+          for (int r = 0; r < ROWS; ++r) x[r] = in_band ? x[r] : 0.0f;
+        }
+        time_means_to_tile<G, TF, P, false>(x, &tile[c], 0);
       }
     }
   } else {
