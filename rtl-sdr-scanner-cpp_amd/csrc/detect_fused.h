@@ -41,9 +41,12 @@
 #endif
 
 // 8192 points, deep pipelining: the averaging tiles whose first rows are halo frames on a straight-line path of their own (1), or on the
-// general path like every non-steady tile (0: until round 6). Build-time so that the two can be timed against each other (scripts/build_ab.py).
+// general path like every non-steady tile (0: ships). Measured in round 6 (profiles/r06/s16_summary.txt, alternating runs, 264 GPU tests
+// green with it): 23.2-23.6 against 23.0-23.1 us per step in 200 steps, 26.2-26.8 against 26.2-26.7 in 20, 31.3 against 31.2 with every
+// tile evaluated — nothing: neither the step nor the drain's detect launch (21.0 / 14.9 us either way) is as long as its slowest tile.
+// Build-time so that the two can be timed against each other (scripts/build_ab.py: steadyhalo).
 #ifndef SS_STEADY_HALO
-#define SS_STEADY_HALO 1
+#define SS_STEADY_HALO 0
 #endif
 
 namespace ss {
@@ -1293,7 +1296,7 @@ __device__ __forceinline__ void detect_tile(const DetectArgs& a, int block, int 
     }
   } else if (PERM8 == 0 && SS_STEADY_HALO && a.halo_psd && a.n_learn == 0 && f0 - (G - 1) >= -a.halo_rows && f0 + TF <= nframes && a.pushed_before >= G && !a.rel_out &&
              !writes_hist) {
-    // Round 6 — a steady tile whose first rows lie before the batch, in the halo frames' dB plane (8192 points, deep pipelining: the first
+    // Round 6 (SS_STEADY_HALO=1 builds; measured, not kept) — a steady tile whose first rows lie before the batch, in the halo frames' dB plane (8192 points, deep pipelining: the first
     // two frame tiles of every batch): every one of its 36 rows is a dB row of a full averager, as a steady tile's, only in two pieces of
     // memory — a scalar select of the row's base, the straight-line path's arithmetic on the same values. (On the general path — an
     // address and three masks per row for cases that cannot occur here — such a tile took 12 us against a steady tile's 6, and the

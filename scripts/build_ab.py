@@ -38,7 +38,7 @@ VARIANTS = {
     "genrows": ["SS_GENERAL_ROW_LANES=0"],   # ... row by row on the scalar unit with session 33's expressions (the shipped form works the 36 rows out on 36 lanes)
     "genold": ["SS_GENERAL_ROW_OLD=1", "SS_GENERAL_ROW_LANES=0"],   # the averaging tiles' general path with its per-row address and value expressions as they were until session 33 of round 5
     "longwt": ["SS_AUX_WORK=16", "SS_AUX_ROWS=16"],   # long transforms: work buffer and dB / ring rows stored write-through (sc1) — measured in round 6: the row launches lose a third
-    "nosteadyhalo": ["SS_STEADY_HALO=0"],   # 8192 points: the tiles at a batch's start on the general path, as until round 6
+    "steadyhalo": ["SS_STEADY_HALO=1"],   # 8192 points: the tiles at a batch's start (rows in the halo frames' plane) on a straight-line path of their own — measured in round 6: no gain
     "plancopy16": ["SS_PLAN_COPY_LOADS=16"],   # 8192 points: the plan copies its columns' maxima sixteen loads at a time — one round trip per 1024-frame batch — instead of eight (measured in round 6: no gain)
     "dif8acc": ["SS_DIF8_BFLY=0"],   # 65536 points: the fold as round 5's accumulating loop over q (round 6 ships a radix-8 butterfly per point)
     "colsnone": ["SS_COLS_TW6=0", "SS_COLS_ABL=3"],   # ... without either  # 8192 points, deep pipelining: ring rows written by three frame tiles of every call
