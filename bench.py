@@ -311,8 +311,8 @@ def parity_sample(n: int, fs: int, fmt: str, no_cull: bool = False, call_frames:
 
 # ---------------------------------------------------------------------------------------------- launcher
 PMC_FILES = {"fetch": "pmc_fetch.csv", "write": "pmc_write.csv"}  # under profiles/<PMC_SET>/, one counter per rocprofv3 pass
-# the committed passes of each configuration's command line (config 2: round 4, scripts/r04/s8.sh; configs 3 and 5: round 6, scripts/r06/s14.sh)
-PMC_SET = {2: "r04/s8_cfg2", 3: "r06/s14_cfg3", 5: "r06/s14_cfg5"}  # (config 2's kernel has not changed its traffic since; its default line measures it live: live_pmc_traffic)
+# the committed passes of each configuration's command line (config 2: round 4, scripts/r04/s8.sh; configs 3 and 5: round 6, scripts/r06/s17.sh)
+PMC_SET = {2: "r04/s8_cfg2", 3: "r06/s17_cfg3", 5: "r06/s17_cfg5"}  # (config 2's kernel has not changed its traffic since; its default line measures it live: live_pmc_traffic)
 
 
 def traffic_from_profiles(config: int, kernel_match: str, threads_per_launch: int | None = None):
