@@ -532,6 +532,7 @@ def parse_args(argv):
     ap.add_argument("--no-cull", action="store_true", help="SS_FLAG_NO_CULL: evaluate every averaging tile, also those whose segment maxima rule out a candidate (the data-independent cost of the chain)")
     ap.add_argument("--launch-check", action="store_true", help="exercise launcher, rendezvous, config broadcast and max-over-ranks timing only (no GPU work)")
     ap.add_argument("--sync-engine-first", action="store_true", help="end of the timed region as in round 2: ss_sync, then torch.cuda.synchronize() (A/B; the default lets the device-wide synchronisation do the waiting)")
+    ap.add_argument("--host-wait", default="auto", choices=["auto", "spin", "yield", "block"], help="how the host thread waits for the device (hipSetDeviceFlags: hipDeviceScheduleAuto / Spin / Yield / BlockingSync)")
     ap.add_argument("--no-also", action="store_true", help="default line only: do not append the short runs of BASELINE configs 3 and 5 (`also`)")
     ap.add_argument("--also-all", action="store_true", help="`also` with two more call sizes (config 3 in 256-frame calls, config 5 in 64-frame calls)")
     ap.add_argument("--sub", action="store_true", help="(internal) this process is one of the `also` runs of another bench.py")
@@ -895,6 +896,12 @@ def run(args):
     plan = rank_plan(rank, local_rank, world, ndev, args, n)
     device_index = plan["device_index"]
     torch.cuda.set_device(device_index)
+    if args.host_wait != "auto":
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so.7")  # (the runtime torch has loaded: same soname)
+        rc = hip.hipSetDeviceFlags(ctypes.c_uint({"spin": 1, "yield": 2, "block": 4}[args.host_wait]))
+        if rc != 0:
+            raise RuntimeError(f"hipSetDeviceFlags({args.host_wait}) failed: {rc}")
     dev = torch.device("cuda", device_index)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
     cfg = dist.broadcast_config(cfg0, device=coll_dev)  # the only collective of the whole job (RCCL, < 1 KiB)
@@ -1080,7 +1087,7 @@ def run(args):
                                    + ("one band per GPU" if not shard_frames else "one band, a contiguous frame range per GPU (halo re-read, no exchange)"),
                        "baseline_config": args.config or 2, "fft_size": n, "frames_per_batch": nb, "bands": int(cfg["n_bands"]), "shard": args.shard if world > 1 else None,
                        "halo_frames": halo_frames, "candidates_per_batch": ncand,
-                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "sync_every_step": bool(args.sync_every_step), "diag_lib": bool(args.diag_lib or args.lib),
+                       "spectrogram_branch": bool(args.spectrogram), "psd_plane_out": not args.no_psd_out, "rel_avg_planes_out": bool(args.planes), "frame_decimation": args.decim, "sync_every_step": bool(args.sync_every_step), "host_wait": args.host_wait, "diag_lib": bool(args.diag_lib or args.lib),
                        # read back from the library (ss_get_stats), not mirrored from its policy: is tile culling on for this context, and of the
                        # averaging tiles of every batch so far how many went through the test and how many were proven empty and never evaluated
                        "tile_culling": bool(lib_stats["culling"]),

@@ -1543,6 +1543,17 @@ __global__ void k_ring_fill(RingFillArgs a, int n, int rows) {
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) dst[e] = src[e] - thr[e % n];
 }
 
+// The drain of the deep pipeline (drain_deep, specscan.hip): a queue says "my last stage has run" (one wave behind it), and one wave
+// on the public stream sleeps until `want` such words have been said since ss_create, or `limit` ticks of the 100 MHz clock have passed.
+__global__ void k_drain_signal(unsigned* done) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_drain_wait(const unsigned* done, unsigned want, long long limit) {
+  const long long t0 = wall_clock64();
+  // (signed distance: the counter wraps after 2^32 signals)
+  while ((int)(__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0 && wall_clock64() - t0 < limit) __builtin_amdgcn_s_sleep(16);
+}
+
 // Candidate lists (CSR) from the mask bits: one wave per frame. The frame's offset is the sum of the
 // counts of the frames before it (8 counts per lane per trip of 512 frames). The wave pulls 256 mask words
 // per trip (one 16-byte load per lane), ranks them with one wave scan, expands the set bits into an LDS

@@ -136,6 +136,8 @@ struct ss_ctx {
     bool dif8 = true;              // 65536 points, int8 IQ, default window, calls that keep no plane: NO work buffer — the radix-8 fold in the load stage of the 8192-point transform, eight workgroups per frame, one launch per call whatever its length (scan_step.h KIND 8, fft65536_dif8.h; SS_DIF8=0: the four-step forms of round 4)
     int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
     bool rows1024x256 = true;      // 262144 points (what getFft picks at 61.44 MS/s): rows through the 1024-point row tile with run maxima and ring rows — culled, no dB plane in detect mode, the 65536-point two-launch pipeline (SS_ROWS1024X256=0: round 2's path, k_fft_rows256xR_psd, every tile evaluated)
+    int drain_waiter_us = 0;       // 8192 points, deep pipelining (SS_DRAIN_WAITER_US=n): the drain's join behind a waiter on the public stream that sleeps at most n us (drain_deep) — measured in round 6 and not kept: 25.3-26.5 against 25.7-26.5 us per step with it, profiles/r06/s19_summary.txt
+    bool drain_tail_event = true;  // ... an event recorded behind the drain's last command on the public stream (SS_DRAIN_TAIL_EVENT=0: none, as until session 18 of round 6): the 20-step form 25.2 against 25.85 us per step, medians of eight alternating runs (s20)
     int dif8_single_max = 0;       // 65536 points, the fold: calls of up to this many frames take ONE residue per workgroup (scan_step.h KIND 11; SS_DIF8_SINGLE_MAX=n) — measured in round 6 and not kept: a workgroup folds the whole frame whether it wants one residue of it or two, so it lives as long either way (16-frame calls 20.6 against 19.5 us, 32-frame calls 26.0 against 20.3: profiles/r06/s13_summary.txt)
     int chunk_65536 = 256;         // 65536 points with tile culling: calls of more frames go through in chunks of this many (SS_CHUNK_65536=0: in one piece)
     int chunk_long = 16;           // 2^20 points in two passes: calls of more frames go through in chunks of this many (SS_CHUNK_LONG=0: in one piece)
@@ -209,6 +211,8 @@ struct ss_ctx {
       chunk_65536 = num("SS_CHUNK_65536", chunk_65536);
       rows1024x256 = tri("SS_ROWS1024X256") != 0;
       dif8_single_max = num("SS_DIF8_SINGLE_MAX", dif8_single_max);
+      drain_waiter_us = num("SS_DRAIN_WAITER_US", drain_waiter_us);
+      drain_tail_event = tri("SS_DRAIN_TAIL_EVENT") != 0;
       plan_first = num("SS_PLAN_FIRST", plan_first);
       det_lag2 = tri("SS_DET_LAG2") != 0;
       dif8 = tri("SS_DIF8") != 0;
@@ -387,7 +391,9 @@ struct ss_ctx {
   // hand-over. Everything said about "even" distances below reads "multiples of nq".)
   int nq = 2;
   hipStream_t s_ab[kMaxQueues] = {};
-  hipEvent_t ev_launch[32] = {}, ev_in[4] = {}, ev_join[kMaxQueues] = {};
+  hipEvent_t ev_launch[32] = {}, ev_in[4] = {}, ev_join[kMaxQueues] = {}, ev_tail = nullptr;
+  unsigned* d_drain_done = nullptr;  // drain_deep: counts the queues' "my last stage has run" signals since ss_create (k_drain_signal), the waiter's word
+  unsigned drain_signals = 0;        // ... how many have been enqueued
   float* d_halo[2 * kMaxQueues] = {};  // [kHistRows][n] each: written by launch L, read by detect(L) in launch L + nq
   const void* deep_prev_iq = nullptr;  // the previous call's frames (caller's buffer: untouched until ss_sync by contract)
   long long deep_prev_stride = 0;
@@ -1168,6 +1174,7 @@ void drain_deep(ss_ctx* c) {
     }
   };
   if (in_order && c->deep_L > 0) join();
+  const bool launched_on_queues = !in_order && c->deep_L > 0;
   for (int parity = 0; parity < (in_order ? 1 : c->nq); ++parity) {
     hipStream_t q = in_order ? c->stream : c->s_ab[parity];
     const auto mine = [&](long ready) { return in_order || (int)(ready % c->nq) == parity; };
@@ -1192,7 +1199,22 @@ void drain_deep(ss_ctx* c) {
       if (has_det) c->pe.push_back(ss_ctx::PendEmit{dd.emit, dd.ready});
     }
   }
-  if (!in_order) join();
+  if (!in_order) {
+    // The join is a pair of barrier packets at the head of the public stream's queue, which is idle: the kernel behind them starts
+    // 11-13 us after the stage they wait for has ended (scripts/ubench/sync_tail_lab.hip, profiles/r06/s18_timeline_k20_tail_all.txt).
+    // Measured and not kept (drain_waiter_us, off): a WAITER in front of them — one wave on the public stream that sleeps until each
+    // queue's last stage has said so in device memory (k_drain_signal, one wave behind it). In the lab, whose kernels are one wave
+    // each, the same 20 launches + drain end 16 us earlier on the device with it; in the product nothing moves — the ring fill still
+    // starts 14-19 us behind the last stage, and the two one-wave launches sit on the tail (profiles/r06/s19_summary.txt).
+    // Correctness never rested on it: the barriers behind it are the join.
+    const bool waiter = c->diag.drain_waiter_us > 0 && c->d_drain_done && launched_on_queues;
+    if (waiter) {
+      for (int q = 0; q < c->nq; ++q) hipLaunchKernelGGL(ss::k_drain_signal, dim3(1), dim3(64), 0, c->s_ab[q], c->d_drain_done);
+      c->drain_signals += (unsigned)c->nq;
+      hipLaunchKernelGGL(ss::k_drain_wait, dim3(1), dim3(64), 0, c->stream, (const unsigned*)c->d_drain_done, c->drain_signals, (long long)c->diag.drain_waiter_us * 100);
+    }
+    join();
+  }
   // the spectrogram partial sums still waiting join their containers, and the public stream waits for all of them
   fold_spectrogram_slots(c, c->deep_folds.size(), true);
   if (c->fold_dirty) {
@@ -1213,6 +1235,9 @@ void drain_deep(ss_ctx* c) {
     }
     if (owed) hipLaunchKernelGGL(ss::k_ring_fill, dim3((unsigned)((size_t)kHistRows * c->n / 1024), owed), dim3(256), 0, c->stream, rf, c->n, kHistRows);
   }
+  // (a device-wide synchronisation that finds an event behind every stream's last command waits for those; otherwise it puts a marker
+  // of its own on each stream first: 27 against 17 us from the device's last word to the host's return in the lab)
+  if (launched_on_queues && c->diag.drain_tail_event && c->ev_tail) (void)hipEventRecord(c->ev_tail, c->stream);
   c->deep_L = 0;
   c->deep_barrier = -10;
   c->deep_prev_ok = false;  // after a drain the caller may reuse its planes: the next call takes its rows from the ring
@@ -2300,6 +2325,8 @@ void free_ctx(ss_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_join)
     if (e) (void)hipEventDestroy(e);
+  if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
+  (void)hipFree(c->d_drain_done);
   for (auto& z : c->noise) (void)hipFree(z.d_thr);
   for (auto& g : c->spec) (void)hipFree(g.d_sum);
   (void)hipFree(c->d_spec_partial);
@@ -2580,6 +2607,9 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
     for (auto& e : c->ev_launch) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_in) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_join) CREATE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    CREATE_HIP(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
+    CREATE_HIP(hipMalloc(&c->d_drain_done, 64));
+    CREATE_HIP(hipMemset(c->d_drain_done, 0, 64));
   }
   if (c->step_path) {
     hipDeviceProp_t prop;
