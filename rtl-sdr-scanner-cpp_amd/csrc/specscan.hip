@@ -1955,12 +1955,17 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
     // frames, writes the ring rows of the batch itself (placed now: moving the ring window drains the deferred stages).
     // 65536 points, int8 IQ: a call that keeps no plane goes through the radix-8 fold (KIND 8) — decided before the ring is placed,
     // because a change of form rewrites the window
-    const bool dif_call = c->dif8 && allow_overlap && c->cull_long && c->diag.pipeline && n_learn == 0 && !d_psd_out && !d_rel_out && !d_avg_out && !spec &&
-                          !(c->cfg.flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN | SS_FLAG_KEEP_PLANES));
+    // (one predicate for the three decisions below — fold, dB rows in the ring, no dB plane at all: a device call without learning frames
+    // that hands out no plane and keeps none; and the room for a whole batch's rows in the ring's buffer is ring_place.h's `whole` branch,
+    // a function of the sizes alone, so a fold call knows before the window is rewritten that its rows have a place — a call that has
+    // none takes the four-step form)
+    const bool keeps_no_plane = allow_overlap && n_learn == 0 && !d_psd_out && !d_rel_out && !d_avg_out && !spec && !c->ref_nan &&
+                                !(c->cfg.flags & SS_FLAG_KEEP_PLANES) && c->diag.ring_only;
+    const bool ring_room = nframes < kHistRows || kHistRows + nframes <= c->hist_rows;
+    const bool dif_call = c->dif8 && c->cull_long && c->diag.pipeline && keeps_no_plane && ring_room && !(c->cfg.flags & (SS_FLAG_STREAM_ORDERED | SS_FLAG_REFERENCE_NAN));
     // ... and the rows the FFT stage of a detect-mode call leaves in the ring are dB values (ring_db_rows): a call of any other kind, and
     // a call under another ceiling, has them turned into noise-relative rows first
-    const bool db_call = c->cull_long && (!c->cull_fold_only || dif_call) && n_learn == 0 && allow_overlap && !d_psd_out && !d_rel_out && !d_avg_out && !spec && !c->ref_nan &&
-                         !(c->cfg.flags & SS_FLAG_KEEP_PLANES) && c->diag.ring_only;  // (what ring_only below comes to, but for the room in the ring's buffer)
+    const bool db_call = c->cull_long && (!c->cull_fold_only || dif_call) && keeps_no_plane;  // (what ring_only below comes to, but for the room in the ring's buffer)
     if (c->ring_db_rows > 0 && (!db_call || c->ring_db_thr != z->d_thr)) settle_ring_db(c);
     set_ring_form(c, dif_call);
     ss::RowsExtra rx{};
@@ -1979,8 +1984,7 @@ int run_batch(ss_ctx* c, const void* d_iq, long long item_stride, int nframes, i
         rx.zero_word = c->d_tlist[c->buf_cur];  // (the list this call's plan appends to; its last reader was the detect stage of the call before last)
         ring_by_rows = true;
         // no dB plane at all: a device call that hands out no plane, shorter than the ring, whose rows the new rows kernel writes
-        ring_only = allow_overlap && !d_psd_out && !d_rel_out && !d_avg_out && !spec && !c->ref_nan && (nframes < kHistRows || rp.batch) &&
-                    !(c->cfg.flags & SS_FLAG_KEEP_PLANES) && c->diag.ring_only;
+        ring_only = keeps_no_plane && (nframes < kHistRows || rp.batch);
         if (ring_only && nframes < kHistRows) {
           ring_rows = rp.in + (size_t)kHistRows * c->n;  // batch frame f = row H + f of the window being read: right behind it (place_ring)
         } else if (ring_only) {  // every frame of the batch as a row of the region place_ring reserved; its last H rows are the next call's ring
