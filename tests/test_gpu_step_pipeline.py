@@ -180,6 +180,20 @@ def test_long_runs_of_overlapped_calls_equal_call_by_call(seed):
 
 def test_flush_then_stream_sync_completes_the_results():
     """ss_flush enqueues the deferred stages; after it any synchronisation of the stream (here: of the device) will do."""
+    _flush_then_device_sync()
+
+
+@pytest.mark.parametrize("env", [{"SS_DRAIN_TAIL_EVENT": "0"}, {"SS_DRAIN_WAITER_US": "500"}, {"SS_DRAIN_WAITER_US": "1", "SS_DRAIN_TAIL_EVENT": "0"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_the_drains_join_in_its_measured_forms(monkeypatch, diag_lib, env):
+    """drain_deep (specscan.hip): without the event behind the drain's last command, and with the one-wave waiter in front of the join
+    (round 6, measured and not kept) — with time to spare and with a limit it runs into: the barriers behind it are the join either way."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _flush_then_device_sync()
+
+
+def _flush_then_device_sync():
     import torch
     dev = torch.device("cuda:0")
     band = pkg.synth.SyntheticBand(N, seed=5, on_frame=40, off_frame=10_000)
