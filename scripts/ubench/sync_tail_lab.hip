@@ -68,8 +68,11 @@ static double us_since(clk::time_point a) { return std::chrono::duration<double,
 
 int main() {
   hipStream_t pub, q[2];
-  CK(hipStreamCreateWithFlags(&pub, hipStreamNonBlocking));
+  // (PUB_LAST=1: the public stream is created behind the two queues — does a device-wide synchronisation visit streams in that order?)
+  const bool pub_last = getenv("PUB_LAST") && atoi(getenv("PUB_LAST"));
+  if (!pub_last) CK(hipStreamCreateWithFlags(&pub, hipStreamNonBlocking));
   for (auto& s : q) CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  if (pub_last) CK(hipStreamCreateWithFlags(&pub, hipStreamNonBlocking));
   hipEvent_t ev[8];
   for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   long long* d_stamps;
