@@ -989,6 +989,10 @@ def run(args):
     if not args.no_kernel_timing and args.time_every > 0:
         every = args.time_every
         eng.kernel_timing(every)
+    import gc
+    gc.collect()
+    if not os.environ.get("SS_BENCH_KEEP_GC"):  # (A/B: scripts/r06/s27.sh)
+        gc.disable()  # (as timeit does: no collector pause of the interpreter inside a region of half a millisecond)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -1003,6 +1007,7 @@ def run(args):
     t_dev = time.perf_counter()
     dist.barrier()
     t1 = time.perf_counter()
+    gc.enable()
     eng.sync()  # (settles the library's own bookkeeping; nothing left to wait for)
     kern_ms, launches, slots = 0.0, 0, {}
     if every:
