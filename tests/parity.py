@@ -54,6 +54,16 @@ def running_sum_drift(n, ref_avg=None):
     return 3.0 * (ulp[:, None] / np.sqrt(12.0)) * walk[None, :]
 
 
+def running_sum_drift_at(n, ref_avg, frames, bins):
+    """running_sum_drift's allowance at chosen (frame, bin) pairs only — the candidates: a [frames x n] float64 plane of it would be
+    hundreds of megabytes at 65536 points and more."""
+    fin = np.where(np.isfinite(ref_avg), np.abs(ref_avg), 0.0)
+    mag = np.maximum(21.0 * fin.max(axis=1), 128.0)
+    ulp = np.exp2(np.floor(np.log2(mag)) - 23.0)
+    walk = np.sqrt(2.0 * (np.asarray(bins, dtype=np.float64) + 1.0)) / 21.0
+    return 3.0 * (ulp[np.asarray(frames)] / np.sqrt(12.0)) * walk
+
+
 def check_plane(name, got, ref, floor=None):
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     exact = got == ref  # covers -100 and +-inf
