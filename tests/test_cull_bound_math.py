@@ -68,3 +68,21 @@ def test_the_bound_on_int8_input_and_a_short_learning_phase(oracle_mod):
     c100, e100, ncand = _bound_check(oracle_mod, 4096, 2_048_000, 300, 100, 25.0, seed=3, fmt="cs8", centres=(0.05, -0.31))
     assert ncand > 200 and c100 > 0 and c16 + e16 > 0
     assert c100 / (c100 + e100) >= c16 / (c16 + e16) - 0.05, (c16, e16, c100, e100)
+
+
+def test_the_drift_allowance_at_chosen_bins_is_the_planes_allowance_there():
+    """tests/parity.py: running_sum_drift_at (what cand_avg is held to at the candidates of a 65536-point frame and longer) is
+    running_sum_drift's value at those (frame, bin) pairs, sentinel frames included."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from parity import running_sum_drift, running_sum_drift_at
+    rng = np.random.default_rng(5)
+    n, frames = 4096, 12
+    avg = rng.normal(0.0, 6.0, (frames, n)).astype(np.float32)
+    avg[3] = -100.0  # a frame that still holds sentinels: its running sum is an order of magnitude larger
+    avg[7, 100:200] = np.inf
+    plane = running_sum_drift(n, avg)
+    f = rng.integers(0, frames, 500)
+    b = rng.integers(0, n, 500)
+    np.testing.assert_allclose(running_sum_drift_at(n, avg, f, b), plane[f, b], rtol=1e-12)
+    assert plane[3].max() > 5 * plane[0].max()
