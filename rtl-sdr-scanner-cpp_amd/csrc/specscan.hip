@@ -136,6 +136,7 @@ struct ss_ctx {
     bool dif8 = true;              // 65536 points, int8 IQ, default window, calls that keep no plane: NO work buffer — the radix-8 fold in the load stage of the 8192-point transform, eight workgroups per frame, one launch per call whatever its length (scan_step.h KIND 8, fft65536_dif8.h; SS_DIF8=0: the four-step forms of round 4)
     int plan_first = 0;            // 8192 points: the first plan_first pairs of every list of the launch's tile plan on detect workgroups of their own ahead of the FFT role (SS_PLAN_FIRST=n; 0: every pair behind an FFT workgroup's frame)
     bool rows1024x256 = true;      // 262144 points (what getFft picks at 61.44 MS/s): rows through the 1024-point row tile with run maxima and ring rows — culled, no dB plane in detect mode, the 65536-point two-launch pipeline (SS_ROWS1024X256=0: round 2's path, k_fft_rows256xR_psd, every tile evaluated)
+    long long abs_start = 0;       // SS_ABS_START=n: the frame counter starts at n instead of 0 at creation and after ss_reset — sessions that cross 2^30 frames (the counter's 30-bit form indexes the long transforms' run maxima) without the twenty seconds of scanning it takes to get there (tests/test_gpu_cull.py)
     int drain_waiter_us = 0;       // 8192 points, deep pipelining (SS_DRAIN_WAITER_US=n): the drain's join behind a waiter on the public stream that sleeps at most n us (drain_deep) — measured in round 6 and not kept: 25.3-26.5 against 25.7-26.5 us per step with it, profiles/r06/s19_summary.txt
     bool drain_tail_event = true;  // ... an event recorded behind the drain's last command on the public stream (SS_DRAIN_TAIL_EVENT=0: none, as until session 18 of round 6): the 20-step form 25.2 against 25.85 us per step, medians of eight alternating runs (s20)
     int dif8_single_max = 0;       // 65536 points, the fold: calls of up to this many frames take ONE residue per workgroup (scan_step.h KIND 11; SS_DIF8_SINGLE_MAX=n) — measured in round 6 and not kept: a workgroup folds the whole frame whether it wants one residue of it or two, so it lives as long either way (16-frame calls 20.6 against 19.5 us, 32-frame calls 26.0 against 20.3: profiles/r06/s13_summary.txt)
@@ -212,6 +213,7 @@ struct ss_ctx {
       rows1024x256 = tri("SS_ROWS1024X256") != 0;
       dif8_single_max = num("SS_DIF8_SINGLE_MAX", dif8_single_max);
       drain_waiter_us = num("SS_DRAIN_WAITER_US", drain_waiter_us);
+      if (const char* v = getenv("SS_ABS_START")) abs_start = atoll(v);
       drain_tail_event = tri("SS_DRAIN_TAIL_EVENT") != 0;
       plan_first = num("SS_PLAN_FIRST", plan_first);
       det_lag2 = tri("SS_DET_LAG2") != 0;
@@ -2493,6 +2495,7 @@ int ss_create(const ss_config* cfg, ss_ctx** out) {
   CREATE_HIP(hipMalloc(&c->d_tw, sizeof(float2) * (size_t)n));
   CREATE_HIP(hipMalloc(&c->d_pass, (size_t)n));
   c->diag.read();
+  c->abs_frames = c->clean_abs = c->diag.abs_start;
   c->fused = G == 21 && cfg->grouping_x == 21 && cfg->max_batch <= 65536 && !c->diag.backend_unfused;
   // 8192 points (and the four-step sizes) with the fused back end: stages of consecutive calls overlap (scan_step.h), so
   // what a deferred stage reads rotates over several buffers; every other configuration uses set 0 only
@@ -3138,8 +3141,8 @@ int ss_reset(ss_ctx* c) {  // Transmission::resetBuffers -> Averager::reset: row
     SS_HIP(c, hipMemsetAsync(c->d_rel, 0, sizeof(float) * (size_t)c->n * (size_t)(G - 1), c->stream));
   }
   c->frames_pushed = 0;
-  c->abs_frames = 0;
-  c->clean_abs = 0;
+  c->abs_frames = c->diag.abs_start;
+  c->clean_abs = c->diag.abs_start;
   c->rot_frames = 0;
   c->last_n = 0;
   c->deep_iq_recycled = false;  // (a retune is a fresh start for the caller's buffers too; ss_get_stats keeps the count)

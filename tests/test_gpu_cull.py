@@ -329,6 +329,21 @@ def _cull_scenario(seed):
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SS_FUZZ_CULL_SEEDS", "10"))))
 def test_random_detect_mode_sessions_culled_equal_unculled(seed, cull_65536):
+    _random_session(seed)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_sessions_across_the_wrap_of_the_frame_counter(seed, cull_65536, monkeypatch):
+    """The long transforms index their run maxima with the 30-bit form of the frame counter (RowsExtra::abs0), and a replay at the
+    8192-point rate gets to 2^30 frames in twenty seconds: the same random sessions with the counter started so that it wraps in the
+    middle of each (SS_ABS_START, diagnostics build; ss_reset starts there again). The engine that evaluates every tile does not
+    look at the maxima: culled == unculled across the wrap is the culling path's wrap-safety."""
+    *_, nframes, _, _, _ = _cull_scenario(seed)
+    monkeypatch.setenv("SS_ABS_START", str((1 << 30) - max(40, nframes // 2) - seed))
+    _random_session(seed)
+
+
+def _random_session(seed):
     import torch
     rng, n, fs, nframes, max_batch, fmt, learn = _cull_scenario(seed)
     on_frame, off_frame = learn + int(rng.integers(3, 40)), nframes - int(rng.integers(4, 20))
